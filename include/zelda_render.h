@@ -1,0 +1,149 @@
+/*
+ * zelda_render.h — C-ABI of the MI355X-native deferred renderer (libzelda_render.so).
+ *
+ * The reference (iceprincefounder/ZeldaEngine) is a monolith with no plugin/FFI
+ * boundary: its renderer is the private body of XkZeldaEngineApp.  The entry
+ * points below are therefore the seam a maintainer would cut: each one replaces
+ * the engine-internal function cited next to it and takes the engine's own byte
+ * layouts (zelda_abi.h).  See INTEGRATION.md for the binding stubs.
+ *
+ * Conventions: 0 = OK, negative = error (message via zr_last_error); no C++
+ * exception crosses the ABI; the caller owns every input pointer (contents are
+ * copied before return); outputs are written into caller buffers.  A context is
+ * bound to one HIP device and is NOT thread-safe, except zr_livelink_* which
+ * hand a parsed world to the render thread under a mutex.
+ *
+ * There is no CPU fallback: every entry point that computes fails with
+ * ZR_ERR_DEVICE when no HIP device is usable.
+ */
+#ifndef ZELDA_RENDER_H
+#define ZELDA_RENDER_H
+
+#include "zelda_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZR_OK            0
+#define ZR_ERR_ARG      -1
+#define ZR_ERR_DEVICE   -2
+#define ZR_ERR_OOM      -3
+#define ZR_ERR_PARSE    -4
+#define ZR_ERR_IO       -5
+#define ZR_ERR_STATE    -6
+#define ZR_ERR_OVERFLOW -7
+#define ZR_ERR_UNSUPPORTED -8
+
+#define ZR_TILE 32            /* screen tile edge in pixels (raster + multi-GPU partition unit) */
+
+typedef struct zr_ctx zr_ctx;
+
+/* Flags for zr_config.flags */
+#define ZR_FLAG_NO_FRUSTUM_CULL 1u  /* disable meshlet frustum culling (parity A/B) */
+#define ZR_FLAG_NO_CONE_CULL    2u  /* disable meshlet cone culling   (parity A/B) */
+#define ZR_FLAG_SKIP_COMPOSITE  4u  /* tile_world>1: caller gathers packed tiles itself */
+
+typedef struct zr_config {
+    uint32_t width, height;   /* swapchain extent, ZE:78-79 (default 1920x1080) */
+    uint32_t shadow_dim;      /* SHADOWMAP_DIM, ZE:87 (0 -> 1024) */
+    uint32_t debug_view;      /* GlobalConstants.SpecConstants 0..9, ZE:1803-1842 */
+    int32_t  device;          /* HIP device ordinal */
+    uint32_t tile_rank;       /* screen-tile partition: this context renders tiles t with */
+    uint32_t tile_world;      /*   t % tile_world == tile_rank (0 -> 1) */
+    uint32_t flags;
+} zr_config;
+
+/* One RGBA8 image; rgba8 == NULL selects the slot's engine default (ZE:4951-4978). */
+typedef struct zr_image { const uint8_t* rgba8; uint32_t width, height; } zr_image;
+/* Material = the 7 PBR samplers of BaseScene.frag:7-13 in order bc, m, r, n, ao, ev, ms. */
+typedef struct zr_material { zr_image tex[XK_PBR_SAMPLER_NUMBER]; } zr_material;
+
+/* XkCameraDesc (ZE:619-669) as plain floats; input of zr_update_uniforms. */
+typedef struct zr_camera { float Position[3]; float Lookat[3]; float Speed, FOV, zNear, zFar; } zr_camera;
+
+/* Per-pass GPU timings of the last zr_render, milliseconds (hipEvents on the render stream). */
+enum { ZR_PASS_CULL_SHADOW = 0, ZR_PASS_SHADOW, ZR_PASS_CULL_CAMERA, ZR_PASS_GBUFFER, ZR_PASS_LIGHTING,
+       ZR_PASS_COMPOSITE, ZR_PASS_TOTAL, ZR_PASS_COUNT };
+
+/* Frame statistics of the last zr_render (read back lazily by zr_get_stats). */
+typedef struct zr_stats {
+    uint64_t work_items[2];     /* meshlet-instances tested   [shadow, camera] */
+    uint64_t survivors[2];      /* meshlet-instances binned   [shadow, camera] */
+    uint64_t bin_entries[2];    /* (tile, meshlet-instance) pairs */
+    uint64_t covered_pixels;    /* GBuffer pixels with geometry */
+    uint32_t overflow;          /* nonzero: a bin list overflowed; frame invalid */
+    uint32_t _pad;
+} zr_stats;
+
+/* --- lifetime (replaces InitVulkan/Cleanup, ZE:1714, 3747) --- */
+int  zr_create(const zr_config* cfg, zr_ctx** out);
+void zr_destroy(zr_ctx* ctx);
+const char* zr_last_error(const zr_ctx* ctx);
+/* Render on a caller-owned hipStream_t (NULL = the context's own stream). */
+int  zr_set_stream(zr_ctx* ctx, void* hip_stream);
+
+/* --- scene submission (replaces CreateRenderObjectsFromProfabs ZE:4922-5000, CreateMeshVertexBuffers
+ *     ZE:4725-4770, CreateInstancedBuffer ZE:4795-4824) --- */
+int  zr_mesh_create(zr_ctx* ctx, const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, uint32_t* mesh_id);
+/* Attach caller-built meshlets (the `.meshlet` payload, ZE:7089-7127).  The mesh's draw order becomes
+ * meshlet order exactly as CreateMeshVertexBuffers<XkMeshIndirect> flattens it (ZE:4733-4756). */
+int  zr_mesh_set_meshlets(zr_ctx* ctx, uint32_t mesh_id, const XkMeshlet* m, uint32_t nm,
+                          const uint32_t* meshlet_vertices, size_t nmv,
+                          const uint8_t* meshlet_triangles, size_t nmt);
+/* Build meshlets with the library's own clusteriser (BuildMeshlets, ZM:132-172: 64 v / 124 t / cone 0.2).
+ * Called implicitly by zr_object_add for meshes that have none.  Draw order stays index order. */
+int  zr_mesh_build_meshlets(zr_ctx* ctx, uint32_t mesh_id, uint32_t max_vertices, uint32_t max_triangles,
+                            float cone_weight);
+/* Copy the mesh's meshlets out (any pointer may be NULL; counts always returned). */
+int  zr_mesh_get_meshlets(zr_ctx* ctx, uint32_t mesh_id, XkMeshlet* m, uint32_t* nm,
+                          uint32_t* meshlet_vertices, size_t* nmv, uint8_t* meshlet_triangles, size_t* nmt);
+/* n_inst == 0: non-instanced draw (Base.vert); n_inst >= 1: instanced draw (BaseInstanced.vert). */
+int  zr_object_add(zr_ctx* ctx, uint32_t mesh_id, const zr_material* mat,
+                   const XkInstanceData* inst, uint32_t n_inst);
+int  zr_scene_clear(zr_ctx* ctx);                   /* CleanupBasePass, ZE:4142 */
+/* 6 RGBA8 sRGB faces in Vulkan layer order +X,-X,+Y,-Y,+Z,-Z (RHICreateTextureCubeResource ZE:5908-6150);
+ * mips are generated like RHIGenerateMipmaps (ZE:6348-6433).  faces == NULL: built-in 1x1 grey. */
+int  zr_set_cubemap(zr_ctx* ctx, const uint8_t* const faces[6], uint32_t dim);
+
+/* --- per-frame uniforms (replaces UpdateWorld ZE:4294-4308 + UpdateUniformBuffer ZE:4585-4664) --- */
+int  zr_update_uniforms(zr_ctx* ctx, const zr_camera* cam,
+                        const XkLight* dir, uint32_t n_dir, const XkLight* point, uint32_t n_point,
+                        const XkLight* spot, uint32_t n_spot, float roll_stage, float roll_light, float time);
+/* Raw form: the three UBOs the engine memcpy's each frame (ZE:4626-4664). */
+int  zr_set_frame(zr_ctx* ctx, const XkUniformBufferMVP* camera, const XkUniformBufferMVP* shadow, const XkView* view);
+int  zr_get_frame(zr_ctx* ctx, XkUniformBufferMVP* camera, XkUniformBufferMVP* shadow, XkView* view);
+int  zr_set_debug_view(zr_ctx* ctx, uint32_t spec_constants);
+
+/* --- the frame (replaces RecordCommandBuffer ZE:3160-3744 + vkQueueSubmit ZE:2014) ---
+ * cull -> shadow -> cull -> gbuffer -> lighting [-> composite].  Asynchronous on the render stream. */
+int  zr_render(zr_ctx* ctx);
+int  zr_finish(zr_ctx* ctx);                        /* stream sync + overflow check */
+int  zr_get_pass_times(zr_ctx* ctx, float ms[ZR_PASS_COUNT]);
+int  zr_get_stats(zr_ctx* ctx, zr_stats* out);
+
+/* --- read-back (there is no swapchain; replaces vkQueuePresentKHR ZE:2030) --- */
+int  zr_read_color(zr_ctx* ctx, uint8_t* rgba8, size_t bytes);         /* W*H*4 row-major, top-left origin */
+/* target 0 depth D32F, 1 SceneColor RGBA8, 2 GBufferA A2R10G10B10, 3 GBufferB RGBA8, 4 GBufferC RGBA8,
+ * 5 GBufferD RGBA16F (ZE:2807-2843); W*H*{4,4,4,4,4,8} bytes. */
+int  zr_read_gbuffer(zr_ctx* ctx, int target, void* dst, size_t bytes);
+int  zr_read_shadowmap(zr_ctx* ctx, float* dst, size_t bytes);        /* dim*dim*4 */
+
+/* --- multi-GPU screen-tile partition --- */
+/* Packed tile-major RGBA8 of the tiles this rank owns (device pointer, stable until zr_destroy). */
+int  zr_tiles_device_buffer(zr_ctx* ctx, void** dev_ptr, size_t* bytes_per_rank);
+/* Scatter the all-gathered buffer (tile_world * bytes_per_rank, rank-major, device pointer) into the frame. */
+int  zr_composite(zr_ctx* ctx, const void* gathered_dev);
+int  zr_color_device_ptr(zr_ctx* ctx, void** dev_ptr);
+
+/* --- world JSON + livelink (replaces XkWorld::Load ZE:1051-1147, socket thread ZE:1617-1710) --- */
+int  zr_world_load_json(zr_ctx* ctx, const char* utf8, size_t len);
+int  zr_world_save_json(zr_ctx* ctx, char* dst, size_t cap, size_t* len);
+int  zr_livelink_serve(zr_ctx* ctx, uint16_t port);
+int  zr_livelink_poll(zr_ctx* ctx, int* reloaded);  /* DrawFrame's bReloadScene pickup, ZE:1943-1951 */
+int  zr_livelink_stop(zr_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZELDA_RENDER_H */

@@ -1,0 +1,166 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liboracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Importable only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; the product
+package (zeldaengine_amd/) must never import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("zo_oracle.c", "zo_math.h", "zo_oracle.h")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        L.zo_create.restype = C.c_void_p
+        L.zo_create.argtypes = [C.c_uint32] * 3
+        L.zo_destroy.argtypes = [C.c_void_p]
+        L.zo_mesh_create.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.zo_object_add.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.zo_scene_clear.argtypes = [C.c_void_p]
+        L.zo_set_cubemap.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.zo_update_uniforms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                         C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_float]
+        L.zo_set_frame.argtypes = [C.c_void_p] * 4
+        L.zo_get_frame.argtypes = [C.c_void_p] * 4
+        L.zo_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        for n in ("zo_color", "zo_shadowmap", "zo_visibility"):
+            getattr(L, n).restype = C.c_void_p
+            getattr(L, n).argtypes = [C.c_void_p]
+        L.zo_gbuffer.restype = C.c_void_p
+        L.zo_gbuffer.argtypes = [C.c_void_p, C.c_int]
+        L.zo_covered_pixels.restype = C.c_uint64
+        L.zo_covered_pixels.argtypes = [C.c_void_p]
+        L.zo_meshlet_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        for n, args, res in [
+            ("zo_kat_D_GGX", 2, C.c_float), ("zo_kat_V_SmithGGXCorrelated", 3, C.c_float),
+            ("zo_kat_F_Schlick", 3, C.c_float), ("zo_kat_Fr_DisneyDiffuse", 4, C.c_float),
+            ("zo_kat_ReflectionMip", 2, C.c_float), ("zo_kat_exp2", 1, C.c_float), ("zo_kat_log2", 1, C.c_float),
+            ("zo_kat_pow", 2, C.c_float)]:
+            getattr(L, n).restype = res
+            getattr(L, n).argtypes = [C.c_float] * args
+        L.zo_kat_srgb8_to_linear.restype = C.c_float
+        L.zo_kat_srgb8_to_linear.argtypes = [C.c_uint32]
+        L.zo_kat_f32_to_f16.restype = C.c_uint16
+        L.zo_kat_f32_to_f16.argtypes = [C.c_float]
+        L.zo_kat_EnvBRDFApproxLazarov.argtypes = [C.c_float, C.c_float, C.c_void_p]
+        L.zo_kat_default_normal_ts.argtypes = [C.c_void_p]
+        L.zo_kat_perspective.argtypes = [C.c_float] * 4 + [C.c_void_p]
+        L.zo_kat_lookat.argtypes = [C.c_void_p] * 4
+        L.zo_kat_sincos.argtypes = [C.c_float, C.c_void_p]
+        L.zo_kat_rotmat.argtypes = [C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+class Oracle:
+    """Same call sequence as zeldaengine_amd.engine.Renderer, on the CPU."""
+
+    def __init__(self, width, height, shadow_dim=1024):
+        self.L = lib()
+        self.W, self.H, self.SD = width, height, shadow_dim
+        self.h = self.L.zo_create(width, height, shadow_dim)
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.L.zo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def mesh_create(self, verts, idx):
+        verts = np.ascontiguousarray(verts)
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        r = self.L.zo_mesh_create(self.h, _ptr(verts), len(verts), _ptr(idx), len(idx))
+        assert r >= 0
+        return r
+
+    def object_add(self, mesh, material=None, instances=None):
+        mat = C.byref(material) if material is not None else None
+        n = 0 if instances is None else len(instances)
+        inst = np.ascontiguousarray(instances) if n else None
+        r = self.L.zo_object_add(self.h, mesh, mat, _ptr(inst) if n else None, n)
+        assert r >= 0
+        return r
+
+    def scene_clear(self):
+        self.L.zo_scene_clear(self.h)
+
+    def set_cubemap(self, faces):
+        if faces is None:
+            self.L.zo_set_cubemap(self.h, None, 0)
+            return
+        faces = [np.ascontiguousarray(f, dtype=np.uint8) for f in faces]
+        arr = (C.c_void_p * 6)(*[f.ctypes.data for f in faces])
+        assert self.L.zo_set_cubemap(self.h, arr, faces[0].shape[0]) == 0
+
+    def update_uniforms(self, cam, dir_l, point_l, spot_l, roll_stage=0.0, roll_light=0.0, time=0.0):
+        self.L.zo_update_uniforms(self.h, C.byref(cam), _ptr(dir_l), len(dir_l), _ptr(point_l), len(point_l),
+                                  _ptr(spot_l), len(spot_l), roll_stage, roll_light, time)
+
+    def get_frame(self):
+        from zeldaengine_amd import abi
+        cam = np.zeros((), dtype=abi.XkUniformBufferMVP)
+        sh = np.zeros((), dtype=abi.XkUniformBufferMVP)
+        view = np.zeros((), dtype=abi.XkView)
+        self.L.zo_get_frame(self.h, cam.ctypes.data, sh.ctypes.data, view.ctypes.data)
+        return cam, sh, view
+
+    def set_frame(self, cam, sh, view):
+        self.L.zo_set_frame(self.h, cam.ctypes.data, sh.ctypes.data, view.ctypes.data)
+
+    def render(self, debug_view=0, passes=7):
+        self.L.zo_render(self.h, debug_view, passes)
+
+    def _view(self, ptr, dtype, shape):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        buf = (C.c_uint8 * n).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape).copy()
+
+    def color(self):
+        return self._view(self.L.zo_color(self.h), np.uint8, (self.H, self.W, 4))
+
+    def gbuffer(self, target):
+        dt = [np.float32, np.uint32, np.uint32, np.uint32, np.uint32, np.uint64][target]
+        return self._view(self.L.zo_gbuffer(self.h, target), dt, (self.H, self.W))
+
+    def shadowmap(self):
+        return self._view(self.L.zo_shadowmap(self.h), np.float32, (self.SD, self.SD))
+
+    def visibility(self):
+        return self._view(self.L.zo_visibility(self.h), np.uint32, (self.H, self.W))
+
+    def covered_pixels(self):
+        return int(self.L.zo_covered_pixels(self.h))
+
+
+def load_scene(r, cfg):
+    """Feed a scenes.config*() dict to an Oracle or a Renderer (same method names)."""
+    r.set_cubemap(cfg.get("cubemap"))
+    for o in cfg["objects"]:
+        m = r.mesh_create(*o["mesh"])
+        r.object_add(m, o.get("material"), o.get("instances"))
+    r.update_uniforms(cfg["camera"], cfg["dir"], cfg["point"], cfg["spot"])
