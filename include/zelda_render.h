@@ -101,7 +101,10 @@ int  zr_mesh_get_meshlets(zr_ctx* ctx, uint32_t mesh_id, XkMeshlet* m, uint32_t*
 /* n_inst == 0: non-instanced draw (Base.vert); n_inst >= 1: instanced draw (BaseInstanced.vert). */
 int  zr_object_add(zr_ctx* ctx, uint32_t mesh_id, const zr_material* mat,
                    const XkInstanceData* inst, uint32_t n_inst);
-int  zr_scene_clear(zr_ctx* ctx);                   /* CleanupBasePass, ZE:4142 */
+int  zr_scene_clear(zr_ctx* ctx);                   /* CleanupBasePass, ZE:4142 (also drops meshes and Profabs) */
+int  zr_object_count(zr_ctx* ctx, uint32_t* n);
+/* Copy out the instance array of object `index` (add order); *n = 0 for a non-instanced draw.  dst may be NULL. */
+int  zr_object_get_instances(zr_ctx* ctx, uint32_t index, uint32_t* mesh_id, XkInstanceData* dst, uint32_t* n);
 /* 6 RGBA8 sRGB faces in Vulkan layer order +X,-X,+Y,-Y,+Z,-Z (RHICreateTextureCubeResource ZE:5908-6150);
  * mips are generated like RHIGenerateMipmaps (ZE:6348-6433).  faces == NULL: built-in 1x1 grey. */
 int  zr_set_cubemap(zr_ctx* ctx, const uint8_t* const faces[6], uint32_t dim);
@@ -137,9 +140,17 @@ int  zr_composite(zr_ctx* ctx, const void* gathered_dev);
 int  zr_color_device_ptr(zr_ctx* ctx, void** dev_ptr);
 
 /* --- world JSON + livelink (replaces XkWorld::Load ZE:1051-1147, socket thread ZE:1617-1710) --- */
+/* A Profab is the engine's asset bundle `Profabs/<name>/{models, textures}` (ZE:4922-5000).  The library has no
+ * file-system asset search yet: the caller registers each model of a Profab (mesh + 7-texture material) under its name;
+ * zr_world_load_json instantiates ObjectDescs from the registry.  Unknown names draw nothing, like a missing directory. */
+int  zr_profab_register(zr_ctx* ctx, const char* name, uint32_t mesh_id, const zr_material* mat);
+/* XkWorld::Load + CreateEngineScene + the first UpdateUniformBuffer: replaces the scene's objects (InstanceCount > 1 ->
+ * GenerateInstance, seeded PCG32(1234 + object index)) and sets camera + lights. */
 int  zr_world_load_json(zr_ctx* ctx, const char* utf8, size_t len);
+int  zr_world_get_camera(zr_ctx* ctx, zr_camera* out);
 int  zr_world_save_json(zr_ctx* ctx, char* dst, size_t cap, size_t* len);
-int  zr_livelink_serve(zr_ctx* ctx, uint16_t port);
+int  zr_livelink_serve(zr_ctx* ctx, uint16_t port);   /* port 0 = ephemeral (tests); the engine's port is 8080 */
+int  zr_livelink_port(zr_ctx* ctx, uint16_t* port);
 int  zr_livelink_poll(zr_ctx* ctx, int* reloaded);  /* DrawFrame's bReloadScene pickup, ZE:1943-1951 */
 int  zr_livelink_stop(zr_ctx* ctx);
 

@@ -1,0 +1,54 @@
+"""Builds zeldaengine_amd/libzelda_render.so (HIP kernels + C-ABI) in-tree with hipcc for gfx950.
+
+    python -m zeldaengine_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off is part of the numerics contract (csrc/zr_math.h).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libzelda_render.so")
+SOURCES = ["zr_kernels.hip", "zr_host.cpp", "zr_world.cpp", "zr_meshlet.cpp"]
+HEADERS = ["zr_math.h", "zr_types.h", "zr_ctx.h", "zr_meshlet.h", "../../include/zelda_abi.h", "../../include/zelda_render.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__"]
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    bdir = os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc, "-x", "hip"] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
+        if verbose and out:
+            print(out.decode(errors="replace"))
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs + ["-lpthread"]
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,92 @@
+// zr_ctx.h — internal context shared by zr_host.cpp (renderer) and zr_world.cpp (JSON world + livelink).
+#pragma once
+
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "zr_meshlet.h"
+#include "zr_types.h"
+
+struct ZrMesh {
+    std::vector<XkVertex> v;
+    std::vector<uint32_t> idx;           // draw-order index buffer
+    ZrMeshletSet ms;
+    bool has_meshlets = false, uploaded = false;
+    float center[3] = { 0, 0, 0 }; float radius = 0;
+    XkVertex* d_v = nullptr; uint32_t* d_idx = nullptr; XkMeshlet* d_meshlets = nullptr;
+    uint32_t* d_mverts = nullptr; uint8_t* d_mtris = nullptr; uint32_t* d_tri_order = nullptr;
+};
+
+struct ZrSceneObject {
+    uint32_t mesh = 0, n_inst = 1; bool instanced = false;
+    std::vector<XkInstanceData> inst;    // host copy (zr_object_get_instances)
+    ZrInstance* d_inst = nullptr;
+    uint32_t texel[7]; float bc_linear[3];
+};
+
+// XkWorld (ZE:1025-1291) as parsed from JSON
+struct ZrLightDesc { float Position[3]; uint32_t Type; float Color[3]; float Intensity; float Direction[3]; float Radius; float ExtraData[4]; };
+struct ZrObjectDesc {
+    uint32_t RenderFlags = 0; std::string ProfabName; uint32_t InstanceCount = 0;
+    float MinRadius = 0, MaxRadius = 0, MinRotYaw = 0, MaxRotYaw = 0, MinRotRoll = 0, MaxRotRoll = 0,
+          MinRotPitch = 0, MaxRotPitch = 0, MinPScale = 0, MaxPScale = 0;
+};
+struct ZrWorld {
+    bool EnableSkydome = true, OverrideSkydome = false; std::string SkydomeFileName;
+    bool OverrideCubemap = false; std::string CubemapFileNames[6];
+    bool EnableBackground = false, OverrideBackground = false; std::string BackgroundFileName;
+    zr_camera MainCamera;
+    std::vector<ZrLightDesc> DirectionalLights, PointLights, SpotLights;
+    std::vector<ZrObjectDesc> ObjectDescs;
+    bool loaded = false;
+};
+struct ZrProfab { uint32_t mesh; bool has_material; uint32_t texel[7]; float bc_linear[3]; };
+
+struct zr_ctx {
+    zr_config cfg;
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+
+    std::vector<ZrMesh> meshes;
+    std::vector<ZrSceneObject> objects;
+    bool scene_dirty = true;
+    ZrObject* d_objs = nullptr; uint32_t n_objs = 0, n_work = 0;
+
+    XkUniformBufferMVP cam, shadow; XkView view; XkView* d_view = nullptr; bool frame_valid = false;
+    uint32_t debug_view = 0;
+
+    uint32_t W = 0, H = 0, SD = 0;
+    uint32_t tiles_x = 0, tiles_y = 0, n_tiles = 0, n_owned = 0, slots_per_rank = 0;
+    uint32_t stiles_x = 0, stiles_y = 0, sn_tiles = 0;
+    uint32_t *d_owned = nullptr, *d_sowned = nullptr;
+    GBufferPtrs G = {};
+    float* d_shadow = nullptr; uint32_t* d_color = nullptr; uint32_t* d_tiles = nullptr;
+
+    uint32_t *d_rects = nullptr, *d_tile_count = nullptr, *d_tile_offset = nullptr, *d_tile_cursor = nullptr, *d_bins = nullptr;
+    uint32_t work_capacity = 0, bin_capacity = 0;
+    ZrDevStats* d_stats = nullptr; ZrDevStats h_stats = {};
+    uint64_t last_work[2] = { 0, 0 };
+
+    std::vector<uint8_t*> d_cube; CubeDesc cube = {}; uint32_t cube_dim = 0, cube_levels = 0;
+    float lut[256]; float* d_lut = nullptr;
+
+    hipEvent_t ev[8] = {}; bool rendered = false;
+
+    // world + livelink
+    ZrWorld world;
+    std::map<std::string, std::vector<ZrProfab>> profabs;
+    std::mutex ll_mutex; std::thread ll_thread; std::atomic<bool> ll_run{ false };
+    int ll_listen_fd = -1; bool ll_pending = false; ZrWorld ll_world; uint16_t ll_port = 0;
+};
+
+int zr_fail(zr_ctx* c, int code, const std::string& msg);
+// helpers implemented in zr_host.cpp and used by zr_world.cpp
+float zr_srgb_decode8(uint32_t c);
+int zr_material_constants(zr_ctx* c, const zr_material* mat, uint32_t texel[7], float bc_linear[3]);
+int zr_object_add_internal(zr_ctx* c, uint32_t mesh_id, const uint32_t texel[7], const float bc_linear[3],
+                           const XkInstanceData* inst, uint32_t n_inst);

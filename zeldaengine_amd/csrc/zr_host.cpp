@@ -1,0 +1,714 @@
+// zr_host.cpp — context, scene upload, per-frame uniforms and the frame graph behind the C-ABI (zelda_render.h).
+//
+// Host counterpart of XkZeldaEngineApp's CreateEngineScene / UpdateUniformBuffer / RecordCommandBuffer / DrawFrame
+// (ZE:4140, 4585, 3160, 1940).  All GPU work is enqueued on ONE HIP stream in pass order; nothing here computes a
+// pixel on the CPU and there is no fallback: without a usable HIP device zr_create fails.
+#include "zr_ctx.h"
+#include "zr_math.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#define HIPCHK(c, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) \
+    return zr_fail((c), ZR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
+#define ARGCHK(c, cond) do { if (!(cond)) return zr_fail((c), ZR_ERR_ARG, "bad argument: " #cond); } while (0)
+
+int zr_fail(zr_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+
+static const uint8_t kDefaultTexel[7][4] = {    // ZE:4951-4978: default_{grey,black,white,normal,white,black,white}.png
+    {127,127,127,255}, {0,0,0,255}, {255,255,255,255}, {127,127,255,255}, {255,255,255,255}, {0,0,0,255}, {255,255,255,255}
+};
+
+float zr_srgb_decode8(uint32_t c)
+{
+    double x = (double)c / 255.0;
+    double l = (x <= 0.04045) ? x / 12.92 : pow((x + 0.055) / 1.055, 2.4);
+    return (float)l;
+}
+static uint8_t srgb_encode8(float l)
+{
+    double x = (double)l;
+    if (!(x > 0.0)) x = 0.0;
+    if (x > 1.0) x = 1.0;
+    double s = (x <= 0.0031308) ? 12.92 * x : 1.055 * pow(x, 1.0 / 2.4) - 0.055;
+    return (uint8_t)floor(s * 255.0 + 0.5);
+}
+
+template <typename T> static hipError_t dev_alloc(T** p, size_t n) { return hipMalloc((void**)p, (n ? n : 1) * sizeof(T)); }
+template <typename T> static void dev_free(T*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } }
+
+// ------------------------------------------------------------------------------------------------ lifetime
+
+static void default_lights(XkView* v)
+{   // XkLight() default constructor, ZE:779
+    XkLight d; memset(&d, 0, sizeof d);
+    d.Color[0] = d.Color[1] = d.Color[2] = d.Color[3] = 1.0f; d.Direction[2] = 1.0f; d.Direction[3] = 1.0f;
+    for (auto& l : v->DirectionalLights) l = d;
+    for (auto& l : v->PointLights) l = d;
+    for (auto& l : v->SpotLights) l = d;
+}
+
+extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
+{
+    if (!cfg || !out) return ZR_ERR_ARG;
+    *out = nullptr;
+    if (cfg->width == 0 || cfg->height == 0 || cfg->width > 255u * ZR_TILE || cfg->height > 255u * ZR_TILE) return ZR_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ZR_ERR_DEVICE;
+    if (cfg->device < 0 || cfg->device >= ndev) return ZR_ERR_DEVICE;
+    if (hipSetDevice(cfg->device) != hipSuccess) return ZR_ERR_DEVICE;
+    zr_ctx* c = new zr_ctx();
+    c->cfg = *cfg;
+    if (c->cfg.tile_world == 0) c->cfg.tile_world = 1;
+    if (c->cfg.tile_rank >= c->cfg.tile_world) { delete c; return ZR_ERR_ARG; }
+    c->device = cfg->device;
+    c->W = cfg->width; c->H = cfg->height; c->SD = cfg->shadow_dim ? cfg->shadow_dim : XK_SHADOWMAP_DIM;
+    if (c->SD > 255u * ZR_TILE) { delete c; return ZR_ERR_ARG; }
+    c->debug_view = cfg->debug_view;
+    memset(&c->cam, 0, sizeof c->cam); memset(&c->shadow, 0, sizeof c->shadow); memset(&c->view, 0, sizeof c->view);
+    default_lights(&c->view);
+    for (int i = 0; i < 256; ++i) c->lut[i] = zr_srgb_decode8((uint32_t)i);
+
+    bool ok = true;
+    ok &= hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess;
+    c->stream = c->own_stream;
+    for (auto& e : c->ev) ok &= hipEventCreate(&e) == hipSuccess;
+    const size_t n = (size_t)c->W * c->H;
+    ok &= dev_alloc(&c->G.depth, n) == hipSuccess;
+    ok &= dev_alloc(&c->G.scene_color, n) == hipSuccess;
+    ok &= dev_alloc(&c->G.gA, n) == hipSuccess;
+    ok &= dev_alloc(&c->G.gB, n) == hipSuccess;
+    ok &= dev_alloc(&c->G.gC, n) == hipSuccess;
+    ok &= dev_alloc(&c->G.gD, n) == hipSuccess;
+    ok &= dev_alloc(&c->d_color, n) == hipSuccess;
+    ok &= dev_alloc(&c->d_shadow, (size_t)c->SD * c->SD) == hipSuccess;
+    ok &= dev_alloc(&c->d_view, 1) == hipSuccess;
+    ok &= dev_alloc(&c->d_stats, 1) == hipSuccess;
+    ok &= dev_alloc(&c->d_lut, 256) == hipSuccess;
+    if (ok) ok &= hipMemcpy(c->d_lut, c->lut, sizeof c->lut, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) ok &= hipMemset(c->d_color, 0, n * 4) == hipSuccess;
+
+    // screen tiles: camera target partitioned t % world == rank; the shadow map is rendered whole on every rank
+    c->tiles_x = (c->W + ZR_TILE - 1) / ZR_TILE; c->tiles_y = (c->H + ZR_TILE - 1) / ZR_TILE; c->n_tiles = c->tiles_x * c->tiles_y;
+    c->stiles_x = (c->SD + ZR_TILE - 1) / ZR_TILE; c->stiles_y = c->stiles_x; c->sn_tiles = c->stiles_x * c->stiles_y;
+    c->slots_per_rank = (c->n_tiles + c->cfg.tile_world - 1) / c->cfg.tile_world;
+    std::vector<uint32_t> owned, sowned(c->sn_tiles);
+    for (uint32_t t = c->cfg.tile_rank; t < c->n_tiles; t += c->cfg.tile_world) owned.push_back(t);
+    for (uint32_t t = 0; t < c->sn_tiles; ++t) sowned[t] = t;
+    c->n_owned = (uint32_t)owned.size();
+    ok &= dev_alloc(&c->d_owned, owned.size()) == hipSuccess;
+    ok &= dev_alloc(&c->d_sowned, sowned.size()) == hipSuccess;
+    ok &= dev_alloc(&c->d_tiles, (size_t)c->slots_per_rank * ZR_TILE * ZR_TILE) == hipSuccess;
+    if (ok && !owned.empty()) ok &= hipMemcpy(c->d_owned, owned.data(), owned.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) ok &= hipMemcpy(c->d_sowned, sowned.data(), sowned.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) ok &= hipMemset(c->d_tiles, 0, (size_t)c->slots_per_rank * ZR_TILE * ZR_TILE * 4) == hipSuccess;
+    const uint32_t mt = (c->n_tiles > c->sn_tiles ? c->n_tiles : c->sn_tiles) + 1;
+    ok &= dev_alloc(&c->d_tile_count, mt) == hipSuccess;
+    ok &= dev_alloc(&c->d_tile_offset, mt) == hipSuccess;
+    ok &= dev_alloc(&c->d_tile_cursor, mt) == hipSuccess;
+    if (ok) ok &= hipMemset(c->d_tile_count, 0, mt * 4) == hipSuccess;
+    if (!ok) { zr_destroy(c); return ZR_ERR_DEVICE; }
+    if (zr_set_cubemap(c, nullptr, 0) != ZR_OK) { zr_destroy(c); return ZR_ERR_DEVICE; }
+    *out = c;
+    return ZR_OK;
+}
+
+static void free_scene(zr_ctx* c)
+{
+    for (auto& o : c->objects) dev_free(o.d_inst);
+    c->objects.clear();
+    for (auto& m : c->meshes) {
+        dev_free(m.d_v); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mverts); dev_free(m.d_mtris); dev_free(m.d_tri_order);
+    }
+    c->meshes.clear();
+    c->profabs.clear();
+    dev_free(c->d_objs); c->n_objs = 0; c->n_work = 0; c->scene_dirty = true;
+}
+
+extern "C" void zr_destroy(zr_ctx* c)
+{
+    if (!c) return;
+    zr_livelink_stop(c);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    for (auto p : c->d_cube) if (p) (void)hipFree(p);
+    dev_free(c->G.depth); dev_free(c->G.scene_color); dev_free(c->G.gA); dev_free(c->G.gB); dev_free(c->G.gC); dev_free(c->G.gD);
+    dev_free(c->d_color); dev_free(c->d_shadow); dev_free(c->d_view); dev_free(c->d_stats); dev_free(c->d_lut);
+    dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles);
+    dev_free(c->d_tile_count); dev_free(c->d_tile_offset); dev_free(c->d_tile_cursor); dev_free(c->d_rects); dev_free(c->d_bins);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" const char* zr_last_error(const zr_ctx* c) { return c ? c->err.c_str() : "no context (no usable HIP device?)"; }
+
+extern "C" int zr_set_stream(zr_ctx* c, void* s)
+{
+    if (!c) return ZR_ERR_ARG;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return ZR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ scene
+
+extern "C" int zr_mesh_create(zr_ctx* c, const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, uint32_t* mesh_id)
+{
+    if (!c) return ZR_ERR_ARG;
+    ARGCHK(c, v && idx && mesh_id && nv > 0 && ni > 0 && ni % 3 == 0);
+    for (uint32_t i = 0; i < ni; ++i) if (idx[i] >= nv) return zr_fail(c, ZR_ERR_ARG, "index out of range");
+    ZrMesh m;
+    m.v.assign(v, v + nv); m.idx.assign(idx, idx + ni);
+    c->meshes.push_back(std::move(m));
+    *mesh_id = (uint32_t)c->meshes.size() - 1;
+    return ZR_OK;
+}
+
+static int validate_meshlets(zr_ctx* c, const ZrMesh& m, const XkMeshlet* ml, uint32_t nm, size_t nmv, const uint32_t* mv,
+                             size_t nmt, const uint8_t* mt)
+{
+    for (uint32_t i = 0; i < nm; ++i) {
+        if (ml[i].VertexCount == 0 || ml[i].VertexCount > 64 || ml[i].TriangleCount == 0 || ml[i].TriangleCount > 128)
+            return zr_fail(c, ZR_ERR_ARG, "meshlet exceeds 64 vertices / 128 triangles");
+        if ((size_t)ml[i].VertexOffset + ml[i].VertexCount > nmv || (size_t)ml[i].TriangleOffset + 3u * ml[i].TriangleCount > nmt)
+            return zr_fail(c, ZR_ERR_ARG, "meshlet range out of bounds");
+        for (uint32_t k = 0; k < ml[i].VertexCount; ++k)
+            if (mv[ml[i].VertexOffset + k] >= m.v.size()) return zr_fail(c, ZR_ERR_ARG, "meshlet vertex index out of range");
+        for (uint32_t k = 0; k < 3u * ml[i].TriangleCount; ++k)
+            if (mt[ml[i].TriangleOffset + k] >= ml[i].VertexCount) return zr_fail(c, ZR_ERR_ARG, "meshlet triangle corner out of range");
+    }
+    return ZR_OK;
+}
+
+extern "C" int zr_mesh_set_meshlets(zr_ctx* c, uint32_t mesh_id, const XkMeshlet* ml, uint32_t nm,
+                                    const uint32_t* mv, size_t nmv, const uint8_t* mt, size_t nmt)
+{
+    if (!c) return ZR_ERR_ARG;
+    ARGCHK(c, mesh_id < c->meshes.size() && ml && nm && mv && mt);
+    ZrMesh& m = c->meshes[mesh_id];
+    if (m.uploaded) return zr_fail(c, ZR_ERR_STATE, "mesh already in use by a rendered scene");
+    int rc = validate_meshlets(c, m, ml, nm, nmv, mv, nmt, mt);
+    if (rc) return rc;
+    // CreateMeshVertexBuffers<XkMeshIndirect> (ZE:4733-4756): the draw becomes "meshlet by meshlet"; rebuild the
+    // draw-order index buffer accordingly so primitive ids follow meshlet order.
+    m.ms.meshlets.assign(ml, ml + nm); m.ms.mverts.assign(mv, mv + nmv); m.ms.mtris.assign(mt, mt + nmt);
+    m.ms.tri_order.clear(); m.idx.clear();
+    uint32_t base = 0;
+    for (uint32_t i = 0; i < nm; ++i) {
+        XkMeshlet& d = m.ms.meshlets[i];
+        d.BindlessContext = base;
+        for (uint32_t t = 0; t < d.TriangleCount; ++t) {
+            for (int k = 0; k < 3; ++k) m.idx.push_back(mv[d.VertexOffset + mt[d.TriangleOffset + 3u * t + (uint32_t)k]]);
+            m.ms.tri_order.push_back(base + t);
+        }
+        base += d.TriangleCount;
+    }
+    m.has_meshlets = true;
+    return ZR_OK;
+}
+
+extern "C" int zr_mesh_build_meshlets(zr_ctx* c, uint32_t mesh_id, uint32_t max_v, uint32_t max_t, float cone_weight)
+{
+    if (!c) return ZR_ERR_ARG;
+    ARGCHK(c, mesh_id < c->meshes.size());
+    if (max_v == 0) max_v = 64;
+    if (max_t == 0) max_t = 124;
+    ARGCHK(c, max_v >= 3 && max_v <= 64 && max_t >= 1 && max_t <= 128);
+    ZrMesh& m = c->meshes[mesh_id];
+    if (m.uploaded) return zr_fail(c, ZR_ERR_STATE, "mesh already in use by a rendered scene");
+    zr_build_meshlets(m.v.data(), (uint32_t)m.v.size(), m.idx.data(), (uint32_t)m.idx.size(), max_v, max_t, cone_weight, &m.ms);
+    m.has_meshlets = true;
+    return ZR_OK;
+}
+
+extern "C" int zr_mesh_get_meshlets(zr_ctx* c, uint32_t mesh_id, XkMeshlet* ml, uint32_t* nm, uint32_t* mv, size_t* nmv,
+                                    uint8_t* mt, size_t* nmt)
+{
+    if (!c) return ZR_ERR_ARG;
+    ARGCHK(c, mesh_id < c->meshes.size());
+    const ZrMesh& m = c->meshes[mesh_id];
+    if (nm) *nm = (uint32_t)m.ms.meshlets.size();
+    if (nmv) *nmv = m.ms.mverts.size();
+    if (nmt) *nmt = m.ms.mtris.size();
+    if (ml) { memcpy(ml, m.ms.meshlets.data(), m.ms.meshlets.size() * sizeof(XkMeshlet));
+              for (size_t i = 0; i < m.ms.meshlets.size(); ++i) ml[i].BindlessContext = 0; }
+    if (mv) memcpy(mv, m.ms.mverts.data(), m.ms.mverts.size() * 4);
+    if (mt) memcpy(mt, m.ms.mtris.data(), m.ms.mtris.size());
+    return ZR_OK;
+}
+
+int zr_material_constants(zr_ctx* c, const zr_material* mat, uint32_t texel[7], float bc_linear[3])
+{
+    for (int t = 0; t < 7; ++t) {
+        const uint8_t* px = kDefaultTexel[t];
+        if (mat && mat->tex[t].rgba8) {
+            const zr_image& im = mat->tex[t];
+            if (im.width == 0 || im.height == 0) return zr_fail(c, ZR_ERR_ARG, "empty material image");
+            const size_t n = (size_t)im.width * im.height * 4;
+            for (size_t i = 4; i < n; ++i)
+                if (im.rgba8[i] != im.rgba8[i & 3])
+                    return zr_fail(c, ZR_ERR_UNSUPPORTED, "non-constant material textures are not supported yet (SURVEY 8f N2)");
+            px = im.rgba8;
+        }
+        texel[t] = (uint32_t)px[0] | (uint32_t)px[1] << 8 | (uint32_t)px[2] << 16 | (uint32_t)px[3] << 24;
+    }
+    for (int k = 0; k < 3; ++k) bc_linear[k] = zr_srgb_decode8((texel[0] >> (8 * k)) & 255u);
+    return ZR_OK;
+}
+
+int zr_object_add_internal(zr_ctx* c, uint32_t mesh_id, const uint32_t texel[7], const float bc_linear[3],
+                           const XkInstanceData* inst, uint32_t n_inst)
+{
+    ZrSceneObject o;
+    o.mesh = mesh_id; o.instanced = n_inst > 0; o.n_inst = n_inst ? n_inst : 1;
+    memcpy(o.texel, texel, sizeof o.texel); memcpy(o.bc_linear, bc_linear, sizeof o.bc_linear);
+    if (n_inst) o.inst.assign(inst, inst + n_inst);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, dev_alloc(&o.d_inst, o.n_inst));
+    XkInstanceData* d_raw = nullptr;
+    if (n_inst) {
+        HIPCHK(c, dev_alloc(&d_raw, n_inst));
+        hipError_t e = hipMemcpyAsync(d_raw, inst, sizeof(XkInstanceData) * n_inst, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { dev_free(d_raw); dev_free(o.d_inst); return zr_fail(c, ZR_ERR_DEVICE, hipGetErrorString(e)); }
+    }
+    zr_launch_instance_prep(d_raw, o.d_inst, o.n_inst, o.instanced ? 1u : 0u, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    dev_free(d_raw);
+    if (e != hipSuccess) { dev_free(o.d_inst); return zr_fail(c, ZR_ERR_DEVICE, hipGetErrorString(e)); }
+    c->objects.push_back(std::move(o));
+    c->scene_dirty = true;
+    return ZR_OK;
+}
+
+extern "C" int zr_object_add(zr_ctx* c, uint32_t mesh_id, const zr_material* mat, const XkInstanceData* inst, uint32_t n_inst)
+{
+    if (!c) return ZR_ERR_ARG;
+    ARGCHK(c, mesh_id < c->meshes.size() && (n_inst == 0 || inst));
+    uint32_t texel[7]; float bcl[3];
+    int rc = zr_material_constants(c, mat, texel, bcl);
+    if (rc) return rc;
+    return zr_object_add_internal(c, mesh_id, texel, bcl, inst, n_inst);
+}
+
+extern "C" int zr_scene_clear(zr_ctx* c)
+{
+    if (!c) return ZR_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    return ZR_OK;
+}
+
+template <typename T> static hipError_t upload(T** d, const std::vector<T>& h)
+{
+    hipError_t e = dev_alloc(d, h.size());
+    if (e != hipSuccess) return e;
+    return h.empty() ? hipSuccess : hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+}
+
+// CreateEngineScene's GPU half (ZE:4140-4284): meshlets, buffers, draw table in the reference's draw order
+static int finalize_scene(zr_ctx* c)
+{
+    if (!c->scene_dirty) return ZR_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto& o : c->objects) {
+        ZrMesh& m = c->meshes[o.mesh];
+        if (m.uploaded) continue;
+        if (!m.has_meshlets) {
+            zr_build_meshlets(m.v.data(), (uint32_t)m.v.size(), m.idx.data(), (uint32_t)m.idx.size(), 64, 124, 0.2f, &m.ms);
+            m.has_meshlets = true;
+        }
+        // whole-mesh bounding sphere (centroid + max distance)
+        double cx = 0, cy = 0, cz = 0;
+        for (auto& v : m.v) { cx += v.Position[0]; cy += v.Position[1]; cz += v.Position[2]; }
+        cx /= (double)m.v.size(); cy /= (double)m.v.size(); cz /= (double)m.v.size();
+        double r = 0;
+        for (auto& v : m.v) { double dx = v.Position[0] - cx, dy = v.Position[1] - cy, dz = v.Position[2] - cz; r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz)); }
+        m.center[0] = (float)cx; m.center[1] = (float)cy; m.center[2] = (float)cz; m.radius = (float)(r * 1.0001) + 1e-30f;
+        HIPCHK(c, upload(&m.d_v, m.v)); HIPCHK(c, upload(&m.d_idx, m.idx)); HIPCHK(c, upload(&m.d_meshlets, m.ms.meshlets));
+        HIPCHK(c, upload(&m.d_mverts, m.ms.mverts)); HIPCHK(c, upload(&m.d_mtris, m.ms.mtris)); HIPCHK(c, upload(&m.d_tri_order, m.ms.tri_order));
+        m.uploaded = true;
+    }
+    std::vector<ZrObject> tab;
+    uint64_t work = 0, prim = 0;
+    for (int pass = 0; pass < 2; ++pass)                 // non-instanced draws, then instanced draws (ZE:3445-3476)
+        for (auto& o : c->objects) {
+            if ((int)o.instanced != pass) continue;
+            const ZrMesh& m = c->meshes[o.mesh];
+            ZrObject d; memset(&d, 0, sizeof d);
+            d.verts = m.d_v; d.indices = m.d_idx; d.meshlets = m.d_meshlets; d.mverts = m.d_mverts; d.mtris = m.d_mtris;
+            d.tri_order = m.d_tri_order; d.inst = o.d_inst;
+            d.n_meshlets = (uint32_t)m.ms.meshlets.size(); d.n_tris = (uint32_t)(m.idx.size() / 3);
+            d.n_inst = o.n_inst; d.instanced = o.instanced;
+            d.work_base = (uint32_t)work; d.prim_base = (uint32_t)prim;
+            memcpy(d.texel, o.texel, sizeof d.texel); memcpy(d.bc_linear, o.bc_linear, sizeof d.bc_linear);
+            memcpy(d.mesh_center, m.center, sizeof d.mesh_center); d.mesh_radius = m.radius;
+            work += (uint64_t)d.n_meshlets * d.n_inst; prim += (uint64_t)d.n_tris * d.n_inst;
+            tab.push_back(d);
+        }
+    if (work >= 0xFFFFFFFFull || prim >= 0xFFFFFFFFull) return zr_fail(c, ZR_ERR_OVERFLOW, "scene exceeds 2^32 meshlet-instances or primitives");
+    dev_free(c->d_objs);
+    HIPCHK(c, upload(&c->d_objs, tab));
+    c->n_objs = (uint32_t)tab.size(); c->n_work = (uint32_t)work;
+    if (c->n_work > c->work_capacity) {
+        dev_free(c->d_rects); dev_free(c->d_bins);
+        c->work_capacity = c->n_work;
+        const uint64_t cap = std::max<uint64_t>(1u << 20, 8ull * c->n_work);
+        c->bin_capacity = (uint32_t)std::min<uint64_t>(cap, 0x3FFFFFFFull);
+        HIPCHK(c, dev_alloc(&c->d_rects, c->work_capacity));
+        HIPCHK(c, dev_alloc(&c->d_bins, c->bin_capacity));
+    }
+    c->scene_dirty = false;
+    return ZR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ cubemap
+
+extern "C" int zr_set_cubemap(zr_ctx* c, const uint8_t* const faces[6], uint32_t dim)
+{
+    if (!c) return ZR_ERR_ARG;
+    static const uint8_t grey[4] = { 127, 127, 127, 255 };
+    if (!faces) dim = 1;
+    ARGCHK(c, dim > 0 && dim <= 16384);
+    if (faces) for (int f = 0; f < 6; ++f) ARGCHK(c, faces[f] != nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto p : c->d_cube) if (p) (void)hipFree(p);
+    c->d_cube.clear();
+    uint32_t levels = 1; for (uint32_t d = dim; d > 1; d >>= 1) levels++;      // floor(log2(dim)) + 1, ZE:6887
+    if (levels > 16) return zr_fail(c, ZR_ERR_ARG, "cubemap too large");
+    std::vector<std::vector<uint8_t>> lv(levels);
+    const size_t fsz = (size_t)dim * dim * 4;
+    lv[0].resize(fsz * 6);
+    for (int f = 0; f < 6; ++f) { if (faces) memcpy(lv[0].data() + fsz * f, faces[f], fsz); else memcpy(lv[0].data() + fsz * f, grey, 4); }
+    uint32_t d = dim;
+    for (uint32_t l = 1; l < levels; ++l) {        // RHIGenerateMipmaps: vkCmdBlitImage LINEAR from level l-1 (2x2 box, linear light)
+        const uint32_t nd = d > 1 ? d >> 1 : 1;
+        lv[l].resize((size_t)nd * nd * 4 * 6);
+        for (int f = 0; f < 6; ++f) {
+            const uint8_t* src = lv[l - 1].data() + (size_t)d * d * 4 * f;
+            uint8_t* dst = lv[l].data() + (size_t)nd * nd * 4 * f;
+            for (uint32_t y = 0; y < nd; ++y) for (uint32_t x = 0; x < nd; ++x) {
+                const uint32_t x0 = 2 * x, x1 = (2 * x + 1 < d) ? 2 * x + 1 : d - 1, y0 = 2 * y, y1 = (2 * y + 1 < d) ? 2 * y + 1 : d - 1;
+                const uint8_t* p00 = src + ((size_t)y0 * d + x0) * 4; const uint8_t* p10 = src + ((size_t)y0 * d + x1) * 4;
+                const uint8_t* p01 = src + ((size_t)y1 * d + x0) * 4; const uint8_t* p11 = src + ((size_t)y1 * d + x1) * 4;
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float a = (c->lut[p00[ch]] + c->lut[p10[ch]]) + (c->lut[p01[ch]] + c->lut[p11[ch]]);
+                    dst[((size_t)y * nd + x) * 4 + ch] = srgb_encode8(a * 0.25f);
+                }
+                const uint32_t al = (uint32_t)p00[3] + p10[3] + p01[3] + p11[3];
+                dst[((size_t)y * nd + x) * 4 + 3] = (uint8_t)((al + 2) >> 2);
+            }
+        }
+        d = nd;
+    }
+    memset(&c->cube, 0, sizeof c->cube);
+    for (uint32_t l = 0; l < levels; ++l) {
+        uint8_t* p = nullptr;
+        HIPCHK(c, upload(&p, lv[l]));
+        c->d_cube.push_back(p); c->cube.levels[l] = p;
+    }
+    c->cube_dim = dim; c->cube_levels = levels;
+    c->view.LightsCount[3] = (int32_t)levels;       // CubemapMaxMips, ZE:4308
+    return ZR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ uniforms
+
+static float radiansf(float deg) { return deg * 0.01745329251994329576923690768489f; }
+static void perspective_rh_zo(float fovy, float aspect, float zn, float zf, float* m)
+{
+    const float t = tanf(fovy / 2.0f);
+    memset(m, 0, 64);
+    m[0] = 1.0f / (aspect * t); m[5] = 1.0f / t; m[10] = zf / (zn - zf); m[11] = -1.0f; m[14] = -(zf * zn) / (zf - zn);
+}
+static void look_at_rh(zf3 eye, zf3 center, zf3 up, float* m)
+{
+    const zf3 f = zr_normalize(center - eye);
+    const zf3 s = zr_normalize(zr_cross(f, up));
+    const zf3 u = zr_cross(s, f);
+    m[0] = s.x; m[4] = s.y; m[8] = s.z; m[1] = u.x; m[5] = u.y; m[9] = u.z; m[2] = -f.x; m[6] = -f.y; m[10] = -f.z;
+    m[3] = 0; m[7] = 0; m[11] = 0; m[12] = -zr_dot(s, eye); m[13] = -zr_dot(u, eye); m[14] = zr_dot(f, eye); m[15] = 1.0f;
+}
+static void rotate_z(float angle, float* m)
+{
+    const float cs = cosf(angle), sn = sinf(angle);
+    memset(m, 0, 64);
+    m[0] = cs; m[1] = sn; m[4] = -sn; m[5] = cs; m[10] = cs + (1.0f - cs); m[15] = 1.0f;
+}
+
+// UpdateWorld (ZE:4294-4308) + UpdateUniformBuffer (ZE:4585-4664) in game mode (editor bars = 0, ZE:4575-4579)
+extern "C" int zr_update_uniforms(zr_ctx* c, const zr_camera* cam, const XkLight* dir, uint32_t n_dir, const XkLight* point,
+                                  uint32_t n_point, const XkLight* spot, uint32_t n_spot, float roll_stage, float roll_light, float time)
+{
+    if (!c) return ZR_ERR_ARG;
+    ARGCHK(c, cam && n_dir <= XK_MAX_DIRECTIONAL_LIGHTS_NUM && n_point <= XK_MAX_POINT_LIGHTS_NUM && n_spot <= XK_MAX_SPOT_LIGHTS_NUM);
+    ARGCHK(c, (n_dir == 0 || dir) && (n_point == 0 || point) && (n_spot == 0 || spot));
+    XkView* V = &c->view;
+    for (uint32_t i = 0; i < n_dir; ++i) V->DirectionalLights[i] = dir[i];
+    for (uint32_t i = 0; i < n_point; ++i) V->PointLights[i] = point[i];
+    for (uint32_t i = 0; i < n_spot; ++i) V->SpotLights[i] = spot[i];
+    V->LightsCount[0] = (int32_t)n_dir; V->LightsCount[1] = (int32_t)n_point; V->LightsCount[2] = (int32_t)n_spot;
+    V->LightsCount[3] = (int32_t)c->cube_levels;
+
+    const zf3 pos = zr3(cam->Position[0], cam->Position[1], cam->Position[2]);
+    const zf3 look = zr3(cam->Lookat[0], cam->Lookat[1], cam->Lookat[2]);
+    const zf3 up = zr3(0.0f, 0.0f, 1.0f);
+    const zf3 lightPos = zr3(V->DirectionalLights[0].Position[0], V->DirectionalLights[0].Position[1], V->DirectionalLights[0].Position[2]);
+    float l2w[16], sview[16], sproj[16], cview[16], cproj[16];
+    rotate_z(roll_stage, l2w);
+    look_at_rh(lightPos, zr3(0.0f, 0.0f, 0.0f), up, sview);
+    perspective_rh_zo(radiansf(cam->FOV), 1.0f, cam->zNear, cam->zFar, sproj);
+    sproj[5] *= -1.0f;
+    look_at_rh(pos, look, up, cview);
+    perspective_rh_zo(radiansf(cam->FOV), (float)c->W / (float)c->H, cam->zNear, cam->zFar, cproj);
+    memcpy(c->cam.Model, l2w, 64); memcpy(c->cam.View, cview, 64); memcpy(c->cam.Proj, cproj, 64);
+    c->cam.Proj[5] *= -1.0f;
+    zr_mat4_mul(cproj, cview, V->ViewProjSpace);
+    zr_mat4_mul(sproj, sview, V->ShadowmapSpace);
+    memcpy(V->LocalToWorld, l2w, 64);
+    V->CameraInfo[0] = pos.x; V->CameraInfo[1] = pos.y; V->CameraInfo[2] = pos.z; V->CameraInfo[3] = cam->FOV;
+    V->ViewportInfo[0] = (float)c->W; V->ViewportInfo[1] = (float)c->H; V->ViewportInfo[2] = 0.0f; V->ViewportInfo[3] = 0.0f;
+    const uint32_t N = n_point;
+    for (uint32_t i = 0; i < N; ++i) {           // point lights ride a spiral, JSON positions are overwritten (ZE:4637-4646)
+        const float deg = ((float)i / (float)N) * 360.0f - roll_light * 100.0f;
+        const float distance = ((float)i / (float)N) * 5.0f + 2.5f;
+        V->PointLights[i].Position[0] = sinf(radiansf(deg)) * distance;
+        V->PointLights[i].Position[1] = cosf(radiansf(deg)) * distance;
+        V->PointLights[i].Position[2] = 1.5f;
+        V->PointLights[i].Position[3] = 1.0f;
+    }
+    V->Time = time; V->zNear = cam->zNear; V->zFar = cam->zFar;
+    memcpy(c->shadow.Model, l2w, 64); memcpy(c->shadow.View, sview, 64); memcpy(c->shadow.Proj, sproj, 64);
+    c->frame_valid = true;
+    return ZR_OK;
+}
+
+extern "C" int zr_set_frame(zr_ctx* c, const XkUniformBufferMVP* cam, const XkUniformBufferMVP* sh, const XkView* v)
+{
+    if (!c) return ZR_ERR_ARG;
+    ARGCHK(c, cam && sh && v);
+    ARGCHK(c, v->LightsCount[0] >= 0 && v->LightsCount[0] <= XK_MAX_DIRECTIONAL_LIGHTS_NUM && v->LightsCount[1] >= 0 &&
+              v->LightsCount[1] <= XK_MAX_POINT_LIGHTS_NUM);
+    c->cam = *cam; c->shadow = *sh; c->view = *v;
+    c->frame_valid = true;
+    return ZR_OK;
+}
+extern "C" int zr_get_frame(zr_ctx* c, XkUniformBufferMVP* cam, XkUniformBufferMVP* sh, XkView* v)
+{
+    if (!c) return ZR_ERR_ARG;
+    if (cam) *cam = c->cam;
+    if (sh) *sh = c->shadow;
+    if (v) *v = c->view;
+    return ZR_OK;
+}
+extern "C" int zr_set_debug_view(zr_ctx* c, uint32_t s) { if (!c) return ZR_ERR_ARG; c->debug_view = s; return ZR_OK; }
+
+static bool finite16(const float* m) { for (int i = 0; i < 16; ++i) if (!std::isfinite(m[i])) return false; return true; }
+static bool rigid3(const float* m)     // upper 3x3 orthonormal, det > 0, last row 0 0 0 1
+{
+    const zf3 a = zr3(m[0], m[1], m[2]), b = zr3(m[4], m[5], m[6]), cc = zr3(m[8], m[9], m[10]);
+    const float e = 1e-3f;
+    if (fabsf(zr_dot(a, a) - 1) > e || fabsf(zr_dot(b, b) - 1) > e || fabsf(zr_dot(cc, cc) - 1) > e) return false;
+    if (fabsf(zr_dot(a, b)) > e || fabsf(zr_dot(a, cc)) > e || fabsf(zr_dot(b, cc)) > e) return false;
+    if (zr_dot(zr_cross(a, b), cc) <= 0) return false;
+    return m[3] == 0 && m[7] == 0 && m[11] == 0 && m[15] == 1;
+}
+
+// Builds the kernarg block of one geometry pass.  Returns false when the pass cannot produce a fragment
+// (non-finite PVM: every vertex is non-finite and every triangle is discarded).
+static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, ZrPass* P)
+{
+    memset(P, 0, sizeof *P);
+    float pv[16];
+    zr_mat4_mul(u.Proj, u.View, pv);
+    zr_mat4_mul(pv, u.Model, P->PVM);           // proj * view * model, left to right
+    memcpy(P->M, u.Model, 64);
+    P->mode = (uint32_t)mode;
+    P->W = mode == ZR_MODE_SHADOW ? c->SD : c->W; P->H = mode == ZR_MODE_SHADOW ? c->SD : c->H;
+    P->hw = 0.5f * (float)P->W; P->hh = 0.5f * (float)P->H;
+    P->tiles_x = mode == ZR_MODE_SHADOW ? c->stiles_x : c->tiles_x; P->tiles_y = mode == ZR_MODE_SHADOW ? c->stiles_y : c->tiles_y;
+    P->tile_rank = mode == ZR_MODE_SHADOW ? 0 : c->cfg.tile_rank; P->tile_world = mode == ZR_MODE_SHADOW ? 1 : c->cfg.tile_world;
+    P->n_objects = c->n_objs; P->n_work = c->n_work; P->bin_capacity = c->bin_capacity;
+    if (!finite16(P->PVM)) return false;
+    // frustum planes of proj*view in world space (sphere centres are taken to world space by M in the kernel)
+    bool fr_ok = !(c->cfg.flags & ZR_FLAG_NO_FRUSTUM_CULL) && finite16(u.Model);
+    if (fr_ok) {
+        float rows[6][4];
+        for (int k = 0; k < 4; ++k) {
+            const float r0 = pv[k * 4 + 0], r1 = pv[k * 4 + 1], r2 = pv[k * 4 + 2], r3 = pv[k * 4 + 3];
+            rows[0][k] = r3 + r0; rows[1][k] = r3 - r0; rows[2][k] = r3 + r1; rows[3][k] = r3 - r1; rows[4][k] = r2; rows[5][k] = r3 - r2;
+        }
+        for (int i = 0; i < 6 && fr_ok; ++i) {
+            const float l = sqrtf(rows[i][0] * rows[i][0] + rows[i][1] * rows[i][1] + rows[i][2] * rows[i][2]);
+            if (!(l > 1e-20f) || !std::isfinite(l)) { fr_ok = false; break; }
+            for (int k = 0; k < 4; ++k) P->planes[i][k] = rows[i][k] / l;
+        }
+    }
+    const bool m_rigid = rigid3(u.Model);
+    if (m_rigid) P->m_scale = 1.002f;
+    else { float s = 0; for (int cidx = 0; cidx < 3; ++cidx) for (int r = 0; r < 3; ++r) s += u.Model[cidx * 4 + r] * u.Model[cidx * 4 + r]; P->m_scale = sqrtf(s) * 1.002f; }
+    if (!std::isfinite(P->m_scale)) fr_ok = false;
+    P->frustum_ok = fr_ok ? 1u : 0u;
+    // cone culling needs: rigid model and view, a perspective projection with its eye at the view origin, and the
+    // engine's handedness (Proj[0][0] > 0, Proj[1][1] < 0 after the Vulkan y-flip, ZE:4624) so that CCW = front
+    bool cone = mode == ZR_MODE_GBUFFER && !(c->cfg.flags & ZR_FLAG_NO_CONE_CULL) && m_rigid && rigid3(u.View);
+    const float* pr = u.Proj;
+    cone = cone && pr[3] == 0 && pr[7] == 0 && pr[11] == -1.0f && pr[15] == 0 && pr[1] == 0 && pr[2] == 0 && pr[4] == 0 && pr[6] == 0 &&
+           pr[12] == 0 && pr[13] == 0 && pr[0] > 0 && pr[5] < 0;
+    if (cone) {     // eye = -R^T t
+        const float* v = u.View;
+        P->cam_pos[0] = -(v[0] * v[12] + v[1] * v[13] + v[2] * v[14]);
+        P->cam_pos[1] = -(v[4] * v[12] + v[5] * v[13] + v[6] * v[14]);
+        P->cam_pos[2] = -(v[8] * v[12] + v[9] * v[13] + v[10] * v[14]);
+    }
+    P->cone_ok = cone ? 1u : 0u;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ the frame
+
+static void geometry_pass(zr_ctx* c, const ZrPass& P, int slot, const uint32_t* d_owned, uint32_t n_owned, uint32_t n_tiles,
+                          hipEvent_t after_bin)
+{
+    zr_launch_cull(P, c->d_objs, c->d_rects, c->d_tile_count, c->stream);
+    zr_launch_scan(c->d_tile_count, c->d_tile_offset, c->d_tile_cursor, n_tiles, c->bin_capacity, c->d_stats, slot, c->stream);
+    zr_launch_bin_fill(P, c->d_rects, c->d_tile_offset, c->d_tile_cursor, c->d_bins, c->d_stats, slot, c->stream);
+    (void)hipEventRecord(after_bin, c->stream);
+    zr_launch_raster(P, c->d_objs, d_owned, n_owned, c->d_tile_offset, c->d_bins, c->G, c->d_shadow, c->d_stats, c->stream);
+}
+
+// RecordCommandBuffer (ZE:3160-3744) + vkQueueSubmit (ZE:2014): shadow -> deferred scene -> deferred lighting
+extern "C" int zr_render(zr_ctx* c)
+{
+    if (!c) return ZR_ERR_ARG;
+    if (!c->frame_valid) return zr_fail(c, ZR_ERR_STATE, "no frame uniforms: call zr_update_uniforms or zr_set_frame first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = finalize_scene(c);
+    if (rc) return rc;
+    c->view.LightsCount[3] = (int32_t)c->cube_levels;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, sizeof(ZrDevStats), s));
+    HIPCHK(c, hipMemcpyAsync(c->d_view, &c->view, sizeof(XkView), hipMemcpyHostToDevice, s));
+
+    ZrPass P;
+    // shadow pass (ZE:3239-3393): every object, light-space, whole map on every rank
+    bool live = build_pass(c, c->shadow, ZR_MODE_SHADOW, &P);
+    if (!live) P.n_work = 0;      // no finite vertex: the pass is its clear
+    c->last_work[0] = P.n_work;
+    geometry_pass(c, P, 0, c->d_sowned, c->sn_tiles, c->sn_tiles, c->ev[1]);
+    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    // deferred-scene pass (ZE:3417-3480)
+    live = build_pass(c, c->cam, ZR_MODE_GBUFFER, &P);
+    if (!live) P.n_work = 0;
+    c->last_work[1] = P.n_work;
+    geometry_pass(c, P, 1, c->d_owned, c->n_owned, c->n_tiles, c->ev[3]);
+    HIPCHK(c, hipEventRecord(c->ev[4], s));
+    // deferred-lighting pass (ZE:3531-3540)
+    ZrLightParams L; memset(&L, 0, sizeof L);
+    static const float Bias[16] = { 0.5f, 0, 0, 0, 0, 0.5f, 0, 0, 0, 0, 1, 0, 0.5f, 0.5f, 0, 1 };
+    zr_mat4_mul(Bias, c->view.ShadowmapSpace, L.SB);
+    L.W = c->W; L.H = c->H; L.SD = c->SD; L.tiles_x = c->tiles_x; L.debug_view = c->debug_view;
+    L.cube_dim = c->cube_dim; L.cube_levels = c->cube_levels; L.tile_world = c->cfg.tile_world;
+    L.packed_out = c->cfg.tile_world > 1 ? 1u : 0u;
+    zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, c->d_shadow, c->cube, c->d_lut,
+                       L.packed_out ? c->d_tiles : c->d_color, s);
+    HIPCHK(c, hipEventRecord(c->ev[5], s));
+    HIPCHK(c, hipGetLastError());
+    c->rendered = true;
+    return ZR_OK;
+}
+
+extern "C" int zr_finish(zr_ctx* c)
+{
+    if (!c) return ZR_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->rendered) {
+        HIPCHK(c, hipMemcpy(&c->h_stats, c->d_stats, sizeof(ZrDevStats), hipMemcpyDeviceToHost));
+        if (c->h_stats.overflow) return zr_fail(c, ZR_ERR_OVERFLOW, "tile bin list overflow: frame is incomplete");
+    }
+    return ZR_OK;
+}
+
+extern "C" int zr_get_pass_times(zr_ctx* c, float ms[ZR_PASS_COUNT])
+{
+    if (!c || !ms) return ZR_ERR_ARG;
+    if (!c->rendered) return zr_fail(c, ZR_ERR_STATE, "nothing rendered yet");
+    int rc = zr_finish(c);
+    if (rc && rc != ZR_ERR_OVERFLOW) return rc;
+    for (int i = 0; i < ZR_PASS_COUNT; ++i) ms[i] = 0.0f;
+    (void)hipEventElapsedTime(&ms[ZR_PASS_CULL_SHADOW], c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&ms[ZR_PASS_SHADOW], c->ev[1], c->ev[2]);
+    (void)hipEventElapsedTime(&ms[ZR_PASS_CULL_CAMERA], c->ev[2], c->ev[3]);
+    (void)hipEventElapsedTime(&ms[ZR_PASS_GBUFFER], c->ev[3], c->ev[4]);
+    (void)hipEventElapsedTime(&ms[ZR_PASS_LIGHTING], c->ev[4], c->ev[5]);
+    (void)hipEventElapsedTime(&ms[ZR_PASS_TOTAL], c->ev[0], c->ev[5]);
+    return ZR_OK;
+}
+
+extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out)
+{
+    if (!c || !out) return ZR_ERR_ARG;
+    int rc = zr_finish(c);
+    memset(out, 0, sizeof *out);
+    for (int i = 0; i < 2; ++i) {
+        out->work_items[i] = c->last_work[i]; out->survivors[i] = c->h_stats.survivors[i]; out->bin_entries[i] = c->h_stats.bin_entries[i];
+    }
+    out->covered_pixels = c->h_stats.covered; out->overflow = c->h_stats.overflow;
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------ read-back
+
+extern "C" int zr_read_color(zr_ctx* c, uint8_t* dst, size_t bytes)
+{
+    if (!c) return ZR_ERR_ARG;
+    ARGCHK(c, dst && bytes == (size_t)c->W * c->H * 4);
+    int rc = zr_finish(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(dst, c->d_color, bytes, hipMemcpyDeviceToHost));
+    return ZR_OK;
+}
+extern "C" int zr_read_gbuffer(zr_ctx* c, int target, void* dst, size_t bytes)
+{
+    if (!c) return ZR_ERR_ARG;
+    const void* src[6] = { c->G.depth, c->G.scene_color, c->G.gA, c->G.gB, c->G.gC, c->G.gD };
+    ARGCHK(c, dst && target >= 0 && target < 6);
+    ARGCHK(c, bytes == (size_t)c->W * c->H * (target == 5 ? 8 : 4));
+    int rc = zr_finish(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(dst, src[target], bytes, hipMemcpyDeviceToHost));
+    return ZR_OK;
+}
+extern "C" int zr_read_shadowmap(zr_ctx* c, float* dst, size_t bytes)
+{
+    if (!c) return ZR_ERR_ARG;
+    ARGCHK(c, dst && bytes == (size_t)c->SD * c->SD * 4);
+    int rc = zr_finish(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(dst, c->d_shadow, bytes, hipMemcpyDeviceToHost));
+    return ZR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ multi-GPU tiles
+
+extern "C" int zr_tiles_device_buffer(zr_ctx* c, void** p, size_t* bytes)
+{
+    if (!c || !p || !bytes) return ZR_ERR_ARG;
+    *p = c->d_tiles; *bytes = (size_t)c->slots_per_rank * ZR_TILE * ZR_TILE * 4;
+    return ZR_OK;
+}
+extern "C" int zr_composite(zr_ctx* c, const void* gathered)
+{
+    if (!c) return ZR_ERR_ARG;
+    ARGCHK(c, gathered != nullptr);
+    HIPCHK(c, hipSetDevice(c->device));
+    zr_launch_untile((const uint32_t*)gathered, c->d_color, c->W, c->H, c->tiles_x, c->n_tiles, c->cfg.tile_world, c->slots_per_rank, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return ZR_OK;
+}
+extern "C" int zr_color_device_ptr(zr_ctx* c, void** p) { if (!c || !p) return ZR_ERR_ARG; *p = c->d_color; return ZR_OK; }

@@ -1,0 +1,901 @@
+// zr_kernels.hip — CDNA4 (gfx950) kernels of the deferred render path.
+//
+//   k_instance_prep   XkInstanceData -> ZrInstance (rotation matrix), once per zr_object_add
+//   k_cull<MODE>      one 64-lane wavefront per meshlet-instance: frustum + cone test on the bounds,
+//                     lane-per-vertex transform, exact snapped screen bbox -> tile rect + tile counters
+//   k_scan            exclusive scan of the per-tile counters (one workgroup)
+//   k_bin_fill        scatter meshlet-instance ids into per-tile lists
+//   k_raster<MODE>    one workgroup per 32x32 screen tile: per wave, stage a meshlet's transformed
+//                     vertices in LDS, set up <=124 triangles (2 per lane), rasterise into the tile's
+//                     LDS depth/visibility keys with ds_min; then resolve BaseScene.frag per pixel and
+//                     write the SoA GBuffer planes (or the shadow-map tile) with coalesced row stores
+//   k_lighting        BaseLighting.frag per pixel (PCF 5x5, all lights, ambient, cubemap IBL, gamma)
+//   k_untile          multi-GPU composite: all-gathered packed tiles -> row-major frame
+//
+// Replaces: SH/Shadowmap*.vert, SH/Base*.vert, SH/BaseScene.frag, SH/Background.vert + SH/BaseLighting.frag,
+// the fixed-function rasteriser/ROP state of RHICreateGraphicsPipelines (ZE:5094-5201) and the draw loops of
+// RecordCommandBuffer (ZE:3239-3540).  Raster rules: DESIGN.md §4.
+#include "zr_math.h"
+#include "zr_types.h"
+
+#define WAVE 64
+#define TILE ZR_TILE
+#define TILE_PIX (TILE * TILE)
+
+// ------------------------------------------------------------------------------------------------ helpers
+
+struct SV { int X, Y; float z, rw; };          // snapped screen vertex (1/256 px), NDC depth, 1/w
+
+__device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
+__device__ __forceinline__ int find_object_work(const ZrObject* __restrict__ objs, int n, uint32_t w)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (objs[mid].work_base <= w) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+__device__ __forceinline__ int find_object_prim(const ZrObject* __restrict__ objs, int n, uint32_t p)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (objs[mid].prim_base <= p) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+// Base.vert:26 / BaseInstanced.vert:70 / Shadowmap*.vert: object-space position fed to PVM
+__device__ __forceinline__ zf3 vs_position(zf3 p, const ZrInstance& I, bool instanced)
+{
+    if (!instanced) return p;
+    zf3 q = zr_rowvec_mat3(p * I.s, I.R);
+    return zr3(q.x + I.t[0], q.y + I.t[1], q.z + I.t[2]);
+}
+// outNormal = (M * vec4(normalize(n), 1)).xyz [* mat3(rotMat)] — the w = 1 is the engine's own (Base.vert:29)
+__device__ __forceinline__ zf3 vs_normal(zf3 n, const ZrInstance& I, bool instanced, const float* M)
+{
+    zf4 mn = zr_mat4_point(M, zr_normalize(n));
+    zf3 r = zr3(mn.x, mn.y, mn.z);
+    return instanced ? zr_rowvec_mat3(r, I.R) : r;
+}
+
+// bit0 non-finite, bits1-6 outside {x<-w, x>w, y<-w, y>w, z<0, z>w}, bit7 needs clipping
+__device__ __forceinline__ uint32_t vertex_flags(zf4 c)
+{
+    const float FM = 3.402823466e38f;
+    uint32_t f = 0;
+    if (!(__builtin_fabsf(c.x) <= FM && __builtin_fabsf(c.y) <= FM && __builtin_fabsf(c.z) <= FM && __builtin_fabsf(c.w) <= FM)) f |= 1u;
+    if (c.x < -c.w) f |= 2u;
+    if (c.x > c.w) f |= 4u;
+    if (c.y < -c.w) f |= 8u;
+    if (c.y > c.w) f |= 16u;
+    if (c.z < 0.0f) f |= 32u;
+    if (c.z > c.w) f |= 64u;
+    float g = ZR_GUARD * c.w;
+    if (c.z < 0.0f || !(c.w > 0.0f) || __builtin_fabsf(c.x) > g || __builtin_fabsf(c.y) > g) f |= 128u;
+    return f;
+}
+// 0 discard, 1 fast path, 2 clip path
+__device__ __forceinline__ int classify(uint32_t f0, uint32_t f1, uint32_t f2)
+{
+    if ((f0 | f1 | f2) & 1u) return 0;
+    if (f0 & f1 & f2 & 0x7Eu) return 0;
+    return ((f0 | f1 | f2) & 128u) ? 2 : 1;
+}
+
+__device__ __forceinline__ SV project(zf4 c, float hw, float hh)
+{
+    SV s;
+    float nx = c.x / c.w, ny = c.y / c.w;
+    float xs = __builtin_fmaf(nx, hw, hw), ys = __builtin_fmaf(ny, hh, hh);
+    s.X = (int)__builtin_floorf(__builtin_fmaf(xs, 256.0f, 0.5f));
+    s.Y = (int)__builtin_floorf(__builtin_fmaf(ys, 256.0f, 0.5f));
+    s.z = c.z / c.w;
+    s.rw = 1.0f / c.w;
+    return s;
+}
+
+__device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
+__device__ __forceinline__ int imax3(int a, int b, int c) { return max(a, max(b, c)); }
+
+// ------------------------------------------------------------------------------------------------ instance prep
+
+// MakeRotMatrix (SH/Common.glsl:60-87): rotMat = mz * my * mx; mx(R.x) turns about Y, my(R.y) about Z, mz(R.z) about X
+__global__ void k_instance_prep(const XkInstanceData* __restrict__ in, ZrInstance* __restrict__ out, uint32_t n, uint32_t instanced)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ZrInstance I;
+    if (!instanced) {
+        for (int k = 0; k < 9; ++k) I.R[k] = (k % 4 == 0) ? 1.0f : 0.0f;
+        I.t[0] = I.t[1] = I.t[2] = 0.0f; I.s = 1.0f;
+    } else {
+        XkInstanceData d = in[i];
+        float s, c, mx[9], my[9], mz[9], t[9];
+        zr_sincos(d.InstanceRotation[0], s, c);
+        mx[0] = c; mx[1] = 0; mx[2] = s;  mx[3] = 0; mx[4] = 1; mx[5] = 0;  mx[6] = -s; mx[7] = 0; mx[8] = c;
+        zr_sincos(d.InstanceRotation[1], s, c);
+        my[0] = c; my[1] = s; my[2] = 0;  my[3] = -s; my[4] = c; my[5] = 0;  my[6] = 0; my[7] = 0; my[8] = 1;
+        zr_sincos(d.InstanceRotation[2], s, c);
+        mz[0] = 1; mz[1] = 0; mz[2] = 0;  mz[3] = 0; mz[4] = c; mz[5] = s;  mz[6] = 0; mz[7] = -s; mz[8] = c;
+        zr_mat3_mul(mz, my, t);
+        zr_mat3_mul(t, mx, I.R);
+        I.t[0] = d.InstancePosition[0]; I.t[1] = d.InstancePosition[1]; I.t[2] = d.InstancePosition[2];
+        I.s = d.InstancePScale;
+    }
+    I._pad[0] = I._pad[1] = I._pad[2] = 0.0f;
+    out[i] = I;
+}
+
+// ------------------------------------------------------------------------------------------------ cull + bin
+
+__device__ __forceinline__ int wave_min(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ int wave_max(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o); return v; }
+__device__ __forceinline__ uint32_t wave_and(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v &= (uint32_t)__shfl_xor((int)v, o); return v; }
+
+// One wavefront per meshlet-instance.  Writes rects[w] (packed tile rect or ZR_RECT_CULLED) and bumps the
+// counters of the owned tiles the rect touches.  Every rejection here is exact or conservative:
+//   sphere-vs-frustum and the normal-cone test use inflated bounds;
+//   "all vertices outside one clip plane" and "snapped bbox holds no pixel centre" are exact.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restrict__ objs,
+                                              uint32_t* __restrict__ rects, uint32_t* __restrict__ tile_count)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t w = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (w >= P.n_work) return;
+    const int oi = find_object_work(objs, (int)P.n_objects, w);
+    const ZrObject* __restrict__ O = objs + oi;
+    const uint32_t local = w - O->work_base;
+    const uint32_t nm = O->n_meshlets;
+    const uint32_t inst_i = local / nm, m = local - inst_i * nm;
+    const XkMeshlet ml = O->meshlets[m];
+    const ZrInstance I = O->inst[inst_i];
+    const bool instanced = O->instanced != 0;
+
+    if (P.frustum_ok | P.cone_ok) {
+        zf3 co = vs_position(zr3(ml.BoundsCenter[0], ml.BoundsCenter[1], ml.BoundsCenter[2]), I, instanced);
+        zf4 cw4 = zr_mat4_point(P.M, co);
+        zf3 cw = zr3(cw4.x, cw4.y, cw4.z);
+        float rw = ml.BoundsRadius * (instanced ? __builtin_fabsf(I.s) : 1.0f) * P.m_scale;
+        rw = __builtin_fmaf(rw, 1.001f, 1e-5f * (__builtin_fabsf(cw.x) + __builtin_fabsf(cw.y) + __builtin_fabsf(cw.z) + 1.0f));
+        bool culled = false;
+        if (P.frustum_ok) {
+            for (int k = 0; k < 6; ++k) {
+                float d = __builtin_fmaf(P.planes[k][0], cw.x, __builtin_fmaf(P.planes[k][1], cw.y,
+                          __builtin_fmaf(P.planes[k][2], cw.z, P.planes[k][3])));
+                if (d < -rw) culled = true;
+            }
+        }
+        if (MODE == ZR_MODE_GBUFFER && P.cone_ok && ml.ConeCutoff < 1.0f && (!instanced || I.s > 0.0f)) {
+            // meshoptimizer's bounding-sphere cone test, widened by ~1 degree (0.02 L): every triangle of the
+            // cluster is back-facing for this eye  <=  dot(c - eye, axis) >= cutoff*|c - eye| + radius
+            zf3 ax = zr3(ml.ConeAxis[0], ml.ConeAxis[1], ml.ConeAxis[2]);
+            if (instanced) ax = zr_rowvec_mat3(ax, I.R);
+            zf3 aw = zr3(__builtin_fmaf(P.M[8], ax.z, __builtin_fmaf(P.M[4], ax.y, P.M[0] * ax.x)),
+                         __builtin_fmaf(P.M[9], ax.z, __builtin_fmaf(P.M[5], ax.y, P.M[1] * ax.x)),
+                         __builtin_fmaf(P.M[10], ax.z, __builtin_fmaf(P.M[6], ax.y, P.M[2] * ax.x)));
+            zf3 d = cw - zr3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+            float L = zr_length(d);
+            if (zr_dot(d, aw) >= __builtin_fmaf(ml.ConeCutoff + 0.02f, L, rw)) culled = true;
+        }
+        if (culled) { if (lane == 0) rects[w] = ZR_RECT_CULLED; return; }
+    }
+
+    // lane-per-vertex transform, exactly as the rasteriser will redo it
+    uint32_t f_or = 0, f_and = 0xFFu;
+    int X0 = 0x7FFFFFFF, X1 = (int)0x80000000, Y0 = 0x7FFFFFFF, Y1 = (int)0x80000000;
+    if (lane < ml.VertexCount) {
+        const uint32_t vi = O->mverts[ml.VertexOffset + lane];
+        const float* pp = O->verts[vi].Position;
+        zf4 c = zr_mat4_point(P.PVM, vs_position(zr3(pp[0], pp[1], pp[2]), I, instanced));
+        uint32_t f = vertex_flags(c);
+        f_or = f; f_and = f;
+        if (!(f & 129u)) { SV s = project(c, P.hw, P.hh); X0 = X1 = s.X; Y0 = Y1 = s.Y; }
+    }
+    f_or = wave_or(f_or); f_and = wave_and(f_and);
+    if (!(f_or & 1u) && (f_and & 0x7Eu)) { if (lane == 0) rects[w] = ZR_RECT_CULLED; return; }
+    int px0 = 0, py0 = 0, px1 = (int)P.W - 1, py1 = (int)P.H - 1;
+    if (!(f_or & 129u)) {
+        X0 = wave_min(X0); X1 = wave_max(X1); Y0 = wave_min(Y0); Y1 = wave_max(Y1);
+        px0 = max(px0, (X0 - 128 + 255) >> 8); px1 = min(px1, (X1 - 128) >> 8);
+        py0 = max(py0, (Y0 - 128 + 255) >> 8); py1 = min(py1, (Y1 - 128) >> 8);
+        if (px0 > px1 || py0 > py1) { if (lane == 0) rects[w] = ZR_RECT_CULLED; return; }
+    }
+    const int tx0 = px0 / TILE, tx1 = px1 / TILE, ty0 = py0 / TILE, ty1 = py1 / TILE;
+    const int rw_ = tx1 - tx0 + 1, n = rw_ * (ty1 - ty0 + 1);
+    uint32_t mine = 0;
+    for (int k = (int)lane; k < n; k += WAVE) {
+        const int ty = ty0 + k / rw_, tx = tx0 + k % rw_;
+        const uint32_t t = (uint32_t)ty * P.tiles_x + (uint32_t)tx;
+        if (t % P.tile_world == P.tile_rank) { atomicAdd(&tile_count[t], 1u); mine = 1; }
+    }
+    mine = wave_or(mine);
+    if (lane == 0)
+        rects[w] = mine ? ((uint32_t)tx0 | (uint32_t)ty0 << 8 | (uint32_t)tx1 << 16 | (uint32_t)ty1 << 24) : ZR_RECT_CULLED;
+}
+
+// Exclusive scan of tile_count[0..n) into tile_offset[0..n]; zeroes tile_count and tile_cursor for the fill.
+__global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
+                                               uint32_t* __restrict__ tile_cursor, uint32_t n, uint32_t capacity,
+                                               ZrDevStats* __restrict__ stats, int slot)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t b = tid * per, e = min(n, b + per);
+    uint32_t s = 0;
+    for (uint32_t i = b; i < e; ++i) s += tile_count[i];
+    part[tid] = s;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t v = (tid >= off) ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;
+    for (uint32_t i = b; i < e; ++i) {
+        uint32_t c = tile_count[i];
+        tile_offset[i] = run; run += c;
+        tile_count[i] = 0; tile_cursor[i] = 0;
+    }
+    if (tid == 1023) {
+        tile_offset[n] = part[1023];
+        stats->bin_entries[slot] = part[1023];
+        if (part[1023] > capacity) stats->overflow = 1u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bin_fill(ZrPass P, const uint32_t* __restrict__ rects,
+                                                  const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
+                                                  uint32_t* __restrict__ bins, ZrDevStats* __restrict__ stats, int slot)
+{
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    uint32_t alive = 0;
+    if (w < P.n_work) {
+        const uint32_t r = rects[w];
+        if (r != ZR_RECT_CULLED) {
+            alive = 1;
+            const uint32_t tx0 = r & 255u, ty0 = (r >> 8) & 255u, tx1 = (r >> 16) & 255u, ty1 = r >> 24;
+            for (uint32_t ty = ty0; ty <= ty1; ++ty)
+                for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+                    const uint32_t t = ty * P.tiles_x + tx;
+                    if (t % P.tile_world != P.tile_rank) continue;
+                    const uint32_t pos = tile_offset[t] + atomicAdd(&tile_cursor[t], 1u);
+                    if (pos < P.bin_capacity) bins[pos] = w;
+                }
+        }
+    }
+    const uint32_t cnt = (uint32_t)__popcll(__ballot(alive));
+    __shared__ uint32_t tot;
+    if (threadIdx.x == 0) tot = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0 && cnt) atomicAdd(&tot, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0 && tot) atomicAdd(&stats->survivors[slot], tot);
+}
+
+// ------------------------------------------------------------------------------------------------ rasteriser
+
+struct TileCtx {
+    int px0, py0;                 // tile origin in pixels
+    int W, H;                     // target extent
+};
+
+// Rasterise one snapped triangle into the tile's LDS keys.
+//   GBUFFER: key = depth_bits << 32 | prim, ds_min_u64  == depth test LESS in draw order (ties: lower prim wins)
+//   SHADOW : key = biased depth bits,        ds_min_u32  == depth test LESS_OR_EQUAL, depth write only
+template <int MODE>
+__device__ __forceinline__ void raster_sub(const SV& v0, const SV& v1, const SV& v2, uint32_t prim, const TileCtx& T,
+                                           unsigned long long* __restrict__ keys64, uint32_t* __restrict__ keys32)
+{
+    const int dX1 = v1.X - v0.X, dY1 = v1.Y - v0.Y, dX2 = v2.X - v0.X, dY2 = v2.Y - v0.Y;
+    const long long A = (long long)dX1 * dY2 - (long long)dX2 * dY1;
+    if (A == 0) return;
+    // Vulkan facing: a = -A/2 in framebuffer coordinates; COUNTER_CLOCKWISE front  <=>  A < 0 (ZE:5113-5123)
+    if (MODE == ZR_MODE_GBUFFER && A > 0) return;
+    int x0 = (imin3(v0.X, v1.X, v2.X) - 128 + 255) >> 8, x1 = (imax3(v0.X, v1.X, v2.X) - 128) >> 8;
+    int y0 = (imin3(v0.Y, v1.Y, v2.Y) - 128 + 255) >> 8, y1 = (imax3(v0.Y, v1.Y, v2.Y) - 128) >> 8;
+    x0 = max(x0, T.px0); y0 = max(y0, T.py0);
+    x1 = min(x1, min(T.px0 + TILE - 1, T.W - 1)); y1 = min(y1, min(T.py0 + TILE - 1, T.H - 1));
+    if (x0 > x1 || y0 > y1) return;
+
+    const int sgn = A > 0 ? 1 : -1;
+    // oriented edges (inside positive): e0 = v1->v2, e1 = v2->v0, e2 = v0->v1; top-left rule folded in as a bias
+    const int ex0 = sgn * (v2.X - v1.X), ey0 = sgn * (v2.Y - v1.Y);
+    const int ex1 = sgn * (v0.X - v2.X), ey1 = sgn * (v0.Y - v2.Y);
+    const int ex2 = sgn * (v1.X - v0.X), ey2 = sgn * (v1.Y - v0.Y);
+    const int Px0 = x0 * 256 + 128, Py0 = y0 * 256 + 128;
+    long long E0 = (long long)ex0 * (Py0 - v1.Y) - (long long)ey0 * (Px0 - v1.X) - (((ey0 < 0) || (ey0 == 0 && ex0 > 0)) ? 0 : 1);
+    long long E1 = (long long)ex1 * (Py0 - v2.Y) - (long long)ey1 * (Px0 - v2.X) - (((ey1 < 0) || (ey1 == 0 && ex1 > 0)) ? 0 : 1);
+    long long E2 = (long long)ex2 * (Py0 - v0.Y) - (long long)ey2 * (Px0 - v0.X) - (((ey2 < 0) || (ey2 == 0 && ex2 > 0)) ? 0 : 1);
+    const long long sx0 = -(long long)ey0 * 256, sx1 = -(long long)ey1 * 256, sx2 = -(long long)ey2 * 256;
+    const long long sy0 = (long long)ex0 * 256, sy1 = (long long)ex1 * 256, sy2 = (long long)ex2 * 256;
+
+    // depth plane anchored at vertex 0, gradients per sub-pixel unit
+    const float fA = (float)A;
+    const float a1 = (float)(v2.Y - v0.Y) / fA, b1 = (float)(v0.X - v2.X) / fA;
+    const float a2 = (float)(v0.Y - v1.Y) / fA, b2 = (float)(v1.X - v0.X) / fA;
+    const float dz1 = v1.z - v0.z, dz2 = v2.z - v0.z;
+    const float gx = __builtin_fmaf(a2, dz2, a1 * dz1), gy = __builtin_fmaf(b2, dz2, b1 * dz1);
+    float bias = 0.0f;
+    if (MODE == ZR_MODE_SHADOW) {
+        // vkCmdSetDepthBias(1.25, 0, 7.5) on D32 (ZE:3280-3287): o = m * slope + r * constant, r = 2^(e - 23)
+        const float m = __builtin_fmaxf(__builtin_fabsf(gx), __builtin_fabsf(gy)) * 256.0f;
+        const float zm = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v0.z), __builtin_fabsf(v1.z)), __builtin_fabsf(v2.z));
+        const uint32_t e = zr_f2u(zm) & 0x7F800000u;
+        const float r = (e > (23u << 23) && e < 0x7F800000u) ? zr_u2f(e - (23u << 23)) : 0.0f;
+        bias = __builtin_fmaf(m, 7.5f, r * 1.25f);
+    }
+    for (int y = y0; y <= y1; ++y) {
+        long long r0 = E0, r1 = E1, r2 = E2;
+        const float fy = (float)(y * 256 + 128 - v0.Y);
+        for (int x = x0; x <= x1; ++x) {
+            if ((r0 | r1 | r2) >= 0) {
+                const float fx = (float)(x * 256 + 128 - v0.X);
+                float z = __builtin_fmaf(gy, fy, __builtin_fmaf(gx, fx, v0.z));
+                z = z + 0.0f;
+                const int li = (y - T.py0) * TILE + (x - T.px0);
+                if (MODE == ZR_MODE_GBUFFER) {
+                    if (z >= 0.0f && z < 1.0f)   // depth clip (depthClampEnable FALSE) + LESS against the 1.0 clear
+                        atomicMin(&keys64[li], (unsigned long long)zr_f2u(z) << 32 | prim);
+                } else {
+                    if (z >= 0.0f && z <= 1.0f) {
+                        const float zb = __builtin_fminf(__builtin_fmaxf(z + bias, 0.0f), 1.0f);
+                        atomicMin(&keys32[li], zr_f2u(zb));
+                    }
+                }
+            }
+            r0 += sx0; r1 += sx1; r2 += sx2;
+        }
+        E0 += sy0; E1 += sy1; E2 += sy2;
+    }
+}
+
+// Sutherland-Hodgman against near (z >= 0) and the 4x guard band; intersections always run inside -> outside.
+__device__ __forceinline__ float plane_dist(zf4 c, int plane)
+{
+    switch (plane) {
+    case 0: return c.z;
+    case 1: return __builtin_fmaf(ZR_GUARD, c.w, c.x);
+    case 2: return __builtin_fmaf(ZR_GUARD, c.w, -c.x);
+    case 3: return __builtin_fmaf(ZR_GUARD, c.w, c.y);
+    default: return __builtin_fmaf(ZR_GUARD, c.w, -c.y);
+    }
+}
+__device__ __forceinline__ zf4 lerp4(zf4 in, zf4 out, float t)
+{
+    zf4 r;
+    r.x = __builtin_fmaf(t, out.x - in.x, in.x); r.y = __builtin_fmaf(t, out.y - in.y, in.y);
+    r.z = __builtin_fmaf(t, out.z - in.z, in.z); r.w = __builtin_fmaf(t, out.w - in.w, in.w);
+    return r;
+}
+template <int MODE>
+__device__ __noinline__ void raster_clipped(zf4 c0, zf4 c1, zf4 c2, uint32_t prim, TileCtx T, float hw, float hh,
+                                            unsigned long long* keys64, uint32_t* keys32)
+{
+    zf4 a[10], b[10];
+    int na = 3;
+    a[0] = c0; a[1] = c1; a[2] = c2;
+    for (int plane = 0; plane < 5; ++plane) {
+        int nb = 0;
+        for (int i = 0; i < na; ++i) {
+            const zf4 p = a[i], q = a[(i + 1 == na) ? 0 : i + 1];
+            const float dp = plane_dist(p, plane), dq = plane_dist(q, plane);
+            const bool ip = dp >= 0.0f, iq = dq >= 0.0f;
+            if (ip) b[nb++] = p;
+            if (ip != iq) b[nb++] = ip ? lerp4(p, q, dp / (dp - dq)) : lerp4(q, p, dq / (dq - dp));
+        }
+        na = nb;
+        if (na < 3) return;
+        for (int i = 0; i < na; ++i) a[i] = b[i];
+    }
+    for (int i = 0; i < na; ++i) if (!(a[i].w > 0.0f)) return;
+    const SV s0 = project(a[0], hw, hh);
+    SV sp = project(a[1], hw, hh);
+    for (int i = 2; i < na; ++i) {
+        const SV sn = project(a[i], hw, hh);
+        raster_sub<MODE>(s0, sp, sn, prim, T, keys64, keys32);
+        sp = sn;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GBuffer resolve
+
+struct Bary { float b0, b1, b2; };
+struct FastSetup { int X0, Y0; float a1, b1, a2, b2, rw0, rw1, rw2; };
+
+__device__ __forceinline__ Bary bary_screen(const FastSetup& s, int px, int py)
+{
+    const float fx = (float)(px * 256 + 128 - s.X0), fy = (float)(py * 256 + 128 - s.Y0);
+    const float l1 = __builtin_fmaf(s.b1, fy, s.a1 * fx), l2 = __builtin_fmaf(s.b2, fy, s.a2 * fx);
+    const float l0 = (1.0f - l1) - l2;
+    const float q0 = l0 * s.rw0, q1 = l1 * s.rw1, q2 = l2 * s.rw2;
+    const float inv = 1.0f / ((q0 + q1) + q2);
+    Bary r; r.b0 = q0 * inv; r.b1 = q1 * inv; r.b2 = q2 * inv;
+    return r;
+}
+// clipped triangles: 2D-homogeneous interpolation from the unclipped clip-space vertices
+__device__ __forceinline__ Bary bary_homog(const zf4* c, float hw, float hh, int px, int py)
+{
+    const float u = (((float)px + 0.5f) - hw) / hw, v = (((float)py + 0.5f) - hh) / hh;
+    float k[3];
+    for (int i = 0; i < 3; ++i) {
+        const zf4 p = c[(i + 1) % 3], q = c[(i + 2) % 3];
+        const float kx = __builtin_fmaf(p.y, q.w, -(q.y * p.w));
+        const float ky = __builtin_fmaf(q.x, p.w, -(p.x * q.w));
+        const float kz = __builtin_fmaf(p.x, q.y, -(q.x * p.y));
+        k[i] = __builtin_fmaf(kx, u, __builtin_fmaf(ky, v, kz));
+    }
+    const float inv = 1.0f / ((k[0] + k[1]) + k[2]);
+    Bary r; r.b0 = k[0] * inv; r.b1 = k[1] * inv; r.b2 = k[2] * inv;
+    return r;
+}
+__device__ __forceinline__ float interp1(Bary b, float a0, float a1, float a2)
+{
+    return __builtin_fmaf(b.b2, a2, __builtin_fmaf(b.b1, a1, b.b0 * a0));
+}
+__device__ __forceinline__ zf3 interp3(Bary b, zf3 a0, zf3 a1, zf3 a2)
+{
+    return zr3(interp1(b, a0.x, a1.x, a2.x), interp1(b, a0.y, a1.y, a2.y), interp1(b, a0.z, a1.z, a2.z));
+}
+
+// ComputeNormal(fragPosition, fragTexCoord, fragNormal, texNormal), SH/Common.glsl:113-127
+__device__ __forceinline__ zf3 compute_normal(zf3 pos_dx, zf3 pos_dy, float s1, float t1, float s2, float t2, zf3 fragN, zf3 texN)
+{
+    const float det = __builtin_fmaf(s1, t2, -(s2 * t1));
+    zf3 T = zr3(__builtin_fmaf(t2, pos_dx.x, -(t1 * pos_dy.x)) / det,
+                __builtin_fmaf(t2, pos_dx.y, -(t1 * pos_dy.y)) / det,
+                __builtin_fmaf(t2, pos_dx.z, -(t1 * pos_dy.z)) / det);
+    const zf3 N = zr_normalize(fragN);
+    T = zr_normalize(T - N * zr_dot(N, T));
+    const zf3 B = zr_normalize(zr_cross(N, T));
+    const zf3 n = zr_normalize(texN);
+    const zf3 ts = zr_normalize(zr3(__builtin_fmaf(2.0f, n.x, -1.0f), __builtin_fmaf(2.0f, n.y, -1.0f), __builtin_fmaf(2.0f, n.z, -1.0f)));
+    const zf3 w = zr3(__builtin_fmaf(N.x, ts.z, __builtin_fmaf(B.x, ts.y, T.x * ts.x)),
+                      __builtin_fmaf(N.y, ts.z, __builtin_fmaf(B.y, ts.y, T.y * ts.x)),
+                      __builtin_fmaf(N.z, ts.z, __builtin_fmaf(B.z, ts.y, T.z * ts.x)));
+    return zr_normalize(w);
+}
+
+// BaseScene.frag:26-48 for the pixel (px, py) whose winning primitive is `prim`
+__device__ __forceinline__ void resolve_pixel(const ZrPass& P, const ZrObject* __restrict__ objs, uint32_t prim, float depth,
+                                              int px, int py, const GBufferPtrs& G)
+{
+    const size_t p = (size_t)py * P.W + (size_t)px;
+    if (prim == ZR_EMPTY_PRIM) {   // clears, ZE:3427-3433
+        G.depth[p] = 1.0f; G.scene_color[p] = 0xFF000000u; G.gA[p] = 0u; G.gB[p] = 0xFF000000u; G.gC[p] = 0xFF000000u;
+        G.gD[p] = make_uint2(0u, 0x3C000000u);
+        return;
+    }
+    const ZrObject* __restrict__ O = objs + find_object_prim(objs, (int)P.n_objects, prim);
+    const uint32_t local = prim - O->prim_base;
+    const uint32_t inst_i = local / O->n_tris, tri = local - inst_i * O->n_tris;
+    const bool instanced = O->instanced != 0;
+    const ZrInstance I = O->inst[inst_i];
+    zf4 clip[3]; zf3 WP[3], WN[3]; float U[3], V[3]; uint32_t fl[3];
+    for (int k = 0; k < 3; ++k) {
+        const XkVertex* __restrict__ vtx = O->verts + O->indices[3u * tri + (uint32_t)k];
+        const zf3 pos = vs_position(zr3(vtx->Position[0], vtx->Position[1], vtx->Position[2]), I, instanced);
+        clip[k] = zr_mat4_point(P.PVM, pos);
+        const zf4 wp = zr_mat4_point(P.M, pos);
+        WP[k] = zr3(wp.x, wp.y, wp.z);
+        WN[k] = vs_normal(zr3(vtx->Normal[0], vtx->Normal[1], vtx->Normal[2]), I, instanced, P.M);
+        U[k] = vtx->TexCoord[0]; V[k] = vtx->TexCoord[1];
+        fl[k] = vertex_flags(clip[k]);
+    }
+    const int cls = classify(fl[0], fl[1], fl[2]);
+    const int qx = px ^ 1, qy = py ^ 1;           // 2x2 quad partners (fine derivatives, helper lanes extrapolate)
+    Bary b0, bh, bv;
+    if (cls == 1) {
+        const SV s0 = project(clip[0], P.hw, P.hh), s1 = project(clip[1], P.hw, P.hh), s2 = project(clip[2], P.hw, P.hh);
+        const long long A = (long long)(s1.X - s0.X) * (s2.Y - s0.Y) - (long long)(s2.X - s0.X) * (s1.Y - s0.Y);
+        const float fA = (float)A;
+        FastSetup fs;
+        fs.X0 = s0.X; fs.Y0 = s0.Y;
+        fs.a1 = (float)(s2.Y - s0.Y) / fA; fs.b1 = (float)(s0.X - s2.X) / fA;
+        fs.a2 = (float)(s0.Y - s1.Y) / fA; fs.b2 = (float)(s1.X - s0.X) / fA;
+        fs.rw0 = s0.rw; fs.rw1 = s1.rw; fs.rw2 = s2.rw;
+        b0 = bary_screen(fs, px, py); bh = bary_screen(fs, qx, py); bv = bary_screen(fs, px, qy);
+    } else {
+        b0 = bary_homog(clip, P.hw, P.hh, px, py); bh = bary_homog(clip, P.hw, P.hh, qx, py); bv = bary_homog(clip, P.hw, P.hh, px, qy);
+    }
+    const zf3 P0 = interp3(b0, WP[0], WP[1], WP[2]), Ph = interp3(bh, WP[0], WP[1], WP[2]), Pv = interp3(bv, WP[0], WP[1], WP[2]);
+    const zf3 N0 = interp3(b0, WN[0], WN[1], WN[2]);
+    const float u0 = interp1(b0, U[0], U[1], U[2]), uh = interp1(bh, U[0], U[1], U[2]), uv_ = interp1(bv, U[0], U[1], U[2]);
+    const float v0 = interp1(b0, V[0], V[1], V[2]), vh = interp1(bh, V[0], V[1], V[2]), vv = interp1(bv, V[0], V[1], V[2]);
+    const float sx = (px & 1) ? 1.0f : -1.0f, sy = (py & 1) ? 1.0f : -1.0f;
+    const zf3 pos_dx = (P0 - Ph) * sx, pos_dy = (P0 - Pv) * sy;
+    const float s1 = (u0 - uh) * sx, t1 = (v0 - vh) * sx, s2 = (u0 - uv_) * sy, t2 = (v0 - vv) * sy;
+
+    // material fetch: constant textures (any filter returns the texel); slot 0 is sRGB
+    const uint32_t tm = O->texel[1], tr = O->texel[2], tn = O->texel[3], ta = O->texel[4], te = O->texel[5], tk = O->texel[6];
+    const float Metallic = (float)(tm & 255u) / 255.0f;
+    const float Rough = __builtin_fmaxf(0.01f, (float)(tr & 255u) / 255.0f);
+    const zf3 texN = zr3((float)(tn & 255u) / 255.0f, (float)((tn >> 8) & 255u) / 255.0f, (float)((tn >> 16) & 255u) / 255.0f);
+    const float AO = (float)(ta & 255u) / 255.0f;
+    const zf3 Em = zr3((float)(te & 255u) / 255.0f, (float)((te >> 8) & 255u) / 255.0f, (float)((te >> 16) & 255u) / 255.0f);
+    const float Mask = (float)(tk & 255u) / 255.0f;
+
+    const zf3 Nw = compute_normal(pos_dx, pos_dy, s1, t1, s2, t2, N0, texN);
+    const zf3 Nn = zr_normalize(Nw);
+    const zf3 NP = zr3((Nn.x + 1.0f) / 2.0f, (Nn.y + 1.0f) / 2.0f, (Nn.z + 1.0f) / 2.0f);
+    G.depth[p] = depth;
+    G.scene_color[p] = zr_unorm(Em.x, 255.0f) | zr_unorm(Em.y, 255.0f) << 8 | zr_unorm(Em.z, 255.0f) << 16 | zr_unorm(Mask, 255.0f) << 24;
+    G.gA[p] = zr_unorm(NP.z, 1023.0f) | zr_unorm(NP.y, 1023.0f) << 10 | zr_unorm(NP.x, 1023.0f) << 20 | 3u << 30;
+    G.gB[p] = zr_unorm(Metallic, 255.0f) | zr_unorm(1.0f, 255.0f) << 8 | zr_unorm(Rough, 255.0f) << 16 | 255u << 24;
+    G.gC[p] = zr_unorm(O->bc_linear[0], 255.0f) | zr_unorm(O->bc_linear[1], 255.0f) << 8 | zr_unorm(O->bc_linear[2], 255.0f) << 16 |
+              zr_unorm(AO, 255.0f) << 24;
+    G.gD[p] = make_uint2(zr_f32_to_f16(P0.x) | zr_f32_to_f16(P0.y) << 16, zr_f32_to_f16(P0.z) | 0x3C000000u);
+}
+
+// ------------------------------------------------------------------------------------------------ tile raster kernel
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_raster(ZrPass P, const ZrObject* __restrict__ objs,
+                                                const uint32_t* __restrict__ owned_tiles,
+                                                const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ bins,
+                                                GBufferPtrs G, float* __restrict__ shadowmap, ZrDevStats* __restrict__ stats)
+{
+    __shared__ unsigned long long keys64[MODE == ZR_MODE_GBUFFER ? TILE_PIX : 1];
+    __shared__ uint32_t keys32[MODE == ZR_MODE_SHADOW ? TILE_PIX : 1];
+    __shared__ int4 vstage[4][WAVE];
+    __shared__ uint32_t fstage[4][WAVE];
+    __shared__ uint32_t covered_s;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t tile = owned_tiles[blockIdx.x];
+    TileCtx T;
+    T.px0 = (int)(tile % P.tiles_x) * TILE; T.py0 = (int)(tile / P.tiles_x) * TILE; T.W = (int)P.W; T.H = (int)P.H;
+
+    for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
+        if (MODE == ZR_MODE_GBUFFER) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
+        else keys32[i] = 0x3F800000u;
+    }
+    if (tid == 0) covered_s = 0;
+    __syncthreads();
+
+    const uint32_t beg = tile_offset[tile];
+    const uint32_t end = min(tile_offset[tile + 1], P.bin_capacity);
+    for (uint32_t e = beg + wv; e < end; e += 4u) {
+        const uint32_t w = wave_uniform(bins[e]);
+        const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w);
+        const uint32_t local = w - O->work_base;
+        const uint32_t nm = O->n_meshlets;
+        const uint32_t inst_i = local / nm, m = local - inst_i * nm;
+        const XkMeshlet ml = O->meshlets[m];
+        const ZrInstance I = O->inst[inst_i];
+        const bool instanced = O->instanced != 0;
+
+        lds_fence();   // previous iteration's readers are done with this wave's staging area
+        if (lane < ml.VertexCount) {
+            const uint32_t vi = O->mverts[ml.VertexOffset + lane];
+            const float* pp = O->verts[vi].Position;
+            const zf4 c = zr_mat4_point(P.PVM, vs_position(zr3(pp[0], pp[1], pp[2]), I, instanced));
+            const uint32_t f = vertex_flags(c);
+            SV s; s.X = 0; s.Y = 0; s.z = 0.0f; s.rw = 0.0f;
+            if (!(f & 129u)) s = project(c, P.hw, P.hh);
+            vstage[wv][lane] = make_int4(s.X, s.Y, (int)zr_f2u(s.z), (int)zr_f2u(s.rw));
+            fstage[wv][lane] = f;
+        }
+        lds_fence();
+
+        const uint32_t pbase = O->prim_base + inst_i * O->n_tris;
+        for (uint32_t t = lane; t < ml.TriangleCount; t += WAVE) {
+            const uint8_t* tp = O->mtris + ml.TriangleOffset + 3u * t;
+            const uint32_t i0 = tp[0], i1 = tp[1], i2 = tp[2];
+            const uint32_t f0 = fstage[wv][i0], f1 = fstage[wv][i1], f2 = fstage[wv][i2];
+            const int cls = classify(f0, f1, f2);
+            if (cls == 0) continue;
+            const uint32_t prim = pbase + O->tri_order[ml.BindlessContext + t];
+            if (cls == 1) {
+                const int4 r0 = vstage[wv][i0], r1 = vstage[wv][i1], r2 = vstage[wv][i2];
+                SV a, b, c;
+                a.X = r0.x; a.Y = r0.y; a.z = zr_u2f((uint32_t)r0.z); a.rw = zr_u2f((uint32_t)r0.w);
+                b.X = r1.x; b.Y = r1.y; b.z = zr_u2f((uint32_t)r1.z); b.rw = zr_u2f((uint32_t)r1.w);
+                c.X = r2.x; c.Y = r2.y; c.z = zr_u2f((uint32_t)r2.z); c.rw = zr_u2f((uint32_t)r2.w);
+                raster_sub<MODE>(a, b, c, prim, T, keys64, keys32);
+            } else {
+                zf4 cc[3];
+                const uint32_t li[3] = { i0, i1, i2 };
+                for (int k = 0; k < 3; ++k) {
+                    const float* pp = O->verts[O->mverts[ml.VertexOffset + li[k]]].Position;
+                    cc[k] = zr_mat4_point(P.PVM, vs_position(zr3(pp[0], pp[1], pp[2]), I, instanced));
+                }
+                raster_clipped<MODE>(cc[0], cc[1], cc[2], prim, T, P.hw, P.hh, keys64, keys32);
+            }
+        }
+    }
+    __syncthreads();
+
+    // resolve: row-major within the tile -> 128 B (256 B for GBufferD) contiguous row segments per wave
+    uint32_t ncov = 0;
+    for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
+        const int px = T.px0 + (int)(i & (TILE - 1)), py = T.py0 + (int)(i / TILE);
+        if (px >= T.W || py >= T.H) continue;
+        if (MODE == ZR_MODE_GBUFFER) {
+            const unsigned long long k = keys64[i];
+            const uint32_t prim = (uint32_t)k;
+            ncov += prim != ZR_EMPTY_PRIM;
+            resolve_pixel(P, objs, prim, zr_u2f((uint32_t)(k >> 32)), px, py, G);
+        } else {
+            shadowmap[(size_t)py * P.W + (size_t)px] = zr_u2f(keys32[i]);
+        }
+    }
+    if (MODE == ZR_MODE_GBUFFER) {
+        if (ncov) atomicAdd(&covered_s, ncov);
+        __syncthreads();
+        if (tid == 0 && covered_s) atomicAdd(&stats->covered, covered_s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ lighting
+
+__device__ __forceinline__ int idx_clamp(float f, int hi) { f = __builtin_fminf(__builtin_fmaxf(f, 0.0f), (float)hi); return (int)f; }
+
+__device__ __forceinline__ zf3 cube_fetch(const CubeDesc& C, const float* __restrict__ lut, uint32_t dim0, int level, int face, int x, int y)
+{
+    uint32_t d = dim0 >> level; if (d == 0) d = 1;
+    const uint8_t* p = C.levels[level] + ((size_t)d * d * (size_t)face + (size_t)y * d + (size_t)x) * 4;
+    const uint32_t t = *(const uint32_t*)p;
+    return zr3(lut[t & 255u], lut[(t >> 8) & 255u], lut[(t >> 16) & 255u]);
+}
+__device__ __forceinline__ zf3 lerp3(float a, zf3 x, zf3 y)
+{
+    return zr3(__builtin_fmaf(a, y.x - x.x, x.x), __builtin_fmaf(a, y.y - x.y, x.y), __builtin_fmaf(a, y.z - x.z, x.z));
+}
+__device__ __forceinline__ zf3 cube_bilinear(const CubeDesc& C, const float* __restrict__ lut, uint32_t dim0, int level, int face, float s, float t)
+{
+    uint32_t d = dim0 >> level; if (d == 0) d = 1;
+    const float u = __builtin_fmaf(s, (float)d, -0.5f), v = __builtin_fmaf(t, (float)d, -0.5f);
+    const float fu = __builtin_floorf(u), fv = __builtin_floorf(v);
+    const float a = u - fu, b = v - fv;
+    const int x0 = idx_clamp(fu, (int)d - 1), x1 = idx_clamp(fu + 1.0f, (int)d - 1);
+    const int y0 = idx_clamp(fv, (int)d - 1), y1 = idx_clamp(fv + 1.0f, (int)d - 1);
+    const zf3 top = lerp3(a, cube_fetch(C, lut, dim0, level, face, x0, y0), cube_fetch(C, lut, dim0, level, face, x1, y0));
+    const zf3 bot = lerp3(a, cube_fetch(C, lut, dim0, level, face, x0, y1), cube_fetch(C, lut, dim0, level, face, x1, y1));
+    return lerp3(b, top, bot);
+}
+// textureLod(samplerCube, R, lod): Vulkan face selection (z wins ties over y over x), trilinear, faces clamp-to-edge
+__device__ __forceinline__ zf3 cube_sample(const CubeDesc& C, const float* __restrict__ lut, uint32_t dim0, int nlevels, zf3 R, float lod)
+{
+    const float ax = __builtin_fabsf(R.x), ay = __builtin_fabsf(R.y), az = __builtin_fabsf(R.z);
+    int face; float sc, tc, ma;
+    if (az >= ax && az >= ay) { ma = az; if (R.z >= 0.0f) { face = 4; sc = R.x; tc = -R.y; } else { face = 5; sc = -R.x; tc = -R.y; } }
+    else if (ay >= ax)        { ma = ay; if (R.y >= 0.0f) { face = 2; sc = R.x; tc = R.z; }  else { face = 3; sc = R.x; tc = -R.z; } }
+    else                      { ma = ax; if (R.x >= 0.0f) { face = 0; sc = -R.z; tc = -R.y; } else { face = 1; sc = R.z; tc = -R.y; } }
+    const float s = __builtin_fmaf(sc / ma, 0.5f, 0.5f), t = __builtin_fmaf(tc / ma, 0.5f, 0.5f);
+    const float l = __builtin_fminf(__builtin_fmaxf(lod, 0.0f), (float)(nlevels - 1));
+    const float fl = __builtin_floorf(l);
+    const int l0 = (int)fl, l1 = min(l0 + 1, nlevels - 1);
+    return lerp3(l - fl, cube_bilinear(C, lut, dim0, l0, face, s, t), cube_bilinear(C, lut, dim0, l1, face, s, t));
+}
+
+__device__ __forceinline__ float F_Schlick(float f0, float f90, float u) { return __builtin_fmaf(f90 - f0, zr_pow5(1.0f - u), f0); }   // SH/Common.glsl:134
+__device__ __forceinline__ float Fr_DisneyDiffuse(float NdotV, float NdotL, float LdotH, float r)                                     // :148
+{
+    const float E_bias = __builtin_fmaf(0.5f, r, 0.0f * (1.0f - r));
+    const float E_factor = __builtin_fmaf(1.0f / 1.51f, r, 1.0f * (1.0f - r));
+    const float fd90 = __builtin_fmaf((2.0f * LdotH) * LdotH, r, E_bias);
+    return (F_Schlick(1.0f, fd90, NdotL) * F_Schlick(1.0f, fd90, NdotV)) * E_factor;
+}
+__device__ __forceinline__ float V_SmithGGXCorrelated(float NdotV, float NdotL, float r)                                             // :161
+{
+    const float a2 = r * r;
+    const float GGXV = NdotL * __builtin_sqrtf(__builtin_fmaf(NdotV * NdotV, 1.0f - a2, a2));
+    const float GGXL = NdotV * __builtin_sqrtf(__builtin_fmaf(NdotL * NdotL, 1.0f - a2, a2));
+    const float GGX = GGXV + GGXL;
+    return GGX > 0.0f ? 0.5f / GGX : 0.0f;
+}
+__device__ __forceinline__ float D_GGX(float NdotH, float r)                                                                         // :178
+{
+    const float a2 = r * r;
+    const float f = __builtin_fmaf(__builtin_fmaf(NdotH, a2, -NdotH), NdotH, 1.0f);
+    return a2 / ((3.14159265359f * f) * f);
+}
+
+// ShadowDepthProject + texture(LINEAR, clamp-to-edge) of the D32 shadow map (SH/Common.glsl:307-319; sampler ZE:2532-2537)
+__device__ __forceinline__ float shadow_tap(const float* __restrict__ S, int SD, float sx, float sy, float sz, float sw, float ox, float oy)
+{
+    float f = 1.0f;
+    if (sz > -1.0f && sz < 1.0f) {
+        const float dim = (float)SD;
+        const float u = __builtin_fmaf(sx + ox, dim, -0.5f), v = __builtin_fmaf(sy + oy, dim, -0.5f);
+        const float fu = __builtin_floorf(u), fv = __builtin_floorf(v), a = u - fu, b = v - fv;
+        const int x0 = idx_clamp(fu, SD - 1), x1 = idx_clamp(fu + 1.0f, SD - 1);
+        const int y0 = idx_clamp(fv, SD - 1), y1 = idx_clamp(fv + 1.0f, SD - 1);
+        const float t00 = S[(size_t)y0 * SD + x0], t10 = S[(size_t)y0 * SD + x1];
+        const float t01 = S[(size_t)y1 * SD + x0], t11 = S[(size_t)y1 * SD + x1];
+        const float top = __builtin_fmaf(a, t10 - t00, t00), bot = __builtin_fmaf(a, t11 - t01, t01);
+        const float dist = __builtin_fmaf(b, bot - top, top);
+        if (sw > 0.0f && dist < sz) f = 0.1f;
+    }
+    return f;
+}
+
+// BaseLighting.frag:147-254 for every pixel of the owned tiles (the full-screen quad of ZE:3531-3540)
+__global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView* __restrict__ view,
+                                                  const uint32_t* __restrict__ owned_tiles, GBufferPtrs G,
+                                                  const float* __restrict__ shadowmap, CubeDesc C,
+                                                  const float* __restrict__ srgb_lut, uint32_t* __restrict__ out)
+{
+    const uint32_t tile = owned_tiles[blockIdx.x];
+    const int tx0 = (int)(tile % L.tiles_x) * TILE, ty0 = (int)(tile / L.tiles_x) * TILE;
+    const zf3 cam = zr3(view->CameraInfo[0], view->CameraInfo[1], view->CameraInfo[2]);
+    const uint32_t nDir = (uint32_t)view->LightsCount[0], nPoint = (uint32_t)view->LightsCount[1];
+    const float maxmips = (float)(uint32_t)view->LightsCount[3];
+    const float dxy = 1.5f * 1.0f / (float)L.SD;
+
+    for (uint32_t i = threadIdx.x; i < TILE_PIX; i += 256u) {
+        const int px = tx0 + (int)(i & (TILE - 1)), py = ty0 + (int)(i / TILE);
+        if (px >= (int)L.W || py >= (int)L.H) continue;
+        const size_t p = (size_t)py * L.W + (size_t)px;
+        const uint32_t sc = G.scene_color[p], A = G.gA[p], B = G.gB[p], Cc = G.gC[p];
+        const uint2 D = G.gD[p];
+        const zf3 BaseColor = zr3((float)(Cc & 255u) / 255.0f, (float)((Cc >> 8) & 255u) / 255.0f, (float)((Cc >> 16) & 255u) / 255.0f);
+        const float Metallic = zr_saturate((float)(B & 255u) / 255.0f);
+        float Roughness = zr_saturate((float)((B >> 16) & 255u) / 255.0f);
+        const zf3 Normal = zr3(__builtin_fmaf((float)((A >> 20) & 1023u) / 1023.0f, 2.0f, -1.0f),
+                               __builtin_fmaf((float)((A >> 10) & 1023u) / 1023.0f, 2.0f, -1.0f),
+                               __builtin_fmaf((float)(A & 1023u) / 1023.0f, 2.0f, -1.0f));
+        const float AO = zr_saturate((float)(Cc >> 24) / 255.0f);
+        const float Mask = (float)(sc >> 24) / 255.0f;
+        Roughness = __builtin_fmaxf(0.01f, Roughness);
+        const zf3 N = zr_normalize(Normal);
+        const zf3 Pw = zr3(zr_f16_to_f32(D.x & 0xFFFFu), zr_f16_to_f32(D.x >> 16), zr_f16_to_f32(D.y & 0xFFFFu));
+        const zf3 Vv = zr_normalize(cam - Pw);
+        const float NdotV = zr_saturate(zr_dot(N, Vv));
+
+        const zf4 s4 = zr_mat4_point(L.SB, Pw);
+        const float sx = s4.x / s4.w, sy = s4.y / s4.w, sz = s4.z / s4.w, sw = s4.w / s4.w;
+        float sum = 0.0f;
+        for (int x = -2; x <= 2; ++x)
+            for (int y = -2; y <= 2; ++y)      // ComputePCF r = 2, SH/Common.glsl:323-342
+                sum += shadow_tap(shadowmap, (int)L.SD, sx, sy, sz, sw, dxy * (float)x, dxy * (float)y);
+        const float ShadowFactor = sum / 25.0f;
+
+        zf3 Direct = zr3(0.0f, 0.0f, 0.0f);
+        const zf3 Nn = zr_normalize(N);                      // Apply*Light and refract() re-normalise N
+        const zf3 DiffuseColor = BaseColor * (1.0f - Metallic);
+        for (uint32_t li = 0; li < nDir + nPoint; ++li) {
+            const bool isdir = li < nDir;
+            const XkLight* __restrict__ Lt = isdir ? &view->DirectionalLights[li] : &view->PointLights[li - nDir];
+            const zf3 lp = zr3(Lt->Position[0], Lt->Position[1], Lt->Position[2]);
+            const zf3 Lv = isdir ? zr_normalize(zr3(Lt->Direction[0], Lt->Direction[1], Lt->Direction[2])) : zr_normalize(lp - Pw);
+            const zf3 Hh = zr_normalize(Vv + Lv);
+            const float LdotH = zr_saturate(zr_dot(Lv, Hh)), NdotH = zr_saturate(zr_dot(N, Hh)), NdotL = zr_saturate(zr_dot(N, Lv));
+            // DefaultLitBxDF (SH/Common.glsl:259-282): F0 = 0.04, F90 = saturate(50 * 0.04)
+            const float F = F_Schlick(0.04f, zr_saturate(50.0f * 0.04f), LdotH);
+            const float Vis = V_SmithGGXCorrelated(NdotV, NdotL, Roughness);
+            const float Dg = D_GGX(NdotH, Roughness);
+            const float Fr = (F * Dg) * Vis;
+            const float Fd = Fr_DisneyDiffuse(NdotV, NdotL, LdotH, Roughness);
+            const zf3 bx = zr3(__builtin_fmaf(DiffuseColor.x * (1.0f - F), Fd, Fr), __builtin_fmaf(DiffuseColor.y * (1.0f - F), Fd, Fr),
+                               __builtin_fmaf(DiffuseColor.z * (1.0f - F), Fd, Fr));
+            // ApplyDirectionalLight / ApplyPointLight (SH/Common.glsl:364-372, 399-416)
+            const float ndotl = zr_clamp(zr_dot(Nn, Lv), 0.0f, 1.0f);
+            const float k = ndotl * Lt->Color[3];
+            zf3 rad = zr3(k * Lt->Color[0], k * Lt->Color[1], k * Lt->Color[2]);
+            if (isdir) {
+                Direct = zr3(__builtin_fmaf(rad.x * bx.x, ShadowFactor, Direct.x), __builtin_fmaf(rad.y * bx.y, ShadowFactor, Direct.y),
+                             __builtin_fmaf(rad.z * bx.z, ShadowFactor, Direct.z));
+            } else {
+                const float dist = zr_length(lp - Pw);
+                const float falloff = Lt->Direction[3];
+                const float att = 1.0f - zr_clamp(dist, 0.0f, falloff) / falloff;   // remap(dist, 0, falloff, 0, 1), :43-47
+                rad = rad * att;
+                Direct = zr3(__builtin_fmaf(rad.x, bx.x, Direct.x), __builtin_fmaf(rad.y, bx.y, Direct.y), __builtin_fmaf(rad.z, bx.z, Direct.z));
+            }
+        }
+        // (2) indirect, BaseLighting.frag:210
+        const zf3 Indirect = zr3((((DiffuseColor.x / 3.14159265359f) * AO) * 0.3f) * ShadowFactor,
+                                 (((DiffuseColor.y / 3.14159265359f) * AO) * 0.3f) * ShadowFactor,
+                                 (((DiffuseColor.z / 3.14159265359f) * AO) * 0.3f) * ShadowFactor);
+        // (3) reflection, :213-221
+        const zf3 bcl = zr3(zr_clamp(BaseColor.x, 0.04f, 1.0f), zr_clamp(BaseColor.y, 0.04f, 1.0f), zr_clamp(BaseColor.z, 0.04f, 1.0f));
+        const float dsf0 = (0.04f * 2.0f) * 0.5f;
+        const zf3 RSpec = zr3(__builtin_fmaf(Metallic, bcl.x, (1.0f - Metallic) * dsf0), __builtin_fmaf(Metallic, bcl.y, (1.0f - Metallic) * dsf0),
+                              __builtin_fmaf(Metallic, bcl.z, (1.0f - Metallic) * dsf0));
+        // EnvBRDFApproxLazarov, SH/Common.glsl:201-211
+        const float rx = __builtin_fmaf(Roughness, -1.0f, 1.0f), ry = __builtin_fmaf(Roughness, -0.0275f, 0.0425f);
+        const float rz = __builtin_fmaf(Roughness, -0.572f, 1.04f), rw = __builtin_fmaf(Roughness, 0.022f, -0.04f);
+        const float a004 = __builtin_fmaf(__builtin_fminf(rx * rx, zr_exp2(-9.28f * NdotV)), rx, ry);
+        const float ABx = __builtin_fmaf(-1.04f, a004, rz), ABy = __builtin_fmaf(1.04f, a004, rw);
+        const float F90 = zr_saturate(50.0f * RSpec.y);
+        const zf3 RBRDF = zr3(__builtin_fmaf(RSpec.x, ABx, F90 * ABy), __builtin_fmaf(RSpec.y, ABx, F90 * ABy), __builtin_fmaf(RSpec.z, ABx, F90 * ABy));
+        const float eta = 1.00f / 1.52f;
+        const float dNI = zr_dot(Nn, Vv);
+        const float kk = __builtin_fmaf(-(eta * eta), __builtin_fmaf(-dNI, dNI, 1.0f), 1.0f);
+        zf3 R;
+        if (kk < 0.0f) R = zr3(0.0f, 0.0f, 0.0f);
+        else {
+            const float q = __builtin_fmaf(eta, dNI, __builtin_sqrtf(kk));
+            R = zr3(__builtin_fmaf(eta, Vv.x, -(q * Nn.x)), __builtin_fmaf(eta, Vv.y, -(q * Nn.y)), __builtin_fmaf(eta, Vv.z, -(q * Nn.z)));
+        }
+        // ComputeReflectionMipFromRoughness, SH/Common.glsl:191-198
+        const float MIPS = (maxmips - 1.0f) - __builtin_fmaf(-1.2f, zr_log2(__builtin_fmaxf(Roughness, 0.001f)), 1.0f);
+        const zf3 RL = cube_sample(C, srgb_lut, L.cube_dim, (int)L.cube_levels, R, MIPS) * 10.0f;
+        const float RV = zr_saturate((zr_pow(NdotV + AO, Roughness * Roughness) - 1.0f) + AO);   // GetSpecularOcclusion :226
+        const zf3 RefC = zr3((RL.x * RV) * RBRDF.x, (RL.y * RV) * RBRDF.y, (RL.z * RV) * RBRDF.z);
+
+        zf3 Final = ((Direct + Indirect) + RefC) * Mask;
+        Final = zr3(zr_pow(Final.x, 0.4545f), zr_pow(Final.y, 0.4545f), zr_pow(Final.z, 0.4545f));
+        zf3 o;
+        switch (L.debug_view) {
+        case 0: o = Final; break;
+        case 1: o = zr3(zr_pow(BaseColor.x, 0.4545f), zr_pow(BaseColor.y, 0.4545f), zr_pow(BaseColor.z, 0.4545f)); break;
+        case 2: o = zr3(Metallic, Metallic, Metallic); break;
+        case 3: o = zr3(Roughness, Roughness, Roughness); break;
+        case 4: o = Normal; break;
+        case 5: o = zr3(AO, AO, AO); break;
+        case 7: o = RefC; break;
+        case 8: o = zr3(ShadowFactor, ShadowFactor, ShadowFactor); break;
+        default: o = Final * ShadowFactor; break;
+        }
+        const uint32_t rgba = zr_unorm(o.x, 255.0f) | zr_unorm(o.y, 255.0f) << 8 | zr_unorm(o.z, 255.0f) << 16 | 255u << 24;
+        if (L.packed_out) out[(size_t)blockIdx.x * TILE_PIX + i] = rgba;
+        else out[p] = rgba;
+    }
+}
+
+// Multi-GPU composite: gathered[rank][slot][TILE_PIX] (slot = tile / world for tiles with tile % world == rank) -> frame
+__global__ __launch_bounds__(256) void k_untile(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ frame,
+                                                uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
+                                                uint32_t world, uint32_t slots_per_rank)
+{
+    const uint32_t tile = blockIdx.x;
+    if (tile >= n_tiles) return;
+    const uint32_t rank = tile % world, slot = tile / world;
+    const uint32_t* src = gathered + ((size_t)rank * slots_per_rank + slot) * TILE_PIX;
+    const uint32_t tx0 = (tile % tiles_x) * TILE, ty0 = (tile / tiles_x) * TILE;
+    for (uint32_t i = threadIdx.x; i < TILE_PIX; i += 256u) {
+        const uint32_t px = tx0 + (i & (TILE - 1)), py = ty0 + i / TILE;
+        if (px < W && py < H) frame[(size_t)py * W + px] = src[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers (C++ linkage, used by zr_host.cpp)
+
+void zr_launch_instance_prep(const XkInstanceData* in, ZrInstance* out, uint32_t n, uint32_t instanced, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_instance_prep, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n, instanced);
+}
+void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* rects, uint32_t* tile_count, hipStream_t s)
+{
+    if (P.n_work == 0) return;
+    const dim3 g((P.n_work + 3) / 4), b(256);
+    if (P.mode == ZR_MODE_GBUFFER) hipLaunchKernelGGL(k_cull<ZR_MODE_GBUFFER>, g, b, 0, s, P, objs, rects, tile_count);
+    else hipLaunchKernelGGL(k_cull<ZR_MODE_SHADOW>, g, b, 0, s, P, objs, rects, tile_count);
+}
+void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t n, uint32_t capacity,
+                    ZrDevStats* stats, int slot, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, n, capacity, stats, slot);
+}
+void zr_launch_bin_fill(const ZrPass& P, const uint32_t* rects, const uint32_t* tile_offset, uint32_t* tile_cursor,
+                        uint32_t* bins, ZrDevStats* stats, int slot, hipStream_t s)
+{
+    if (P.n_work == 0) return;
+    hipLaunchKernelGGL(k_bin_fill, dim3((P.n_work + 255) / 256), dim3(256), 0, s, P, rects, tile_offset, tile_cursor, bins, stats, slot);
+}
+void zr_launch_raster(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
+                      const uint32_t* tile_offset, const uint32_t* bins, const GBufferPtrs& G, float* shadowmap,
+                      ZrDevStats* stats, hipStream_t s)
+{
+    if (n_owned == 0) return;
+    if (P.mode == ZR_MODE_GBUFFER)
+        hipLaunchKernelGGL(k_raster<ZR_MODE_GBUFFER>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, tile_offset, bins, G, shadowmap, stats);
+    else
+        hipLaunchKernelGGL(k_raster<ZR_MODE_SHADOW>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, tile_offset, bins, G, shadowmap, stats);
+}
+void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32_t* owned_tiles, uint32_t n_owned,
+                        const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C, const float* lut, uint32_t* out, hipStream_t s)
+{
+    if (n_owned == 0) return;
+    hipLaunchKernelGGL(k_lighting, dim3(n_owned), dim3(256), 0, s, L, view, owned_tiles, G, shadowmap, C, lut, out);
+}
+void zr_launch_untile(const uint32_t* gathered, uint32_t* frame, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
+                      uint32_t world, uint32_t slots_per_rank, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_untile, dim3(n_tiles), dim3(256), 0, s, gathered, frame, W, H, tiles_x, n_tiles, world, slots_per_rank);
+}

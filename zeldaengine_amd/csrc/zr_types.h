@@ -1,0 +1,102 @@
+// zr_types.h — device-resident scene and per-pass parameter blocks (HBM layout).
+#pragma once
+
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+#include "../../include/zelda_abi.h"
+#include "../../include/zelda_render.h"
+
+#define ZR_EMPTY_PRIM 0xFFFFFFFFu
+#define ZR_GUARD 4.0f                       // guard band, multiples of w
+#define ZR_RECT_CULLED 0xFFFFFFFFu
+
+enum { ZR_MODE_GBUFFER = 0, ZR_MODE_SHADOW = 1 };
+
+// Per-instance transform, prepared once at zr_object_add from XkInstanceData (32 B -> 64 B):
+// R = mat3(MakeRotMatrix(InstanceRotation)) column-major, t = InstancePosition, s = InstancePScale.
+struct ZrInstance {
+    float R[9];
+    float t[3];
+    float s;
+    float _pad[3];
+};
+static_assert(sizeof(ZrInstance) == 64, "ZrInstance");
+
+// One draw (object) of the scene, in the reference's draw order (non-instanced draws first, ZE:3445-3476).
+struct ZrObject {
+    const XkVertex*   verts;
+    const uint32_t*   indices;       // draw-order index buffer (3 per triangle)
+    const XkMeshlet*  meshlets;
+    const uint32_t*   mverts;        // meshlet -> mesh vertex index
+    const uint8_t*    mtris;         // meshlet-local triangle corners, 3 B per triangle
+    const uint32_t*   tri_order;     // meshlet triangle slot (tri_base + t) -> draw-order triangle index; the device copy of
+                                     // XkMeshlet carries tri_base (triangles before this meshlet) in BindlessContext
+    const ZrInstance* inst;
+    uint32_t n_meshlets, n_tris, n_inst, instanced;
+    uint32_t work_base;              // first meshlet-instance id of this draw
+    uint32_t prim_base;              // first primitive id of this draw
+    uint32_t texel[7];               // constant material: RGBA8 per PBR slot (bc, m, r, n, ao, ev, ms)
+    float    bc_linear[3];           // sRGB-decoded base colour (slot 0 is R8G8B8A8_SRGB, ZE:5878)
+    float    mesh_center[3];         // object-space bounding sphere of the whole mesh
+    float    mesh_radius;
+    uint32_t _pad[2];
+};
+
+// Parameters of one geometry pass (camera or shadow), passed by value in the kernarg segment.
+struct ZrPass {
+    float PVM[16];                   // proj * view * model
+    float M[16];                     // model (world) matrix
+    float planes[6][4];              // world-space frustum planes, inward, normalised xyz
+    float cam_pos[3];                // world-space eye (cone test); valid when cone_ok
+    float m_scale;                   // upper bound of |M x| / |x| (Frobenius norm of mat3(M))
+    float hw, hh;                    // half extent of the target in pixels
+    uint32_t W, H;                   // target extent
+    uint32_t tiles_x, tiles_y;
+    uint32_t tile_rank, tile_world;  // this device owns tiles with t % tile_world == tile_rank
+    uint32_t n_objects, n_work;
+    uint32_t mode;                   // ZR_MODE_*
+    uint32_t frustum_ok, cone_ok;    // culling enabled (cone_ok also needs a standard perspective eye)
+    uint32_t bin_capacity;
+};
+
+// Frame statistics block in device memory (one per pass slot: [shadow, camera]).
+struct ZrDevStats {
+    uint32_t survivors[2];
+    uint32_t bin_entries[2];
+    uint32_t covered;
+    uint32_t overflow;
+};
+
+// Uniforms of the lighting pass that are not in XkView.
+struct ZrLightParams {
+    float SB[16];                    // BiasMat * shadowmapSpace (SH/Common.glsl:294-304), folded on the host
+    uint32_t W, H, SD;
+    uint32_t tiles_x;
+    uint32_t debug_view;
+    uint32_t cube_dim, cube_levels;
+    uint32_t packed_out;             // 1: write tile-major packed output (multi-GPU), 0: row-major frame
+    uint32_t tile_world;
+};
+
+// SoA GBuffer planes in HBM, row-major W x H each (formats ZE:2807-2843): D32F, RGBA8, A2R10G10B10, RGBA8, RGBA8, RGBA16F.
+struct GBufferPtrs {
+    float* depth; uint32_t* scene_color; uint32_t* gA; uint32_t* gB; uint32_t* gC; uint2* gD;
+};
+// Cubemap mip chain, level l = 6 faces of (dim >> l)^2 RGBA8 sRGB texels, face-major.
+struct CubeDesc { const uint8_t* levels[16]; };
+
+// launchers defined in zr_kernels.hip
+void zr_launch_instance_prep(const XkInstanceData* in, ZrInstance* out, uint32_t n, uint32_t instanced, hipStream_t s);
+void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* rects, uint32_t* tile_count, hipStream_t s);
+void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t n, uint32_t capacity,
+                    ZrDevStats* stats, int slot, hipStream_t s);
+void zr_launch_bin_fill(const ZrPass& P, const uint32_t* rects, const uint32_t* tile_offset, uint32_t* tile_cursor,
+                        uint32_t* bins, ZrDevStats* stats, int slot, hipStream_t s);
+void zr_launch_raster(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
+                      const uint32_t* tile_offset, const uint32_t* bins, const GBufferPtrs& G, float* shadowmap,
+                      ZrDevStats* stats, hipStream_t s);
+void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32_t* owned_tiles, uint32_t n_owned,
+                        const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C, const float* lut, uint32_t* out,
+                        hipStream_t s);
+void zr_launch_untile(const uint32_t* gathered, uint32_t* frame, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
+                      uint32_t world, uint32_t slots_per_rank, hipStream_t s);

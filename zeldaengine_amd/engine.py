@@ -1,0 +1,301 @@
+"""ctypes binding of libzelda_render.so — the HIP renderer behind the C-ABI of include/zelda_render.h.
+
+`Renderer` mirrors the call sequence of XkZeldaEngineApp (ZE = Engine/ZeldaEngine/ZeldaEngine.cpp):
+CreateEngineScene (ZE:4140) -> mesh_create / object_add, UpdateUniformBuffer (ZE:4585) -> update_uniforms,
+DrawFrame (ZE:1940) -> render, plus read-back in place of the swapchain.
+
+There is no CPU path here: the library fails loudly when the HIP extension or a GPU is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzelda_render.so")
+
+_lib = None
+
+
+class ZeldaRenderError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("zelda_render error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Loads the in-tree shared library (built by zeldaengine_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libzelda_render.so is not built: run `python -m zeldaengine_amd.build` "
+                          "(hipcc --offload-arch=gfx950); there is no fallback path")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
+    sig = {
+        "zr_create": [C.POINTER(abi.Config), C.POINTER(vp)],
+        "zr_set_stream": [vp, vp],
+        "zr_mesh_create": [vp, vp, u32, vp, u32, C.POINTER(u32)],
+        "zr_mesh_set_meshlets": [vp, u32, vp, u32, vp, sz, vp, sz],
+        "zr_mesh_build_meshlets": [vp, u32, u32, u32, C.c_float],
+        "zr_mesh_get_meshlets": [vp, u32, vp, C.POINTER(u32), vp, C.POINTER(sz), vp, C.POINTER(sz)],
+        "zr_object_add": [vp, u32, vp, vp, u32],
+        "zr_scene_clear": [vp],
+        "zr_object_count": [vp, C.POINTER(u32)],
+        "zr_object_get_instances": [vp, u32, C.POINTER(u32), vp, C.POINTER(u32)],
+        "zr_set_cubemap": [vp, vp, u32],
+        "zr_update_uniforms": [vp, vp, vp, u32, vp, u32, vp, u32, C.c_float, C.c_float, C.c_float],
+        "zr_set_frame": [vp, vp, vp, vp],
+        "zr_get_frame": [vp, vp, vp, vp],
+        "zr_set_debug_view": [vp, u32],
+        "zr_render": [vp],
+        "zr_finish": [vp],
+        "zr_get_pass_times": [vp, vp],
+        "zr_get_stats": [vp, C.POINTER(abi.Stats)],
+        "zr_read_color": [vp, vp, sz],
+        "zr_read_gbuffer": [vp, C.c_int, vp, sz],
+        "zr_read_shadowmap": [vp, vp, sz],
+        "zr_tiles_device_buffer": [vp, C.POINTER(vp), C.POINTER(sz)],
+        "zr_composite": [vp, vp],
+        "zr_color_device_ptr": [vp, C.POINTER(vp)],
+        "zr_profab_register": [vp, C.c_char_p, u32, vp],
+        "zr_world_load_json": [vp, C.c_char_p, sz],
+        "zr_world_save_json": [vp, vp, sz, C.POINTER(sz)],
+        "zr_world_get_camera": [vp, vp],
+        "zr_livelink_serve": [vp, C.c_uint16],
+        "zr_livelink_port": [vp, C.POINTER(C.c_uint16)],
+        "zr_livelink_poll": [vp, C.POINTER(C.c_int)],
+        "zr_livelink_stop": [vp],
+    }
+    for name, args in sig.items():
+        f = getattr(L, name)
+        f.argtypes = args
+        f.restype = C.c_int
+    L.zr_destroy.argtypes = [vp]
+    L.zr_destroy.restype = None
+    L.zr_last_error.argtypes = [vp]
+    L.zr_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+class Renderer:
+    def __init__(self, width=1920, height=1080, shadow_dim=1024, device=0, tile_rank=0, tile_world=1, flags=0,
+                 debug_view=0):
+        self.L = lib()
+        self.W, self.H, self.SD = width, height, shadow_dim
+        self.tile_rank, self.tile_world = tile_rank, tile_world
+        cfg = abi.Config(width, height, shadow_dim, debug_view, device, tile_rank, tile_world, flags)
+        h = C.c_void_p()
+        rc = self.L.zr_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise ZeldaRenderError(rc, "zr_create failed (no usable HIP device or bad config); there is no CPU fallback")
+        self.h = h
+
+    # ---- plumbing
+    def _chk(self, rc):
+        if rc != 0:
+            raise ZeldaRenderError(rc, (self.L.zr_last_error(self.h) or b"").decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.zr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_stream(self, hip_stream):
+        self._chk(self.L.zr_set_stream(self.h, C.c_void_p(hip_stream)))
+
+    # ---- scene
+    def mesh_create(self, verts, idx):
+        verts = np.ascontiguousarray(verts)
+        assert verts.dtype == abi.XkVertex
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        mid = C.c_uint32()
+        self._chk(self.L.zr_mesh_create(self.h, _ptr(verts), len(verts), _ptr(idx), len(idx), C.byref(mid)))
+        return mid.value
+
+    def mesh_set_meshlets(self, mesh, meshlets, mverts, mtris):
+        meshlets = np.ascontiguousarray(meshlets)
+        assert meshlets.dtype == abi.XkMeshlet
+        mverts = np.ascontiguousarray(mverts, dtype=np.uint32)
+        mtris = np.ascontiguousarray(mtris, dtype=np.uint8)
+        self._chk(self.L.zr_mesh_set_meshlets(self.h, mesh, _ptr(meshlets), len(meshlets), _ptr(mverts), len(mverts),
+                                              _ptr(mtris), len(mtris)))
+
+    def mesh_build_meshlets(self, mesh, max_vertices=64, max_triangles=124, cone_weight=0.2):
+        self._chk(self.L.zr_mesh_build_meshlets(self.h, mesh, max_vertices, max_triangles, cone_weight))
+
+    def mesh_get_meshlets(self, mesh):
+        nm, nmv, nmt = C.c_uint32(), C.c_size_t(), C.c_size_t()
+        self._chk(self.L.zr_mesh_get_meshlets(self.h, mesh, None, C.byref(nm), None, C.byref(nmv), None, C.byref(nmt)))
+        ml = np.zeros(nm.value, dtype=abi.XkMeshlet)
+        mv = np.zeros(nmv.value, dtype=np.uint32)
+        mt = np.zeros(nmt.value, dtype=np.uint8)
+        self._chk(self.L.zr_mesh_get_meshlets(self.h, mesh, _ptr(ml), C.byref(nm), _ptr(mv), C.byref(nmv), _ptr(mt),
+                                              C.byref(nmt)))
+        return ml, mv, mt
+
+    def object_add(self, mesh, material=None, instances=None):
+        mat = C.cast(C.pointer(material), C.c_void_p) if material is not None else None
+        n = 0 if instances is None else len(instances)
+        inst = np.ascontiguousarray(instances) if n else None
+        if n:
+            assert inst.dtype == abi.XkInstanceData
+        self._chk(self.L.zr_object_add(self.h, mesh, mat, _ptr(inst) if n else None, n))
+
+    def scene_clear(self):
+        self._chk(self.L.zr_scene_clear(self.h))
+
+    def object_count(self):
+        n = C.c_uint32()
+        self._chk(self.L.zr_object_count(self.h, C.byref(n)))
+        return n.value
+
+    def object_get_instances(self, index):
+        n, mesh = C.c_uint32(), C.c_uint32()
+        self._chk(self.L.zr_object_get_instances(self.h, index, C.byref(mesh), None, C.byref(n)))
+        inst = np.zeros(n.value, dtype=abi.XkInstanceData)
+        if n.value:
+            self._chk(self.L.zr_object_get_instances(self.h, index, C.byref(mesh), _ptr(inst), C.byref(n)))
+        return mesh.value, (inst if n.value else None)
+
+    def set_cubemap(self, faces):
+        if faces is None:
+            self._chk(self.L.zr_set_cubemap(self.h, None, 0))
+            return
+        faces = [np.ascontiguousarray(f, dtype=np.uint8) for f in faces]
+        assert len(faces) == 6 and all(f.shape == faces[0].shape and f.shape[0] == f.shape[1] and f.shape[2] == 4 for f in faces)
+        arr = (C.c_void_p * 6)(*[f.ctypes.data for f in faces])
+        self._chk(self.L.zr_set_cubemap(self.h, arr, faces[0].shape[0]))
+
+    # ---- uniforms
+    def update_uniforms(self, cam, dir_l, point_l, spot_l, roll_stage=0.0, roll_light=0.0, time=0.0):
+        self._chk(self.L.zr_update_uniforms(self.h, C.cast(C.pointer(cam), C.c_void_p), _ptr(dir_l), len(dir_l),
+                                            _ptr(point_l), len(point_l), _ptr(spot_l), len(spot_l),
+                                            roll_stage, roll_light, time))
+
+    def set_frame(self, cam, shadow, view):
+        self._chk(self.L.zr_set_frame(self.h, cam.ctypes.data, shadow.ctypes.data, view.ctypes.data))
+
+    def get_frame(self):
+        cam = np.zeros((), dtype=abi.XkUniformBufferMVP)
+        sh = np.zeros((), dtype=abi.XkUniformBufferMVP)
+        view = np.zeros((), dtype=abi.XkView)
+        self._chk(self.L.zr_get_frame(self.h, cam.ctypes.data, sh.ctypes.data, view.ctypes.data))
+        return cam, sh, view
+
+    def set_debug_view(self, v):
+        self._chk(self.L.zr_set_debug_view(self.h, v))
+
+    # ---- frame
+    def render(self, debug_view=None, passes=None):
+        if debug_view is not None:
+            self.set_debug_view(debug_view)
+        self._chk(self.L.zr_render(self.h))
+
+    def finish(self):
+        self._chk(self.L.zr_finish(self.h))
+
+    def pass_times(self):
+        ms = (C.c_float * len(abi.PASS_NAMES))()
+        self._chk(self.L.zr_get_pass_times(self.h, ms))
+        return dict(zip(abi.PASS_NAMES, [float(x) for x in ms]))
+
+    def stats(self):
+        s = abi.Stats()
+        self._chk(self.L.zr_get_stats(self.h, C.byref(s)))
+        return {"work_items": list(s.work_items), "survivors": list(s.survivors), "bin_entries": list(s.bin_entries),
+                "covered_pixels": int(s.covered_pixels), "overflow": int(s.overflow)}
+
+    # ---- read-back
+    def color(self):
+        out = np.zeros((self.H, self.W, 4), dtype=np.uint8)
+        self._chk(self.L.zr_read_color(self.h, _ptr(out), out.nbytes))
+        return out
+
+    def gbuffer(self, target):
+        out = np.zeros((self.H, self.W), dtype=abi.GBUFFER_DTYPES[target])
+        self._chk(self.L.zr_read_gbuffer(self.h, target, _ptr(out), out.nbytes))
+        return out
+
+    def shadowmap(self):
+        out = np.zeros((self.SD, self.SD), dtype=np.float32)
+        self._chk(self.L.zr_read_shadowmap(self.h, _ptr(out), out.nbytes))
+        return out
+
+    # ---- multi-GPU
+    def tiles_device_buffer(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.L.zr_tiles_device_buffer(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def composite(self, gathered_dev_ptr):
+        self._chk(self.L.zr_composite(self.h, C.c_void_p(gathered_dev_ptr)))
+
+    def color_device_ptr(self):
+        p = C.c_void_p()
+        self._chk(self.L.zr_color_device_ptr(self.h, C.byref(p)))
+        return p.value
+
+    # ---- world / livelink
+    def profab_register(self, name, mesh, material=None):
+        mat = C.cast(C.pointer(material), C.c_void_p) if material is not None else None
+        self._chk(self.L.zr_profab_register(self.h, name.encode(), mesh, mat))
+
+    def world_load_json(self, text):
+        b = text.encode() if isinstance(text, str) else bytes(text)
+        self._chk(self.L.zr_world_load_json(self.h, b, len(b)))
+
+    def world_save_json(self):
+        n = C.c_size_t()
+        self._chk(self.L.zr_world_save_json(self.h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        self._chk(self.L.zr_world_save_json(self.h, buf, n.value, C.byref(n)))
+        return buf.raw[:n.value].decode()
+
+    def world_camera(self):
+        cam = abi.Camera()
+        self._chk(self.L.zr_world_get_camera(self.h, C.cast(C.pointer(cam), C.c_void_p)))
+        return cam
+
+    def livelink_serve(self, port=8080):
+        self._chk(self.L.zr_livelink_serve(self.h, port))
+        p = C.c_uint16()
+        self._chk(self.L.zr_livelink_port(self.h, C.byref(p)))
+        return p.value
+
+    def livelink_poll(self):
+        r = C.c_int()
+        self._chk(self.L.zr_livelink_poll(self.h, C.byref(r)))
+        return bool(r.value)
+
+    def livelink_stop(self):
+        self._chk(self.L.zr_livelink_stop(self.h))
+
+
+def load_scene(r, cfg):
+    """Feed a scenes.config*() dict to a Renderer."""
+    r.set_cubemap(cfg.get("cubemap"))
+    for o in cfg["objects"]:
+        m = r.mesh_create(*o["mesh"])
+        r.object_add(m, o.get("material"), o.get("instances"))
+    r.update_uniforms(cfg["camera"], cfg["dir"], cfg["point"], cfg["spot"])
