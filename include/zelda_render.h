@@ -72,6 +72,7 @@ typedef struct zr_stats {
     uint64_t survivors[2];      /* meshlet-instances binned   [shadow, camera] */
     uint64_t bin_entries[2];    /* (tile, meshlet-instance) pairs */
     uint64_t covered_pixels;    /* GBuffer pixels with geometry */
+    uint64_t covered_shadow_texels; /* shadow-map texels with depth < 1 */
     uint32_t overflow;          /* nonzero: a bin list overflowed; frame invalid */
     uint32_t _pad;
 } zr_stats;
@@ -122,7 +123,8 @@ int  zr_set_debug_view(zr_ctx* ctx, uint32_t spec_constants);
  * cull -> shadow -> cull -> gbuffer -> lighting [-> composite].  Asynchronous on the render stream. */
 int  zr_render(zr_ctx* ctx);
 int  zr_finish(zr_ctx* ctx);                        /* stream sync + overflow check */
-int  zr_get_pass_times(zr_ctx* ctx, float ms[ZR_PASS_COUNT]);
+int  zr_get_pass_times(zr_ctx* ctx, float ms[ZR_PASS_COUNT]);              /* last frame */
+int  zr_get_pass_times_avg(zr_ctx* ctx, uint32_t last_n, float ms[ZR_PASS_COUNT]);  /* mean of the last n <= 64 frames */
 int  zr_get_stats(zr_ctx* ctx, zr_stats* out);
 
 /* --- read-back (there is no swapchain; replaces vkQueuePresentKHR ZE:2030) --- */

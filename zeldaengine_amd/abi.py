@@ -53,7 +53,7 @@ class Config(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("work_items", C.c_uint64 * 2), ("survivors", C.c_uint64 * 2), ("bin_entries", C.c_uint64 * 2),
-                ("covered_pixels", C.c_uint64), ("overflow", C.c_uint32), ("_pad", C.c_uint32)]
+                ("covered_pixels", C.c_uint64), ("covered_shadow_texels", C.c_uint64), ("overflow", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 PASS_NAMES = ["cull_shadow", "shadow", "cull_camera", "gbuffer", "lighting", "composite", "total"]

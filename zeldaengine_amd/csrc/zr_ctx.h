@@ -75,7 +75,8 @@ struct zr_ctx {
     std::vector<uint8_t*> d_cube; CubeDesc cube = {}; uint32_t cube_dim = 0, cube_levels = 0;
     float lut[256]; float* d_lut = nullptr;
 
-    hipEvent_t ev[8] = {}; bool rendered = false;
+    static constexpr int EV_RING = 64;     // per-pass hipEvents of the last EV_RING frames (bench averages over them)
+    hipEvent_t evr[EV_RING][6] = {}; uint64_t frame_no = 0; bool rendered = false;
 
     // world + livelink
     ZrWorld world;

@@ -73,7 +73,7 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     bool ok = true;
     ok &= hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess;
     c->stream = c->own_stream;
-    for (auto& e : c->ev) ok &= hipEventCreate(&e) == hipSuccess;
+    for (auto& fr : c->evr) for (auto& e : fr) ok &= hipEventCreate(&e) == hipSuccess;
     const size_t n = (size_t)c->W * c->H;
     ok &= dev_alloc(&c->G.depth, n) == hipSuccess;
     ok &= dev_alloc(&c->G.scene_color, n) == hipSuccess;
@@ -138,7 +138,7 @@ extern "C" void zr_destroy(zr_ctx* c)
     dev_free(c->d_color); dev_free(c->d_shadow); dev_free(c->d_view); dev_free(c->d_stats); dev_free(c->d_lut);
     dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles);
     dev_free(c->d_tile_count); dev_free(c->d_tile_offset); dev_free(c->d_tile_cursor); dev_free(c->d_rects); dev_free(c->d_bins);
-    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& fr : c->evr) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -590,7 +590,8 @@ extern "C" int zr_render(zr_ctx* c)
     if (rc) return rc;
     c->view.LightsCount[3] = (int32_t)c->cube_levels;
     hipStream_t s = c->stream;
-    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    hipEvent_t* ev = c->evr[c->frame_no % zr_ctx::EV_RING];
+    HIPCHK(c, hipEventRecord(ev[0], s));
     HIPCHK(c, hipMemsetAsync(c->d_stats, 0, sizeof(ZrDevStats), s));
     HIPCHK(c, hipMemcpyAsync(c->d_view, &c->view, sizeof(XkView), hipMemcpyHostToDevice, s));
 
@@ -599,14 +600,14 @@ extern "C" int zr_render(zr_ctx* c)
     bool live = build_pass(c, c->shadow, ZR_MODE_SHADOW, &P);
     if (!live) P.n_work = 0;      // no finite vertex: the pass is its clear
     c->last_work[0] = P.n_work;
-    geometry_pass(c, P, 0, c->d_sowned, c->sn_tiles, c->sn_tiles, c->ev[1]);
-    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    geometry_pass(c, P, 0, c->d_sowned, c->sn_tiles, c->sn_tiles, ev[1]);
+    HIPCHK(c, hipEventRecord(ev[2], s));
     // deferred-scene pass (ZE:3417-3480)
     live = build_pass(c, c->cam, ZR_MODE_GBUFFER, &P);
     if (!live) P.n_work = 0;
     c->last_work[1] = P.n_work;
-    geometry_pass(c, P, 1, c->d_owned, c->n_owned, c->n_tiles, c->ev[3]);
-    HIPCHK(c, hipEventRecord(c->ev[4], s));
+    geometry_pass(c, P, 1, c->d_owned, c->n_owned, c->n_tiles, ev[3]);
+    HIPCHK(c, hipEventRecord(ev[4], s));
     // deferred-lighting pass (ZE:3531-3540)
     ZrLightParams L; memset(&L, 0, sizeof L);
     static const float Bias[16] = { 0.5f, 0, 0, 0, 0, 0.5f, 0, 0, 0, 0, 1, 0, 0.5f, 0.5f, 0, 1 };
@@ -616,9 +617,9 @@ extern "C" int zr_render(zr_ctx* c)
     L.packed_out = c->cfg.tile_world > 1 ? 1u : 0u;
     zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, c->d_shadow, c->cube, c->d_lut,
                        L.packed_out ? c->d_tiles : c->d_color, s);
-    HIPCHK(c, hipEventRecord(c->ev[5], s));
+    HIPCHK(c, hipEventRecord(ev[5], s));
     HIPCHK(c, hipGetLastError());
-    c->rendered = true;
+    c->rendered = true; c->frame_no++;
     return ZR_OK;
 }
 
@@ -634,21 +635,32 @@ extern "C" int zr_finish(zr_ctx* c)
     return ZR_OK;
 }
 
-extern "C" int zr_get_pass_times(zr_ctx* c, float ms[ZR_PASS_COUNT])
+// Mean per-pass GPU time over the last `last_n` frames (<= EV_RING), from hipEvents recorded on the render stream.
+extern "C" int zr_get_pass_times_avg(zr_ctx* c, uint32_t last_n, float ms[ZR_PASS_COUNT])
 {
     if (!c || !ms) return ZR_ERR_ARG;
     if (!c->rendered) return zr_fail(c, ZR_ERR_STATE, "nothing rendered yet");
     int rc = zr_finish(c);
     if (rc && rc != ZR_ERR_OVERFLOW) return rc;
-    for (int i = 0; i < ZR_PASS_COUNT; ++i) ms[i] = 0.0f;
-    (void)hipEventElapsedTime(&ms[ZR_PASS_CULL_SHADOW], c->ev[0], c->ev[1]);
-    (void)hipEventElapsedTime(&ms[ZR_PASS_SHADOW], c->ev[1], c->ev[2]);
-    (void)hipEventElapsedTime(&ms[ZR_PASS_CULL_CAMERA], c->ev[2], c->ev[3]);
-    (void)hipEventElapsedTime(&ms[ZR_PASS_GBUFFER], c->ev[3], c->ev[4]);
-    (void)hipEventElapsedTime(&ms[ZR_PASS_LIGHTING], c->ev[4], c->ev[5]);
-    (void)hipEventElapsedTime(&ms[ZR_PASS_TOTAL], c->ev[0], c->ev[5]);
+    if (last_n == 0) last_n = 1;
+    if (last_n > (uint32_t)zr_ctx::EV_RING) last_n = zr_ctx::EV_RING;
+    if ((uint64_t)last_n > c->frame_no) last_n = (uint32_t)c->frame_no;
+    double acc[ZR_PASS_COUNT] = { 0 };
+    for (uint32_t k = 0; k < last_n; ++k) {
+        hipEvent_t* ev = c->evr[(c->frame_no - 1 - k) % zr_ctx::EV_RING];
+        float t[ZR_PASS_COUNT] = { 0 };
+        (void)hipEventElapsedTime(&t[ZR_PASS_CULL_SHADOW], ev[0], ev[1]);
+        (void)hipEventElapsedTime(&t[ZR_PASS_SHADOW], ev[1], ev[2]);
+        (void)hipEventElapsedTime(&t[ZR_PASS_CULL_CAMERA], ev[2], ev[3]);
+        (void)hipEventElapsedTime(&t[ZR_PASS_GBUFFER], ev[3], ev[4]);
+        (void)hipEventElapsedTime(&t[ZR_PASS_LIGHTING], ev[4], ev[5]);
+        (void)hipEventElapsedTime(&t[ZR_PASS_TOTAL], ev[0], ev[5]);
+        for (int i = 0; i < ZR_PASS_COUNT; ++i) acc[i] += t[i];
+    }
+    for (int i = 0; i < ZR_PASS_COUNT; ++i) ms[i] = (float)(acc[i] / last_n);
     return ZR_OK;
 }
+extern "C" int zr_get_pass_times(zr_ctx* c, float ms[ZR_PASS_COUNT]) { return zr_get_pass_times_avg(c, 1, ms); }
 
 extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out)
 {
@@ -658,7 +670,7 @@ extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out)
     for (int i = 0; i < 2; ++i) {
         out->work_items[i] = c->last_work[i]; out->survivors[i] = c->h_stats.survivors[i]; out->bin_entries[i] = c->h_stats.bin_entries[i];
     }
-    out->covered_pixels = c->h_stats.covered; out->overflow = c->h_stats.overflow;
+    out->covered_pixels = c->h_stats.covered; out->covered_shadow_texels = c->h_stats.covered_shadow; out->overflow = c->h_stats.overflow;
     return rc;
 }
 

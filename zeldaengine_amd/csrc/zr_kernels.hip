@@ -619,14 +619,14 @@ __global__ __launch_bounds__(256) void k_raster(ZrPass P, const ZrObject* __rest
             ncov += prim != ZR_EMPTY_PRIM;
             resolve_pixel(P, objs, prim, zr_u2f((uint32_t)(k >> 32)), px, py, G);
         } else {
-            shadowmap[(size_t)py * P.W + (size_t)px] = zr_u2f(keys32[i]);
+            const uint32_t k = keys32[i];
+            ncov += k != 0x3F800000u;
+            shadowmap[(size_t)py * P.W + (size_t)px] = zr_u2f(k);
         }
     }
-    if (MODE == ZR_MODE_GBUFFER) {
-        if (ncov) atomicAdd(&covered_s, ncov);
-        __syncthreads();
-        if (tid == 0 && covered_s) atomicAdd(&stats->covered, covered_s);
-    }
+    if (ncov) atomicAdd(&covered_s, ncov);
+    __syncthreads();
+    if (tid == 0 && covered_s) atomicAdd(MODE == ZR_MODE_GBUFFER ? &stats->covered : &stats->covered_shadow, covered_s);
 }
 
 // ------------------------------------------------------------------------------------------------ lighting

@@ -64,6 +64,7 @@ struct ZrDevStats {
     uint32_t survivors[2];
     uint32_t bin_entries[2];
     uint32_t covered;
+    uint32_t covered_shadow;
     uint32_t overflow;
 };
 

@@ -54,6 +54,7 @@ def lib():
         "zr_render": [vp],
         "zr_finish": [vp],
         "zr_get_pass_times": [vp, vp],
+        "zr_get_pass_times_avg": [vp, u32, vp],
         "zr_get_stats": [vp, C.POINTER(abi.Stats)],
         "zr_read_color": [vp, vp, sz],
         "zr_read_gbuffer": [vp, C.c_int, vp, sz],
@@ -215,16 +216,17 @@ class Renderer:
     def finish(self):
         self._chk(self.L.zr_finish(self.h))
 
-    def pass_times(self):
+    def pass_times(self, last_n=1):
+        """Mean GPU milliseconds per pass over the last `last_n` (<= 64) frames."""
         ms = (C.c_float * len(abi.PASS_NAMES))()
-        self._chk(self.L.zr_get_pass_times(self.h, ms))
+        self._chk(self.L.zr_get_pass_times_avg(self.h, last_n, ms))
         return dict(zip(abi.PASS_NAMES, [float(x) for x in ms]))
 
     def stats(self):
         s = abi.Stats()
         self._chk(self.L.zr_get_stats(self.h, C.byref(s)))
         return {"work_items": list(s.work_items), "survivors": list(s.survivors), "bin_entries": list(s.bin_entries),
-                "covered_pixels": int(s.covered_pixels), "overflow": int(s.overflow)}
+                "covered_pixels": int(s.covered_pixels), "covered_shadow_texels": int(s.covered_shadow_texels), "overflow": int(s.overflow)}
 
     # ---- read-back
     def color(self):
