@@ -107,6 +107,10 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     ok &= dev_alloc(&c->d_tile_count, mt) == hipSuccess;
     ok &= dev_alloc(&c->d_tile_offset, mt) == hipSuccess;
     ok &= dev_alloc(&c->d_tile_cursor, mt) == hipSuccess;
+    ok &= dev_alloc(&c->d_chunk_offset, mt) == hipSuccess;
+    ok &= dev_alloc(&c->d_vis, n) == hipSuccess;
+    if (ok) { zr_launch_fill64(c->d_vis, (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM, n, c->stream); ok &= hipStreamSynchronize(c->stream) == hipSuccess; }
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->raster_blocks = (uint32_t)prop.multiProcessorCount * 8u; }
     if (ok) ok &= hipMemset(c->d_tile_count, 0, mt * 4) == hipSuccess;
     if (!ok) { zr_destroy(c); return ZR_ERR_DEVICE; }
     if (zr_set_cubemap(c, nullptr, 0) != ZR_OK) { zr_destroy(c); return ZR_ERR_DEVICE; }
@@ -137,7 +141,7 @@ extern "C" void zr_destroy(zr_ctx* c)
     dev_free(c->G.depth); dev_free(c->G.scene_color); dev_free(c->G.gA); dev_free(c->G.gB); dev_free(c->G.gC); dev_free(c->G.gD);
     dev_free(c->d_color); dev_free(c->d_shadow); dev_free(c->d_view); dev_free(c->d_stats); dev_free(c->d_lut);
     dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles);
-    dev_free(c->d_tile_count); dev_free(c->d_tile_offset); dev_free(c->d_tile_cursor); dev_free(c->d_rects); dev_free(c->d_bins);
+    dev_free(c->d_tile_count); dev_free(c->d_tile_offset); dev_free(c->d_tile_cursor); dev_free(c->d_chunk_offset); dev_free(c->d_vis); dev_free(c->d_rects); dev_free(c->d_bins);
     for (auto& fr : c->evr) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -570,14 +574,14 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
 
 // ------------------------------------------------------------------------------------------------ the frame
 
-static void geometry_pass(zr_ctx* c, const ZrPass& P, int slot, const uint32_t* d_owned, uint32_t n_owned, uint32_t n_tiles,
-                          hipEvent_t after_bin)
+static void geometry_pass(zr_ctx* c, const ZrPass& P, int slot, uint32_t n_tiles, hipEvent_t after_bin)
 {
     zr_launch_cull(P, c->d_objs, c->d_rects, c->d_tile_count, c->stream);
-    zr_launch_scan(c->d_tile_count, c->d_tile_offset, c->d_tile_cursor, n_tiles, c->bin_capacity, c->d_stats, slot, c->stream);
+    zr_launch_scan(c->d_tile_count, c->d_tile_offset, c->d_tile_cursor, c->d_chunk_offset, n_tiles, c->bin_capacity, c->d_stats, slot, c->stream);
     zr_launch_bin_fill(P, c->d_rects, c->d_tile_offset, c->d_tile_cursor, c->d_bins, c->d_stats, slot, c->stream);
     (void)hipEventRecord(after_bin, c->stream);
-    zr_launch_raster(P, c->d_objs, d_owned, n_owned, c->d_tile_offset, c->d_bins, c->G, c->d_shadow, c->d_stats, c->stream);
+    zr_launch_raster_chunks(P, c->d_objs, c->d_tile_offset, c->d_chunk_offset, c->d_bins, c->d_stats, slot, c->d_vis,
+                            (uint32_t*)c->d_shadow, c->raster_blocks, c->stream);
 }
 
 // RecordCommandBuffer (ZE:3160-3744) + vkQueueSubmit (ZE:2014): shadow -> deferred scene -> deferred lighting
@@ -600,13 +604,15 @@ extern "C" int zr_render(zr_ctx* c)
     bool live = build_pass(c, c->shadow, ZR_MODE_SHADOW, &P);
     if (!live) P.n_work = 0;      // no finite vertex: the pass is its clear
     c->last_work[0] = P.n_work;
-    geometry_pass(c, P, 0, c->d_sowned, c->sn_tiles, c->sn_tiles, ev[1]);
+    zr_launch_fill32((uint32_t*)c->d_shadow, 0x3F800000u, (size_t)c->SD * c->SD, s);      // clear depth 1.0, ZE:3248
+    geometry_pass(c, P, 0, c->sn_tiles, ev[1]);
     HIPCHK(c, hipEventRecord(ev[2], s));
     // deferred-scene pass (ZE:3417-3480)
     live = build_pass(c, c->cam, ZR_MODE_GBUFFER, &P);
     if (!live) P.n_work = 0;
     c->last_work[1] = P.n_work;
-    geometry_pass(c, P, 1, c->d_owned, c->n_owned, c->n_tiles, ev[3]);
+    geometry_pass(c, P, 1, c->n_tiles, ev[3]);
+    zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_stats, s);
     HIPCHK(c, hipEventRecord(ev[4], s));
     // deferred-lighting pass (ZE:3531-3540)
     ZrLightParams L; memset(&L, 0, sizeof L);
@@ -630,6 +636,7 @@ extern "C" int zr_finish(zr_ctx* c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->rendered) {
         HIPCHK(c, hipMemcpy(&c->h_stats, c->d_stats, sizeof(ZrDevStats), hipMemcpyDeviceToHost));
+        c->h_stats.covered_shadow = 0;
         if (c->h_stats.overflow) return zr_fail(c, ZR_ERR_OVERFLOW, "tile bin list overflow: frame is incomplete");
     }
     return ZR_OK;
@@ -666,6 +673,14 @@ extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out)
 {
     if (!c || !out) return ZR_ERR_ARG;
     int rc = zr_finish(c);
+    if (c->rendered && (rc == ZR_OK || rc == ZR_ERR_OVERFLOW)) {      // shadow coverage is a statistic, counted on demand
+        ZrDevStats z; (void)hipMemcpy(&z, c->d_stats, sizeof z, hipMemcpyDeviceToHost);
+        uint32_t zero = 0;
+        (void)hipMemcpy(&c->d_stats->covered_shadow, &zero, 4, hipMemcpyHostToDevice);
+        zr_launch_count_shadow((const uint32_t*)c->d_shadow, (size_t)c->SD * c->SD, c->d_stats, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipMemcpy(&c->h_stats, c->d_stats, sizeof(ZrDevStats), hipMemcpyDeviceToHost);
+    }
     memset(out, 0, sizeof *out);
     for (int i = 0; i < 2; ++i) {
         out->work_items[i] = c->last_work[i]; out->survivors[i] = c->h_stats.survivors[i]; out->bin_entries[i] = c->h_stats.bin_entries[i];

@@ -5,10 +5,10 @@
 //                     lane-per-vertex transform, exact snapped screen bbox -> tile rect + tile counters
 //   k_scan            exclusive scan of the per-tile counters (one workgroup)
 //   k_bin_fill        scatter meshlet-instance ids into per-tile lists
-//   k_raster<MODE>    one workgroup per 32x32 screen tile: per wave, stage a meshlet's transformed
-//                     vertices in LDS, set up <=124 triangles (2 per lane), rasterise into the tile's
-//                     LDS depth/visibility keys with ds_min; then resolve BaseScene.frag per pixel and
-//                     write the SoA GBuffer planes (or the shadow-map tile) with coalesced row stores
+//   k_raster_chunks<MODE>  persistent workgroups pull chunks (<= ZR_CHUNK entries of one 32x32 tile's list): per wave,
+//                     stage a meshlet's transformed vertices in LDS, set up <=124 triangles (2 per lane), rasterise
+//                     into the tile's LDS depth/visibility keys with ds_min; merge touched keys into HBM (atomic min)
+//   k_resolve_gbuffer BaseScene.frag per pixel from the key buffer; SoA GBuffer planes, coalesced row stores
 //   k_lighting        BaseLighting.frag per pixel (PCF 5x5, all lights, ambient, cubemap IBL, gamma)
 //   k_untile          multi-GPU composite: all-gathered packed tiles -> row-major frame
 //
@@ -214,34 +214,40 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
         rects[w] = mine ? ((uint32_t)tx0 | (uint32_t)ty0 << 8 | (uint32_t)tx1 << 16 | (uint32_t)ty1 << 24) : ZR_RECT_CULLED;
 }
 
-// Exclusive scan of tile_count[0..n) into tile_offset[0..n]; zeroes tile_count and tile_cursor for the fill.
+// Exclusive scan of tile_count[0..n) into tile_offset[0..n] and of the per-tile chunk counts ceil(count / ZR_CHUNK)
+// into chunk_offset[0..n]; zeroes tile_count and tile_cursor for the fill and resets the chunk work counter.
 __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
-                                               uint32_t* __restrict__ tile_cursor, uint32_t n, uint32_t capacity,
-                                               ZrDevStats* __restrict__ stats, int slot)
+                                               uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ chunk_offset,
+                                               uint32_t n, uint32_t capacity, ZrDevStats* __restrict__ stats, int slot)
 {
     __shared__ uint32_t part[1024];
+    __shared__ uint32_t cpart[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t b = tid * per, e = min(n, b + per);
-    uint32_t s = 0;
-    for (uint32_t i = b; i < e; ++i) s += tile_count[i];
-    part[tid] = s;
+    uint32_t s = 0, cs = 0;
+    for (uint32_t i = b; i < e; ++i) { const uint32_t c = tile_count[i]; s += c; cs += (c + ZR_CHUNK - 1u) / ZR_CHUNK; }
+    part[tid] = s; cpart[tid] = cs;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t v = (tid >= off) ? part[tid - off] : 0u;
+        const uint32_t v = (tid >= off) ? part[tid - off] : 0u, cv = (tid >= off) ? cpart[tid - off] : 0u;
         __syncthreads();
-        part[tid] += v;
+        part[tid] += v; cpart[tid] += cv;
         __syncthreads();
     }
-    uint32_t run = part[tid] - s;
+    uint32_t run = part[tid] - s, crun = cpart[tid] - cs;
     for (uint32_t i = b; i < e; ++i) {
-        uint32_t c = tile_count[i];
+        const uint32_t c = tile_count[i];
         tile_offset[i] = run; run += c;
+        chunk_offset[i] = crun; crun += (c + ZR_CHUNK - 1u) / ZR_CHUNK;
         tile_count[i] = 0; tile_cursor[i] = 0;
     }
     if (tid == 1023) {
         tile_offset[n] = part[1023];
+        chunk_offset[n] = cpart[1023];
         stats->bin_entries[slot] = part[1023];
+        stats->n_chunks[slot] = cpart[1023];
+        stats->chunk_counter[slot] = 0;
         if (part[1023] > capacity) stats->overflow = 1u;
     }
 }
@@ -529,104 +535,163 @@ __device__ __forceinline__ void resolve_pixel(const ZrPass& P, const ZrObject* _
     G.gD[p] = make_uint2(zr_f32_to_f16(P0.x) | zr_f32_to_f16(P0.y) << 16, zr_f32_to_f16(P0.z) | 0x3C000000u);
 }
 
-// ------------------------------------------------------------------------------------------------ tile raster kernel
+// ------------------------------------------------------------------------------------------------ tile raster kernels
 
+__global__ void k_fill32(uint32_t* __restrict__ p, uint32_t v, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void k_fill64(unsigned long long* __restrict__ p, unsigned long long v, size_t n)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// Persistent chunk rasteriser.  A chunk = up to ZR_CHUNK consecutive entries of ONE tile's bin list, so a hot tile is
+// spread over many workgroups and the pass is bounded by total work, not by the fullest tile.  Every workgroup pulls
+// chunk ids from one device counter until they run out (each wave reaches the exit test).  Per chunk: clear the
+// tile's LDS keys, 4 waves rasterise the chunk's meshlets into them (ds_min), then the touched keys are merged into
+// the frame-sized key buffer in HBM with global atomic min (skipped when the resident key already wins).
+//   GBUFFER: vis64[W*H] (depth bits << 32 | prim), resolved later by k_resolve_gbuffer
+//   SHADOW : the shadow map itself (float bits as uint): the merge IS the LESS_OR_EQUAL depth write
 template <int MODE>
-__global__ __launch_bounds__(256) void k_raster(ZrPass P, const ZrObject* __restrict__ objs,
-                                                const uint32_t* __restrict__ owned_tiles,
-                                                const uint32_t* __restrict__ tile_offset, const uint32_t* __restrict__ bins,
-                                                GBufferPtrs G, float* __restrict__ shadowmap, ZrDevStats* __restrict__ stats)
+__global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs,
+                                                       const uint32_t* __restrict__ tile_offset,
+                                                       const uint32_t* __restrict__ chunk_offset,
+                                                       const uint32_t* __restrict__ bins, ZrDevStats* __restrict__ stats, int slot,
+                                                       unsigned long long* __restrict__ vis64, uint32_t* __restrict__ shadow_bits)
 {
     __shared__ unsigned long long keys64[MODE == ZR_MODE_GBUFFER ? TILE_PIX : 1];
     __shared__ uint32_t keys32[MODE == ZR_MODE_SHADOW ? TILE_PIX : 1];
     __shared__ int4 vstage[4][WAVE];
     __shared__ uint32_t fstage[4][WAVE];
-    __shared__ uint32_t covered_s;
+    __shared__ uint32_t cur_chunk;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const uint32_t tile = owned_tiles[blockIdx.x];
-    TileCtx T;
-    T.px0 = (int)(tile % P.tiles_x) * TILE; T.py0 = (int)(tile / P.tiles_x) * TILE; T.W = (int)P.W; T.H = (int)P.H;
+    const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    const uint32_t n_chunks = stats->n_chunks[slot];
 
-    for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
-        if (MODE == ZR_MODE_GBUFFER) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
-        else keys32[i] = 0x3F800000u;
-    }
-    if (tid == 0) covered_s = 0;
-    __syncthreads();
-
-    const uint32_t beg = tile_offset[tile];
-    const uint32_t end = min(tile_offset[tile + 1], P.bin_capacity);
-    for (uint32_t e = beg + wv; e < end; e += 4u) {
-        const uint32_t w = wave_uniform(bins[e]);
-        const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w);
-        const uint32_t local = w - O->work_base;
-        const uint32_t nm = O->n_meshlets;
-        const uint32_t inst_i = local / nm, m = local - inst_i * nm;
-        const XkMeshlet ml = O->meshlets[m];
-        const ZrInstance I = O->inst[inst_i];
-        const bool instanced = O->instanced != 0;
-
-        lds_fence();   // previous iteration's readers are done with this wave's staging area
-        if (lane < ml.VertexCount) {
-            const uint32_t vi = O->mverts[ml.VertexOffset + lane];
-            const float* pp = O->verts[vi].Position;
-            const zf4 c = zr_mat4_point(P.PVM, vs_position(zr3(pp[0], pp[1], pp[2]), I, instanced));
-            const uint32_t f = vertex_flags(c);
-            SV s; s.X = 0; s.Y = 0; s.z = 0.0f; s.rw = 0.0f;
-            if (!(f & 129u)) s = project(c, P.hw, P.hh);
-            vstage[wv][lane] = make_int4(s.X, s.Y, (int)zr_f2u(s.z), (int)zr_f2u(s.rw));
-            fstage[wv][lane] = f;
+    for (;;) {
+        if (tid == 0) cur_chunk = atomicAdd(&stats->chunk_counter[slot], 1u);
+        for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
+            if (MODE == ZR_MODE_GBUFFER) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
+            else keys32[i] = 0x3F800000u;
         }
-        lds_fence();
+        __syncthreads();
+        const uint32_t chunk = cur_chunk;
+        if (chunk >= n_chunks) break;
+        // tile = last t with chunk_offset[t] <= chunk (tiles without entries have zero-width ranges and are skipped)
+        uint32_t lo = 0, hi = n_tiles;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (chunk_offset[mid] <= chunk) lo = mid; else hi = mid; }
+        const uint32_t tile = lo;
+        const uint32_t beg = tile_offset[tile] + (chunk - chunk_offset[tile]) * ZR_CHUNK;
+        const uint32_t end = min(min(beg + ZR_CHUNK, tile_offset[tile + 1]), P.bin_capacity);
+        TileCtx T;
+        T.px0 = (int)(tile % P.tiles_x) * TILE; T.py0 = (int)(tile / P.tiles_x) * TILE; T.W = (int)P.W; T.H = (int)P.H;
 
-        const uint32_t pbase = O->prim_base + inst_i * O->n_tris;
-        for (uint32_t t = lane; t < ml.TriangleCount; t += WAVE) {
-            const uint8_t* tp = O->mtris + ml.TriangleOffset + 3u * t;
-            const uint32_t i0 = tp[0], i1 = tp[1], i2 = tp[2];
-            const uint32_t f0 = fstage[wv][i0], f1 = fstage[wv][i1], f2 = fstage[wv][i2];
-            const int cls = classify(f0, f1, f2);
-            if (cls == 0) continue;
-            const uint32_t prim = pbase + O->tri_order[ml.BindlessContext + t];
-            if (cls == 1) {
-                const int4 r0 = vstage[wv][i0], r1 = vstage[wv][i1], r2 = vstage[wv][i2];
-                SV a, b, c;
-                a.X = r0.x; a.Y = r0.y; a.z = zr_u2f((uint32_t)r0.z); a.rw = zr_u2f((uint32_t)r0.w);
-                b.X = r1.x; b.Y = r1.y; b.z = zr_u2f((uint32_t)r1.z); b.rw = zr_u2f((uint32_t)r1.w);
-                c.X = r2.x; c.Y = r2.y; c.z = zr_u2f((uint32_t)r2.z); c.rw = zr_u2f((uint32_t)r2.w);
-                raster_sub<MODE>(a, b, c, prim, T, keys64, keys32);
-            } else {
-                zf4 cc[3];
-                const uint32_t li[3] = { i0, i1, i2 };
-                for (int k = 0; k < 3; ++k) {
-                    const float* pp = O->verts[O->mverts[ml.VertexOffset + li[k]]].Position;
-                    cc[k] = zr_mat4_point(P.PVM, vs_position(zr3(pp[0], pp[1], pp[2]), I, instanced));
+        for (uint32_t e = beg + wv; e < end; e += 4u) {
+            const uint32_t w = wave_uniform(bins[e]);
+            const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w);
+            const uint32_t local = w - O->work_base;
+            const uint32_t nm = O->n_meshlets;
+            const uint32_t inst_i = local / nm, m = local - inst_i * nm;
+            const XkMeshlet ml = O->meshlets[m];
+            const ZrInstance I = O->inst[inst_i];
+            const bool instanced = O->instanced != 0;
+
+            lds_fence();   // this wave's previous readers are done with its staging area
+            if (lane < ml.VertexCount) {
+                const uint32_t vi = O->mverts[ml.VertexOffset + lane];
+                const float* pp = O->verts[vi].Position;
+                const zf4 c = zr_mat4_point(P.PVM, vs_position(zr3(pp[0], pp[1], pp[2]), I, instanced));
+                const uint32_t f = vertex_flags(c);
+                SV s; s.X = 0; s.Y = 0; s.z = 0.0f; s.rw = 0.0f;
+                if (!(f & 129u)) s = project(c, P.hw, P.hh);
+                vstage[wv][lane] = make_int4(s.X, s.Y, (int)zr_f2u(s.z), (int)zr_f2u(s.rw));
+                fstage[wv][lane] = f;
+            }
+            lds_fence();
+
+            const uint32_t pbase = O->prim_base + inst_i * O->n_tris;
+            for (uint32_t t = lane; t < ml.TriangleCount; t += WAVE) {
+                const uint8_t* tp = O->mtris + ml.TriangleOffset + 3u * t;
+                const uint32_t i0 = tp[0], i1 = tp[1], i2 = tp[2];
+                const uint32_t f0 = fstage[wv][i0], f1 = fstage[wv][i1], f2 = fstage[wv][i2];
+                const int cls = classify(f0, f1, f2);
+                if (cls == 0) continue;
+                const uint32_t prim = MODE == ZR_MODE_GBUFFER ? pbase + O->tri_order[ml.BindlessContext + t] : 0u;
+                if (cls == 1) {
+                    const int4 r0 = vstage[wv][i0], r1 = vstage[wv][i1], r2 = vstage[wv][i2];
+                    SV a, b, c;
+                    a.X = r0.x; a.Y = r0.y; a.z = zr_u2f((uint32_t)r0.z); a.rw = zr_u2f((uint32_t)r0.w);
+                    b.X = r1.x; b.Y = r1.y; b.z = zr_u2f((uint32_t)r1.z); b.rw = zr_u2f((uint32_t)r1.w);
+                    c.X = r2.x; c.Y = r2.y; c.z = zr_u2f((uint32_t)r2.z); c.rw = zr_u2f((uint32_t)r2.w);
+                    raster_sub<MODE>(a, b, c, prim, T, keys64, keys32);
+                } else {
+                    zf4 cc[3];
+                    const uint32_t li[3] = { i0, i1, i2 };
+                    for (int k = 0; k < 3; ++k) {
+                        const float* pp = O->verts[O->mverts[ml.VertexOffset + li[k]]].Position;
+                        cc[k] = zr_mat4_point(P.PVM, vs_position(zr3(pp[0], pp[1], pp[2]), I, instanced));
+                    }
+                    raster_clipped<MODE>(cc[0], cc[1], cc[2], prim, T, P.hw, P.hh, keys64, keys32);
                 }
-                raster_clipped<MODE>(cc[0], cc[1], cc[2], prim, T, P.hw, P.hh, keys64, keys32);
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 
-    // resolve: row-major within the tile -> 128 B (256 B for GBufferD) contiguous row segments per wave
-    uint32_t ncov = 0;
-    for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
-        const int px = T.px0 + (int)(i & (TILE - 1)), py = T.py0 + (int)(i / TILE);
-        if (px >= T.W || py >= T.H) continue;
-        if (MODE == ZR_MODE_GBUFFER) {
-            const unsigned long long k = keys64[i];
-            const uint32_t prim = (uint32_t)k;
-            ncov += prim != ZR_EMPTY_PRIM;
-            resolve_pixel(P, objs, prim, zr_u2f((uint32_t)(k >> 32)), px, py, G);
-        } else {
-            const uint32_t k = keys32[i];
-            ncov += k != 0x3F800000u;
-            shadowmap[(size_t)py * P.W + (size_t)px] = zr_u2f(k);
+        // merge the touched keys into HBM
+        for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
+            const int px = T.px0 + (int)(i & (TILE - 1)), py = T.py0 + (int)(i / TILE);
+            if (px >= T.W || py >= T.H) continue;
+            const size_t p = (size_t)py * P.W + (size_t)px;
+            if (MODE == ZR_MODE_GBUFFER) {
+                const unsigned long long k = keys64[i];
+                if ((uint32_t)k != ZR_EMPTY_PRIM && k < vis64[p]) atomicMin(&vis64[p], k);
+            } else {
+                const uint32_t k = keys32[i];
+                if (k < shadow_bits[p]) atomicMin(&shadow_bits[p], k);
+            }
         }
+        __syncthreads();   // keys are re-cleared at the top of the loop
+    }
+}
+
+// BaseScene.frag for every pixel of the owned tiles, from the frame's key buffer; resets the keys for the next frame.
+__global__ __launch_bounds__(256) void k_resolve_gbuffer(ZrPass P, const ZrObject* __restrict__ objs,
+                                                         const uint32_t* __restrict__ owned_tiles,
+                                                         unsigned long long* __restrict__ vis64, GBufferPtrs G,
+                                                         ZrDevStats* __restrict__ stats)
+{
+    __shared__ uint32_t covered_s;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = owned_tiles[blockIdx.x];
+    const int tx0 = (int)(tile % P.tiles_x) * TILE, ty0 = (int)(tile / P.tiles_x) * TILE;
+    if (tid == 0) covered_s = 0;
+    __syncthreads();
+    uint32_t ncov = 0;
+    // row-major within the tile -> 128 B (256 B for GBufferD / keys) contiguous row segments per wave
+    for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
+        const int px = tx0 + (int)(i & (TILE - 1)), py = ty0 + (int)(i / TILE);
+        if (px >= (int)P.W || py >= (int)P.H) continue;
+        const size_t p = (size_t)py * P.W + (size_t)px;
+        const unsigned long long k = vis64[p];
+        vis64[p] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
+        const uint32_t prim = (uint32_t)k;
+        ncov += prim != ZR_EMPTY_PRIM;
+        resolve_pixel(P, objs, prim, zr_u2f((uint32_t)(k >> 32)), px, py, G);
     }
     if (ncov) atomicAdd(&covered_s, ncov);
     __syncthreads();
-    if (tid == 0 && covered_s) atomicAdd(MODE == ZR_MODE_GBUFFER ? &stats->covered : &stats->covered_shadow, covered_s);
+    if (tid == 0 && covered_s) atomicAdd(&stats->covered, covered_s);
+}
+
+// statistics only (not part of the frame): shadow-map texels with depth < 1
+__global__ void k_count_shadow(const uint32_t* __restrict__ bits, size_t n, ZrDevStats* __restrict__ stats)
+{
+    uint32_t c = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += bits[i] != 0x3F800000u;
+    for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+    if ((threadIdx.x & 63u) == 0 && c) atomicAdd(&stats->covered_shadow, c);
 }
 
 // ------------------------------------------------------------------------------------------------ lighting
@@ -867,10 +932,10 @@ void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* rects, uint
     if (P.mode == ZR_MODE_GBUFFER) hipLaunchKernelGGL(k_cull<ZR_MODE_GBUFFER>, g, b, 0, s, P, objs, rects, tile_count);
     else hipLaunchKernelGGL(k_cull<ZR_MODE_SHADOW>, g, b, 0, s, P, objs, rects, tile_count);
 }
-void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t n, uint32_t capacity,
-                    ZrDevStats* stats, int slot, hipStream_t s)
+void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint32_t n,
+                    uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, n, capacity, stats, slot);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, chunk_offset, n, capacity, stats, slot);
 }
 void zr_launch_bin_fill(const ZrPass& P, const uint32_t* rects, const uint32_t* tile_offset, uint32_t* tile_cursor,
                         uint32_t* bins, ZrDevStats* stats, int slot, hipStream_t s)
@@ -878,15 +943,32 @@ void zr_launch_bin_fill(const ZrPass& P, const uint32_t* rects, const uint32_t* 
     if (P.n_work == 0) return;
     hipLaunchKernelGGL(k_bin_fill, dim3((P.n_work + 255) / 256), dim3(256), 0, s, P, rects, tile_offset, tile_cursor, bins, stats, slot);
 }
-void zr_launch_raster(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
-                      const uint32_t* tile_offset, const uint32_t* bins, const GBufferPtrs& G, float* shadowmap,
-                      ZrDevStats* stats, hipStream_t s)
+void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fill32, dim3(1024), dim3(256), 0, s, p, v, n);
+}
+void zr_launch_fill64(unsigned long long* p, unsigned long long v, size_t n, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_fill64, dim3(1024), dim3(256), 0, s, p, v, n);
+}
+void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint32_t* tile_offset, const uint32_t* chunk_offset,
+                             const uint32_t* bins, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t* shadow_bits,
+                             uint32_t n_blocks, hipStream_t s)
+{
+    if (P.mode == ZR_MODE_GBUFFER)
+        hipLaunchKernelGGL(k_raster_chunks<ZR_MODE_GBUFFER>, dim3(n_blocks), dim3(256), 0, s, P, objs, tile_offset, chunk_offset, bins, stats, slot, vis64, shadow_bits);
+    else
+        hipLaunchKernelGGL(k_raster_chunks<ZR_MODE_SHADOW>, dim3(n_blocks), dim3(256), 0, s, P, objs, tile_offset, chunk_offset, bins, stats, slot, vis64, shadow_bits);
+}
+void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
+                               unsigned long long* vis64, const GBufferPtrs& G, ZrDevStats* stats, hipStream_t s)
 {
     if (n_owned == 0) return;
-    if (P.mode == ZR_MODE_GBUFFER)
-        hipLaunchKernelGGL(k_raster<ZR_MODE_GBUFFER>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, tile_offset, bins, G, shadowmap, stats);
-    else
-        hipLaunchKernelGGL(k_raster<ZR_MODE_SHADOW>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, tile_offset, bins, G, shadowmap, stats);
+    hipLaunchKernelGGL(k_resolve_gbuffer, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, stats);
+}
+void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_count_shadow, dim3(256), dim3(256), 0, s, bits, n, stats);
 }
 void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32_t* owned_tiles, uint32_t n_owned,
                         const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C, const float* lut, uint32_t* out, hipStream_t s)

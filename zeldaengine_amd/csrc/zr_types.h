@@ -9,6 +9,7 @@
 #define ZR_EMPTY_PRIM 0xFFFFFFFFu
 #define ZR_GUARD 4.0f                       // guard band, multiples of w
 #define ZR_RECT_CULLED 0xFFFFFFFFu
+#define ZR_CHUNK 32u                         // bin entries (meshlet-instances) per raster work unit
 
 enum { ZR_MODE_GBUFFER = 0, ZR_MODE_SHADOW = 1 };
 
@@ -66,6 +67,8 @@ struct ZrDevStats {
     uint32_t covered;
     uint32_t covered_shadow;
     uint32_t overflow;
+    uint32_t n_chunks[2];
+    uint32_t chunk_counter[2];
 };
 
 // Uniforms of the lighting pass that are not in XkView.
@@ -89,13 +92,18 @@ struct CubeDesc { const uint8_t* levels[16]; };
 // launchers defined in zr_kernels.hip
 void zr_launch_instance_prep(const XkInstanceData* in, ZrInstance* out, uint32_t n, uint32_t instanced, hipStream_t s);
 void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* rects, uint32_t* tile_count, hipStream_t s);
-void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t n, uint32_t capacity,
-                    ZrDevStats* stats, int slot, hipStream_t s);
+void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint32_t n,
+                    uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s);
 void zr_launch_bin_fill(const ZrPass& P, const uint32_t* rects, const uint32_t* tile_offset, uint32_t* tile_cursor,
                         uint32_t* bins, ZrDevStats* stats, int slot, hipStream_t s);
-void zr_launch_raster(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
-                      const uint32_t* tile_offset, const uint32_t* bins, const GBufferPtrs& G, float* shadowmap,
-                      ZrDevStats* stats, hipStream_t s);
+void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s);
+void zr_launch_fill64(unsigned long long* p, unsigned long long v, size_t n, hipStream_t s);
+void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint32_t* tile_offset, const uint32_t* chunk_offset,
+                             const uint32_t* bins, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t* shadow_bits,
+                             uint32_t n_blocks, hipStream_t s);
+void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
+                               unsigned long long* vis64, const GBufferPtrs& G, ZrDevStats* stats, hipStream_t s);
+void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, hipStream_t s);
 void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32_t* owned_tiles, uint32_t n_owned,
                         const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C, const float* lut, uint32_t* out,
                         hipStream_t s);
