@@ -404,12 +404,12 @@ static int zo_finite4(zo_v4 a)
 static zo_sv zo_project(zo_v4 c, float hw, float hh)
 {
     zo_sv s;
-    float nx = c.x / c.w, ny = c.y / c.w;
+    s.rw = 1.0f / c.w;                       /* perspective divide: one IEEE reciprocal, then multiplies */
+    float nx = c.x * s.rw, ny = c.y * s.rw;
     float xs = fmaf(nx, hw, hw), ys = fmaf(ny, hh, hh);
     s.X = (int32_t)floorf(fmaf(xs, 256.0f, 0.5f));
     s.Y = (int32_t)floorf(fmaf(ys, 256.0f, 0.5f));
-    s.z = c.z / c.w;
-    s.rw = 1.0f / c.w;
+    s.z = c.z * s.rw;
     return s;
 }
 
@@ -498,9 +498,9 @@ static int zo_tri_setup(const zo_sv v[3], int cull_back, zo_setup* s)
         s->ax[e] = v[ea[e]].X; s->ay[e] = v[ea[e]].Y;
         s->tl[e] = (s->ey[e] < 0) || (s->ey[e] == 0 && s->ex[e] > 0);
     }
-    float fA = (float)A;
-    s->a1 = (float)(v[2].Y - v[0].Y) / fA; s->b1 = (float)(v[0].X - v[2].X) / fA;
-    s->a2 = (float)(v[0].Y - v[1].Y) / fA; s->b2 = (float)(v[1].X - v[0].X) / fA;
+    float invA = 1.0f / (float)A;
+    s->a1 = (float)(v[2].Y - v[0].Y) * invA; s->b1 = (float)(v[0].X - v[2].X) * invA;
+    s->a2 = (float)(v[0].Y - v[1].Y) * invA; s->b2 = (float)(v[1].X - v[0].X) * invA;
     float dz1 = v[1].z - v[0].z, dz2 = v[2].z - v[0].z;
     s->z0 = v[0].z;
     s->gx = fmaf(s->a2, dz2, s->a1 * dz1);

@@ -18,7 +18,7 @@ struct ZrMesh {
     bool has_meshlets = false, uploaded = false;
     float center[3] = { 0, 0, 0 }; float radius = 0;
     XkVertex* d_v = nullptr; uint32_t* d_idx = nullptr; XkMeshlet* d_meshlets = nullptr;
-    uint32_t* d_mverts = nullptr; uint8_t* d_mtris = nullptr; uint32_t* d_tri_order = nullptr;
+    float4* d_mpos = nullptr; uint2* d_mtri = nullptr;
 };
 
 struct ZrSceneObject {

@@ -92,6 +92,7 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     // screen tiles: camera target partitioned t % world == rank; the shadow map is rendered whole on every rank
     c->tiles_x = (c->W + ZR_TILE - 1) / ZR_TILE; c->tiles_y = (c->H + ZR_TILE - 1) / ZR_TILE; c->n_tiles = c->tiles_x * c->tiles_y;
     c->stiles_x = (c->SD + ZR_TILE - 1) / ZR_TILE; c->stiles_y = c->stiles_x; c->sn_tiles = c->stiles_x * c->stiles_y;
+    if (c->n_tiles > 16384u || c->sn_tiles > 16384u) { zr_destroy(c); return ZR_ERR_ARG; }   // binning histograms live in 64 KB of LDS
     c->slots_per_rank = (c->n_tiles + c->cfg.tile_world - 1) / c->cfg.tile_world;
     std::vector<uint32_t> owned, sowned(c->sn_tiles);
     for (uint32_t t = c->cfg.tile_rank; t < c->n_tiles; t += c->cfg.tile_world) owned.push_back(t);
@@ -123,7 +124,7 @@ static void free_scene(zr_ctx* c)
     for (auto& o : c->objects) dev_free(o.d_inst);
     c->objects.clear();
     for (auto& m : c->meshes) {
-        dev_free(m.d_v); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mverts); dev_free(m.d_mtris); dev_free(m.d_tri_order);
+        dev_free(m.d_v); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mtri);
     }
     c->meshes.clear();
     c->profabs.clear();
@@ -331,8 +332,21 @@ static int finalize_scene(zr_ctx* c)
         double r = 0;
         for (auto& v : m.v) { double dx = v.Position[0] - cx, dy = v.Position[1] - cy, dz = v.Position[2] - cz; r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz)); }
         m.center[0] = (float)cx; m.center[1] = (float)cy; m.center[2] = (float)cz; m.radius = (float)(r * 1.0001) + 1e-30f;
+        // flatten for the kernels: one coalesced 16 B load per meshlet vertex, one 8 B load per meshlet triangle
+        std::vector<float4> mpos(m.ms.mverts.size());
+        for (size_t i = 0; i < mpos.size(); ++i) {
+            const float* p = m.v[m.ms.mverts[i]].Position;
+            mpos[i] = make_float4(p[0], p[1], p[2], 1.0f);
+        }
+        std::vector<uint2> mtri(m.ms.tri_order.size());
+        for (const XkMeshlet& ml : m.ms.meshlets)
+            for (uint32_t t = 0; t < ml.TriangleCount; ++t) {
+                const uint8_t* tp = m.ms.mtris.data() + ml.TriangleOffset + 3u * t;
+                mtri[ml.BindlessContext + t] = make_uint2((uint32_t)tp[0] | (uint32_t)tp[1] << 8 | (uint32_t)tp[2] << 16,
+                                                          m.ms.tri_order[ml.BindlessContext + t]);
+            }
         HIPCHK(c, upload(&m.d_v, m.v)); HIPCHK(c, upload(&m.d_idx, m.idx)); HIPCHK(c, upload(&m.d_meshlets, m.ms.meshlets));
-        HIPCHK(c, upload(&m.d_mverts, m.ms.mverts)); HIPCHK(c, upload(&m.d_mtris, m.ms.mtris)); HIPCHK(c, upload(&m.d_tri_order, m.ms.tri_order));
+        HIPCHK(c, upload(&m.d_mpos, mpos)); HIPCHK(c, upload(&m.d_mtri, mtri));
         m.uploaded = true;
     }
     std::vector<ZrObject> tab;
@@ -342,8 +356,8 @@ static int finalize_scene(zr_ctx* c)
             if ((int)o.instanced != pass) continue;
             const ZrMesh& m = c->meshes[o.mesh];
             ZrObject d; memset(&d, 0, sizeof d);
-            d.verts = m.d_v; d.indices = m.d_idx; d.meshlets = m.d_meshlets; d.mverts = m.d_mverts; d.mtris = m.d_mtris;
-            d.tri_order = m.d_tri_order; d.inst = o.d_inst;
+            d.verts = m.d_v; d.indices = m.d_idx; d.meshlets = m.d_meshlets; d.mpos = m.d_mpos; d.mtri = m.d_mtri;
+            d.inst = o.d_inst;
             d.n_meshlets = (uint32_t)m.ms.meshlets.size(); d.n_tris = (uint32_t)(m.idx.size() / 3);
             d.n_inst = o.n_inst; d.instanced = o.instanced;
             d.work_base = (uint32_t)work; d.prim_base = (uint32_t)prim;

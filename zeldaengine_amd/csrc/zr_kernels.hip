@@ -21,6 +21,7 @@
 #define WAVE 64
 #define TILE ZR_TILE
 #define TILE_PIX (TILE * TILE)
+#define QCAP 128u
 
 // ------------------------------------------------------------------------------------------------ helpers
 
@@ -84,12 +85,12 @@ __device__ __forceinline__ int classify(uint32_t f0, uint32_t f1, uint32_t f2)
 __device__ __forceinline__ SV project(zf4 c, float hw, float hh)
 {
     SV s;
-    float nx = c.x / c.w, ny = c.y / c.w;
-    float xs = __builtin_fmaf(nx, hw, hw), ys = __builtin_fmaf(ny, hh, hh);
+    s.rw = 1.0f / c.w;                     // one IEEE reciprocal, then multiplies (the perspective divide)
+    const float nx = c.x * s.rw, ny = c.y * s.rw;
+    const float xs = __builtin_fmaf(nx, hw, hw), ys = __builtin_fmaf(ny, hh, hh);
     s.X = (int)__builtin_floorf(__builtin_fmaf(xs, 256.0f, 0.5f));
     s.Y = (int)__builtin_floorf(__builtin_fmaf(ys, 256.0f, 0.5f));
-    s.z = c.z / c.w;
-    s.rw = 1.0f / c.w;
+    s.z = c.z * s.rw;
     return s;
 }
 
@@ -132,13 +133,11 @@ __device__ __forceinline__ int wave_max(int v) { for (int o = 32; o > 0; o >>= 1
 __device__ __forceinline__ uint32_t wave_or(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o); return v; }
 __device__ __forceinline__ uint32_t wave_and(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v &= (uint32_t)__shfl_xor((int)v, o); return v; }
 
-// One wavefront per meshlet-instance.  Writes rects[w] (packed tile rect or ZR_RECT_CULLED) and bumps the
-// counters of the owned tiles the rect touches.  Every rejection here is exact or conservative:
+// One wavefront per meshlet-instance.  Writes rects[w] (packed tile rect or ZR_RECT_CULLED).  Every rejection here is exact or conservative:
 //   sphere-vs-frustum and the normal-cone test use inflated bounds;
 //   "all vertices outside one clip plane" and "snapped bbox holds no pixel centre" are exact.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restrict__ objs,
-                                              uint32_t* __restrict__ rects, uint32_t* __restrict__ tile_count)
+__global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restrict__ objs, uint32_t* __restrict__ rects)
 {
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t w = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
@@ -185,9 +184,8 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
     uint32_t f_or = 0, f_and = 0xFFu;
     int X0 = 0x7FFFFFFF, X1 = (int)0x80000000, Y0 = 0x7FFFFFFF, Y1 = (int)0x80000000;
     if (lane < ml.VertexCount) {
-        const uint32_t vi = O->mverts[ml.VertexOffset + lane];
-        const float* pp = O->verts[vi].Position;
-        zf4 c = zr_mat4_point(P.PVM, vs_position(zr3(pp[0], pp[1], pp[2]), I, instanced));
+        const float4 pp = O->mpos[ml.VertexOffset + lane];
+        zf4 c = zr_mat4_point(P.PVM, vs_position(zr3(pp.x, pp.y, pp.z), I, instanced));
         uint32_t f = vertex_flags(c);
         f_or = f; f_and = f;
         if (!(f & 129u)) { SV s = project(c, P.hw, P.hh); X0 = X1 = s.X; Y0 = Y1 = s.Y; }
@@ -202,16 +200,31 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
         if (px0 > px1 || py0 > py1) { if (lane == 0) rects[w] = ZR_RECT_CULLED; return; }
     }
     const int tx0 = px0 / TILE, tx1 = px1 / TILE, ty0 = py0 / TILE, ty1 = py1 / TILE;
-    const int rw_ = tx1 - tx0 + 1, n = rw_ * (ty1 - ty0 + 1);
-    uint32_t mine = 0;
-    for (int k = (int)lane; k < n; k += WAVE) {
-        const int ty = ty0 + k / rw_, tx = tx0 + k % rw_;
-        const uint32_t t = (uint32_t)ty * P.tiles_x + (uint32_t)tx;
-        if (t % P.tile_world == P.tile_rank) { atomicAdd(&tile_count[t], 1u); mine = 1; }
+    if (lane == 0) rects[w] = (uint32_t)tx0 | (uint32_t)ty0 << 8 | (uint32_t)tx1 << 16 | (uint32_t)ty1 << 24;
+}
+
+// Per-tile entry counts from the rects.  Counting goes through an LDS histogram per 1024 work items so that a hot
+// tile costs one global atomic per workgroup instead of one per meshlet-instance (same-address atomics serialise).
+__global__ __launch_bounds__(1024) void k_bin_count(ZrPass P, const uint32_t* __restrict__ rects, uint32_t* __restrict__ tile_count)
+{
+    extern __shared__ uint32_t hist[];
+    const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    for (uint32_t i = threadIdx.x; i < n_tiles; i += 1024u) hist[i] = 0;
+    __syncthreads();
+    const uint32_t w = blockIdx.x * 1024u + threadIdx.x;
+    if (w < P.n_work) {
+        const uint32_t r = rects[w];
+        if (r != ZR_RECT_CULLED) {
+            const uint32_t tx0 = r & 255u, ty0 = (r >> 8) & 255u, tx1 = (r >> 16) & 255u, ty1 = r >> 24;
+            for (uint32_t ty = ty0; ty <= ty1; ++ty)
+                for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+                    const uint32_t t = ty * P.tiles_x + tx;
+                    if (t % P.tile_world == P.tile_rank) atomicAdd(&hist[t], 1u);
+                }
+        }
     }
-    mine = wave_or(mine);
-    if (lane == 0)
-        rects[w] = mine ? ((uint32_t)tx0 | (uint32_t)ty0 << 8 | (uint32_t)tx1 << 16 | (uint32_t)ty1 << 24) : ZR_RECT_CULLED;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_tiles; i += 1024u) { const uint32_t c = hist[i]; if (c) atomicAdd(&tile_count[i], c); }
 }
 
 // Exclusive scan of tile_count[0..n) into tile_offset[0..n] and of the per-tile chunk counts ceil(count / ZR_CHUNK)
@@ -252,30 +265,43 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
     }
 }
 
-__global__ __launch_bounds__(256) void k_bin_fill(ZrPass P, const uint32_t* __restrict__ rects,
-                                                  const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
-                                                  uint32_t* __restrict__ bins, ZrDevStats* __restrict__ stats, int slot)
+// Scatter meshlet-instance ids into the per-tile lists.  Same LDS aggregation as k_bin_count: the workgroup reserves
+// a contiguous range per tile with one global atomic, then hands out slots from LDS.
+__global__ __launch_bounds__(1024) void k_bin_fill(ZrPass P, const uint32_t* __restrict__ rects,
+                                                   const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
+                                                   uint32_t* __restrict__ bins, ZrDevStats* __restrict__ stats, int slot)
 {
-    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
-    uint32_t alive = 0;
-    if (w < P.n_work) {
-        const uint32_t r = rects[w];
-        if (r != ZR_RECT_CULLED) {
-            alive = 1;
-            const uint32_t tx0 = r & 255u, ty0 = (r >> 8) & 255u, tx1 = (r >> 16) & 255u, ty1 = r >> 24;
-            for (uint32_t ty = ty0; ty <= ty1; ++ty)
-                for (uint32_t tx = tx0; tx <= tx1; ++tx) {
-                    const uint32_t t = ty * P.tiles_x + tx;
-                    if (t % P.tile_world != P.tile_rank) continue;
-                    const uint32_t pos = tile_offset[t] + atomicAdd(&tile_cursor[t], 1u);
-                    if (pos < P.bin_capacity) bins[pos] = w;
-                }
-        }
-    }
-    const uint32_t cnt = (uint32_t)__popcll(__ballot(alive));
+    extern __shared__ uint32_t hist[];
     __shared__ uint32_t tot;
+    const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    for (uint32_t i = threadIdx.x; i < n_tiles; i += 1024u) hist[i] = 0;
     if (threadIdx.x == 0) tot = 0;
     __syncthreads();
+    const uint32_t w = blockIdx.x * 1024u + threadIdx.x;
+    uint32_t r = ZR_RECT_CULLED;
+    if (w < P.n_work) r = rects[w];
+    const uint32_t tx0 = r & 255u, ty0 = (r >> 8) & 255u, tx1 = (r >> 16) & 255u, ty1 = r >> 24;
+    if (r != ZR_RECT_CULLED)
+        for (uint32_t ty = ty0; ty <= ty1; ++ty)
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+                const uint32_t t = ty * P.tiles_x + tx;
+                if (t % P.tile_world == P.tile_rank) atomicAdd(&hist[t], 1u);
+            }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_tiles; i += 1024u) {
+        const uint32_t c = hist[i];
+        if (c) hist[i] = tile_offset[i] + atomicAdd(&tile_cursor[i], c);      // hist now holds the next free slot
+    }
+    __syncthreads();
+    if (r != ZR_RECT_CULLED)
+        for (uint32_t ty = ty0; ty <= ty1; ++ty)
+            for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+                const uint32_t t = ty * P.tiles_x + tx;
+                if (t % P.tile_world != P.tile_rank) continue;
+                const uint32_t pos = atomicAdd(&hist[t], 1u);
+                if (pos < P.bin_capacity) bins[pos] = w;
+            }
+    const uint32_t cnt = (uint32_t)__popcll(__ballot(r != ZR_RECT_CULLED));
     if ((threadIdx.x & 63u) == 0 && cnt) atomicAdd(&tot, cnt);
     __syncthreads();
     if (threadIdx.x == 0 && tot) atomicAdd(&stats->survivors[slot], tot);
@@ -288,9 +314,43 @@ struct TileCtx {
     int W, H;                     // target extent
 };
 
+// Cheap per-triangle rejection, identical in effect to the early-outs of raster_sub: degenerate, back-facing
+// (GBUFFER only), or no pixel centre of this tile inside the snapped bounding box.
+template <int MODE>
+__device__ __forceinline__ bool tri_prefilter(int X0, int Y0, int X1, int Y1, int X2, int Y2, const TileCtx& T)
+{
+    const long long A = (long long)(X1 - X0) * (Y2 - Y0) - (long long)(X2 - X0) * (Y1 - Y0);
+    if (A == 0) return false;
+    if (MODE == ZR_MODE_GBUFFER && A > 0) return false;
+    const int x0 = max((imin3(X0, X1, X2) - 128 + 255) >> 8, T.px0), x1 = min((imax3(X0, X1, X2) - 128) >> 8, min(T.px0 + TILE - 1, T.W - 1));
+    const int y0 = max((imin3(Y0, Y1, Y2) - 128 + 255) >> 8, T.py0), y1 = min((imax3(Y0, Y1, Y2) - 128) >> 8, min(T.py0 + TILE - 1, T.H - 1));
+    return x0 <= x1 && y0 <= y1;
+}
+
+template <int MODE>
+__device__ __forceinline__ void shade_key(int x, int y, float fy, const SV& v0, float gx, float gy, float bias, uint32_t prim,
+                                          const TileCtx& T, unsigned long long* __restrict__ keys64, uint32_t* __restrict__ keys32)
+{
+    const float fx = (float)(x * 256 + 128 - v0.X);
+    float z = __builtin_fmaf(gy, fy, __builtin_fmaf(gx, fx, v0.z));
+    z = z + 0.0f;
+    const int li = (y - T.py0) * TILE + (x - T.px0);
+    if (MODE == ZR_MODE_GBUFFER) {
+        if (z >= 0.0f && z < 1.0f)   // depth clip (depthClampEnable FALSE) + LESS against the 1.0 clear
+            atomicMin(&keys64[li], (unsigned long long)zr_f2u(z) << 32 | prim);
+    } else {
+        if (z >= 0.0f && z <= 1.0f) {
+            const float zb = __builtin_fminf(__builtin_fmaxf(z + bias, 0.0f), 1.0f);
+            atomicMin(&keys32[li], zr_f2u(zb));
+        }
+    }
+}
+
 // Rasterise one snapped triangle into the tile's LDS keys.
 //   GBUFFER: key = depth_bits << 32 | prim, ds_min_u64  == depth test LESS in draw order (ties: lower prim wins)
 //   SHADOW : key = biased depth bits,        ds_min_u32  == depth test LESS_OR_EQUAL, depth write only
+// Coverage is exact integer arithmetic (edge functions of the snapped vertices, top-left rule as a -1 bias); the
+// 32-bit loop is taken when every edge value met while walking the clipped bounding box fits, and is bit-identical.
 template <int MODE>
 __device__ __forceinline__ void raster_sub(const SV& v0, const SV& v1, const SV& v2, uint32_t prim, const TileCtx& T,
                                            unsigned long long* __restrict__ keys64, uint32_t* __restrict__ keys32)
@@ -315,13 +375,11 @@ __device__ __forceinline__ void raster_sub(const SV& v0, const SV& v1, const SV&
     long long E0 = (long long)ex0 * (Py0 - v1.Y) - (long long)ey0 * (Px0 - v1.X) - (((ey0 < 0) || (ey0 == 0 && ex0 > 0)) ? 0 : 1);
     long long E1 = (long long)ex1 * (Py0 - v2.Y) - (long long)ey1 * (Px0 - v2.X) - (((ey1 < 0) || (ey1 == 0 && ex1 > 0)) ? 0 : 1);
     long long E2 = (long long)ex2 * (Py0 - v0.Y) - (long long)ey2 * (Px0 - v0.X) - (((ey2 < 0) || (ey2 == 0 && ex2 > 0)) ? 0 : 1);
-    const long long sx0 = -(long long)ey0 * 256, sx1 = -(long long)ey1 * 256, sx2 = -(long long)ey2 * 256;
-    const long long sy0 = (long long)ex0 * 256, sy1 = (long long)ex1 * 256, sy2 = (long long)ex2 * 256;
 
     // depth plane anchored at vertex 0, gradients per sub-pixel unit
-    const float fA = (float)A;
-    const float a1 = (float)(v2.Y - v0.Y) / fA, b1 = (float)(v0.X - v2.X) / fA;
-    const float a2 = (float)(v0.Y - v1.Y) / fA, b2 = (float)(v1.X - v0.X) / fA;
+    const float invA = 1.0f / (float)A;
+    const float a1 = (float)(v2.Y - v0.Y) * invA, b1 = (float)(v0.X - v2.X) * invA;
+    const float a2 = (float)(v0.Y - v1.Y) * invA, b2 = (float)(v1.X - v0.X) * invA;
     const float dz1 = v1.z - v0.z, dz2 = v2.z - v0.z;
     const float gx = __builtin_fmaf(a2, dz2, a1 * dz1), gy = __builtin_fmaf(b2, dz2, b1 * dz1);
     float bias = 0.0f;
@@ -333,28 +391,36 @@ __device__ __forceinline__ void raster_sub(const SV& v0, const SV& v1, const SV&
         const float r = (e > (23u << 23) && e < 0x7F800000u) ? zr_u2f(e - (23u << 23)) : 0.0f;
         bias = __builtin_fmaf(m, 7.5f, r * 1.25f);
     }
-    for (int y = y0; y <= y1; ++y) {
-        long long r0 = E0, r1 = E1, r2 = E2;
-        const float fy = (float)(y * 256 + 128 - v0.Y);
-        for (int x = x0; x <= x1; ++x) {
-            if ((r0 | r1 | r2) >= 0) {
-                const float fx = (float)(x * 256 + 128 - v0.X);
-                float z = __builtin_fmaf(gy, fy, __builtin_fmaf(gx, fx, v0.z));
-                z = z + 0.0f;
-                const int li = (y - T.py0) * TILE + (x - T.px0);
-                if (MODE == ZR_MODE_GBUFFER) {
-                    if (z >= 0.0f && z < 1.0f)   // depth clip (depthClampEnable FALSE) + LESS against the 1.0 clear
-                        atomicMin(&keys64[li], (unsigned long long)zr_f2u(z) << 32 | prim);
-                } else {
-                    if (z >= 0.0f && z <= 1.0f) {
-                        const float zb = __builtin_fminf(__builtin_fmaxf(z + bias, 0.0f), 1.0f);
-                        atomicMin(&keys32[li], zr_f2u(zb));
-                    }
-                }
+    // |E| anywhere in the walk <= |E at the origin| + nx*|sx| + ny*|sy|
+    const long long nx = x1 - x0 + 1, ny = y1 - y0 + 1;
+    const long long lim = 0x3FFFFFFFll;
+    const long long m0 = (E0 < 0 ? -E0 : E0) + 256 * (nx * (ey0 < 0 ? -(long long)ey0 : ey0) + ny * (ex0 < 0 ? -(long long)ex0 : ex0));
+    const long long m1 = (E1 < 0 ? -E1 : E1) + 256 * (nx * (ey1 < 0 ? -(long long)ey1 : ey1) + ny * (ex1 < 0 ? -(long long)ex1 : ex1));
+    const long long m2 = (E2 < 0 ? -E2 : E2) + 256 * (nx * (ey2 < 0 ? -(long long)ey2 : ey2) + ny * (ex2 < 0 ? -(long long)ex2 : ex2));
+    if (m0 < lim && m1 < lim && m2 < lim) {
+        int e0 = (int)E0, e1 = (int)E1, e2 = (int)E2;
+        const int sx0 = -ey0 * 256, sx1 = -ey1 * 256, sx2 = -ey2 * 256, sy0 = ex0 * 256, sy1 = ex1 * 256, sy2 = ex2 * 256;
+        for (int y = y0; y <= y1; ++y) {
+            int r0 = e0, r1 = e1, r2 = e2;
+            const float fy = (float)(y * 256 + 128 - v0.Y);
+            for (int x = x0; x <= x1; ++x) {
+                if ((r0 | r1 | r2) >= 0) shade_key<MODE>(x, y, fy, v0, gx, gy, bias, prim, T, keys64, keys32);
+                r0 += sx0; r1 += sx1; r2 += sx2;
             }
-            r0 += sx0; r1 += sx1; r2 += sx2;
+            e0 += sy0; e1 += sy1; e2 += sy2;
         }
-        E0 += sy0; E1 += sy1; E2 += sy2;
+    } else {
+        const long long sx0 = -(long long)ey0 * 256, sx1 = -(long long)ey1 * 256, sx2 = -(long long)ey2 * 256;
+        const long long sy0 = (long long)ex0 * 256, sy1 = (long long)ex1 * 256, sy2 = (long long)ex2 * 256;
+        for (int y = y0; y <= y1; ++y) {
+            long long r0 = E0, r1 = E1, r2 = E2;
+            const float fy = (float)(y * 256 + 128 - v0.Y);
+            for (int x = x0; x <= x1; ++x) {
+                if ((r0 | r1 | r2) >= 0) shade_key<MODE>(x, y, fy, v0, gx, gy, bias, prim, T, keys64, keys32);
+                r0 += sx0; r1 += sx1; r2 += sx2;
+            }
+            E0 += sy0; E1 += sy1; E2 += sy2;
+        }
     }
 }
 
@@ -496,11 +562,11 @@ __device__ __forceinline__ void resolve_pixel(const ZrPass& P, const ZrObject* _
     if (cls == 1) {
         const SV s0 = project(clip[0], P.hw, P.hh), s1 = project(clip[1], P.hw, P.hh), s2 = project(clip[2], P.hw, P.hh);
         const long long A = (long long)(s1.X - s0.X) * (s2.Y - s0.Y) - (long long)(s2.X - s0.X) * (s1.Y - s0.Y);
-        const float fA = (float)A;
+        const float invA = 1.0f / (float)A;
         FastSetup fs;
         fs.X0 = s0.X; fs.Y0 = s0.Y;
-        fs.a1 = (float)(s2.Y - s0.Y) / fA; fs.b1 = (float)(s0.X - s2.X) / fA;
-        fs.a2 = (float)(s0.Y - s1.Y) / fA; fs.b2 = (float)(s1.X - s0.X) / fA;
+        fs.a1 = (float)(s2.Y - s0.Y) * invA; fs.b1 = (float)(s0.X - s2.X) * invA;
+        fs.a2 = (float)(s0.Y - s1.Y) * invA; fs.b2 = (float)(s1.X - s0.X) * invA;
         fs.rw0 = s0.rw; fs.rw1 = s1.rw; fs.rw2 = s2.rw;
         b0 = bary_screen(fs, px, py); bh = bary_screen(fs, qx, py); bv = bary_screen(fs, px, qy);
     } else {
@@ -564,6 +630,7 @@ __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject*
     __shared__ uint32_t keys32[MODE == ZR_MODE_SHADOW ? TILE_PIX : 1];
     __shared__ int4 vstage[4][WAVE];
     __shared__ uint32_t fstage[4][WAVE];
+    __shared__ int queue[4][10][QCAP];      // per-wave ring of surviving triangles: 3 x (X, Y, z) + prim, SoA
     __shared__ uint32_t cur_chunk;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -588,8 +655,11 @@ __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject*
         TileCtx T;
         T.px0 = (int)(tile % P.tiles_x) * TILE; T.py0 = (int)(tile / P.tiles_x) * TILE; T.W = (int)P.W; T.H = (int)P.H;
 
+        uint32_t qhead = 0, qn = 0;
+        uint32_t w_next = beg + wv < end ? bins[beg + wv] : 0u;
         for (uint32_t e = beg + wv; e < end; e += 4u) {
-            const uint32_t w = wave_uniform(bins[e]);
+            const uint32_t w = wave_uniform(w_next);
+            if (e + 4u < end) w_next = bins[e + 4u];      // next entry's id is in flight while this one is processed
             const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w);
             const uint32_t local = w - O->work_base;
             const uint32_t nm = O->n_meshlets;
@@ -598,11 +668,16 @@ __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject*
             const ZrInstance I = O->inst[inst_i];
             const bool instanced = O->instanced != 0;
 
+            // both rounds' triangle words are requested before the vertex stage so their latency hides under it
+            const uint2* __restrict__ tw = O->mtri + ml.BindlessContext;
+            uint2 tri_w[2];
+            tri_w[0] = lane < ml.TriangleCount ? tw[lane] : make_uint2(0u, 0u);
+            tri_w[1] = lane + WAVE < ml.TriangleCount ? tw[lane + WAVE] : make_uint2(0u, 0u);
+
             lds_fence();   // this wave's previous readers are done with its staging area
             if (lane < ml.VertexCount) {
-                const uint32_t vi = O->mverts[ml.VertexOffset + lane];
-                const float* pp = O->verts[vi].Position;
-                const zf4 c = zr_mat4_point(P.PVM, vs_position(zr3(pp[0], pp[1], pp[2]), I, instanced));
+                const float4 pp = O->mpos[ml.VertexOffset + lane];
+                const zf4 c = zr_mat4_point(P.PVM, vs_position(zr3(pp.x, pp.y, pp.z), I, instanced));
                 const uint32_t f = vertex_flags(c);
                 SV s; s.X = 0; s.Y = 0; s.z = 0.0f; s.rw = 0.0f;
                 if (!(f & 129u)) s = project(c, P.hw, P.hh);
@@ -611,31 +686,66 @@ __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject*
             }
             lds_fence();
 
+            // phase 1: every triangle gets the cheap tests; survivors are compacted into this wave's LDS ring so that
+            // phase 2 (setup + pixel walk) always runs with full lanes, across meshlet boundaries
             const uint32_t pbase = O->prim_base + inst_i * O->n_tris;
-            for (uint32_t t = lane; t < ml.TriangleCount; t += WAVE) {
-                const uint8_t* tp = O->mtris + ml.TriangleOffset + 3u * t;
-                const uint32_t i0 = tp[0], i1 = tp[1], i2 = tp[2];
-                const uint32_t f0 = fstage[wv][i0], f1 = fstage[wv][i1], f2 = fstage[wv][i2];
-                const int cls = classify(f0, f1, f2);
-                if (cls == 0) continue;
-                const uint32_t prim = MODE == ZR_MODE_GBUFFER ? pbase + O->tri_order[ml.BindlessContext + t] : 0u;
-                if (cls == 1) {
-                    const int4 r0 = vstage[wv][i0], r1 = vstage[wv][i1], r2 = vstage[wv][i2];
-                    SV a, b, c;
-                    a.X = r0.x; a.Y = r0.y; a.z = zr_u2f((uint32_t)r0.z); a.rw = zr_u2f((uint32_t)r0.w);
-                    b.X = r1.x; b.Y = r1.y; b.z = zr_u2f((uint32_t)r1.z); b.rw = zr_u2f((uint32_t)r1.w);
-                    c.X = r2.x; c.Y = r2.y; c.z = zr_u2f((uint32_t)r2.z); c.rw = zr_u2f((uint32_t)r2.w);
-                    raster_sub<MODE>(a, b, c, prim, T, keys64, keys32);
-                } else {
-                    zf4 cc[3];
-                    const uint32_t li[3] = { i0, i1, i2 };
-                    for (int k = 0; k < 3; ++k) {
-                        const float* pp = O->verts[O->mverts[ml.VertexOffset + li[k]]].Position;
-                        cc[k] = zr_mat4_point(P.PVM, vs_position(zr3(pp[0], pp[1], pp[2]), I, instanced));
+#pragma unroll
+            for (int round = 0; round < 2; ++round) {
+                const uint32_t t0 = (uint32_t)round * WAVE;
+                if (t0 >= ml.TriangleCount) break;
+                const uint32_t t = t0 + lane;
+                bool alive = false;
+                int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0;
+                const uint32_t prim = pbase + tri_w[round].y;
+                if (t < ml.TriangleCount) {
+                    const uint32_t i0 = tri_w[round].x & 255u, i1 = (tri_w[round].x >> 8) & 255u, i2 = (tri_w[round].x >> 16) & 255u;
+                    const int cls = classify(fstage[wv][i0], fstage[wv][i1], fstage[wv][i2]);
+                    if (cls == 1) {
+                        r0 = vstage[wv][i0]; r1 = vstage[wv][i1]; r2 = vstage[wv][i2];
+                        alive = tri_prefilter<MODE>(r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, T);
+                    } else if (cls == 2) {
+                        zf4 cc[3];
+                        const uint32_t li[3] = { i0, i1, i2 };
+                        for (int k = 0; k < 3; ++k) {
+                            const float4 pp = O->mpos[ml.VertexOffset + li[k]];
+                            cc[k] = zr_mat4_point(P.PVM, vs_position(zr3(pp.x, pp.y, pp.z), I, instanced));
+                        }
+                        raster_clipped<MODE>(cc[0], cc[1], cc[2], prim, T, P.hw, P.hh, keys64, keys32);
                     }
-                    raster_clipped<MODE>(cc[0], cc[1], cc[2], prim, T, P.hw, P.hh, keys64, keys32);
+                }
+                const unsigned long long mask = __ballot(alive);
+                if (alive) {
+                    const uint32_t slot = (qhead + qn + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))) & (QCAP - 1u);
+                    int* q = &queue[wv][0][slot];
+                    q[0 * QCAP] = r0.x; q[1 * QCAP] = r0.y; q[2 * QCAP] = r0.z;
+                    q[3 * QCAP] = r1.x; q[4 * QCAP] = r1.y; q[5 * QCAP] = r1.z;
+                    q[6 * QCAP] = r2.x; q[7 * QCAP] = r2.y; q[8 * QCAP] = r2.z;
+                    q[9 * QCAP] = (int)prim;
+                }
+                qn += (uint32_t)__popcll(mask);
+                if (qn >= WAVE) {
+                    lds_fence();
+                    const int* q = &queue[wv][0][(qhead + lane) & (QCAP - 1u)];
+                    SV a, b, c;
+                    a.X = q[0 * QCAP]; a.Y = q[1 * QCAP]; a.z = zr_u2f((uint32_t)q[2 * QCAP]); a.rw = 0.0f;
+                    b.X = q[3 * QCAP]; b.Y = q[4 * QCAP]; b.z = zr_u2f((uint32_t)q[5 * QCAP]); b.rw = 0.0f;
+                    c.X = q[6 * QCAP]; c.Y = q[7 * QCAP]; c.z = zr_u2f((uint32_t)q[8 * QCAP]); c.rw = 0.0f;
+                    raster_sub<MODE>(a, b, c, (uint32_t)q[9 * QCAP], T, keys64, keys32);
+                    qhead = (qhead + WAVE) & (QCAP - 1u); qn -= WAVE;
                 }
             }
+        }
+        if (qn) {      // flush the tail of this chunk
+            lds_fence();
+            if (lane < qn) {
+                const int* q = &queue[wv][0][(qhead + lane) & (QCAP - 1u)];
+                SV a, b, c;
+                a.X = q[0 * QCAP]; a.Y = q[1 * QCAP]; a.z = zr_u2f((uint32_t)q[2 * QCAP]); a.rw = 0.0f;
+                b.X = q[3 * QCAP]; b.Y = q[4 * QCAP]; b.z = zr_u2f((uint32_t)q[5 * QCAP]); b.rw = 0.0f;
+                c.X = q[6 * QCAP]; c.Y = q[7 * QCAP]; c.z = zr_u2f((uint32_t)q[8 * QCAP]); c.rw = 0.0f;
+                raster_sub<MODE>(a, b, c, (uint32_t)q[9 * QCAP], T, keys64, keys32);
+            }
+            qhead = (qhead + qn) & (QCAP - 1u); qn = 0;
         }
         __syncthreads();
 
@@ -826,7 +936,22 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
             const bool isdir = li < nDir;
             const XkLight* __restrict__ Lt = isdir ? &view->DirectionalLights[li] : &view->PointLights[li - nDir];
             const zf3 lp = zr3(Lt->Position[0], Lt->Position[1], Lt->Position[2]);
+            // A light whose radiance factor is exactly 0 adds fma(0, bxdf, Direct) = Direct: skip its BxDF.  That is the
+            // case beyond a point light's radius (attenuation 1 - clamp(d, 0, r) / r = 0) and for N.L <= 0.  The skip
+            // needs finite colour * intensity (0 * finite = 0); the test is wave-uniform per light.
+            const bool lfinite = __builtin_fabsf(Lt->Color[0]) <= 3.402823466e38f && __builtin_fabsf(Lt->Color[1]) <= 3.402823466e38f &&
+                                 __builtin_fabsf(Lt->Color[2]) <= 3.402823466e38f && __builtin_fabsf(Lt->Color[3]) <= 3.402823466e38f;
+            float att = 1.0f;
+            if (!isdir) {
+                const float dist = zr_length(lp - Pw);
+                const float falloff = Lt->Direction[3];
+                att = 1.0f - zr_clamp(dist, 0.0f, falloff) / falloff;   // remap(dist, 0, falloff, 0, 1), SH/Common.glsl:43-47
+                if (lfinite && att == 0.0f) continue;
+            }
             const zf3 Lv = isdir ? zr_normalize(zr3(Lt->Direction[0], Lt->Direction[1], Lt->Direction[2])) : zr_normalize(lp - Pw);
+            // ApplyDirectionalLight / ApplyPointLight (SH/Common.glsl:364-372, 399-416)
+            const float ndotl = zr_clamp(zr_dot(Nn, Lv), 0.0f, 1.0f);
+            if (lfinite && ndotl == 0.0f) continue;
             const zf3 Hh = zr_normalize(Vv + Lv);
             const float LdotH = zr_saturate(zr_dot(Lv, Hh)), NdotH = zr_saturate(zr_dot(N, Hh)), NdotL = zr_saturate(zr_dot(N, Lv));
             // DefaultLitBxDF (SH/Common.glsl:259-282): F0 = 0.04, F90 = saturate(50 * 0.04)
@@ -837,17 +962,12 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
             const float Fd = Fr_DisneyDiffuse(NdotV, NdotL, LdotH, Roughness);
             const zf3 bx = zr3(__builtin_fmaf(DiffuseColor.x * (1.0f - F), Fd, Fr), __builtin_fmaf(DiffuseColor.y * (1.0f - F), Fd, Fr),
                                __builtin_fmaf(DiffuseColor.z * (1.0f - F), Fd, Fr));
-            // ApplyDirectionalLight / ApplyPointLight (SH/Common.glsl:364-372, 399-416)
-            const float ndotl = zr_clamp(zr_dot(Nn, Lv), 0.0f, 1.0f);
             const float k = ndotl * Lt->Color[3];
             zf3 rad = zr3(k * Lt->Color[0], k * Lt->Color[1], k * Lt->Color[2]);
             if (isdir) {
                 Direct = zr3(__builtin_fmaf(rad.x * bx.x, ShadowFactor, Direct.x), __builtin_fmaf(rad.y * bx.y, ShadowFactor, Direct.y),
                              __builtin_fmaf(rad.z * bx.z, ShadowFactor, Direct.z));
             } else {
-                const float dist = zr_length(lp - Pw);
-                const float falloff = Lt->Direction[3];
-                const float att = 1.0f - zr_clamp(dist, 0.0f, falloff) / falloff;   // remap(dist, 0, falloff, 0, 1), :43-47
                 rad = rad * att;
                 Direct = zr3(__builtin_fmaf(rad.x, bx.x, Direct.x), __builtin_fmaf(rad.y, bx.y, Direct.y), __builtin_fmaf(rad.z, bx.z, Direct.z));
             }
@@ -929,8 +1049,10 @@ void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* rects, uint
 {
     if (P.n_work == 0) return;
     const dim3 g((P.n_work + 3) / 4), b(256);
-    if (P.mode == ZR_MODE_GBUFFER) hipLaunchKernelGGL(k_cull<ZR_MODE_GBUFFER>, g, b, 0, s, P, objs, rects, tile_count);
-    else hipLaunchKernelGGL(k_cull<ZR_MODE_SHADOW>, g, b, 0, s, P, objs, rects, tile_count);
+    if (P.mode == ZR_MODE_GBUFFER) hipLaunchKernelGGL(k_cull<ZR_MODE_GBUFFER>, g, b, 0, s, P, objs, rects);
+    else hipLaunchKernelGGL(k_cull<ZR_MODE_SHADOW>, g, b, 0, s, P, objs, rects);
+    const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    hipLaunchKernelGGL(k_bin_count, dim3((P.n_work + 1023) / 1024), dim3(1024), n_tiles * sizeof(uint32_t), s, P, rects, tile_count);
 }
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint32_t n,
                     uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s)
@@ -941,7 +1063,9 @@ void zr_launch_bin_fill(const ZrPass& P, const uint32_t* rects, const uint32_t* 
                         uint32_t* bins, ZrDevStats* stats, int slot, hipStream_t s)
 {
     if (P.n_work == 0) return;
-    hipLaunchKernelGGL(k_bin_fill, dim3((P.n_work + 255) / 256), dim3(256), 0, s, P, rects, tile_offset, tile_cursor, bins, stats, slot);
+    const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    hipLaunchKernelGGL(k_bin_fill, dim3((P.n_work + 1023) / 1024), dim3(1024), n_tiles * sizeof(uint32_t), s, P, rects, tile_offset,
+                       tile_cursor, bins, stats, slot);
 }
 void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s)
 {

@@ -27,11 +27,11 @@ static_assert(sizeof(ZrInstance) == 64, "ZrInstance");
 struct ZrObject {
     const XkVertex*   verts;
     const uint32_t*   indices;       // draw-order index buffer (3 per triangle)
-    const XkMeshlet*  meshlets;
-    const uint32_t*   mverts;        // meshlet -> mesh vertex index
-    const uint8_t*    mtris;         // meshlet-local triangle corners, 3 B per triangle
-    const uint32_t*   tri_order;     // meshlet triangle slot (tri_base + t) -> draw-order triangle index; the device copy of
-                                     // XkMeshlet carries tri_base (triangles before this meshlet) in BindlessContext
+    const XkMeshlet*  meshlets;      // device copy; BindlessContext = tri_base (triangles in earlier meshlets)
+    const float4*     mpos;          // flattened meshlet vertices: mpos[VertexOffset + k] = position of meshlet vertex k
+                                     // (CreateMeshVertexBuffers<XkMeshIndirect> flattens the same way, ZE:4733-4756)
+    const uint2*      mtri;          // per meshlet triangle slot (tri_base + t): x = corners i0 | i1 << 8 | i2 << 16,
+                                     // y = draw-order triangle index (primitive id within the instance)
     const ZrInstance* inst;
     uint32_t n_meshlets, n_tris, n_inst, instanced;
     uint32_t work_base;              // first meshlet-instance id of this draw
