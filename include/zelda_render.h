@@ -96,6 +96,10 @@ int  zr_mesh_set_meshlets(zr_ctx* ctx, uint32_t mesh_id, const XkMeshlet* m, uin
  * Called implicitly by zr_object_add for meshes that have none.  Draw order stays index order. */
 int  zr_mesh_build_meshlets(zr_ctx* ctx, uint32_t mesh_id, uint32_t max_vertices, uint32_t max_triangles,
                             float cone_weight);
+/* The clusteriser without a context (pure host code, no GPU needed): the ZeldaMeshlet tool's job.  NULL outputs = size query. */
+int  zr_meshlets_build(const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, uint32_t max_vertices,
+                       uint32_t max_triangles, float cone_weight, XkMeshlet* m, uint32_t* nm, uint32_t* meshlet_vertices,
+                       size_t* nmv, uint8_t* meshlet_triangles, size_t* nmt, uint32_t* tri_order);
 /* Copy the mesh's meshlets out (any pointer may be NULL; counts always returned). */
 int  zr_mesh_get_meshlets(zr_ctx* ctx, uint32_t mesh_id, XkMeshlet* m, uint32_t* nm,
                           uint32_t* meshlet_vertices, size_t* nmv, uint8_t* meshlet_triangles, size_t* nmt);
@@ -151,6 +155,8 @@ int  zr_profab_register(zr_ctx* ctx, const char* name, uint32_t mesh_id, const z
 int  zr_world_load_json(zr_ctx* ctx, const char* utf8, size_t len);
 int  zr_world_get_camera(zr_ctx* ctx, zr_camera* out);
 int  zr_world_save_json(zr_ctx* ctx, char* dst, size_t cap, size_t* len);
+/* Context-free Load -> Save (pure host code, no GPU): validates a payload; on error dst receives the message. */
+int  zr_world_json_normalize(const char* utf8, size_t len_in, char* dst, size_t cap, size_t* len);
 int  zr_livelink_serve(zr_ctx* ctx, uint16_t port);   /* port 0 = ephemeral (tests); the engine's port is 8080 */
 int  zr_livelink_port(zr_ctx* ctx, uint16_t* port);
 int  zr_livelink_poll(zr_ctx* ctx, int* reloaded);  /* DrawFrame's bReloadScene pickup, ZE:1943-1951 */

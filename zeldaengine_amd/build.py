@@ -24,17 +24,20 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, out=None, extra_flags=()):
+    """out / extra_flags build an A/B variant (e.g. -DZR_CHUNK=64u) next to the default library."""
+    global OUT
+    if out is None and not force and not needs_build():
         return OUT
+    out_path = out or OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
-    bdir = os.path.join(HERE, "build")
+    bdir = os.path.join(HERE, "build" if out is None else "build_" + os.path.basename(out))
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for src in SOURCES:
         obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, "-x", "hip"] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, "-x", "hip"] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -45,9 +48,9 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
         if verbose and out:
             print(out.decode(errors="replace"))
-    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", OUT] + objs + ["-lpthread"]
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", out_path] + objs + ["-lpthread"]
     subprocess.check_call(cmd)
-    return OUT
+    return out_path
 
 
 if __name__ == "__main__":

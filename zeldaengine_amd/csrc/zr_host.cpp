@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 #define HIPCHK(c, expr) do { hipError_t _e = (expr); if (_e != hipSuccess) \
     return zr_fail((c), ZR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
@@ -225,6 +226,27 @@ extern "C" int zr_mesh_build_meshlets(zr_ctx* c, uint32_t mesh_id, uint32_t max_
     if (m.uploaded) return zr_fail(c, ZR_ERR_STATE, "mesh already in use by a rendered scene");
     zr_build_meshlets(m.v.data(), (uint32_t)m.v.size(), m.idx.data(), (uint32_t)m.idx.size(), max_v, max_t, cone_weight, &m.ms);
     m.has_meshlets = true;
+    return ZR_OK;
+}
+
+// Context-free form of the clusteriser: the ZeldaMeshlet tool's BuildMeshlets (ZM:132-172) as a library call.  Pure host
+// code (runs without a GPU).  Pass NULL outputs to query the sizes.  tri_order[k] = index-buffer triangle of slot k.
+extern "C" int zr_meshlets_build(const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, uint32_t max_v, uint32_t max_t,
+                                 float cone_weight, XkMeshlet* ml, uint32_t* nm, uint32_t* mv, size_t* nmv, uint8_t* mt, size_t* nmt,
+                                 uint32_t* tri_order)
+{
+    if (!v || !idx || !nm || !nmv || !nmt || nv == 0 || ni == 0 || ni % 3) return ZR_ERR_ARG;
+    if (max_v == 0) max_v = 64;
+    if (max_t == 0) max_t = 124;
+    if (max_v < 3 || max_v > 64 || max_t < 1 || max_t > 128) return ZR_ERR_ARG;
+    for (uint32_t i = 0; i < ni; ++i) if (idx[i] >= nv) return ZR_ERR_ARG;
+    ZrMeshletSet ms;
+    zr_build_meshlets(v, nv, idx, ni, max_v, max_t, cone_weight, &ms);
+    *nm = (uint32_t)ms.meshlets.size(); *nmv = ms.mverts.size(); *nmt = ms.mtris.size();
+    if (ml) { memcpy(ml, ms.meshlets.data(), ms.meshlets.size() * sizeof(XkMeshlet)); for (uint32_t i = 0; i < *nm; ++i) ml[i].BindlessContext = 0; }
+    if (mv) memcpy(mv, ms.mverts.data(), ms.mverts.size() * 4);
+    if (mt) memcpy(mt, ms.mtris.data(), ms.mtris.size());
+    if (tri_order) memcpy(tri_order, ms.tri_order.data(), ms.tri_order.size() * 4);
     return ZR_OK;
 }
 
@@ -550,6 +572,7 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
     P->tiles_x = mode == ZR_MODE_SHADOW ? c->stiles_x : c->tiles_x; P->tiles_y = mode == ZR_MODE_SHADOW ? c->stiles_y : c->tiles_y;
     P->tile_rank = mode == ZR_MODE_SHADOW ? 0 : c->cfg.tile_rank; P->tile_world = mode == ZR_MODE_SHADOW ? 1 : c->cfg.tile_world;
     P->n_objects = c->n_objs; P->n_work = c->n_work; P->bin_capacity = c->bin_capacity;
+    { const char* dbg = getenv("ZR_DEBUG_SKIP"); P->debug_skip = dbg ? (uint32_t)atoi(dbg) : 0u; }
     if (!finite16(P->PVM)) return false;
     // frustum planes of proj*view in world space (sphere centres are taken to world space by M in the kernel)
     bool fr_ok = !(c->cfg.flags & ZR_FLAG_NO_FRUSTUM_CULL) && finite16(u.Model);

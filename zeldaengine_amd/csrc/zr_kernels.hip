@@ -28,7 +28,9 @@
 struct SV { int X, Y; float z, rw; };          // snapped screen vertex (1/256 px), NDC depth, 1/w
 
 __device__ __forceinline__ uint32_t wave_uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+// Ordering point between LDS accesses of ONE wave (a lane reads what another lane of the same wave wrote).  The LDS
+// executes a wave's DS instructions in issue order, so no s_waitcnt is needed: only the compiler must not reorder.
+__device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 __device__ __forceinline__ int find_object_work(const ZrObject* __restrict__ objs, int n, uint32_t w)
 {
@@ -629,7 +631,6 @@ __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject*
     __shared__ unsigned long long keys64[MODE == ZR_MODE_GBUFFER ? TILE_PIX : 1];
     __shared__ uint32_t keys32[MODE == ZR_MODE_SHADOW ? TILE_PIX : 1];
     __shared__ int4 vstage[4][WAVE];
-    __shared__ uint32_t fstage[4][WAVE];
     __shared__ int queue[4][10][QCAP];      // per-wave ring of surviving triangles: 3 x (X, Y, z) + prim, SoA
     __shared__ uint32_t cur_chunk;
 
@@ -681,8 +682,7 @@ __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject*
                 const uint32_t f = vertex_flags(c);
                 SV s; s.X = 0; s.Y = 0; s.z = 0.0f; s.rw = 0.0f;
                 if (!(f & 129u)) s = project(c, P.hw, P.hh);
-                vstage[wv][lane] = make_int4(s.X, s.Y, (int)zr_f2u(s.z), (int)zr_f2u(s.rw));
-                fstage[wv][lane] = f;
+                vstage[wv][lane] = make_int4(s.X, s.Y, (int)zr_f2u(s.z), (int)f);      // snapped x, y, depth, clip flags
             }
             lds_fence();
 
@@ -692,16 +692,16 @@ __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject*
 #pragma unroll
             for (int round = 0; round < 2; ++round) {
                 const uint32_t t0 = (uint32_t)round * WAVE;
-                if (t0 >= ml.TriangleCount) break;
+                if (t0 >= ml.TriangleCount || P.debug_skip >= 2u) break;
                 const uint32_t t = t0 + lane;
                 bool alive = false;
                 int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0;
                 const uint32_t prim = pbase + tri_w[round].y;
                 if (t < ml.TriangleCount) {
                     const uint32_t i0 = tri_w[round].x & 255u, i1 = (tri_w[round].x >> 8) & 255u, i2 = (tri_w[round].x >> 16) & 255u;
-                    const int cls = classify(fstage[wv][i0], fstage[wv][i1], fstage[wv][i2]);
+                    r0 = vstage[wv][i0]; r1 = vstage[wv][i1]; r2 = vstage[wv][i2];
+                    const int cls = classify((uint32_t)r0.w, (uint32_t)r1.w, (uint32_t)r2.w);
                     if (cls == 1) {
-                        r0 = vstage[wv][i0]; r1 = vstage[wv][i1]; r2 = vstage[wv][i2];
                         alive = tri_prefilter<MODE>(r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, T);
                     } else if (cls == 2) {
                         zf4 cc[3];
@@ -723,6 +723,7 @@ __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject*
                     q[9 * QCAP] = (int)prim;
                 }
                 qn += (uint32_t)__popcll(mask);
+                if (P.debug_skip >= 1u) { qhead = (qhead + qn) & (QCAP - 1u); qn = 0; }
                 if (qn >= WAVE) {
                     lds_fence();
                     const int* q = &queue[wv][0][(qhead + lane) & (QCAP - 1u)];

@@ -114,6 +114,7 @@ void zr_build_meshlets(const XkVertex* verts, uint32_t nv, const uint32_t* idx, 
     std::vector<uint32_t> cur_t; cur_t.reserve(max_triangles);
     V3 csum = { 0, 0, 0 }, nsum = { 0, 0, 0 };
     uint32_t seed = 0, done = 0, tri_base = 0;
+    (void)0;
 
     auto flush = [&]() {
         if (cur_t.empty()) return;
@@ -149,8 +150,13 @@ void zr_build_meshlets(const XkVertex* verts, uint32_t nv, const uint32_t* idx, 
         csum = csum + cen[t]; nsum = nsum + nrm[t];
     };
 
+    // mean squared triangle "size" (centroid-to-vertex), used to price a new vertex against distance from the centroid
+    double size2 = 0;
+    for (uint32_t t = 0; t < nt; ++t) { V3 d = pos(verts[idx[3 * t]]) - cen[t]; size2 += dot(d, d); }
+    size2 /= (double)nt;
+
     while (done < nt) {
-        uint32_t best = 0xFFFFFFFFu; double best_score = 0; uint32_t best_extra = 4;
+        uint32_t best = 0xFFFFFFFFu; double best_score = 0;
         if (!cur_t.empty()) {
             const double inv = 1.0 / (double)cur_t.size();
             const V3 cc = csum * inv;
@@ -162,18 +168,34 @@ void zr_build_meshlets(const XkVertex* verts, uint32_t nv, const uint32_t* idx, 
                     const uint32_t t = vtri[k];
                     if (used[t] || stamp[t] == mark) continue;
                     stamp[t] = mark;
-                    const uint32_t ex = extra_of(t);
+                    // compact, cone-coherent growth: distance to the running centroid, widened by the normal deviation,
+                    // plus a price per vertex the triangle would add (triangles closing a fan are nearly free)
                     const V3 d = cen[t] - cc;
-                    const double score = dot(d, d) * (1.0 + (double)cone_weight * (1.0 - dot(nrm[t], na)));
-                    if (ex < best_extra || (ex == best_extra && score < best_score)) { best = t; best_extra = ex; best_score = score; }
+                    const double score = dot(d, d) * (1.0 + (double)cone_weight * (1.0 - dot(nrm[t], na))) + size2 * (double)extra_of(t);
+                    if (best == 0xFFFFFFFFu || score < best_score) { best = t; best_score = score; }
                 }
         }
-        if (best == 0xFFFFFFFFu) {          // no neighbour left: close the cluster and reseed at the first unused triangle
+        if (best == 0xFFFFFFFFu) {          // no neighbour left: close the cluster and reseed
             flush();
             while (used[seed]) seed++;
             best = seed;
+        } else if (cur_t.size() + 1 > max_triangles || cur_v.size() + extra_of(best) > max_vertices) {
+            // full: close it and reseed next to it, at the frontier triangle with the fewest unused neighbours (keeps the
+            // uncovered region convex-ish and avoids stranding islands of a few triangles)
+            uint32_t pick = 0xFFFFFFFFu; uint32_t pick_live = 0xFFFFFFFFu;
+            const uint32_t mark = done | 0x80000000u;
+            for (uint32_t v : cur_v)
+                for (uint32_t k = vstart[v]; k < vstart[v + 1]; ++k) {
+                    const uint32_t t = vtri[k];
+                    if (used[t] || stamp[t] == mark) continue;
+                    stamp[t] = mark;
+                    uint32_t live = 0;
+                    for (int c3 = 0; c3 < 3; ++c3) { const uint32_t vv = idx[3 * t + c3]; for (uint32_t kk = vstart[vv]; kk < vstart[vv + 1]; ++kk) live += !used[vtri[kk]]; }
+                    if (live < pick_live) { pick_live = live; pick = t; }
+                }
+            flush();
+            best = pick != 0xFFFFFFFFu ? pick : best;
         }
-        if (cur_t.size() + 1 > max_triangles || cur_v.size() + extra_of(best) > max_vertices) flush();
         add(best);
     }
     flush();

@@ -9,7 +9,9 @@
 #define ZR_EMPTY_PRIM 0xFFFFFFFFu
 #define ZR_GUARD 4.0f                       // guard band, multiples of w
 #define ZR_RECT_CULLED 0xFFFFFFFFu
-#define ZR_CHUNK 32u                         // bin entries (meshlet-instances) per raster work unit
+#ifndef ZR_CHUNK
+#define ZR_CHUNK 64u                         // bin entries (meshlet-instances) per raster work unit
+#endif
 
 enum { ZR_MODE_GBUFFER = 0, ZR_MODE_SHADOW = 1 };
 
@@ -58,6 +60,7 @@ struct ZrPass {
     uint32_t mode;                   // ZR_MODE_*
     uint32_t frustum_ok, cone_ok;    // culling enabled (cone_ok also needs a standard perspective eye)
     uint32_t bin_capacity;
+    uint32_t debug_skip;             // diagnostics only (env ZR_DEBUG_SKIP): 1 skip pixel walk, 2 skip triangle phase too
 };
 
 // Frame statistics block in device memory (one per pass slot: [shadow, camera]).

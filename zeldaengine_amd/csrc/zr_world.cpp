@@ -346,10 +346,8 @@ extern "C" int zr_world_load_json(zr_ctx* c, const char* utf8, size_t len)
 
 // XkWorld::Save (ZE:1149-1263), PrettyWriter layout (4-space indent).  The engine writes OverrideCubemap from
 // EnableSkydome (ZE:1175); that bug is NOT reproduced, so Load(Save(w)) == w.
-extern "C" int zr_world_save_json(zr_ctx* c, char* dst, size_t cap, size_t* len)
+static std::string world_to_json(const ZrWorld& w)
 {
-    if (!c || !len) return ZR_ERR_ARG;
-    const ZrWorld& w = c->world;
     std::string o;
     auto arr3 = [&](const char* k, const float* v, int n, const char* ind) {
         o += ind; o += "\""; o += k; o += "\": [\n";
@@ -396,12 +394,36 @@ extern "C" int zr_world_save_json(zr_ctx* c, char* dst, size_t cap, size_t* len)
         o += "\n        }";
     }
     o += w.ObjectDescs.empty() ? "]\n}" : "\n    ]\n}";
+    return o;
+}
+
+extern "C" int zr_world_save_json(zr_ctx* c, char* dst, size_t cap, size_t* len)
+{
+    if (!c || !len) return ZR_ERR_ARG;
+    const std::string o = world_to_json(c->world);
     *len = o.size();
     if (dst) {
         if (cap < o.size()) return zr_fail(c, ZR_ERR_ARG, "buffer too small");
         memcpy(dst, o.data(), o.size());
     }
     return ZR_OK;
+}
+
+// Context-free Load -> Save: parses a livelink payload / World.json with the same strictness as zr_world_load_json and
+// writes it back in XkWorld::Save's layout.  Pure host code (no GPU): used to validate scenes before submission.
+// On a parse/schema error returns ZR_ERR_PARSE and, if dst is given, the error text.
+extern "C" int zr_world_json_normalize(const char* utf8, size_t len_in, char* dst, size_t cap, size_t* len)
+{
+    if (!utf8 || !len) return ZR_ERR_ARG;
+    ZrWorld w; std::string err;
+    const bool ok = world_parse(utf8, len_in, w, err);
+    const std::string o = ok ? world_to_json(w) : err;
+    *len = o.size();
+    if (dst) {
+        if (cap < o.size()) return ZR_ERR_ARG;
+        memcpy(dst, o.data(), o.size());
+    }
+    return ok ? ZR_OK : ZR_ERR_PARSE;
 }
 
 extern "C" int zr_world_get_camera(zr_ctx* c, zr_camera* out)

@@ -14,7 +14,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzelda_render.so")
+LIB_PATH = os.environ.get("ZELDA_RENDER_LIB") or os.path.join(_HERE, "libzelda_render.so")   # env: A/B builds only
 
 _lib = None
 
@@ -42,6 +42,7 @@ def lib():
         "zr_mesh_set_meshlets": [vp, u32, vp, u32, vp, sz, vp, sz],
         "zr_mesh_build_meshlets": [vp, u32, u32, u32, C.c_float],
         "zr_mesh_get_meshlets": [vp, u32, vp, C.POINTER(u32), vp, C.POINTER(sz), vp, C.POINTER(sz)],
+        "zr_meshlets_build": [vp, u32, vp, u32, u32, u32, C.c_float, vp, C.POINTER(u32), vp, C.POINTER(sz), vp, C.POINTER(sz), vp],
         "zr_object_add": [vp, u32, vp, vp, u32],
         "zr_scene_clear": [vp],
         "zr_object_count": [vp, C.POINTER(u32)],
@@ -66,6 +67,7 @@ def lib():
         "zr_world_load_json": [vp, C.c_char_p, sz],
         "zr_world_save_json": [vp, vp, sz, C.POINTER(sz)],
         "zr_world_get_camera": [vp, vp],
+        "zr_world_json_normalize": [C.c_char_p, sz, vp, sz, C.POINTER(sz)],
         "zr_livelink_serve": [vp, C.c_uint16],
         "zr_livelink_port": [vp, C.POINTER(C.c_uint16)],
         "zr_livelink_poll": [vp, C.POINTER(C.c_int)],
@@ -85,6 +87,41 @@ def lib():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else None
+
+
+def build_meshlets(verts, idx, max_vertices=64, max_triangles=124, cone_weight=0.2):
+    """Context-free clusteriser (host code only; works without a GPU).  Returns (meshlets, mverts, mtris, tri_order)."""
+    L = lib()
+    verts = np.ascontiguousarray(verts)
+    assert verts.dtype == abi.XkVertex
+    idx = np.ascontiguousarray(idx, dtype=np.uint32)
+    nm, nmv, nmt = C.c_uint32(), C.c_size_t(), C.c_size_t()
+    args = (_ptr(verts), len(verts), _ptr(idx), len(idx), max_vertices, max_triangles, cone_weight)
+    rc = L.zr_meshlets_build(*args, None, C.byref(nm), None, C.byref(nmv), None, C.byref(nmt), None)
+    if rc:
+        raise ZeldaRenderError(rc, "zr_meshlets_build")
+    ml = np.zeros(nm.value, dtype=abi.XkMeshlet)
+    mv = np.zeros(nmv.value, dtype=np.uint32)
+    mt = np.zeros(nmt.value, dtype=np.uint8)
+    order = np.zeros(nmt.value // 3, dtype=np.uint32)
+    rc = L.zr_meshlets_build(*args, _ptr(ml), C.byref(nm), _ptr(mv), C.byref(nmv), _ptr(mt), C.byref(nmt), _ptr(order))
+    if rc:
+        raise ZeldaRenderError(rc, "zr_meshlets_build")
+    return ml, mv, mt, order
+
+
+def world_json_normalize(text):
+    """Context-free XkWorld Load -> Save (host code only).  Raises ZeldaRenderError(ZR_ERR_PARSE) with the loader's message."""
+    L = lib()
+    b = text.encode() if isinstance(text, str) else bytes(text)
+    n = C.c_size_t()
+    L.zr_world_json_normalize(b, len(b), None, 0, C.byref(n))
+    buf = C.create_string_buffer(max(1, n.value))
+    rc = L.zr_world_json_normalize(b, len(b), buf, n.value, C.byref(n))
+    out = buf.raw[:n.value].decode(errors="replace")
+    if rc:
+        raise ZeldaRenderError(rc, out)
+    return out
 
 
 class Renderer:
