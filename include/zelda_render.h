@@ -141,6 +141,7 @@ int  zr_read_shadowmap(zr_ctx* ctx, float* dst, size_t bytes);        /* dim*dim
 /* --- multi-GPU screen-tile partition --- */
 /* Packed tile-major RGBA8 of the tiles this rank owns (device pointer, stable until zr_destroy). */
 int  zr_tiles_device_buffer(zr_ctx* ctx, void** dev_ptr, size_t* bytes_per_rank);
+int  zr_read_tiles(zr_ctx* ctx, uint8_t* dst, size_t bytes);             /* host copy of that buffer (tests) */
 /* Scatter the all-gathered buffer (tile_world * bytes_per_rank, rank-major, device pointer) into the frame. */
 int  zr_composite(zr_ctx* ctx, const void* gathered_dev);
 int  zr_color_device_ptr(zr_ctx* ctx, void** dev_ptr);

@@ -1,0 +1,74 @@
+"""Multi-GPU path on CPU: the screen-tile partition + all-gather + untile logic with world_size 2 over gloo.
+
+Each rank stands in for a GPU: it takes the frame the oracle rendered, keeps only the tiles it owns (pack_tiles = the
+layout k_lighting writes), all-gathers the packed buffers and untiles (= k_untile).  The result must be the full frame on
+every rank.  On the GPU box the same layout is exercised through the kernels (tests/test_gpu_tiles.py).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from zeldaengine_amd import dist as zdist
+
+
+def test_layout_arithmetic():
+    lay = zdist.tile_layout(1920, 1080, 8)
+    assert lay == {"tiles_x": 60, "tiles_y": 34, "n_tiles": 2040, "slots_per_rank": 255}
+    lay = zdist.tile_layout(3840, 2160, 8)
+    assert lay["n_tiles"] == 8160 and lay["slots_per_rank"] == 1020
+    for world in (1, 2, 3, 4, 8):
+        owned = [zdist.owned_tiles(r, world, 2040) for r in range(world)]
+        assert sorted(sum(owned, [])) == list(range(2040))
+        assert max(map(len, owned)) - min(map(len, owned)) <= 1
+        assert all(len(o) <= zdist.tile_layout(1920, 1080, world)["slots_per_rank"] for o in owned)
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (100, 70), (33, 31)])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_pack_untile_roundtrip(shape, world):
+    rng = np.random.default_rng(7)
+    frame = rng.integers(0, 256, size=(shape[1], shape[0], 4), dtype=np.uint8)
+    gathered = np.stack([zdist.pack_tiles(frame, r, world) for r in range(world)])
+    assert np.array_equal(zdist.untile(gathered, shape[0], shape[1]), frame)
+
+
+def _rank_main(rank, world, port, W, H, q):
+    import torch
+    import torch.distributed as dist
+    from oracle import pyoracle
+    from zeldaengine_amd import scenes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = scenes.config3(60, W, H)
+    o = pyoracle.Oracle(W, H, 128)
+    pyoracle.load_scene(o, cfg)
+    o.render()
+    full = o.color()
+    mine = torch.from_numpy(zdist.pack_tiles(full, rank, world).reshape(-1).copy())
+    gathered = torch.empty(mine.numel() * world, dtype=torch.uint8)
+    dist.all_gather_into_tensor(gathered, mine)
+    lay = zdist.tile_layout(W, H, world)
+    frame = zdist.untile(gathered.numpy().reshape(world, lay["slots_per_rank"], 32, 32, 4), W, H)
+    q.put((rank, bool(np.array_equal(frame, full)), int(mine.numel())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_allgather_composite():
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    W, H, world = 160, 96, 2
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, W, H, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True]
+    assert res[0][2] == res[1][2] == zdist.tile_layout(W, H, world)["slots_per_rank"] * 32 * 32 * 4

@@ -1,0 +1,164 @@
+"""GPU parity over the scene-submission surface: draw kinds, clipping, raw frames, caller meshlets, debug views, sizes.
+
+All comparisons are bit-exact against the CPU oracle (see test_gpu_parity.py for the rationale).
+"""
+import numpy as np
+import pytest
+
+from parity_util import compare_all
+from zeldaengine_amd import abi, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _identical(o, g, what=""):
+    d = compare_all(o, g)
+    bad = {k: v for k, v in d.items() if v}
+    assert not bad, "%s: HIP path differs from the oracle: %r" % (what, bad)
+
+
+def _const_image(rgba, n=4):
+    return np.tile(np.array(rgba, dtype=np.uint8), (n, n, 1))
+
+
+def _mixed_scene(r, instanced_boxes=40):
+    """ground plane + big box (non-instanced draws), spheres + boxes (instanced draws), two materials."""
+    r.set_cubemap(scenes.synthetic_cubemap(32))
+    plane = r.mesh_create(*scenes.grid_plane(16.0, 6, 0.0))
+    box = r.mesh_create(*scenes.box((0.8, 0.5, 0.4), (0.0, 0.0, 0.4)))
+    sph = r.mesh_create(*scenes.uv_sphere())
+    mat, keep = abi.make_material([_const_image((200, 40, 30, 255)), _const_image((255, 255, 255, 255)), _const_image((90, 90, 90, 255)),
+                                   None, _const_image((180, 180, 180, 255)), _const_image((0, 20, 40, 255)), None])
+    r._keepalive = keep
+    r.object_add(sph, None, scenes.generate_instances(150, 1.5, 7.0, 0.2, 0.6, seed=7))
+    r.object_add(plane)
+    r.object_add(box, mat)
+    r.object_add(box, mat, scenes.generate_instances(instanced_boxes, 2.0, 6.0, 0.3, 0.9, seed=11))
+
+
+def _both(oracle_lib, gpu_engine, W, H, SD, build, frame, flags=0, debug_view=0):
+    o = oracle_lib.Oracle(W, H, SD)
+    g = gpu_engine.Renderer(W, H, SD, flags=flags)
+    for r in (o, g):
+        build(r)
+        frame(r)
+    o.render(debug_view)
+    g.render(debug_view)
+    g.finish()
+    return o, g
+
+
+def _std_frame(cam=None, roll_stage=0.0, roll_light=0.0, n_point=16):
+    w = scenes.sample_world()
+    d, _, s = scenes.lights_from_world(w)
+    w["PointLights"] = scenes.sample_point_lights(n_point)
+    _, p, _ = scenes.lights_from_world(w)
+
+    def f(r):
+        r.update_uniforms(cam or abi.make_camera(), d, p, s, roll_stage, roll_light, 1.0)
+    return f
+
+
+def test_mixed_draws_materials_and_animation(oracle_lib, gpu_engine):
+    o, g = _both(oracle_lib, gpu_engine, 416, 240, 512, _mixed_scene, _std_frame(roll_stage=0.4, roll_light=0.03))
+    assert o.covered_pixels() > 0.5 * 416 * 240
+    _identical(o, g, "mixed scene")
+
+
+def test_odd_resolution_and_small_shadow_map(oracle_lib, gpu_engine):
+    o, g = _both(oracle_lib, gpu_engine, 333, 211, 96, _mixed_scene, _std_frame(abi.make_camera((4.0, -6.0, 3.0), (0.0, 0.0, 0.5), fov=60.0)))
+    _identical(o, g, "333x211")
+
+
+def test_near_plane_and_guard_band_clipping(oracle_lib, gpu_engine):
+    """Camera just above a huge ground quad, inside a crowd of spheres: triangles cross the near plane and the guard band."""
+    def build(r):
+        r.set_cubemap(None)
+        r.object_add(r.mesh_create(*scenes.grid_plane(400.0, 2, 0.0)))
+        r.object_add(r.mesh_create(*scenes.box((30.0, 0.2, 3.0), (0.0, 2.0, 3.0))))
+        r.object_add(r.mesh_create(*scenes.uv_sphere()), None, scenes.generate_instances(60, 0.2, 2.5, 0.8, 1.6, seed=3))
+    cam = abi.make_camera((0.3, -0.6, 0.45), (0.0, 4.0, 0.6), fov=75.0, znear=0.05, zfar=200.0)
+    o, g = _both(oracle_lib, gpu_engine, 320, 200, 256, build, _std_frame(cam))
+    assert o.covered_pixels() > 0.6 * 320 * 200
+    _identical(o, g, "clipping")
+
+
+def test_raw_frame_without_the_y_flip(oracle_lib, gpu_engine):
+    """zr_set_frame with the engine's matrices but Proj[1][1] un-flipped: handedness reverses, so cone culling must switch
+    itself off (what is front-facing changes) and the frame must still match."""
+    def frame(r):
+        _std_frame()(r)
+        cam, sh, view = r.get_frame()
+        cam["Proj"][5] *= -1.0
+        r.set_frame(cam, sh, view)
+    o, g = _both(oracle_lib, gpu_engine, 256, 160, 128, _mixed_scene, frame)
+    _identical(o, g, "un-flipped projection")
+
+
+def test_caller_supplied_meshlets_follow_the_indirect_draw_order(oracle_lib, gpu_engine):
+    """zr_mesh_set_meshlets flattens like CreateMeshVertexBuffers<XkMeshIndirect> (ZE:4733-4756): primitive order becomes
+    meshlet order.  The oracle gets the equivalent flattened index buffer."""
+    v, idx = scenes.uv_sphere()
+    ml, mv, mt, order = gpu_engine.build_meshlets(v, idx, 48, 60, 0.5)
+    flat = idx.reshape(-1, 3)[order].reshape(-1)
+    inst = scenes.generate_instances(80, 1.0, 5.0, 0.3, 0.8, seed=5)
+    o = oracle_lib.Oracle(320, 180, 128)
+    o.object_add(o.mesh_create(v, flat), None, inst)
+    g = gpu_engine.Renderer(320, 180, 128)
+    m = g.mesh_create(v, idx)
+    g.mesh_set_meshlets(m, ml, mv, mt)
+    g.object_add(m, None, inst)
+    for r in (o, g):
+        r.set_cubemap(scenes.synthetic_cubemap(16))
+        _std_frame()(r)
+    o.render(); g.render(); g.finish()
+    _identical(o, g, "caller meshlets")
+
+
+@pytest.mark.parametrize("view", [1, 2, 3, 4, 5, 7, 8])
+def test_debug_views(oracle_lib, gpu_engine, view):
+    o, g = _both(oracle_lib, gpu_engine, 192, 128, 128, _mixed_scene, _std_frame(), debug_view=view)
+    assert np.array_equal(o.color(), g.color())
+
+
+def test_empty_scene_and_scene_reuse(oracle_lib, gpu_engine):
+    o = oracle_lib.Oracle(96, 64, 64)
+    g = gpu_engine.Renderer(96, 64, 64)
+    for r in (o, g):
+        r.set_cubemap(scenes.synthetic_cubemap(8))
+        _std_frame()(r)
+    o.render(); g.render(); g.finish()
+    _identical(o, g, "empty scene")
+    assert g.stats()["covered_pixels"] == 0
+    for r in (o, g):
+        _mixed_scene(r, 5)
+    o.render(); g.render(); g.finish()
+    _identical(o, g, "after adding objects")
+    for r in (o, g):
+        r.scene_clear()
+        r.object_add(r.mesh_create(*scenes.box()))
+    o.render(); g.render(); g.finish()
+    _identical(o, g, "after scene_clear")
+
+
+def test_many_lights_config5_style(oracle_lib, gpu_engine):
+    """256 point lights (config 5's count): the zero-radiance skip in k_lighting must stay exact."""
+    o, g = _both(oracle_lib, gpu_engine, 160, 96, 128, _mixed_scene, _std_frame(n_point=256))
+    _identical(o, g, "256 lights")
+
+
+def test_errors_are_reported_not_swallowed(gpu_engine):
+    g = gpu_engine.Renderer(64, 64, 64)
+    with pytest.raises(gpu_engine.ZeldaRenderError) as e:
+        g.render()
+    assert e.value.code == -6                                   # no frame uniforms yet
+    v, idx = scenes.box()
+    bad = idx.copy(); bad[0] = 10 ** 6
+    with pytest.raises(gpu_engine.ZeldaRenderError):
+        g.mesh_create(v, bad)
+    m = g.mesh_create(v, idx)
+    checker = np.zeros((4, 4, 4), np.uint8); checker[::2, ::2] = 255
+    mat, _keep = abi.make_material([checker, None, None, None, None, None, None])
+    with pytest.raises(gpu_engine.ZeldaRenderError) as e:
+        g.object_add(m, mat)
+    assert e.value.code == -8                                   # textured materials: SURVEY 8f N2, not built yet

@@ -1,0 +1,147 @@
+"""GPU: screen-tile partition through the kernels, world JSON + Profabs, the livelink server, full-size properties."""
+import json
+import time
+
+import numpy as np
+import pytest
+
+from parity_util import compare_all
+from zeldaengine_amd import abi, dist as zdist, livelink, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tile_partition_composites_to_the_single_gpu_frame(gpu_engine, world):
+    """Rank contexts on one GPU (run in turn), packed tiles gathered on the host, composited by k_untile."""
+    import torch
+    cfg = scenes.config3(300, 416, 250)
+    single = gpu_engine.Renderer(cfg["width"], cfg["height"], 256)
+    gpu_engine.load_scene(single, cfg)
+    single.render()
+    want = single.color()
+    packs, ranks = [], []
+    for r in range(world):
+        g = gpu_engine.Renderer(cfg["width"], cfg["height"], 256, tile_rank=r, tile_world=world)
+        gpu_engine.load_scene(g, cfg)
+        g.render()
+        packs.append(g.read_tiles())
+        ranks.append(g)
+        assert np.array_equal(packs[-1], zdist.pack_tiles(want, r, world))          # the packed layout is the documented one
+    gathered = torch.from_numpy(np.stack(packs).reshape(-1).copy()).cuda()
+    for g in ranks:
+        g.composite(gathered.data_ptr())
+        assert np.array_equal(g.color(), want)
+    st = [g.stats() for g in ranks]
+    assert sum(s["covered_pixels"] for s in st) == single.stats()["covered_pixels"]
+
+
+def _register_sample_profabs(r):
+    plane = r.mesh_create(*scenes.grid_plane(20.0, 4, 0.0))
+    box = r.mesh_create(*scenes.box((0.5, 0.5, 0.5), (0, 0, 0.5)))
+    sph = r.mesh_create(*scenes.uv_sphere())
+    r.profab_register("terrain", plane)
+    r.profab_register("rock_01", box)
+    r.profab_register("rock_02", box)
+    r.profab_register("grass_01", sph)
+    return {"terrain": plane, "rock_01": box, "rock_02": box, "grass_01": sph}
+
+
+def _oracle_from_renderer(oracle_lib, g, meshes, W, H, SD, cubemap):
+    """Rebuild the renderer's scene on the oracle from what the library reports (instances it generated itself)."""
+    o = oracle_lib.Oracle(W, H, SD)
+    o.set_cubemap(cubemap)
+    cache = {}
+    for i in range(g.object_count()):
+        mesh_id, inst = g.object_get_instances(i)
+        if mesh_id not in cache:
+            cache[mesh_id] = o.mesh_create(*meshes[mesh_id])
+        o.object_add(cache[mesh_id], None, inst)
+    o.set_frame(*g.get_frame())
+    return o
+
+
+def test_world_json_builds_the_scene_from_registered_profabs(oracle_lib, gpu_engine):
+    W, H, SD = 384, 216, 256
+    g = gpu_engine.Renderer(W, H, SD)
+    cube = scenes.synthetic_cubemap(16)
+    g.set_cubemap(cube)
+    ids = _register_sample_profabs(g)
+    world = scenes.sample_world()
+    world["Objects"][3]["InstanceCount"] = 700                   # keep the oracle fast; grass_02 has no Profab -> draws nothing
+    g.world_load_json(json.dumps(world))
+    assert g.object_count() == 4
+    counts = [None if g.object_get_instances(i)[1] is None else len(g.object_get_instances(i)[1]) for i in range(4)]
+    assert counts == [None, None, 64, 700]                       # InstanceCount <= 1 -> non-instanced draw (ZE:4250-4267)
+    cam = g.world_camera()
+    assert list(cam.Lookat) == [0.0, 0.0, 0.5] and cam.FOV == 45.0
+    saved = json.loads(g.world_save_json())
+    assert saved["Objects"][3]["InstanceCount"] == 700 and len(saved["PointLights"]) == 16
+    g.render(); g.finish()
+    meshes = {ids["terrain"]: scenes.grid_plane(20.0, 4, 0.0), ids["rock_01"]: scenes.box((0.5, 0.5, 0.5), (0, 0, 0.5)),
+              ids["grass_01"]: scenes.uv_sphere()}
+    o = _oracle_from_renderer(oracle_lib, g, meshes, W, H, SD, cube)
+    o.render()
+    bad = {k: v for k, v in compare_all(o, g).items() if v}
+    assert not bad, bad
+    inst = g.object_get_instances(3)[1]
+    d = np.linalg.norm(inst["InstancePosition"][:, :2], axis=1)
+    assert d.min() >= 2.0 - 1e-5 and d.max() <= 8.0 + 1e-5 and (inst["InstancePosition"][:, 2] == 0).all()
+    assert inst["InstancePScale"].min() >= 0.1 and inst["InstancePScale"].max() <= 0.5
+    assert (inst["InstanceRotation"][:, 0] == 0).all() and inst["InstanceRotation"][:, 1].max() <= np.pi * 180.0
+
+
+def test_livelink_end_to_end(gpu_engine):
+    """The reference client's bytes over TCP -> listener thread -> poll on the render thread -> new scene (ZE:1617-1710)."""
+    g = gpu_engine.Renderer(128, 96, 64)
+    _register_sample_profabs(g)
+    port = g.livelink_serve(0)
+    assert port > 0 and not g.livelink_poll()
+    world = scenes.sample_world()
+    world["Objects"][3]["InstanceCount"] = 50
+    assert livelink.send_world(world, port=port, host="127.0.0.1") == b""
+    for _ in range(100):
+        if g.livelink_poll():
+            break
+        time.sleep(0.02)
+    else:
+        pytest.fail("the livelink payload never reached the render thread")
+    assert g.object_count() == 4
+    g.render(); g.finish()
+    assert g.stats()["covered_pixels"] > 1000
+    # a malformed payload is logged and ignored; the server keeps serving (the engine would terminate, ZE:1071-1073)
+    livelink.sendDataToEngine("{not json", port=port, host="127.0.0.1")
+    time.sleep(0.1)
+    assert not g.livelink_poll()
+    livelink.send_world(scenes.sample_world() | {"Objects": []}, port=port, host="127.0.0.1")
+    for _ in range(100):
+        if g.livelink_poll():
+            break
+        time.sleep(0.02)
+    assert g.object_count() == 0
+    g.livelink_stop()
+
+
+def test_full_size_config3_against_the_oracle(oracle_lib, gpu_engine):
+    """BASELINE's own size: 10 000 instances / 140 000 meshlet-instances at 1920x1080, every target bit-exact."""
+    cfg = scenes.config3()
+    o = oracle_lib.Oracle(cfg["width"], cfg["height"], 1024)
+    oracle_lib.load_scene(o, cfg)
+    o.render()
+    g = gpu_engine.Renderer(cfg["width"], cfg["height"], 1024)
+    gpu_engine.load_scene(g, cfg)
+    g.render(); g.finish()
+    bad = {k: v for k, v in compare_all(o, g).items() if v}
+    assert not bad, bad
+    st = g.stats()
+    assert st["covered_pixels"] == o.covered_pixels() and st["overflow"] == 0
+    assert st["survivors"][1] < 0.7 * st["work_items"][1]          # frustum + cone culling bite
+    # size-independent properties: determinism across frames, and culling is invisible at full size too
+    first = (g.color(), g.gbuffer(2), g.shadowmap())
+    g.render()
+    assert np.array_equal(first[0], g.color()) and np.array_equal(first[1], g.gbuffer(2))
+    h = gpu_engine.Renderer(cfg["width"], cfg["height"], 1024, flags=abi.FLAG_NO_FRUSTUM_CULL | abi.FLAG_NO_CONE_CULL)
+    gpu_engine.load_scene(h, cfg)
+    h.render()
+    assert np.array_equal(first[0], h.color()) and np.array_equal(first[2].view(np.uint32), h.shadowmap().view(np.uint32))
+    assert h.stats()["survivors"][1] > st["survivors"][1]

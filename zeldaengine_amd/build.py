@@ -48,7 +48,20 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
         if verbose and out:
             print(out.decode(errors="replace"))
-    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", out_path] + objs + ["-lpthread"]
+    # ONE HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7, like /opt/rocm's).
+    # The library is linked with plain g++ against that SONAME; engine.lib() imports torch first, so in a torch process the
+    # loader binds us to torch's already-loaded copy (one ROCr, shared streams and allocations), and to /opt/rocm/lib's
+    # (RUNPATH) in a process without torch.  Loading ours first and torch second would start a second runtime.
+    hip_dir = "/opt/rocm/lib"
+    try:
+        import torch
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib")
+        if os.path.exists(os.path.join(cand, "libamdhip64.so")):
+            hip_dir = cand
+    except Exception:      # noqa: BLE001
+        pass
+    cmd = ["g++", "-shared", "-fPIC", "-o", out_path] + objs + ["-L" + hip_dir, "-l:libamdhip64.so", "-Wl,-rpath,/opt/rocm/lib",
+                                                                 "-Wl,--no-as-needed", "-lpthread"]
     subprocess.check_call(cmd)
     return out_path
 

@@ -766,6 +766,15 @@ extern "C" int zr_tiles_device_buffer(zr_ctx* c, void** p, size_t* bytes)
     *p = c->d_tiles; *bytes = (size_t)c->slots_per_rank * ZR_TILE * ZR_TILE * 4;
     return ZR_OK;
 }
+extern "C" int zr_read_tiles(zr_ctx* c, uint8_t* dst, size_t bytes)
+{
+    if (!c) return ZR_ERR_ARG;
+    ARGCHK(c, dst && bytes == (size_t)c->slots_per_rank * ZR_TILE * ZR_TILE * 4);
+    int rc = zr_finish(c);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(dst, c->d_tiles, bytes, hipMemcpyDeviceToHost));
+    return ZR_OK;
+}
 extern "C" int zr_composite(zr_ctx* c, const void* gathered)
 {
     if (!c) return ZR_ERR_ARG;

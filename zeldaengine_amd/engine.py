@@ -33,6 +33,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libzelda_render.so is not built: run `python -m zeldaengine_amd.build` "
                           "(hipcc --offload-arch=gfx950); there is no fallback path")
+    try:
+        import torch  # noqa: F401  -- first, so that this process has ONE HIP runtime (torch's bundled libamdhip64.so)
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
     sig = {
@@ -62,6 +66,7 @@ def lib():
         "zr_read_shadowmap": [vp, vp, sz],
         "zr_tiles_device_buffer": [vp, C.POINTER(vp), C.POINTER(sz)],
         "zr_composite": [vp, vp],
+        "zr_read_tiles": [vp, vp, sz],
         "zr_color_device_ptr": [vp, C.POINTER(vp)],
         "zr_profab_register": [vp, C.c_char_p, u32, vp],
         "zr_world_load_json": [vp, C.c_char_p, sz],
@@ -286,6 +291,12 @@ class Renderer:
         p, n = C.c_void_p(), C.c_size_t()
         self._chk(self.L.zr_tiles_device_buffer(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def read_tiles(self):
+        _, nbytes = self.tiles_device_buffer()
+        out = np.zeros((nbytes // (abi.TILE * abi.TILE * 4), abi.TILE, abi.TILE, 4), dtype=np.uint8)
+        self._chk(self.L.zr_read_tiles(self.h, _ptr(out), out.nbytes))
+        return out
 
     def composite(self, gathered_dev_ptr):
         self._chk(self.L.zr_composite(self.h, C.c_void_p(gathered_dev_ptr)))
