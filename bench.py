@@ -28,20 +28,27 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
 def algorithmic_bytes(stats, cfg, n_tiles_owned_px):
-    """per-frame algorithmic HBM bytes of each pass (geometry counted once per surviving meshlet-instance)."""
+    """SURVEY 8d per-frame algorithmic HBM bytes, split over the kernels that carry each term.
+
+    GBuffer-write pass = 28 B x W*H (clear) + 28 B x covered px + geometry once per surviving meshlet-instance: the geometry
+    term belongs to the rasteriser kernel (plus its 8 B visibility key per covered pixel), the 28 B terms to the resolve
+    kernel, which is the one that writes the GBuffer.
+    """
     geo = cfg["_geo_bytes_per_meshlet_instance"]
-    W, H, SD = cfg["width"], cfg["height"], 1024
+    SD = 1024
     return {
         "cull_shadow": 64 * stats["work_items"][0] + 4 * stats["survivors"][0],
         "shadow": geo * stats["survivors"][0] + 4 * SD * SD + 4 * stats["covered_shadow_texels"],
         "cull_camera": 64 * stats["work_items"][1] + 4 * stats["survivors"][1],
-        "gbuffer": geo * stats["survivors"][1] + 28 * n_tiles_owned_px + 28 * stats["covered_pixels"],
+        "gbuffer": geo * stats["survivors"][1] + 8 * stats["covered_pixels"],
+        "resolve": 28 * n_tiles_owned_px + 28 * stats["covered_pixels"],
         "lighting": 28 * n_tiles_owned_px + 35068 + 4 * SD * SD,
     }
 
 
 KERNEL_OF_PASS = {"cull_shadow": "k_cull<SHADOW>+k_scan+k_bin_fill", "shadow": "k_raster<SHADOW>",
-                  "cull_camera": "k_cull<GBUFFER>+k_scan+k_bin_fill", "gbuffer": "k_raster<GBUFFER>", "lighting": "k_lighting"}
+                  "cull_camera": "k_cull<GBUFFER>+k_scan+k_bin_fill", "gbuffer": "k_raster<GBUFFER>",
+                  "resolve": "k_resolve_gbuffer", "lighting": "k_lighting"}
 
 
 def main():

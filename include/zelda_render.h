@@ -63,7 +63,12 @@ typedef struct zr_material { zr_image tex[XK_PBR_SAMPLER_NUMBER]; } zr_material;
 typedef struct zr_camera { float Position[3]; float Lookat[3]; float Speed, FOV, zNear, zFar; } zr_camera;
 
 /* Per-pass GPU timings of the last zr_render, milliseconds (hipEvents on the render stream). */
-enum { ZR_PASS_CULL_SHADOW = 0, ZR_PASS_SHADOW, ZR_PASS_CULL_CAMERA, ZR_PASS_GBUFFER, ZR_PASS_LIGHTING,
+enum { ZR_PASS_CULL_SHADOW = 0,   /* k_fill32 + k_cull<SHADOW> + k_bin_count + k_scan + k_bin_fill */
+       ZR_PASS_SHADOW,            /* k_raster_chunks<SHADOW> */
+       ZR_PASS_CULL_CAMERA,       /* k_cull<GBUFFER> + k_bin_count + k_scan + k_bin_fill */
+       ZR_PASS_GBUFFER,           /* k_raster_chunks<GBUFFER> */
+       ZR_PASS_RESOLVE,           /* k_resolve_gbuffer: the GBuffer write */
+       ZR_PASS_LIGHTING,          /* k_lighting */
        ZR_PASS_COMPOSITE, ZR_PASS_TOTAL, ZR_PASS_COUNT };
 
 /* Frame statistics of the last zr_render (read back lazily by zr_get_stats). */

@@ -56,7 +56,7 @@ class Stats(C.Structure):
                 ("covered_pixels", C.c_uint64), ("covered_shadow_texels", C.c_uint64), ("overflow", C.c_uint32), ("_pad", C.c_uint32)]
 
 
-PASS_NAMES = ["cull_shadow", "shadow", "cull_camera", "gbuffer", "lighting", "composite", "total"]
+PASS_NAMES = ["cull_shadow", "shadow", "cull_camera", "gbuffer", "resolve", "lighting", "composite", "total"]
 GBUFFER_DTYPES = [np.dtype("<f4"), np.dtype("<u4"), np.dtype("<u4"), np.dtype("<u4"), np.dtype("<u4"), np.dtype("<u8")]
 
 FLAG_NO_FRUSTUM_CULL = 1

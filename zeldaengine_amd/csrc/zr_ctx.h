@@ -77,7 +77,7 @@ struct zr_ctx {
     float lut[256]; float* d_lut = nullptr;
 
     static constexpr int EV_RING = 64;     // per-pass hipEvents of the last EV_RING frames (bench averages over them)
-    hipEvent_t evr[EV_RING][6] = {}; uint64_t frame_no = 0; bool rendered = false;
+    hipEvent_t evr[EV_RING][7] = {}; uint64_t frame_no = 0; bool rendered = false;
 
     // world + livelink
     ZrWorld world;

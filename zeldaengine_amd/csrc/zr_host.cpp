@@ -649,8 +649,9 @@ extern "C" int zr_render(zr_ctx* c)
     if (!live) P.n_work = 0;
     c->last_work[1] = P.n_work;
     geometry_pass(c, P, 1, c->n_tiles, ev[3]);
-    zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_stats, s);
     HIPCHK(c, hipEventRecord(ev[4], s));
+    zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_stats, s);
+    HIPCHK(c, hipEventRecord(ev[5], s));
     // deferred-lighting pass (ZE:3531-3540)
     ZrLightParams L; memset(&L, 0, sizeof L);
     static const float Bias[16] = { 0.5f, 0, 0, 0, 0, 0.5f, 0, 0, 0, 0, 1, 0, 0.5f, 0.5f, 0, 1 };
@@ -660,7 +661,7 @@ extern "C" int zr_render(zr_ctx* c)
     L.packed_out = c->cfg.tile_world > 1 ? 1u : 0u;
     zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, c->d_shadow, c->cube, c->d_lut,
                        L.packed_out ? c->d_tiles : c->d_color, s);
-    HIPCHK(c, hipEventRecord(ev[5], s));
+    HIPCHK(c, hipEventRecord(ev[6], s));
     HIPCHK(c, hipGetLastError());
     c->rendered = true; c->frame_no++;
     return ZR_OK;
@@ -697,8 +698,9 @@ extern "C" int zr_get_pass_times_avg(zr_ctx* c, uint32_t last_n, float ms[ZR_PAS
         (void)hipEventElapsedTime(&t[ZR_PASS_SHADOW], ev[1], ev[2]);
         (void)hipEventElapsedTime(&t[ZR_PASS_CULL_CAMERA], ev[2], ev[3]);
         (void)hipEventElapsedTime(&t[ZR_PASS_GBUFFER], ev[3], ev[4]);
-        (void)hipEventElapsedTime(&t[ZR_PASS_LIGHTING], ev[4], ev[5]);
-        (void)hipEventElapsedTime(&t[ZR_PASS_TOTAL], ev[0], ev[5]);
+        (void)hipEventElapsedTime(&t[ZR_PASS_RESOLVE], ev[4], ev[5]);
+        (void)hipEventElapsedTime(&t[ZR_PASS_LIGHTING], ev[5], ev[6]);
+        (void)hipEventElapsedTime(&t[ZR_PASS_TOTAL], ev[0], ev[6]);
         for (int i = 0; i < ZR_PASS_COUNT; ++i) acc[i] += t[i];
     }
     for (int i = 0; i < ZR_PASS_COUNT; ++i) ms[i] = (float)(acc[i] / last_n);
