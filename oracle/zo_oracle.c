@@ -26,7 +26,7 @@
 /* ------------------------------------------------------------------ scene */
 
 typedef struct { XkVertex* v; uint32_t nv; uint32_t* idx; uint32_t ni; } zo_mesh;
-typedef struct { uint8_t* px; uint32_t w, h; int constant; } zo_tex;
+typedef struct { uint8_t* px; uint32_t w, h; int constant; int levels; uint8_t* mip[16]; } zo_tex;   /* mip[0] == px */
 typedef struct {
     int mesh; uint32_t n_inst; int instanced; XkInstanceData* inst;
     zo_tex tex[7]; uint32_t prim_base;
@@ -47,6 +47,9 @@ struct zo_ctx {
     uint32_t* vis; float* shadowmap; uint8_t* color;
     uint64_t covered;
 };
+
+static int zo_idx_clamp(float f, int hi);
+static uint8_t zo_srgb_encode(float l);
 
 static const uint8_t zo_default_texel[7][4] = {   /* ZE:4951-4978: grey, black, white, normal, white, black, white */
     {127,127,127,255}, {0,0,0,255}, {255,255,255,255}, {127,127,255,255}, {255,255,255,255}, {0,0,0,255}, {255,255,255,255}
@@ -102,7 +105,7 @@ void zo_scene_clear(zo_ctx* c)
 {
     for (int i = 0; i < c->n_objects; ++i) {
         free(c->objects[i].inst);
-        for (int t = 0; t < 7; ++t) free(c->objects[i].tex[t].px);
+        for (int t = 0; t < 7; ++t) for (int l = 0; l < c->objects[i].tex[t].levels; ++l) free(c->objects[i].tex[t].mip[l]);
     }
     free(c->objects); c->objects = NULL; c->n_objects = 0;
     for (int i = 0; i < c->n_meshes; ++i) { free(c->meshes[i].v); free(c->meshes[i].idx); }
@@ -129,6 +132,40 @@ int zo_mesh_create(zo_ctx* c, const XkVertex* v, uint32_t nv, const uint32_t* id
     return c->n_meshes++;
 }
 
+/* RHIGenerateMipmaps (ZE:6348-6433): level l+1 = vkCmdBlitImage(LINEAR) of level l at half size (floor, min 1);
+ * mipLevels = floor(log2(max(w, h))) + 1 (ZE:6887).  Filtering is done on decoded values (sRGB for the base-colour slot,
+ * whose format is R8G8B8A8_SRGB, ZE:5878) and re-encoded. */
+static float zo_decode8(const zo_ctx* c, uint8_t v, int srgb) { return srgb ? c->srgb_lut[v] : (float)v / 255.0f; }
+static void zo_build_mips(zo_ctx* c, zo_tex* tx, int srgb)
+{
+    uint32_t m = tx->w > tx->h ? tx->w : tx->h;
+    int levels = 1; while (m > 1) { m >>= 1; levels++; }
+    tx->levels = levels; tx->mip[0] = tx->px;
+    uint32_t sw = tx->w, sh = tx->h;
+    for (int l = 1; l < levels; ++l) {
+        uint32_t dw = sw > 1 ? sw >> 1 : 1, dh = sh > 1 ? sh >> 1 : 1;
+        const uint8_t* src = tx->mip[l - 1];
+        uint8_t* dst = (uint8_t*)malloc((size_t)dw * dh * 4);
+        float kx = (float)sw / (float)dw, ky = (float)sh / (float)dh;
+        for (uint32_t y = 0; y < dh; ++y) for (uint32_t x = 0; x < dw; ++x) {
+            float fu = fmaf((float)x + 0.5f, kx, -0.5f), fv = fmaf((float)y + 0.5f, ky, -0.5f);
+            float fx = floorf(fu), fy = floorf(fv), a = fu - fx, b = fv - fy;
+            int x0 = zo_idx_clamp(fx, (int)sw - 1), x1 = zo_idx_clamp(fx + 1.0f, (int)sw - 1);
+            int y0 = zo_idx_clamp(fy, (int)sh - 1), y1 = zo_idx_clamp(fy + 1.0f, (int)sh - 1);
+            const uint8_t* p00 = src + ((size_t)y0 * sw + x0) * 4; const uint8_t* p10 = src + ((size_t)y0 * sw + x1) * 4;
+            const uint8_t* p01 = src + ((size_t)y1 * sw + x0) * 4; const uint8_t* p11 = src + ((size_t)y1 * sw + x1) * 4;
+            for (int ch = 0; ch < 4; ++ch) {
+                int sr = srgb && ch < 3;
+                float t00 = zo_decode8(c, p00[ch], sr), t10 = zo_decode8(c, p10[ch], sr), t01 = zo_decode8(c, p01[ch], sr), t11 = zo_decode8(c, p11[ch], sr);
+                float top = fmaf(a, t10 - t00, t00), bot = fmaf(a, t11 - t01, t01);
+                float v = fmaf(b, bot - top, top);
+                dst[((size_t)y * dw + x) * 4 + ch] = sr ? zo_srgb_encode(v) : (uint8_t)zo_unorm(v, 255.0f);
+            }
+        }
+        tx->mip[l] = dst; sw = dw; sh = dh;
+    }
+}
+
 int zo_object_add(zo_ctx* c, int mesh, const zo_material* mat, const XkInstanceData* inst, uint32_t n_inst)
 {
     if (mesh < 0 || mesh >= c->n_meshes) return -1;
@@ -146,8 +183,10 @@ int zo_object_add(zo_ctx* c, int mesh, const zo_material* mat, const XkInstanceD
             tx->px = (uint8_t*)malloc(n); memcpy(tx->px, mat->tex[t].rgba8, n);
             tx->constant = 1;
             for (size_t i = 4; i < n; ++i) if (tx->px[i] != tx->px[i & 3]) { tx->constant = 0; break; }
+            zo_build_mips(c, tx, t == 0);
         } else {
             tx->w = tx->h = 1; tx->px = (uint8_t*)malloc(4); memcpy(tx->px, zo_default_texel[t], 4); tx->constant = 1;
+            tx->levels = 1; tx->mip[0] = tx->px;
         }
     }
     c->order_valid = 0;
@@ -653,10 +692,46 @@ static zo_varyings zo_interp(const float b[3], const zo_v3 P[3], const zo_v3 N[3
     return r;
 }
 
-static void zo_tex_const(const zo_tex* t, int srgb, const float* lut, float out[4])
+static void zo_tex_fetch(const zo_ctx* c, const zo_tex* t, int srgb, int level, int x, int y, float out[4])
 {
-    for (int ch = 0; ch < 4; ++ch)
-        out[ch] = (srgb && ch < 3) ? lut[t->px[ch]] : (float)t->px[ch] / 255.0f;
+    uint32_t w = t->w >> level, h = t->h >> level; if (!w) w = 1; if (!h) h = 1;
+    const uint8_t* p = t->mip[level] + ((size_t)y * w + (size_t)x) * 4;
+    for (int ch = 0; ch < 4; ++ch) out[ch] = zo_decode8(c, p[ch], srgb && ch < 3);
+}
+/* bilinear, REPEAT addressing (RHICreateSampler defaults, ZE:6523-6557) */
+static void zo_tex_bilinear(const zo_ctx* c, const zo_tex* t, int srgb, int level, float u, float v, float out[4])
+{
+    uint32_t w = t->w >> level, h = t->h >> level; if (!w) w = 1; if (!h) h = 1;
+    float ur = u - floorf(u), vr = v - floorf(v);
+    float x = fmaf(ur, (float)w, -0.5f), y = fmaf(vr, (float)h, -0.5f);
+    float fx = floorf(x), fy = floorf(y), a = x - fx, b = y - fy;
+    int x0 = zo_idx_clamp(fx + 1.0f, (int)w) - 1, y0 = zo_idx_clamp(fy + 1.0f, (int)h) - 1;     /* -1 .. w-1, NaN -> -1 */
+    int x1 = x0 + 1; if (x1 >= (int)w) x1 = 0; if (x0 < 0) x0 = (int)w - 1;
+    int y1 = y0 + 1; if (y1 >= (int)h) y1 = 0; if (y0 < 0) y0 = (int)h - 1;
+    float t00[4], t10[4], t01[4], t11[4];
+    zo_tex_fetch(c, t, srgb, level, x0, y0, t00); zo_tex_fetch(c, t, srgb, level, x1, y0, t10);
+    zo_tex_fetch(c, t, srgb, level, x0, y1, t01); zo_tex_fetch(c, t, srgb, level, x1, y1, t11);
+    for (int ch = 0; ch < 4; ++ch) {
+        float top = fmaf(a, t10[ch] - t00[ch], t00[ch]), bot = fmaf(a, t11[ch] - t01[ch], t01[ch]);
+        out[ch] = fmaf(b, bot - top, top);
+    }
+}
+/* texture(sampler2D, uv) in the fragment stage: isotropic LOD from the quad derivatives, trilinear.  Anisotropic filtering
+ * (maxAnisotropy = device max, ZE:6540) is implementation-defined and NOT reproduced: documented deviation. */
+static void zo_tex_sample(const zo_ctx* c, const zo_tex* t, int srgb, float u, float v, float dudx, float dvdx, float dudy, float dvdy, float out[4])
+{
+    if (t->constant) { zo_tex_fetch(c, t, srgb, 0, 0, 0, out); return; }
+    float W = (float)t->w, H = (float)t->h;
+    float ax = dudx * W, ay = dvdx * H, bx = dudy * W, by = dvdy * H;
+    float rho2 = fmaxf(fmaf(ax, ax, ay * ay), fmaf(bx, bx, by * by));
+    float lambda = 0.5f * zo_log2f(rho2);
+    lambda = fminf(fmaxf(lambda, 0.0f), (float)(t->levels - 1));
+    float fl = floorf(lambda);
+    int l0 = (int)fl, l1 = l0 + 1 < t->levels ? l0 + 1 : t->levels - 1;
+    float f = lambda - fl;
+    float c0[4], c1[4];
+    zo_tex_bilinear(c, t, srgb, l0, u, v, c0); zo_tex_bilinear(c, t, srgb, l1, u, v, c1);
+    for (int ch = 0; ch < 4; ++ch) out[ch] = fmaf(f, c1[ch] - c0[ch], c0[ch]);
 }
 
 /* ComputeNormal(fragPosition, fragTexCoord, fragNormal, texNormal), SH/Common.glsl:113-127 */
@@ -746,10 +821,11 @@ static void zo_resolve_gbuffer(zo_ctx* c, const float* PVM)
         float s1 = (f0.u - fh.u) * sx, t1 = (f0.v - fh.v) * sx, s2 = (f0.u - fv.u) * sy, t2 = (f0.v - fv.v) * sy;
 
         float bc[4], me[4], ro[4], nm[4], ao[4], em[4], ms[4];
-        zo_tex_const(&o->tex[0], 1, c->srgb_lut, bc);         /* base colour is R8G8B8A8_SRGB, ZE:5878 */
-        zo_tex_const(&o->tex[1], 0, c->srgb_lut, me); zo_tex_const(&o->tex[2], 0, c->srgb_lut, ro);
-        zo_tex_const(&o->tex[3], 0, c->srgb_lut, nm); zo_tex_const(&o->tex[4], 0, c->srgb_lut, ao);
-        zo_tex_const(&o->tex[5], 0, c->srgb_lut, em); zo_tex_const(&o->tex[6], 0, c->srgb_lut, ms);
+        /* texture(samplerN, fragTexCoord), BaseScene.frag:30-36; s1,t1 = dFdx(uv), s2,t2 = dFdy(uv) */
+        zo_tex_sample(c, &o->tex[0], 1, f0.u, f0.v, s1, t1, s2, t2, bc);         /* base colour is R8G8B8A8_SRGB, ZE:5878 */
+        zo_tex_sample(c, &o->tex[1], 0, f0.u, f0.v, s1, t1, s2, t2, me); zo_tex_sample(c, &o->tex[2], 0, f0.u, f0.v, s1, t1, s2, t2, ro);
+        zo_tex_sample(c, &o->tex[3], 0, f0.u, f0.v, s1, t1, s2, t2, nm); zo_tex_sample(c, &o->tex[4], 0, f0.u, f0.v, s1, t1, s2, t2, ao);
+        zo_tex_sample(c, &o->tex[5], 0, f0.u, f0.v, s1, t1, s2, t2, em); zo_tex_sample(c, &o->tex[6], 0, f0.u, f0.v, s1, t1, s2, t2, ms);
 
         zo_v3 Nw = zo_compute_normal(pos_dx, pos_dy, s1, t1, s2, t2, f0.N, zo_v3make(nm[0], nm[1], nm[2]));
         float Rough = fmaxf(0.01f, ro[0]);

@@ -157,8 +157,40 @@ def test_errors_are_reported_not_swallowed(gpu_engine):
     with pytest.raises(gpu_engine.ZeldaRenderError):
         g.mesh_create(v, bad)
     m = g.mesh_create(v, idx)
-    checker = np.zeros((4, 4, 4), np.uint8); checker[::2, ::2] = 255
-    mat, _keep = abi.make_material([checker, None, None, None, None, None, None])
     with pytest.raises(gpu_engine.ZeldaRenderError) as e:
-        g.object_add(m, mat)
-    assert e.value.code == -8                                   # textured materials: SURVEY 8f N2, not built yet
+        g.object_add(m + 5)
+    assert e.value.code == -1
+
+
+def _textures(seed=0):
+    """7 non-constant RGBA8 images of assorted (also non-power-of-two) sizes."""
+    rng = np.random.default_rng(seed)
+    def checker(w, h, a, b, cell):
+        yy, xx = np.mgrid[0:h, 0:w]
+        m = (((xx // cell) + (yy // cell)) & 1).astype(bool)
+        img = np.empty((h, w, 4), np.uint8); img[m] = a; img[~m] = b
+        return img
+    def noise(w, h, lo, hi):
+        img = rng.integers(lo, hi, size=(h, w, 4), dtype=np.uint8); img[..., 3] = 255
+        return img
+    nrm = noise(48, 20, 100, 156); nrm[..., 2] = 255
+    return [checker(64, 64, (220, 60, 40, 255), (40, 90, 200, 255), 8), noise(16, 16, 0, 255), noise(37, 23, 30, 255), nrm,
+            checker(8, 32, (255, 255, 255, 255), (120, 120, 120, 255), 2), noise(5, 3, 0, 60), checker(32, 32, (255,) * 4, (200, 200, 200, 255), 16)]
+
+
+def test_textured_materials_trilinear_repeat_srgb(oracle_lib, gpu_engine):
+    """N2: real material textures - blit-generated mips, sRGB base colour, REPEAT addressing, LOD from quad derivatives."""
+    def build(r):
+        r.set_cubemap(scenes.synthetic_cubemap(16))
+        mat, keep = abi.make_material(_textures())
+        r._keepalive = keep
+        v, idx = scenes.grid_plane(24.0, 6, 0.0)
+        v = v.copy(); v["TexCoord"] *= 5.0                     # tiles: exercises REPEAT and minification far away
+        r.object_add(r.mesh_create(v, idx), mat)
+        r.object_add(r.mesh_create(*scenes.uv_sphere()), mat, scenes.generate_instances(60, 1.0, 6.0, 0.4, 1.2, seed=9))
+        mat2, keep2 = abi.make_material([None, None, None, _textures(3)[3], None, None, None])   # only the normal map sampled
+        r._keepalive2 = keep2
+        r.object_add(r.mesh_create(*scenes.box((0.7, 0.7, 0.7), (0, 0, 0.7))), mat2)
+    o, g = _both(oracle_lib, gpu_engine, 400, 240, 256, build, _std_frame(abi.make_camera((5.0, 4.0, 2.5), (0.0, 0.0, 0.3))))
+    assert len(np.unique(o.gbuffer(4))) > 200                  # base colour really varies
+    _identical(o, g, "textured")

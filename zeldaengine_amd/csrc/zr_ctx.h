@@ -21,11 +21,20 @@ struct ZrMesh {
     float4* d_mpos = nullptr; uint2* d_mtri = nullptr;
 };
 
+// Host form of one material: per slot either a constant texel or an RGBA8 image (mips are built at zr_object_add).
+struct ZrMaterialHost {
+    uint32_t texel[7]; float bc_linear[3];
+    std::vector<uint8_t> image[7];       // empty: the slot is constant
+    uint32_t w[7], h[7];
+};
+
 struct ZrSceneObject {
     uint32_t mesh = 0, n_inst = 1; bool instanced = false;
     std::vector<XkInstanceData> inst;    // host copy (zr_object_get_instances)
     ZrInstance* d_inst = nullptr;
     uint32_t texel[7]; float bc_linear[3];
+    uint8_t* d_tex[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    uint32_t tex_w[7] = { 0 }, tex_h[7] = { 0 }, tex_levels[7] = { 0 };
 };
 
 // XkWorld (ZE:1025-1291) as parsed from JSON
@@ -44,7 +53,7 @@ struct ZrWorld {
     std::vector<ZrObjectDesc> ObjectDescs;
     bool loaded = false;
 };
-struct ZrProfab { uint32_t mesh; bool has_material; uint32_t texel[7]; float bc_linear[3]; };
+struct ZrProfab { uint32_t mesh; ZrMaterialHost mat; };
 
 struct zr_ctx {
     zr_config cfg;
@@ -89,6 +98,5 @@ struct zr_ctx {
 int zr_fail(zr_ctx* c, int code, const std::string& msg);
 // helpers implemented in zr_host.cpp and used by zr_world.cpp
 float zr_srgb_decode8(uint32_t c);
-int zr_material_constants(zr_ctx* c, const zr_material* mat, uint32_t texel[7], float bc_linear[3]);
-int zr_object_add_internal(zr_ctx* c, uint32_t mesh_id, const uint32_t texel[7], const float bc_linear[3],
-                           const XkInstanceData* inst, uint32_t n_inst);
+int zr_material_prepare(zr_ctx* c, const zr_material* mat, ZrMaterialHost* out);
+int zr_object_add_internal(zr_ctx* c, uint32_t mesh_id, const ZrMaterialHost& mat, const XkInstanceData* inst, uint32_t n_inst);

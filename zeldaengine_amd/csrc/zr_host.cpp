@@ -122,7 +122,7 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
 
 static void free_scene(zr_ctx* c)
 {
-    for (auto& o : c->objects) dev_free(o.d_inst);
+    for (auto& o : c->objects) { dev_free(o.d_inst); for (auto& t : o.d_tex) dev_free(t); }
     c->objects.clear();
     for (auto& m : c->meshes) {
         dev_free(m.d_v); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mtri);
@@ -266,44 +266,94 @@ extern "C" int zr_mesh_get_meshlets(zr_ctx* c, uint32_t mesh_id, XkMeshlet* ml, 
     return ZR_OK;
 }
 
-int zr_material_constants(zr_ctx* c, const zr_material* mat, uint32_t texel[7], float bc_linear[3])
+int zr_material_prepare(zr_ctx* c, const zr_material* mat, ZrMaterialHost* out)
 {
     for (int t = 0; t < 7; ++t) {
         const uint8_t* px = kDefaultTexel[t];
+        out->image[t].clear(); out->w[t] = out->h[t] = 1;
         if (mat && mat->tex[t].rgba8) {
             const zr_image& im = mat->tex[t];
-            if (im.width == 0 || im.height == 0) return zr_fail(c, ZR_ERR_ARG, "empty material image");
+            if (im.width == 0 || im.height == 0 || im.width > 16384 || im.height > 16384) return zr_fail(c, ZR_ERR_ARG, "bad material image size");
             const size_t n = (size_t)im.width * im.height * 4;
-            for (size_t i = 4; i < n; ++i)
-                if (im.rgba8[i] != im.rgba8[i & 3])
-                    return zr_fail(c, ZR_ERR_UNSUPPORTED, "non-constant material textures are not supported yet (SURVEY 8f N2)");
+            bool constant = true;
+            for (size_t i = 4; i < n; ++i) if (im.rgba8[i] != im.rgba8[i & 3]) { constant = false; break; }
             px = im.rgba8;
+            if (!constant) { out->image[t].assign(im.rgba8, im.rgba8 + n); out->w[t] = im.width; out->h[t] = im.height; }
         }
-        texel[t] = (uint32_t)px[0] | (uint32_t)px[1] << 8 | (uint32_t)px[2] << 16 | (uint32_t)px[3] << 24;
+        out->texel[t] = (uint32_t)px[0] | (uint32_t)px[1] << 8 | (uint32_t)px[2] << 16 | (uint32_t)px[3] << 24;
     }
-    for (int k = 0; k < 3; ++k) bc_linear[k] = zr_srgb_decode8((texel[0] >> (8 * k)) & 255u);
+    for (int k = 0; k < 3; ++k) out->bc_linear[k] = zr_srgb_decode8((out->texel[0] >> (8 * k)) & 255u);
     return ZR_OK;
 }
 
-int zr_object_add_internal(zr_ctx* c, uint32_t mesh_id, const uint32_t texel[7], const float bc_linear[3],
-                           const XkInstanceData* inst, uint32_t n_inst)
+static int idx_clamp_h(float f, int hi) { f = fminf(fmaxf(f, 0.0f), (float)hi); return (int)f; }
+
+// RHIGenerateMipmaps (ZE:6348-6433): level l+1 = vkCmdBlitImage(LINEAR) of level l at half size; mipLevels =
+// floor(log2(max(w, h))) + 1 (ZE:6887).  Filtered on decoded values (sRGB for the base-colour slot, ZE:5878), re-encoded.
+static void build_mip_chain(const zr_ctx* c, const std::vector<uint8_t>& img, uint32_t w, uint32_t h, bool srgb,
+                            std::vector<uint8_t>* chain, uint32_t* levels)
+{
+    uint32_t m = w > h ? w : h;
+    uint32_t nl = 1; while (m > 1) { m >>= 1; nl++; }
+    *levels = nl;
+    *chain = img;
+    size_t src_off = 0;
+    uint32_t sw = w, sh = h;
+    for (uint32_t l = 1; l < nl; ++l) {
+        const uint32_t dw = sw > 1 ? sw >> 1 : 1, dh = sh > 1 ? sh >> 1 : 1;
+        const size_t dst_off = chain->size();
+        chain->resize(dst_off + (size_t)dw * dh * 4);
+        const uint8_t* src = chain->data() + src_off;
+        uint8_t* dst = chain->data() + dst_off;
+        const float kx = (float)sw / (float)dw, ky = (float)sh / (float)dh;
+        for (uint32_t y = 0; y < dh; ++y) for (uint32_t x = 0; x < dw; ++x) {
+            const float fu = fmaf((float)x + 0.5f, kx, -0.5f), fv = fmaf((float)y + 0.5f, ky, -0.5f);
+            const float fx = floorf(fu), fy = floorf(fv), a = fu - fx, b = fv - fy;
+            const int x0 = idx_clamp_h(fx, (int)sw - 1), x1 = idx_clamp_h(fx + 1.0f, (int)sw - 1);
+            const int y0 = idx_clamp_h(fy, (int)sh - 1), y1 = idx_clamp_h(fy + 1.0f, (int)sh - 1);
+            const uint8_t* p00 = src + ((size_t)y0 * sw + x0) * 4; const uint8_t* p10 = src + ((size_t)y0 * sw + x1) * 4;
+            const uint8_t* p01 = src + ((size_t)y1 * sw + x0) * 4; const uint8_t* p11 = src + ((size_t)y1 * sw + x1) * 4;
+            for (int ch = 0; ch < 4; ++ch) {
+                const bool sr = srgb && ch < 3;
+                const float t00 = sr ? c->lut[p00[ch]] : (float)p00[ch] / 255.0f, t10 = sr ? c->lut[p10[ch]] : (float)p10[ch] / 255.0f;
+                const float t01 = sr ? c->lut[p01[ch]] : (float)p01[ch] / 255.0f, t11 = sr ? c->lut[p11[ch]] : (float)p11[ch] / 255.0f;
+                const float top = fmaf(a, t10 - t00, t00), bot = fmaf(a, t11 - t01, t01);
+                const float v = fmaf(b, bot - top, top);
+                dst[((size_t)y * dw + x) * 4 + ch] = sr ? srgb_encode8(v) : (uint8_t)zr_unorm(v, 255.0f);
+            }
+        }
+        src_off = dst_off; sw = dw; sh = dh;
+    }
+}
+
+int zr_object_add_internal(zr_ctx* c, uint32_t mesh_id, const ZrMaterialHost& mat, const XkInstanceData* inst, uint32_t n_inst)
 {
     ZrSceneObject o;
     o.mesh = mesh_id; o.instanced = n_inst > 0; o.n_inst = n_inst ? n_inst : 1;
-    memcpy(o.texel, texel, sizeof o.texel); memcpy(o.bc_linear, bc_linear, sizeof o.bc_linear);
+    memcpy(o.texel, mat.texel, sizeof o.texel); memcpy(o.bc_linear, mat.bc_linear, sizeof o.bc_linear);
     if (n_inst) o.inst.assign(inst, inst + n_inst);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, dev_alloc(&o.d_inst, o.n_inst));
+    auto cleanup = [&]() { dev_free(o.d_inst); for (auto& t : o.d_tex) dev_free(t); };
+    for (int t = 0; t < 7; ++t) {
+        if (mat.image[t].empty()) continue;
+        std::vector<uint8_t> chain; uint32_t levels = 1;
+        build_mip_chain(c, mat.image[t], mat.w[t], mat.h[t], t == 0, &chain, &levels);
+        hipError_t e = dev_alloc(&o.d_tex[t], chain.size());
+        if (e == hipSuccess) e = hipMemcpy(o.d_tex[t], chain.data(), chain.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { cleanup(); return zr_fail(c, ZR_ERR_DEVICE, hipGetErrorString(e)); }
+        o.tex_w[t] = mat.w[t]; o.tex_h[t] = mat.h[t]; o.tex_levels[t] = levels;
+    }
+    { hipError_t e = dev_alloc(&o.d_inst, o.n_inst); if (e != hipSuccess) { cleanup(); return zr_fail(c, ZR_ERR_DEVICE, hipGetErrorString(e)); } }
     XkInstanceData* d_raw = nullptr;
     if (n_inst) {
-        HIPCHK(c, dev_alloc(&d_raw, n_inst));
-        hipError_t e = hipMemcpyAsync(d_raw, inst, sizeof(XkInstanceData) * n_inst, hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) { dev_free(d_raw); dev_free(o.d_inst); return zr_fail(c, ZR_ERR_DEVICE, hipGetErrorString(e)); }
+        hipError_t e = dev_alloc(&d_raw, n_inst);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_raw, inst, sizeof(XkInstanceData) * n_inst, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) { dev_free(d_raw); cleanup(); return zr_fail(c, ZR_ERR_DEVICE, hipGetErrorString(e)); }
     }
     zr_launch_instance_prep(d_raw, o.d_inst, o.n_inst, o.instanced ? 1u : 0u, c->stream);
     hipError_t e = hipStreamSynchronize(c->stream);
     dev_free(d_raw);
-    if (e != hipSuccess) { dev_free(o.d_inst); return zr_fail(c, ZR_ERR_DEVICE, hipGetErrorString(e)); }
+    if (e != hipSuccess) { cleanup(); return zr_fail(c, ZR_ERR_DEVICE, hipGetErrorString(e)); }
     c->objects.push_back(std::move(o));
     c->scene_dirty = true;
     return ZR_OK;
@@ -313,10 +363,10 @@ extern "C" int zr_object_add(zr_ctx* c, uint32_t mesh_id, const zr_material* mat
 {
     if (!c) return ZR_ERR_ARG;
     ARGCHK(c, mesh_id < c->meshes.size() && (n_inst == 0 || inst));
-    uint32_t texel[7]; float bcl[3];
-    int rc = zr_material_constants(c, mat, texel, bcl);
+    ZrMaterialHost m;
+    int rc = zr_material_prepare(c, mat, &m);
     if (rc) return rc;
-    return zr_object_add_internal(c, mesh_id, texel, bcl, inst, n_inst);
+    return zr_object_add_internal(c, mesh_id, m, inst, n_inst);
 }
 
 extern "C" int zr_scene_clear(zr_ctx* c)
@@ -384,6 +434,7 @@ static int finalize_scene(zr_ctx* c)
             d.n_inst = o.n_inst; d.instanced = o.instanced;
             d.work_base = (uint32_t)work; d.prim_base = (uint32_t)prim;
             memcpy(d.texel, o.texel, sizeof d.texel); memcpy(d.bc_linear, o.bc_linear, sizeof d.bc_linear);
+            for (int t = 0; t < 7; ++t) { d.tex[t].data = o.d_tex[t]; d.tex[t].w = o.tex_w[t]; d.tex[t].h = o.tex_h[t]; d.tex[t].levels = o.tex_levels[t]; d.tex[t]._pad = 0; }
             memcpy(d.mesh_center, m.center, sizeof d.mesh_center); d.mesh_radius = m.radius;
             work += (uint64_t)d.n_meshlets * d.n_inst; prim += (uint64_t)d.n_tris * d.n_inst;
             tab.push_back(d);
@@ -650,7 +701,7 @@ extern "C" int zr_render(zr_ctx* c)
     c->last_work[1] = P.n_work;
     geometry_pass(c, P, 1, c->n_tiles, ev[3]);
     HIPCHK(c, hipEventRecord(ev[4], s));
-    zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_stats, s);
+    zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_lut, c->d_stats, s);
     HIPCHK(c, hipEventRecord(ev[5], s));
     // deferred-lighting pass (ZE:3531-3540)
     ZrLightParams L; memset(&L, 0, sizeof L);

@@ -532,9 +532,67 @@ __device__ __forceinline__ zf3 compute_normal(zf3 pos_dx, zf3 pos_dy, float s1, 
     return zr_normalize(w);
 }
 
+// ---- material sampling: texture(sampler2D, uv) with LINEAR mag/min/mip, REPEAT (RHICreateSampler, ZE:6523-6557) ----
+__device__ __forceinline__ int tex_idx_clamp(float f, int hi) { f = __builtin_fminf(__builtin_fmaxf(f, 0.0f), (float)hi); return (int)f; }
+__device__ __forceinline__ float tex_decode(uint32_t v, bool srgb, const float* __restrict__ lut) { return srgb ? lut[v] : (float)v / 255.0f; }
+__device__ __forceinline__ zf4 tex_fetch(const uint8_t* __restrict__ lvl, uint32_t w, int x, int y, bool srgb, const float* __restrict__ lut)
+{
+    const uint32_t t = *(const uint32_t*)(lvl + ((size_t)y * w + (size_t)x) * 4);
+    zf4 r;
+    r.x = tex_decode(t & 255u, srgb, lut); r.y = tex_decode((t >> 8) & 255u, srgb, lut);
+    r.z = tex_decode((t >> 16) & 255u, srgb, lut); r.w = tex_decode(t >> 24, false, lut);
+    return r;
+}
+__device__ __forceinline__ zf4 tex_bilinear(const ZrTex& T, int level, float u, float v, bool srgb, const float* __restrict__ lut)
+{
+    size_t off = 0;
+    for (int l = 0; l < level; ++l) { uint32_t lw = T.w >> l, lh = T.h >> l; if (!lw) lw = 1; if (!lh) lh = 1; off += (size_t)lw * lh * 4; }
+    uint32_t w = T.w >> level, h = T.h >> level; if (!w) w = 1; if (!h) h = 1;
+    const uint8_t* __restrict__ lvl = T.data + off;
+    const float ur = u - __builtin_floorf(u), vr = v - __builtin_floorf(v);
+    const float x = __builtin_fmaf(ur, (float)w, -0.5f), y = __builtin_fmaf(vr, (float)h, -0.5f);
+    const float fx = __builtin_floorf(x), fy = __builtin_floorf(y), a = x - fx, b = y - fy;
+    int x0 = tex_idx_clamp(fx + 1.0f, (int)w) - 1, y0 = tex_idx_clamp(fy + 1.0f, (int)h) - 1;
+    int x1 = x0 + 1; if (x1 >= (int)w) x1 = 0; if (x0 < 0) x0 = (int)w - 1;
+    int y1 = y0 + 1; if (y1 >= (int)h) y1 = 0; if (y0 < 0) y0 = (int)h - 1;
+    const zf4 t00 = tex_fetch(lvl, w, x0, y0, srgb, lut), t10 = tex_fetch(lvl, w, x1, y0, srgb, lut);
+    const zf4 t01 = tex_fetch(lvl, w, x0, y1, srgb, lut), t11 = tex_fetch(lvl, w, x1, y1, srgb, lut);
+    zf4 r;
+    { const float top = __builtin_fmaf(a, t10.x - t00.x, t00.x), bot = __builtin_fmaf(a, t11.x - t01.x, t01.x); r.x = __builtin_fmaf(b, bot - top, top); }
+    { const float top = __builtin_fmaf(a, t10.y - t00.y, t00.y), bot = __builtin_fmaf(a, t11.y - t01.y, t01.y); r.y = __builtin_fmaf(b, bot - top, top); }
+    { const float top = __builtin_fmaf(a, t10.z - t00.z, t00.z), bot = __builtin_fmaf(a, t11.z - t01.z, t01.z); r.z = __builtin_fmaf(b, bot - top, top); }
+    { const float top = __builtin_fmaf(a, t10.w - t00.w, t00.w), bot = __builtin_fmaf(a, t11.w - t01.w, t01.w); r.w = __builtin_fmaf(b, bot - top, top); }
+    return r;
+}
+// Isotropic LOD from the quad derivatives, trilinear.  Anisotropic filtering (maxAnisotropy = device max, ZE:6540) is
+// implementation-defined and not reproduced.  A constant slot returns its texel.
+__device__ __forceinline__ zf4 tex_sample(const ZrTex& T, uint32_t texel, bool srgb, const float* __restrict__ lut,
+                                          float u, float v, float dudx, float dvdx, float dudy, float dvdy)
+{
+    if (T.data == nullptr) {
+        zf4 r;
+        r.x = tex_decode(texel & 255u, srgb, lut); r.y = tex_decode((texel >> 8) & 255u, srgb, lut);
+        r.z = tex_decode((texel >> 16) & 255u, srgb, lut); r.w = tex_decode(texel >> 24, false, lut);
+        return r;
+    }
+    const float W = (float)T.w, H = (float)T.h;
+    const float ax = dudx * W, ay = dvdx * H, bx = dudy * W, by = dvdy * H;
+    const float rho2 = __builtin_fmaxf(__builtin_fmaf(ax, ax, ay * ay), __builtin_fmaf(bx, bx, by * by));
+    float lambda = 0.5f * zr_log2(rho2);
+    lambda = __builtin_fminf(__builtin_fmaxf(lambda, 0.0f), (float)(T.levels - 1u));
+    const float fl = __builtin_floorf(lambda);
+    const int l0 = (int)fl, l1 = min(l0 + 1, (int)T.levels - 1);
+    const float f = lambda - fl;
+    const zf4 c0 = tex_bilinear(T, l0, u, v, srgb, lut), c1 = tex_bilinear(T, l1, u, v, srgb, lut);
+    zf4 r;
+    r.x = __builtin_fmaf(f, c1.x - c0.x, c0.x); r.y = __builtin_fmaf(f, c1.y - c0.y, c0.y);
+    r.z = __builtin_fmaf(f, c1.z - c0.z, c0.z); r.w = __builtin_fmaf(f, c1.w - c0.w, c0.w);
+    return r;
+}
+
 // BaseScene.frag:26-48 for the pixel (px, py) whose winning primitive is `prim`
 __device__ __forceinline__ void resolve_pixel(const ZrPass& P, const ZrObject* __restrict__ objs, uint32_t prim, float depth,
-                                              int px, int py, const GBufferPtrs& G)
+                                              int px, int py, const GBufferPtrs& G, const float* __restrict__ lut)
 {
     const size_t p = (size_t)py * P.W + (size_t)px;
     if (prim == ZR_EMPTY_PRIM) {   // clears, ZE:3427-3433
@@ -582,14 +640,20 @@ __device__ __forceinline__ void resolve_pixel(const ZrPass& P, const ZrObject* _
     const zf3 pos_dx = (P0 - Ph) * sx, pos_dy = (P0 - Pv) * sy;
     const float s1 = (u0 - uh) * sx, t1 = (v0 - vh) * sx, s2 = (u0 - uv_) * sy, t2 = (v0 - vv) * sy;
 
-    // material fetch: constant textures (any filter returns the texel); slot 0 is sRGB
-    const uint32_t tm = O->texel[1], tr = O->texel[2], tn = O->texel[3], ta = O->texel[4], te = O->texel[5], tk = O->texel[6];
-    const float Metallic = (float)(tm & 255u) / 255.0f;
-    const float Rough = __builtin_fmaxf(0.01f, (float)(tr & 255u) / 255.0f);
-    const zf3 texN = zr3((float)(tn & 255u) / 255.0f, (float)((tn >> 8) & 255u) / 255.0f, (float)((tn >> 16) & 255u) / 255.0f);
-    const float AO = (float)(ta & 255u) / 255.0f;
-    const zf3 Em = zr3((float)(te & 255u) / 255.0f, (float)((te >> 8) & 255u) / 255.0f, (float)((te >> 16) & 255u) / 255.0f);
-    const float Mask = (float)(tk & 255u) / 255.0f;
+    // texture(samplerN, fragTexCoord), BaseScene.frag:30-36; slot 0 (base colour) is R8G8B8A8_SRGB (ZE:5878)
+    const zf4 tb = tex_sample(O->tex[0], O->texel[0], true, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tme = tex_sample(O->tex[1], O->texel[1], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tro = tex_sample(O->tex[2], O->texel[2], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tno = tex_sample(O->tex[3], O->texel[3], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tao = tex_sample(O->tex[4], O->texel[4], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tem = tex_sample(O->tex[5], O->texel[5], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tms = tex_sample(O->tex[6], O->texel[6], false, lut, u0, v0, s1, t1, s2, t2);
+    const float Metallic = tme.x;
+    const float Rough = __builtin_fmaxf(0.01f, tro.x);
+    const zf3 texN = zr3(tno.x, tno.y, tno.z);
+    const float AO = tao.x;
+    const zf3 Em = zr3(tem.x, tem.y, tem.z);
+    const float Mask = tms.x;
 
     const zf3 Nw = compute_normal(pos_dx, pos_dy, s1, t1, s2, t2, N0, texN);
     const zf3 Nn = zr_normalize(Nw);
@@ -598,8 +662,7 @@ __device__ __forceinline__ void resolve_pixel(const ZrPass& P, const ZrObject* _
     G.scene_color[p] = zr_unorm(Em.x, 255.0f) | zr_unorm(Em.y, 255.0f) << 8 | zr_unorm(Em.z, 255.0f) << 16 | zr_unorm(Mask, 255.0f) << 24;
     G.gA[p] = zr_unorm(NP.z, 1023.0f) | zr_unorm(NP.y, 1023.0f) << 10 | zr_unorm(NP.x, 1023.0f) << 20 | 3u << 30;
     G.gB[p] = zr_unorm(Metallic, 255.0f) | zr_unorm(1.0f, 255.0f) << 8 | zr_unorm(Rough, 255.0f) << 16 | 255u << 24;
-    G.gC[p] = zr_unorm(O->bc_linear[0], 255.0f) | zr_unorm(O->bc_linear[1], 255.0f) << 8 | zr_unorm(O->bc_linear[2], 255.0f) << 16 |
-              zr_unorm(AO, 255.0f) << 24;
+    G.gC[p] = zr_unorm(tb.x, 255.0f) | zr_unorm(tb.y, 255.0f) << 8 | zr_unorm(tb.z, 255.0f) << 16 | zr_unorm(AO, 255.0f) << 24;
     G.gD[p] = make_uint2(zr_f32_to_f16(P0.x) | zr_f32_to_f16(P0.y) << 16, zr_f32_to_f16(P0.z) | 0x3C000000u);
 }
 
@@ -771,7 +834,7 @@ __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject*
 __global__ __launch_bounds__(256) void k_resolve_gbuffer(ZrPass P, const ZrObject* __restrict__ objs,
                                                          const uint32_t* __restrict__ owned_tiles,
                                                          unsigned long long* __restrict__ vis64, GBufferPtrs G,
-                                                         ZrDevStats* __restrict__ stats)
+                                                         const float* __restrict__ srgb_lut, ZrDevStats* __restrict__ stats)
 {
     __shared__ uint32_t covered_s;
     const uint32_t tid = threadIdx.x;
@@ -789,7 +852,7 @@ __global__ __launch_bounds__(256) void k_resolve_gbuffer(ZrPass P, const ZrObjec
         vis64[p] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
         const uint32_t prim = (uint32_t)k;
         ncov += prim != ZR_EMPTY_PRIM;
-        resolve_pixel(P, objs, prim, zr_u2f((uint32_t)(k >> 32)), px, py, G);
+        resolve_pixel(P, objs, prim, zr_u2f((uint32_t)(k >> 32)), px, py, G, srgb_lut);
     }
     if (ncov) atomicAdd(&covered_s, ncov);
     __syncthreads();
@@ -1086,10 +1149,10 @@ void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint32
         hipLaunchKernelGGL(k_raster_chunks<ZR_MODE_SHADOW>, dim3(n_blocks), dim3(256), 0, s, P, objs, tile_offset, chunk_offset, bins, stats, slot, vis64, shadow_bits);
 }
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
-                               unsigned long long* vis64, const GBufferPtrs& G, ZrDevStats* stats, hipStream_t s)
+                               unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, ZrDevStats* stats, hipStream_t s)
 {
     if (n_owned == 0) return;
-    hipLaunchKernelGGL(k_resolve_gbuffer, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, stats);
+    hipLaunchKernelGGL(k_resolve_gbuffer, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, stats);
 }
 void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, hipStream_t s)
 {

@@ -25,6 +25,9 @@ struct ZrInstance {
 };
 static_assert(sizeof(ZrInstance) == 64, "ZrInstance");
 
+// One material texture: RGBA8 mip chain, level l = max(1, w >> l) x max(1, h >> l) texels, levels concatenated.
+struct ZrTex { const uint8_t* data; uint32_t w, h, levels, _pad; };
+
 // One draw (object) of the scene, in the reference's draw order (non-instanced draws first, ZE:3445-3476).
 struct ZrObject {
     const XkVertex*   verts;
@@ -38,6 +41,7 @@ struct ZrObject {
     uint32_t n_meshlets, n_tris, n_inst, instanced;
     uint32_t work_base;              // first meshlet-instance id of this draw
     uint32_t prim_base;              // first primitive id of this draw
+    ZrTex    tex[7];                 // sampled material slots (data == nullptr: the slot is the constant `texel`)
     uint32_t texel[7];               // constant material: RGBA8 per PBR slot (bc, m, r, n, ao, ev, ms)
     float    bc_linear[3];           // sRGB-decoded base colour (slot 0 is R8G8B8A8_SRGB, ZE:5878)
     float    mesh_center[3];         // object-space bounding sphere of the whole mesh
@@ -105,7 +109,7 @@ void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint32
                              const uint32_t* bins, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t* shadow_bits,
                              uint32_t n_blocks, hipStream_t s);
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
-                               unsigned long long* vis64, const GBufferPtrs& G, ZrDevStats* stats, hipStream_t s);
+                               unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, ZrDevStats* stats, hipStream_t s);
 void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, hipStream_t s);
 void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32_t* owned_tiles, uint32_t n_owned,
                         const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C, const float* lut, uint32_t* out,

@@ -268,7 +268,10 @@ int apply_world(zr_ctx* c, const ZrWorld& w)
     int rc = ZR_OK;
     {
         auto keep_m = std::move(c->meshes); auto keep_p = std::move(c->profabs);
-        for (auto& o : c->objects) if (o.d_inst) { (void)hipFree(o.d_inst); o.d_inst = nullptr; }
+        for (auto& o : c->objects) {
+            if (o.d_inst) { (void)hipFree(o.d_inst); o.d_inst = nullptr; }
+            for (auto& t : o.d_tex) if (t) { (void)hipFree(t); t = nullptr; }
+        }
         c->objects.clear(); c->scene_dirty = true;
         c->meshes = std::move(keep_m); c->profabs = std::move(keep_p);
     }
@@ -280,7 +283,7 @@ int apply_world(zr_ctx* c, const ZrWorld& w)
         std::vector<XkInstanceData> inst;
         if (d.InstanceCount > 1) generate_instances(d, 1234u + oi, inst);
         for (const ZrProfab& pf : it->second) {
-            rc = zr_object_add_internal(c, pf.mesh, pf.texel, pf.bc_linear, inst.empty() ? nullptr : inst.data(), (uint32_t)inst.size());
+            rc = zr_object_add_internal(c, pf.mesh, pf.mat, inst.empty() ? nullptr : inst.data(), (uint32_t)inst.size());
             if (rc) break;
         }
     }
@@ -329,8 +332,8 @@ extern "C" int zr_profab_register(zr_ctx* c, const char* name, uint32_t mesh_id,
 {
     if (!c || !name) return ZR_ERR_ARG;
     if (mesh_id >= c->meshes.size()) return zr_fail(c, ZR_ERR_ARG, "bad mesh id");
-    ZrProfab pf; pf.mesh = mesh_id; pf.has_material = mat != nullptr;
-    int rc = zr_material_constants(c, mat, pf.texel, pf.bc_linear);
+    ZrProfab pf; pf.mesh = mesh_id;
+    int rc = zr_material_prepare(c, mat, &pf.mat);
     if (rc) return rc;
     c->profabs[name].push_back(pf);
     return ZR_OK;
