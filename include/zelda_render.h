@@ -119,6 +119,14 @@ int  zr_object_get_instances(zr_ctx* ctx, uint32_t index, uint32_t* mesh_id, XkI
  * mips are generated like RHIGenerateMipmaps (ZE:6348-6433).  faces == NULL: built-in 1x1 grey. */
 int  zr_set_cubemap(zr_ctx* ctx, const uint8_t* const faces[6], uint32_t dim);
 
+/* Skydome pass (CreateSkydomePass ZE:2690-2744, draw ZE:3681-3691): the sky mesh (Content/Models/skydome.obj in the engine)
+ * with its sRGB texture, drawn unlit after the lighting quad with depth LESS against the deferred depth.  tex == NULL removes it.
+ * Background pass (ZE:2657-2688, 3693-3699): full-screen quad at z = 1, LESS_OR_EQUAL, sRGB texture.  Both only in debug view 0. */
+int  zr_set_skydome(zr_ctx* ctx, const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const zr_image* tex);
+int  zr_set_background(zr_ctx* ctx, const zr_image* tex);
+/* XkWorld::EnableSkydome / EnableBackground (zr_world_load_json sets them from the JSON). */
+int  zr_set_sky_flags(zr_ctx* ctx, int enable_skydome, int enable_background);
+
 /* --- per-frame uniforms (replaces UpdateWorld ZE:4294-4308 + UpdateUniformBuffer ZE:4585-4664) --- */
 int  zr_update_uniforms(zr_ctx* ctx, const zr_camera* cam,
                         const XkLight* dir, uint32_t n_dir, const XkLight* point, uint32_t n_point,

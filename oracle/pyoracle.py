@@ -36,6 +36,9 @@ def lib():
         L.zo_object_add.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32]
         L.zo_scene_clear.argtypes = [C.c_void_p]
         L.zo_set_cubemap.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.zo_set_skydome.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.zo_set_background.argtypes = [C.c_void_p, C.c_void_p]
+        L.zo_set_sky_flags.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.zo_update_uniforms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                          C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_float]
         L.zo_set_frame.argtypes = [C.c_void_p] * 4
@@ -116,6 +119,28 @@ class Oracle:
         faces = [np.ascontiguousarray(f, dtype=np.uint8) for f in faces]
         arr = (C.c_void_p * 6)(*[f.ctypes.data for f in faces])
         assert self.L.zo_set_cubemap(self.h, arr, faces[0].shape[0]) == 0
+
+    def set_skydome(self, verts, idx, image):
+        from zeldaengine_amd import abi
+        if image is None:
+            self.L.zo_set_skydome(self.h, None, 0, None, 0, None)
+            return
+        verts = np.ascontiguousarray(verts); idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        im = abi.Image(img.ctypes.data, img.shape[1], img.shape[0])
+        self.L.zo_set_skydome(self.h, _ptr(verts), len(verts), _ptr(idx), len(idx), C.byref(im))
+
+    def set_background(self, image):
+        from zeldaengine_amd import abi
+        if image is None:
+            self.L.zo_set_background(self.h, None)
+            return
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        im = abi.Image(img.ctypes.data, img.shape[1], img.shape[0])
+        self.L.zo_set_background(self.h, C.byref(im))
+
+    def set_sky_flags(self, enable_skydome=True, enable_background=True):
+        self.L.zo_set_sky_flags(self.h, int(enable_skydome), int(enable_background))
 
     def update_uniforms(self, cam, dir_l, point_l, spot_l, roll_stage=0.0, roll_light=0.0, time=0.0):
         self.L.zo_update_uniforms(self.h, C.byref(cam), _ptr(dir_l), len(dir_l), _ptr(point_l), len(point_l),

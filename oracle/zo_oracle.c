@@ -46,6 +46,9 @@ struct zo_ctx {
     float* depth; uint32_t* scene_color; uint32_t* gA; uint32_t* gB; uint32_t* gC; uint64_t* gD;
     uint32_t* vis; float* shadowmap; uint8_t* color;
     uint64_t covered;
+    /* skydome + background passes (ZE:2657-2744, 3681-3699) */
+    zo_mesh sky_mesh; zo_tex sky_tex; int sky_set, sky_enabled; zo_tex bg_tex; int bg_set, bg_enabled;
+    uint32_t* overlay; float* main_depth; uint32_t* sky_vis;
 };
 
 static int zo_idx_clamp(float f, int hi);
@@ -95,6 +98,8 @@ zo_ctx* zo_create(uint32_t W, uint32_t H, uint32_t SD)
     c->gA = (uint32_t*)malloc(n * 4); c->gB = (uint32_t*)malloc(n * 4); c->gC = (uint32_t*)malloc(n * 4);
     c->gD = (uint64_t*)malloc(n * 8); c->vis = (uint32_t*)malloc(n * 4); c->color = (uint8_t*)calloc(n, 4);
     c->shadowmap = (float*)malloc((size_t)c->SD * c->SD * 4);
+    c->overlay = (uint32_t*)calloc(n, 4); c->main_depth = (float*)malloc(n * 4); c->sky_vis = (uint32_t*)malloc(n * 4);
+    c->sky_enabled = c->bg_enabled = 1;
     for (int i = 0; i < 256; ++i) c->srgb_lut[i] = zo_srgb_decode((uint32_t)i);
     zo_default_lights(&c->view);
     zo_set_cubemap(c, NULL, 0);
@@ -118,7 +123,9 @@ void zo_destroy(zo_ctx* c)
     if (!c) return;
     zo_scene_clear(c); zo_free_cube(c);
     free(c->depth); free(c->scene_color); free(c->gA); free(c->gB); free(c->gC); free(c->gD);
-    free(c->vis); free(c->color); free(c->shadowmap); free(c);
+    free(c->vis); free(c->color); free(c->shadowmap); free(c->overlay); free(c->main_depth); free(c->sky_vis);
+    zo_set_skydome(c, NULL, 0, NULL, 0, NULL); zo_set_background(c, NULL);
+    free(c);
 }
 
 int zo_mesh_create(zo_ctx* c, const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni)
@@ -1002,11 +1009,109 @@ static void zo_lighting(zo_ctx* c, uint32_t debug_view)
         case 5: out = zo_v3make(AO, AO, AO); break;
         case 7: out = RefC; break;
         case 8: out = zo_v3make(ShadowFactor, ShadowFactor, ShadowFactor); break;
-        default: out = zo_scale(Final, ShadowFactor); break;   /* 6 (quad vertex colour) and 9 (mosaic): see DESIGN.md */
+        case 6: {   /* fragColor of the full-screen quad: vertex colours of Background.vert:10-17 interpolated over its two triangles */
+            float u = ((float)px + 0.5f) / (float)c->W, v = ((float)py + 0.5f) / (float)c->H;
+            out = v >= u ? zo_v3make(1.0f - v, u, v - u) : zo_v3make(1.0f - u, v, u - v);
+            break;
+        }
+        default: out = zo_scale(Final, ShadowFactor); break;   /* 9 (GBufferVis mosaic) is not restated: DESIGN.md */
         }
         uint8_t* o = c->color + p * 4;
         o[0] = (uint8_t)zo_unorm(out.x, 255.0f); o[1] = (uint8_t)zo_unorm(out.y, 255.0f);
         o[2] = (uint8_t)zo_unorm(out.z, 255.0f); o[3] = 255;
+        if (debug_view == 0 && c->overlay[p]) memcpy(o, &c->overlay[p], 4);   /* skydome / background drawn over the lit quad */
+    }
+}
+
+/* ------------------------------------------------------------------ skydome + background (ZE:3681-3699) */
+
+static void zo_tex_free(zo_tex* t) { for (int l = 0; l < t->levels; ++l) free(t->mip[l]); memset(t, 0, sizeof *t); }
+static void zo_tex_from_image(zo_ctx* c, zo_tex* tx, const zo_image* im, int srgb)
+{
+    size_t n = (size_t)im->width * im->height * 4;
+    tx->w = im->width; tx->h = im->height;
+    tx->px = (uint8_t*)malloc(n); memcpy(tx->px, im->rgba8, n);
+    tx->constant = 1;
+    for (size_t i = 4; i < n; ++i) if (tx->px[i] != tx->px[i & 3]) { tx->constant = 0; break; }
+    zo_build_mips(c, tx, srgb);
+}
+int zo_set_skydome(zo_ctx* c, const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const zo_image* tex)
+{
+    if (c->sky_set) { free(c->sky_mesh.v); free(c->sky_mesh.idx); zo_tex_free(&c->sky_tex); c->sky_set = 0; }
+    if (!v || !idx || !tex || !tex->rgba8) return 0;
+    c->sky_mesh.v = (XkVertex*)malloc(sizeof(XkVertex) * nv); memcpy(c->sky_mesh.v, v, sizeof(XkVertex) * nv); c->sky_mesh.nv = nv;
+    c->sky_mesh.idx = (uint32_t*)malloc(4u * ni); memcpy(c->sky_mesh.idx, idx, 4u * ni); c->sky_mesh.ni = ni;
+    zo_tex_from_image(c, &c->sky_tex, tex, 1);               /* RHICreateTextureResource defaults to sRGB, ZE:5860 */
+    c->sky_set = 1;
+    return 0;
+}
+int zo_set_background(zo_ctx* c, const zo_image* tex)
+{
+    if (c->bg_set) { zo_tex_free(&c->bg_tex); c->bg_set = 0; }
+    if (!tex || !tex->rgba8) return 0;
+    zo_tex_from_image(c, &c->bg_tex, tex, 1);
+    c->bg_set = 1;
+    return 0;
+}
+void zo_set_sky_flags(zo_ctx* c, int enable_skydome, int enable_background) { c->sky_enabled = enable_skydome; c->bg_enabled = enable_background; }
+
+static uint32_t zo_pack_gamma(const float rgb[3])            /* pow(color, 0.4545), alpha 1 (Skydome.frag / Background.frag) */
+{
+    return zo_unorm(zo_powf(rgb[0], 0.4545f), 255.0f) | zo_unorm(zo_powf(rgb[1], 0.4545f), 255.0f) << 8 |
+           zo_unorm(zo_powf(rgb[2], 0.4545f), 255.0f) << 16 | 255u << 24;
+}
+
+/* Main render pass after the lighting quad: skydome mesh (Skydome.vert/.frag, cull BACK, depth LESS against the copied
+ * deferred depth, ZE:3482-3506), then the background quad at z = 1 with LESS_OR_EQUAL.  overlay[p] != 0 replaces the lit pixel. */
+static void zo_sky_background(zo_ctx* c, const float* PVM)
+{
+    size_t n = (size_t)c->W * c->H;
+    float hw = 0.5f * (float)c->W, hh = 0.5f * (float)c->H;
+    memset(c->overlay, 0, n * 4);
+    memcpy(c->main_depth, c->depth, n * 4);
+    for (size_t i = 0; i < n; ++i) c->sky_vis[i] = ZO_EMPTY;
+    if (c->sky_set && c->sky_enabled) {
+        const zo_mesh* m = &c->sky_mesh;
+        zo_target T = { 0, c->W, c->H, c->main_depth, c->sky_vis };
+        zo_v4* clip = (zo_v4*)malloc(sizeof(zo_v4) * m->nv);
+        for (uint32_t vi = 0; vi < m->nv; ++vi)
+            clip[vi] = zo_mat4_point(PVM, zo_v3make(m->v[vi].Position[0], m->v[vi].Position[1], m->v[vi].Position[2]));
+        for (uint32_t t = 0; t < m->ni / 3; ++t) {
+            zo_v4 tc[3] = { clip[m->idx[3 * t]], clip[m->idx[3 * t + 1]], clip[m->idx[3 * t + 2]] };
+            zo_raster_tri(&T, tc, t);
+        }
+        for (uint32_t py = 0; py < c->H; ++py) for (uint32_t px = 0; px < c->W; ++px) {
+            size_t p = (size_t)py * c->W + px;
+            uint32_t tri = c->sky_vis[p];
+            if (tri == ZO_EMPTY) continue;
+            zo_v4 tc[3]; float uv[3][2];
+            for (int k = 0; k < 3; ++k) { uint32_t vi = m->idx[3 * tri + (uint32_t)k]; tc[k] = clip[vi]; uv[k][0] = m->v[vi].TexCoord[0]; uv[k][1] = m->v[vi].TexCoord[1]; }
+            int cls = zo_classify(tc);
+            zo_sv sv[3]; zo_setup s;
+            if (cls == 1) { for (int k = 0; k < 3; ++k) sv[k] = zo_project(tc[k], hw, hh); zo_tri_setup(sv, 0, &s); }
+            int32_t qx = (int32_t)(px ^ 1u), qy = (int32_t)(py ^ 1u);
+            float b0[3], bh[3], bv[3];
+            if (cls == 1) { zo_bary_screen(&s, sv, (int32_t)px, (int32_t)py, b0); zo_bary_screen(&s, sv, qx, (int32_t)py, bh); zo_bary_screen(&s, sv, (int32_t)px, qy, bv); }
+            else { zo_bary_homog(tc, hw, hh, (int32_t)px, (int32_t)py, b0); zo_bary_homog(tc, hw, hh, qx, (int32_t)py, bh); zo_bary_homog(tc, hw, hh, (int32_t)px, qy, bv); }
+            float u0 = fmaf(b0[2], uv[2][0], fmaf(b0[1], uv[1][0], b0[0] * uv[0][0])), v0 = fmaf(b0[2], uv[2][1], fmaf(b0[1], uv[1][1], b0[0] * uv[0][1]));
+            float uh = fmaf(bh[2], uv[2][0], fmaf(bh[1], uv[1][0], bh[0] * uv[0][0])), vh = fmaf(bh[2], uv[2][1], fmaf(bh[1], uv[1][1], bh[0] * uv[0][1]));
+            float uvv = fmaf(bv[2], uv[2][0], fmaf(bv[1], uv[1][0], bv[0] * uv[0][0])), vv = fmaf(bv[2], uv[2][1], fmaf(bv[1], uv[1][1], bv[0] * uv[0][1]));
+            float sx = (px & 1u) ? 1.0f : -1.0f, sy = (py & 1u) ? 1.0f : -1.0f;
+            float col[4];
+            zo_tex_sample(c, &c->sky_tex, 1, u0, v0, (u0 - uh) * sx, (v0 - vh) * sx, (u0 - uvv) * sy, (v0 - vv) * sy, col);
+            c->overlay[p] = zo_pack_gamma(col);
+        }
+        free(clip);
+    }
+    if (c->bg_set && c->bg_enabled) {      /* quad at z = 1.0, LESS_OR_EQUAL: only where nothing was drawn (Background.vert:33-37) */
+        for (uint32_t py = 0; py < c->H; ++py) for (uint32_t px = 0; px < c->W; ++px) {
+            size_t p = (size_t)py * c->W + px;
+            if (!(1.0f <= c->main_depth[p])) continue;
+            float u = ((float)px + 0.5f) / (float)c->W, v = ((float)py + 0.5f) / (float)c->H;
+            float col[4];
+            zo_tex_sample(c, &c->bg_tex, 1, u, v, 1.0f / (float)c->W, 0.0f, 0.0f, 1.0f / (float)c->H, col);
+            c->overlay[p] = zo_pack_gamma(col);
+        }
     }
 }
 
@@ -1028,6 +1133,7 @@ void zo_render(zo_ctx* c, uint32_t debug_view, uint32_t passes)
         zo_target T = { 0, c->W, c->H, c->depth, c->vis };
         zo_raster_scene(c, &T, PVM);
         zo_resolve_gbuffer(c, PVM);
+        zo_sky_background(c, PVM);
     }
     if (passes & 4u) zo_lighting(c, debug_view);             /* lighting quad, ZE:3531-3540 */
 }

@@ -29,6 +29,9 @@ int     zo_mesh_create(zo_ctx*, const XkVertex* v, uint32_t nv, const uint32_t* 
 int     zo_object_add(zo_ctx*, int mesh, const zo_material* mat, const XkInstanceData* inst, uint32_t n_inst);
 void    zo_scene_clear(zo_ctx*);
 int     zo_set_cubemap(zo_ctx*, const uint8_t* const faces[6], uint32_t dim);
+int     zo_set_skydome(zo_ctx*, const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const zo_image* tex);
+int     zo_set_background(zo_ctx*, const zo_image* tex);
+void    zo_set_sky_flags(zo_ctx*, int enable_skydome, int enable_background);
 void    zo_update_uniforms(zo_ctx*, const zo_camera* cam, const XkLight* dir, uint32_t n_dir,
                            const XkLight* point, uint32_t n_point, const XkLight* spot, uint32_t n_spot,
                            float roll_stage, float roll_light, float time);

@@ -121,6 +121,40 @@ def test_debug_views(oracle_lib, gpu_engine, view):
     assert np.array_equal(o.color(), g.color())
 
 
+def test_skydome_and_background_passes(oracle_lib, gpu_engine):
+    """N3: skydome mesh (unlit, depth LESS vs the deferred depth) + background quad at z = 1 (LESS_OR_EQUAL), view 0 only."""
+    bg = scenes.synthetic_sky_image(90, 60)[:, ::-1].copy()
+
+    def build_all(r):
+        _mixed_scene(r, 10)
+        r.set_skydome(*scenes.sky_dome(), scenes.synthetic_sky_image())
+        r.set_background(bg)
+    cam = abi.make_camera((6.0, 5.0, 2.0), (0.0, 0.0, 1.5), zfar=20.0)      # zFar 20: part of the dome is beyond the far plane
+    o, g = _both(oracle_lib, gpu_engine, 352, 208, 128, build_all, _std_frame(cam))
+    _identical(o, g, "sky + background")
+    lit = _both(oracle_lib, gpu_engine, 352, 208, 128, lambda r: _mixed_scene(r, 10), _std_frame(cam))[1].color()
+    both = g.color()
+    assert (both != lit).any(axis=2).mean() > 0.2                          # the passes really drew
+    # the dome is not a shadow caster and leaves the GBuffer untouched
+    assert np.array_equal(g.shadowmap().view(np.uint32), _both(oracle_lib, gpu_engine, 352, 208, 128, lambda r: _mixed_scene(r, 10), _std_frame(cam))[1].shadowmap().view(np.uint32))
+    # flags (XkWorld::EnableSkydome / EnableBackground) and debug views switch them off
+    for r in (o, g):
+        r.set_sky_flags(False, True)
+    o.render(); g.render(); g.finish()
+    _identical(o, g, "background only")
+    for r in (o, g):
+        r.set_sky_flags(True, False)
+    o.render(3); g.render(3); g.finish()
+    assert np.array_equal(o.color(), g.color())
+
+
+def test_debug_view_6_quad_vertex_colour(oracle_lib, gpu_engine):
+    o, g = _both(oracle_lib, gpu_engine, 200, 120, 64, lambda r: _mixed_scene(r, 5), _std_frame(), debug_view=6)
+    assert np.array_equal(o.color(), g.color())
+    c = g.color()
+    assert c[0, 0, 0] > 250 and c[-1, 0, 2] > 250 and c[-1, -1, 1] > 250     # red top-left, blue bottom-left, green bottom-right
+
+
 def test_empty_scene_and_scene_reuse(oracle_lib, gpu_engine):
     o = oracle_lib.Oracle(96, 64, 64)
     g = gpu_engine.Renderer(96, 64, 64)

@@ -86,6 +86,10 @@ struct zr_ctx {
     float lut[256]; float* d_lut = nullptr;
 
     static constexpr int EV_RING = 64;     // per-pass hipEvents of the last EV_RING frames (bench averages over them)
+    // skydome + background passes (ZE:2657-2744, 3681-3699)
+    ZrMesh sky_mesh; ZrSceneObject sky_obj; bool sky_set = false, sky_enabled = true;
+    uint8_t* d_bg = nullptr; uint32_t bg_w = 0, bg_h = 0, bg_levels = 0; bool bg_set = false, bg_enabled = true;
+
     hipEvent_t evr[EV_RING][7] = {}; uint64_t frame_no = 0; bool rendered = false;
 
     // world + livelink

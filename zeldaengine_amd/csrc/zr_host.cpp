@@ -82,6 +82,8 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     ok &= dev_alloc(&c->G.gB, n) == hipSuccess;
     ok &= dev_alloc(&c->G.gC, n) == hipSuccess;
     ok &= dev_alloc(&c->G.gD, n) == hipSuccess;
+    ok &= dev_alloc(&c->G.overlay, n) == hipSuccess;
+    if (ok) ok &= hipMemset(c->G.overlay, 0, n * 4) == hipSuccess;
     ok &= dev_alloc(&c->d_color, n) == hipSuccess;
     ok &= dev_alloc(&c->d_shadow, (size_t)c->SD * c->SD) == hipSuccess;
     ok &= dev_alloc(&c->d_view, 1) == hipSuccess;
@@ -120,6 +122,12 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     return ZR_OK;
 }
 
+static void free_mesh_buffers(ZrMesh& m)
+{
+    dev_free(m.d_v); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mtri);
+    m.uploaded = false;
+}
+
 static void free_scene(zr_ctx* c)
 {
     for (auto& o : c->objects) { dev_free(o.d_inst); for (auto& t : o.d_tex) dev_free(t); }
@@ -139,8 +147,9 @@ extern "C" void zr_destroy(zr_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_scene(c);
+    free_mesh_buffers(c->sky_mesh); dev_free(c->sky_obj.d_inst); for (auto& t : c->sky_obj.d_tex) dev_free(t); dev_free(c->d_bg);
     for (auto p : c->d_cube) if (p) (void)hipFree(p);
-    dev_free(c->G.depth); dev_free(c->G.scene_color); dev_free(c->G.gA); dev_free(c->G.gB); dev_free(c->G.gC); dev_free(c->G.gD);
+    dev_free(c->G.depth); dev_free(c->G.scene_color); dev_free(c->G.gA); dev_free(c->G.gB); dev_free(c->G.gC); dev_free(c->G.gD); dev_free(c->G.overlay);
     dev_free(c->d_color); dev_free(c->d_shadow); dev_free(c->d_view); dev_free(c->d_stats); dev_free(c->d_lut);
     dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles);
     dev_free(c->d_tile_count); dev_free(c->d_tile_offset); dev_free(c->d_tile_cursor); dev_free(c->d_chunk_offset); dev_free(c->d_vis); dev_free(c->d_rects); dev_free(c->d_bins);
@@ -385,60 +394,66 @@ template <typename T> static hipError_t upload(T** d, const std::vector<T>& h)
     return h.empty() ? hipSuccess : hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
 }
 
+static int upload_mesh(zr_ctx* c, ZrMesh& m)
+{
+    if (m.uploaded) return ZR_OK;
+    if (!m.has_meshlets) {
+        zr_build_meshlets(m.v.data(), (uint32_t)m.v.size(), m.idx.data(), (uint32_t)m.idx.size(), 64, 124, 0.2f, &m.ms);
+        m.has_meshlets = true;
+    }
+    // whole-mesh bounding sphere (centroid + max distance)
+    double cx = 0, cy = 0, cz = 0;
+    for (auto& v : m.v) { cx += v.Position[0]; cy += v.Position[1]; cz += v.Position[2]; }
+    cx /= (double)m.v.size(); cy /= (double)m.v.size(); cz /= (double)m.v.size();
+    double r = 0;
+    for (auto& v : m.v) { double dx = v.Position[0] - cx, dy = v.Position[1] - cy, dz = v.Position[2] - cz; r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz)); }
+    m.center[0] = (float)cx; m.center[1] = (float)cy; m.center[2] = (float)cz; m.radius = (float)(r * 1.0001) + 1e-30f;
+    // flatten for the kernels: one coalesced 16 B load per meshlet vertex, one 8 B load per meshlet triangle
+    std::vector<float4> mpos(m.ms.mverts.size());
+    for (size_t i = 0; i < mpos.size(); ++i) {
+        const float* p = m.v[m.ms.mverts[i]].Position;
+        mpos[i] = make_float4(p[0], p[1], p[2], 1.0f);
+    }
+    std::vector<uint2> mtri(m.ms.tri_order.size());
+    for (const XkMeshlet& ml : m.ms.meshlets)
+        for (uint32_t t = 0; t < ml.TriangleCount; ++t) {
+            const uint8_t* tp = m.ms.mtris.data() + ml.TriangleOffset + 3u * t;
+            mtri[ml.BindlessContext + t] = make_uint2((uint32_t)tp[0] | (uint32_t)tp[1] << 8 | (uint32_t)tp[2] << 16,
+                                                      m.ms.tri_order[ml.BindlessContext + t]);
+        }
+    HIPCHK(c, upload(&m.d_v, m.v)); HIPCHK(c, upload(&m.d_idx, m.idx)); HIPCHK(c, upload(&m.d_meshlets, m.ms.meshlets));
+    HIPCHK(c, upload(&m.d_mpos, mpos)); HIPCHK(c, upload(&m.d_mtri, mtri));
+    m.uploaded = true;
+    return ZR_OK;
+}
+
 // CreateEngineScene's GPU half (ZE:4140-4284): meshlets, buffers, draw table in the reference's draw order
 static int finalize_scene(zr_ctx* c)
 {
     if (!c->scene_dirty) return ZR_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (auto& o : c->objects) {
-        ZrMesh& m = c->meshes[o.mesh];
-        if (m.uploaded) continue;
-        if (!m.has_meshlets) {
-            zr_build_meshlets(m.v.data(), (uint32_t)m.v.size(), m.idx.data(), (uint32_t)m.idx.size(), 64, 124, 0.2f, &m.ms);
-            m.has_meshlets = true;
-        }
-        // whole-mesh bounding sphere (centroid + max distance)
-        double cx = 0, cy = 0, cz = 0;
-        for (auto& v : m.v) { cx += v.Position[0]; cy += v.Position[1]; cz += v.Position[2]; }
-        cx /= (double)m.v.size(); cy /= (double)m.v.size(); cz /= (double)m.v.size();
-        double r = 0;
-        for (auto& v : m.v) { double dx = v.Position[0] - cx, dy = v.Position[1] - cy, dz = v.Position[2] - cz; r = std::max(r, std::sqrt(dx * dx + dy * dy + dz * dz)); }
-        m.center[0] = (float)cx; m.center[1] = (float)cy; m.center[2] = (float)cz; m.radius = (float)(r * 1.0001) + 1e-30f;
-        // flatten for the kernels: one coalesced 16 B load per meshlet vertex, one 8 B load per meshlet triangle
-        std::vector<float4> mpos(m.ms.mverts.size());
-        for (size_t i = 0; i < mpos.size(); ++i) {
-            const float* p = m.v[m.ms.mverts[i]].Position;
-            mpos[i] = make_float4(p[0], p[1], p[2], 1.0f);
-        }
-        std::vector<uint2> mtri(m.ms.tri_order.size());
-        for (const XkMeshlet& ml : m.ms.meshlets)
-            for (uint32_t t = 0; t < ml.TriangleCount; ++t) {
-                const uint8_t* tp = m.ms.mtris.data() + ml.TriangleOffset + 3u * t;
-                mtri[ml.BindlessContext + t] = make_uint2((uint32_t)tp[0] | (uint32_t)tp[1] << 8 | (uint32_t)tp[2] << 16,
-                                                          m.ms.tri_order[ml.BindlessContext + t]);
-            }
-        HIPCHK(c, upload(&m.d_v, m.v)); HIPCHK(c, upload(&m.d_idx, m.idx)); HIPCHK(c, upload(&m.d_meshlets, m.ms.meshlets));
-        HIPCHK(c, upload(&m.d_mpos, mpos)); HIPCHK(c, upload(&m.d_mtri, mtri));
-        m.uploaded = true;
-    }
+    for (auto& o : c->objects) { int rc = upload_mesh(c, c->meshes[o.mesh]); if (rc) return rc; }
+    const bool sky = c->sky_set && c->sky_enabled;
+    if (sky) { int rc = upload_mesh(c, c->sky_mesh); if (rc) return rc; }
     std::vector<ZrObject> tab;
     uint64_t work = 0, prim = 0;
+    auto emit = [&](const ZrSceneObject& o, const ZrMesh& m, uint32_t flags) {
+        ZrObject d; memset(&d, 0, sizeof d);
+        d.verts = m.d_v; d.indices = m.d_idx; d.meshlets = m.d_meshlets; d.mpos = m.d_mpos; d.mtri = m.d_mtri;
+        d.inst = o.d_inst;
+        d.n_meshlets = (uint32_t)m.ms.meshlets.size(); d.n_tris = (uint32_t)(m.idx.size() / 3);
+        d.n_inst = o.n_inst; d.instanced = o.instanced; d.flags = flags;
+        d.work_base = (uint32_t)work; d.prim_base = (uint32_t)prim;
+        memcpy(d.texel, o.texel, sizeof d.texel); memcpy(d.bc_linear, o.bc_linear, sizeof d.bc_linear);
+        for (int t = 0; t < 7; ++t) { d.tex[t].data = o.d_tex[t]; d.tex[t].w = o.tex_w[t]; d.tex[t].h = o.tex_h[t]; d.tex[t].levels = o.tex_levels[t]; d.tex[t]._pad = 0; }
+        memcpy(d.mesh_center, m.center, sizeof d.mesh_center); d.mesh_radius = m.radius;
+        work += (uint64_t)d.n_meshlets * d.n_inst; prim += (uint64_t)d.n_tris * d.n_inst;
+        tab.push_back(d);
+    };
     for (int pass = 0; pass < 2; ++pass)                 // non-instanced draws, then instanced draws (ZE:3445-3476)
-        for (auto& o : c->objects) {
-            if ((int)o.instanced != pass) continue;
-            const ZrMesh& m = c->meshes[o.mesh];
-            ZrObject d; memset(&d, 0, sizeof d);
-            d.verts = m.d_v; d.indices = m.d_idx; d.meshlets = m.d_meshlets; d.mpos = m.d_mpos; d.mtri = m.d_mtri;
-            d.inst = o.d_inst;
-            d.n_meshlets = (uint32_t)m.ms.meshlets.size(); d.n_tris = (uint32_t)(m.idx.size() / 3);
-            d.n_inst = o.n_inst; d.instanced = o.instanced;
-            d.work_base = (uint32_t)work; d.prim_base = (uint32_t)prim;
-            memcpy(d.texel, o.texel, sizeof d.texel); memcpy(d.bc_linear, o.bc_linear, sizeof d.bc_linear);
-            for (int t = 0; t < 7; ++t) { d.tex[t].data = o.d_tex[t]; d.tex[t].w = o.tex_w[t]; d.tex[t].h = o.tex_h[t]; d.tex[t].levels = o.tex_levels[t]; d.tex[t]._pad = 0; }
-            memcpy(d.mesh_center, m.center, sizeof d.mesh_center); d.mesh_radius = m.radius;
-            work += (uint64_t)d.n_meshlets * d.n_inst; prim += (uint64_t)d.n_tris * d.n_inst;
-            tab.push_back(d);
-        }
+        for (auto& o : c->objects)
+            if ((int)o.instanced == pass) emit(o, c->meshes[o.mesh], 0u);
+    if (sky) emit(c->sky_obj, c->sky_mesh, ZR_OBJ_SKY);   // drawn last, after the lighting quad (ZE:3681-3691)
     if (work >= 0xFFFFFFFFull || prim >= 0xFFFFFFFFull) return zr_fail(c, ZR_ERR_OVERFLOW, "scene exceeds 2^32 meshlet-instances or primitives");
     dev_free(c->d_objs);
     HIPCHK(c, upload(&c->d_objs, tab));
@@ -452,6 +467,65 @@ static int finalize_scene(zr_ctx* c)
         HIPCHK(c, dev_alloc(&c->d_bins, c->bin_capacity));
     }
     c->scene_dirty = false;
+    return ZR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ skydome + background
+
+static int upload_texture(zr_ctx* c, const zr_image* tex, bool srgb, uint8_t** d, uint32_t* w, uint32_t* h, uint32_t* levels)
+{
+    if (tex->width == 0 || tex->height == 0 || tex->width > 16384 || tex->height > 16384) return zr_fail(c, ZR_ERR_ARG, "bad image size");
+    std::vector<uint8_t> img(tex->rgba8, tex->rgba8 + (size_t)tex->width * tex->height * 4), chain;
+    build_mip_chain(c, img, tex->width, tex->height, srgb, &chain, levels);
+    HIPCHK(c, dev_alloc(d, chain.size()));
+    HIPCHK(c, hipMemcpy(*d, chain.data(), chain.size(), hipMemcpyHostToDevice));
+    *w = tex->width; *h = tex->height;
+    return ZR_OK;
+}
+
+extern "C" int zr_set_skydome(zr_ctx* c, const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const zr_image* tex)
+{
+    if (!c) return ZR_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_mesh_buffers(c->sky_mesh); c->sky_mesh = ZrMesh();
+    dev_free(c->sky_obj.d_inst); for (auto& t : c->sky_obj.d_tex) dev_free(t);
+    c->sky_obj = ZrSceneObject(); c->sky_set = false; c->scene_dirty = true;
+    if (!tex || !tex->rgba8) return ZR_OK;
+    ARGCHK(c, v && idx && nv > 0 && ni > 0 && ni % 3 == 0);
+    for (uint32_t i = 0; i < ni; ++i) if (idx[i] >= nv) return zr_fail(c, ZR_ERR_ARG, "index out of range");
+    c->sky_mesh.v.assign(v, v + nv); c->sky_mesh.idx.assign(idx, idx + ni);
+    ZrSceneObject& o = c->sky_obj;
+    o.mesh = 0; o.instanced = false; o.n_inst = 1;
+    for (int t = 0; t < 7; ++t) o.texel[t] = 0xFFFFFFFFu;
+    o.bc_linear[0] = o.bc_linear[1] = o.bc_linear[2] = 1.0f;
+    int rc = upload_texture(c, tex, true, &o.d_tex[0], &o.tex_w[0], &o.tex_h[0], &o.tex_levels[0]);   // sRGB by default, ZE:5860
+    if (rc) return rc;
+    HIPCHK(c, dev_alloc(&o.d_inst, 1));
+    zr_launch_instance_prep(nullptr, o.d_inst, 1, 0u, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->sky_set = true;
+    return ZR_OK;
+}
+
+extern "C" int zr_set_background(zr_ctx* c, const zr_image* tex)
+{
+    if (!c) return ZR_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dev_free(c->d_bg); c->bg_set = false;
+    if (!tex || !tex->rgba8) return ZR_OK;
+    int rc = upload_texture(c, tex, true, &c->d_bg, &c->bg_w, &c->bg_h, &c->bg_levels);
+    if (rc) return rc;
+    c->bg_set = true;
+    return ZR_OK;
+}
+
+extern "C" int zr_set_sky_flags(zr_ctx* c, int sky, int bg)
+{
+    if (!c) return ZR_ERR_ARG;
+    if ((sky != 0) != c->sky_enabled) c->scene_dirty = true;
+    c->sky_enabled = sky != 0; c->bg_enabled = bg != 0;
     return ZR_OK;
 }
 
@@ -710,6 +784,8 @@ extern "C" int zr_render(zr_ctx* c)
     L.W = c->W; L.H = c->H; L.SD = c->SD; L.tiles_x = c->tiles_x; L.debug_view = c->debug_view;
     L.cube_dim = c->cube_dim; L.cube_levels = c->cube_levels; L.tile_world = c->cfg.tile_world;
     L.packed_out = c->cfg.tile_world > 1 ? 1u : 0u;
+    L.bg_enabled = (c->bg_set && c->bg_enabled) ? 1u : 0u;
+    L.bg.data = c->d_bg; L.bg.w = c->bg_w; L.bg.h = c->bg_h; L.bg.levels = c->bg_levels; L.bg._pad = 0;
     zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, c->d_shadow, c->cube, c->d_lut,
                        L.packed_out ? c->d_tiles : c->d_color, s);
     HIPCHK(c, hipEventRecord(ev[6], s));

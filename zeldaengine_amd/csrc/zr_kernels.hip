@@ -152,6 +152,10 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
     const XkMeshlet ml = O->meshlets[m];
     const ZrInstance I = O->inst[inst_i];
     const bool instanced = O->instanced != 0;
+    if (MODE == ZR_MODE_SHADOW && (O->flags & ZR_OBJ_SKY)) {       // the skydome is not a shadow caster (ZE:4709-4720)
+        if (lane == 0) rects[w] = ZR_RECT_CULLED;
+        return;
+    }
 
     if (P.frustum_ok | P.cone_ok) {
         zf3 co = vs_position(zr3(ml.BoundsCenter[0], ml.BoundsCenter[1], ml.BoundsCenter[2]), I, instanced);
@@ -591,14 +595,16 @@ __device__ __forceinline__ zf4 tex_sample(const ZrTex& T, uint32_t texel, bool s
 }
 
 // BaseScene.frag:26-48 for the pixel (px, py) whose winning primitive is `prim`
-__device__ __forceinline__ void resolve_pixel(const ZrPass& P, const ZrObject* __restrict__ objs, uint32_t prim, float depth,
+// returns true when the pixel holds scene geometry (not empty, not sky)
+__device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* __restrict__ objs, uint32_t prim, float depth,
                                               int px, int py, const GBufferPtrs& G, const float* __restrict__ lut)
 {
     const size_t p = (size_t)py * P.W + (size_t)px;
     if (prim == ZR_EMPTY_PRIM) {   // clears, ZE:3427-3433
         G.depth[p] = 1.0f; G.scene_color[p] = 0xFF000000u; G.gA[p] = 0u; G.gB[p] = 0xFF000000u; G.gC[p] = 0xFF000000u;
         G.gD[p] = make_uint2(0u, 0x3C000000u);
-        return;
+        G.overlay[p] = 0u;
+        return false;
     }
     const ZrObject* __restrict__ O = objs + find_object_prim(objs, (int)P.n_objects, prim);
     const uint32_t local = prim - O->prim_base;
@@ -640,6 +646,15 @@ __device__ __forceinline__ void resolve_pixel(const ZrPass& P, const ZrObject* _
     const zf3 pos_dx = (P0 - Ph) * sx, pos_dy = (P0 - Pv) * sy;
     const float s1 = (u0 - uh) * sx, t1 = (v0 - vh) * sx, s2 = (u0 - uv_) * sy, t2 = (v0 - vv) * sy;
 
+    if (O->flags & ZR_OBJ_SKY) {    // Skydome.frag: texture(skydomeSampler, uv).rgb, gamma; the GBuffer keeps its clear values
+        const zf4 sk = tex_sample(O->tex[0], O->texel[0], true, lut, u0, v0, s1, t1, s2, t2);
+        G.depth[p] = 1.0f; G.scene_color[p] = 0xFF000000u; G.gA[p] = 0u; G.gB[p] = 0xFF000000u; G.gC[p] = 0xFF000000u;
+        G.gD[p] = make_uint2(0u, 0x3C000000u);
+        G.overlay[p] = zr_unorm(zr_pow(sk.x, 0.4545f), 255.0f) | zr_unorm(zr_pow(sk.y, 0.4545f), 255.0f) << 8 |
+                       zr_unorm(zr_pow(sk.z, 0.4545f), 255.0f) << 16 | 255u << 24;
+        return false;
+    }
+    G.overlay[p] = 0u;
     // texture(samplerN, fragTexCoord), BaseScene.frag:30-36; slot 0 (base colour) is R8G8B8A8_SRGB (ZE:5878)
     const zf4 tb = tex_sample(O->tex[0], O->texel[0], true, lut, u0, v0, s1, t1, s2, t2);
     const zf4 tme = tex_sample(O->tex[1], O->texel[1], false, lut, u0, v0, s1, t1, s2, t2);
@@ -664,6 +679,7 @@ __device__ __forceinline__ void resolve_pixel(const ZrPass& P, const ZrObject* _
     G.gB[p] = zr_unorm(Metallic, 255.0f) | zr_unorm(1.0f, 255.0f) << 8 | zr_unorm(Rough, 255.0f) << 16 | 255u << 24;
     G.gC[p] = zr_unorm(tb.x, 255.0f) | zr_unorm(tb.y, 255.0f) << 8 | zr_unorm(tb.z, 255.0f) << 16 | zr_unorm(AO, 255.0f) << 24;
     G.gD[p] = make_uint2(zr_f32_to_f16(P0.x) | zr_f32_to_f16(P0.y) << 16, zr_f32_to_f16(P0.z) | 0x3C000000u);
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------ tile raster kernels
@@ -850,9 +866,7 @@ __global__ __launch_bounds__(256) void k_resolve_gbuffer(ZrPass P, const ZrObjec
         const size_t p = (size_t)py * P.W + (size_t)px;
         const unsigned long long k = vis64[p];
         vis64[p] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
-        const uint32_t prim = (uint32_t)k;
-        ncov += prim != ZR_EMPTY_PRIM;
-        resolve_pixel(P, objs, prim, zr_u2f((uint32_t)(k >> 32)), px, py, G, srgb_lut);
+        ncov += resolve_pixel(P, objs, (uint32_t)k, zr_u2f((uint32_t)(k >> 32)), px, py, G, srgb_lut) ? 1u : 0u;
     }
     if (ncov) atomicAdd(&covered_s, ncov);
     __syncthreads();
@@ -1079,9 +1093,24 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
         case 5: o = zr3(AO, AO, AO); break;
         case 7: o = RefC; break;
         case 8: o = zr3(ShadowFactor, ShadowFactor, ShadowFactor); break;
+        case 6: {   // fragColor of the full-screen quad: Background.vert:10-17 vertex colours over its two triangles
+            const float u = ((float)px + 0.5f) / (float)L.W, v = ((float)py + 0.5f) / (float)L.H;
+            o = v >= u ? zr3(1.0f - v, u, v - u) : zr3(1.0f - u, v, u - v);
+            break;
+        }
         default: o = Final * ShadowFactor; break;
         }
-        const uint32_t rgba = zr_unorm(o.x, 255.0f) | zr_unorm(o.y, 255.0f) << 8 | zr_unorm(o.z, 255.0f) << 16 | 255u << 24;
+        uint32_t rgba = zr_unorm(o.x, 255.0f) | zr_unorm(o.y, 255.0f) << 8 | zr_unorm(o.z, 255.0f) << 16 | 255u << 24;
+        if (L.debug_view == 0u) {      // skydome, then background quad at z = 1 (LESS_OR_EQUAL): drawn over the lit quad (ZE:3681-3699)
+            const uint32_t ov = G.overlay[p];
+            if (ov) rgba = ov;
+            else if (L.bg_enabled && 1.0f <= G.depth[p]) {
+                const float u = ((float)px + 0.5f) / (float)L.W, v = ((float)py + 0.5f) / (float)L.H;
+                const zf4 bgc = tex_sample(L.bg, 0xFFFFFFFFu, true, srgb_lut, u, v, 1.0f / (float)L.W, 0.0f, 0.0f, 1.0f / (float)L.H);
+                rgba = zr_unorm(zr_pow(bgc.x, 0.4545f), 255.0f) | zr_unorm(zr_pow(bgc.y, 0.4545f), 255.0f) << 8 |
+                       zr_unorm(zr_pow(bgc.z, 0.4545f), 255.0f) << 16 | 255u << 24;
+            }
+        }
         if (L.packed_out) out[(size_t)blockIdx.x * TILE_PIX + i] = rgba;
         else out[p] = rgba;
     }

@@ -14,6 +14,7 @@
 #endif
 
 enum { ZR_MODE_GBUFFER = 0, ZR_MODE_SHADOW = 1 };
+#define ZR_OBJ_SKY 1u                        // the skydome draw: camera pass only, unlit, written to the overlay plane
 
 // Per-instance transform, prepared once at zr_object_add from XkInstanceData (32 B -> 64 B):
 // R = mat3(MakeRotMatrix(InstanceRotation)) column-major, t = InstancePosition, s = InstancePScale.
@@ -46,7 +47,8 @@ struct ZrObject {
     float    bc_linear[3];           // sRGB-decoded base colour (slot 0 is R8G8B8A8_SRGB, ZE:5878)
     float    mesh_center[3];         // object-space bounding sphere of the whole mesh
     float    mesh_radius;
-    uint32_t _pad[2];
+    uint32_t flags;                  // ZR_OBJ_*
+    uint32_t _pad;
 };
 
 // Parameters of one geometry pass (camera or shadow), passed by value in the kernarg segment.
@@ -87,11 +89,14 @@ struct ZrLightParams {
     uint32_t cube_dim, cube_levels;
     uint32_t packed_out;             // 1: write tile-major packed output (multi-GPU), 0: row-major frame
     uint32_t tile_world;
+    uint32_t bg_enabled;             // background quad (Background.vert/.frag) on
+    ZrTex    bg;                     // its sRGB texture
 };
 
 // SoA GBuffer planes in HBM, row-major W x H each (formats ZE:2807-2843): D32F, RGBA8, A2R10G10B10, RGBA8, RGBA8, RGBA16F.
 struct GBufferPtrs {
     float* depth; uint32_t* scene_color; uint32_t* gA; uint32_t* gB; uint32_t* gC; uint2* gD;
+    uint32_t* overlay;               // RGBA8 of the skydome pass (0 = nothing drawn); not a GBuffer attachment
 };
 // Cubemap mip chain, level l = 6 faces of (dim >> l)^2 RGBA8 sRGB texels, face-major.
 struct CubeDesc { const uint8_t* levels[16]; };

@@ -276,6 +276,7 @@ int apply_world(zr_ctx* c, const ZrWorld& w)
         c->meshes = std::move(keep_m); c->profabs = std::move(keep_p);
     }
     c->world = w;
+    zr_set_sky_flags(c, w.EnableSkydome ? 1 : 0, w.EnableBackground ? 1 : 0);       // gates of ZE:3682 / ZE:3693
     for (size_t oi = 0; oi < w.ObjectDescs.size() && rc == ZR_OK; ++oi) {
         const ZrObjectDesc& d = w.ObjectDescs[oi];
         auto it = c->profabs.find(d.ProfabName);

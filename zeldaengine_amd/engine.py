@@ -52,6 +52,9 @@ def lib():
         "zr_object_count": [vp, C.POINTER(u32)],
         "zr_object_get_instances": [vp, u32, C.POINTER(u32), vp, C.POINTER(u32)],
         "zr_set_cubemap": [vp, vp, u32],
+        "zr_set_skydome": [vp, vp, u32, vp, u32, vp],
+        "zr_set_background": [vp, vp],
+        "zr_set_sky_flags": [vp, C.c_int, C.c_int],
         "zr_update_uniforms": [vp, vp, vp, u32, vp, u32, vp, u32, C.c_float, C.c_float, C.c_float],
         "zr_set_frame": [vp, vp, vp, vp],
         "zr_get_frame": [vp, vp, vp, vp],
@@ -229,6 +232,28 @@ class Renderer:
         assert len(faces) == 6 and all(f.shape == faces[0].shape and f.shape[0] == f.shape[1] and f.shape[2] == 4 for f in faces)
         arr = (C.c_void_p * 6)(*[f.ctypes.data for f in faces])
         self._chk(self.L.zr_set_cubemap(self.h, arr, faces[0].shape[0]))
+
+    def set_skydome(self, verts, idx, image):
+        """Sky mesh + its sRGB RGBA8 image (H, W, 4); image None removes the pass (CreateSkydomePass, ZE:2690-2744)."""
+        if image is None:
+            self._chk(self.L.zr_set_skydome(self.h, None, 0, None, 0, None))
+            return
+        verts = np.ascontiguousarray(verts)
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        im = abi.Image(img.ctypes.data, img.shape[1], img.shape[0])
+        self._chk(self.L.zr_set_skydome(self.h, _ptr(verts), len(verts), _ptr(idx), len(idx), C.cast(C.pointer(im), C.c_void_p)))
+
+    def set_background(self, image):
+        if image is None:
+            self._chk(self.L.zr_set_background(self.h, None))
+            return
+        img = np.ascontiguousarray(image, dtype=np.uint8)
+        im = abi.Image(img.ctypes.data, img.shape[1], img.shape[0])
+        self._chk(self.L.zr_set_background(self.h, C.cast(C.pointer(im), C.c_void_p)))
+
+    def set_sky_flags(self, enable_skydome=True, enable_background=True):
+        self._chk(self.L.zr_set_sky_flags(self.h, int(enable_skydome), int(enable_background)))
 
     # ---- uniforms
     def update_uniforms(self, cam, dir_l, point_l, spot_l, roll_stage=0.0, roll_light=0.0, time=0.0):

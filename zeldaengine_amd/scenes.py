@@ -262,6 +262,24 @@ def synthetic_cubemap(dim=64):
     return faces
 
 
+def sky_dome(radius=20.48, segments=32, rings=16):
+    """Inward-facing sphere standing in for Content/Models/skydome.obj (radius 20.48 about the origin, 3968 triangles there)."""
+    v, idx = uv_sphere(segments, rings, radius)
+    return v, idx.reshape(-1, 3)[:, ::-1].reshape(-1).copy()
+
+
+def synthetic_sky_image(width=256, height=128):
+    """Deterministic gradient + bands, RGBA8 (sampled as sRGB)."""
+    x = np.arange(width, dtype=np.float32)[None, :] / width
+    y = np.arange(height, dtype=np.float32)[:, None] / height
+    img = np.zeros((height, width, 4), dtype=np.uint8)
+    img[..., 0] = (40 + 120 * x + 30 * np.sin(20 * y)).clip(0, 255).astype(np.uint8)
+    img[..., 1] = (70 + 150 * y).astype(np.uint8) + np.zeros_like(x, dtype=np.uint8)
+    img[..., 2] = (200 - 60 * x * y).astype(np.uint8)
+    img[..., 3] = 255
+    return img
+
+
 def config2():
     """Single 960-triangle sphere, 512x512, 0 directional + 1 point light."""
     v, idx = uv_sphere()
