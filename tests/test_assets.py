@@ -1,0 +1,95 @@
+"""File side of the asset contract (CPU): OBJ ingest quirks, the .meshlet container, Profab directory search."""
+import os
+
+import numpy as np
+import pytest
+
+from zeldaengine_amd import abi, assets, engine, scenes
+
+OBJ = """# two triangles sharing an edge, a quad face, per-corner uv and normal indices
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+vt 0.5 0.25
+vn 0 0 1
+vn 0 1 0
+vn 1 0 0
+vn 0.6 0 0.8
+f 1/1/4 2/2/4 3/3/4 4/4/4
+f 1/5/1 3/3/2 -1/4/3
+"""
+
+
+def test_obj_ingest_quirks(tmp_path):
+    p = tmp_path / "m.obj"
+    p.write_text(OBJ)
+    v, idx = assets.load_obj(str(p))
+    assert len(idx) == 9                                        # quad -> fan of 2, plus 1 triangle
+    assert idx.tolist() == [0, 1, 2, 0, 2, 3, 4, 2, 3]          # vertex 1 with uv 5 is a new record; 3 and 4 are reused
+    assert np.allclose(v["Color"], 1.0)
+    assert np.allclose(v[1]["TexCoord"], (1.0, 1.0 - 0.0)) and np.allclose(v[4]["TexCoord"], (0.5, 0.75))     # v flipped
+    # quirk (ZE:6927-6931): the normal comes from the POSITION index, not the face's normal index
+    assert np.allclose(v[0]["Normal"], (0, 0, 1)) and np.allclose(v[1]["Normal"], (0, 1, 0)) and np.allclose(v[3]["Normal"], (0.6, 0, 0.8))
+    fv, fidx = assets.load_obj_for_meshlet_tool(str(p))         # the tool indexes normals properly (ZM:201-203)
+    assert np.allclose(fv[1]["nrm"], (0.6, 0, 0.8)) and len(fidx) == 9
+
+
+def test_obj_roundtrip_of_a_generated_mesh(tmp_path):
+    v, idx = scenes.uv_sphere(12, 6, 0.5)
+    p = str(tmp_path / "s.obj")
+    assets.write_obj(p, v, idx)
+    v2, idx2 = assets.load_obj(p)
+    assert np.array_equal(idx, idx2) and len(v) == len(v2)
+    assert np.allclose(v["Position"], v2["Position"]) and np.allclose(v["TexCoord"], v2["TexCoord"], atol=1e-6)
+
+
+def test_meshlet_container_layout_and_tool(tmp_path):
+    v, idx = scenes.uv_sphere()
+    obj = str(tmp_path / "sphere.obj")
+    assets.write_obj(obj, v, idx)
+    out = str(tmp_path / "sphere.meshlet")
+    n = assets.meshlet_tool(obj, out)
+    raw = open(out, "rb").read()
+    assert int(np.frombuffer(raw[:8], "<u8")[0]) == n           # size_t count, then n * 64 bytes of Meshlet
+    m = assets.read_meshlet(out)
+    assert len(m["meshlets"]) == n and m["meshlets"].dtype.itemsize == 64
+    assert m["mtris"].dtype == np.uint8 and m["file_vertices"].dtype.itemsize == 32
+    off = 8 + 64 * n
+    assert int(np.frombuffer(raw[off:off + 8], "<u8")[0]) == len(m["mverts"])
+    assert len(raw) == 5 * 8 + 64 * n + 4 * len(m["mverts"]) + len(m["mtris"]) + 32 * len(m["file_vertices"]) + 4 * len(m["indices"])
+    assert m["meshlets"]["TriangleCount"].sum() == len(m["indices"]) // 3 == 960
+    assert (m["vertices"]["Color"] == 1.0).all()
+    # the payload is accepted by the context-free validator path: rebuild from it gives the same partition sizes
+    ml2, _, _, _ = engine.build_meshlets(m["vertices"], m["indices"])
+    assert len(ml2) == n
+    with open(out, "wb") as f:
+        f.write(raw[:100])
+    with pytest.raises(ValueError):
+        assets.read_meshlet(out)
+
+
+def test_profab_directory_search(tmp_path):
+    from PIL import Image
+    root = tmp_path / "Profabs"
+    for name in ("rock_01", "broken"):
+        os.makedirs(root / name / "models")
+    os.makedirs(root / "rock_01" / "textures")
+    v, idx = scenes.box()
+    assets.write_obj(str(root / "rock_01" / "models" / "rock_a.obj"), v, idx)
+    assets.write_obj(str(root / "rock_01" / "models" / "rock_b.obj"), v, idx)
+    (root / "rock_01" / "models" / "notes.txt").write_text("ignored")
+    Image.fromarray(np.full((4, 4, 3), 200, np.uint8)).save(str(root / "rock_01" / "textures" / "rock_a_bc.png"))
+    Image.fromarray(np.full((2, 2, 3), 10, np.uint8)).save(str(root / "rock_01" / "textures" / "rock_a_r.png"))
+    found = assets.find_profabs(str(root))
+    assert list(found) == ["rock_01"]                           # "broken" has no textures dir: skipped (ZE:4936-4940)
+    (obj_a, tex_a), (obj_b, tex_b) = found["rock_01"]
+    assert obj_a.endswith("rock_a.obj") and obj_b.endswith("rock_b.obj")
+    assert [t is not None for t in tex_a] == [True, False, True, False, False, False, False]
+    assert tex_b == [None] * 7                                  # every slot falls back to the engine default
+    img = assets.load_image_rgba8(tex_a[0])
+    assert img.shape == (4, 4, 4) and (img[..., 3] == 255).all() and (img[..., :3] == 200).all()

@@ -91,6 +91,47 @@ def test_world_json_builds_the_scene_from_registered_profabs(oracle_lib, gpu_eng
     assert (inst["InstanceRotation"][:, 0] == 0).all() and inst["InstanceRotation"][:, 1].max() <= np.pi * 180.0
 
 
+def test_profab_tree_on_disk_drops_in(oracle_lib, gpu_engine, tmp_path):
+    """A content tree in the engine's layout (Profabs/<name>/{models,textures}) + a World.json -> frame equal to the oracle's."""
+    from PIL import Image
+    from zeldaengine_amd import assets
+    root = tmp_path / "Profabs"
+    meshes = {"terrain": scenes.grid_plane(18.0, 5, 0.0), "rock_02": scenes.uv_sphere(16, 8, 0.5)}
+    for name, (v, idx) in meshes.items():
+        (root / name / "models").mkdir(parents=True)
+        (root / name / "textures").mkdir(parents=True)
+        assets.write_obj(str(root / name / "models" / (name + ".obj")), v, idx)
+    yy, xx = np.mgrid[0:32, 0:32]
+    chk = np.where(((xx // 4 + yy // 4) & 1)[..., None].astype(bool), np.uint8(210), np.uint8(60)) * np.ones((1, 1, 3), np.uint8)
+    Image.fromarray(chk.astype(np.uint8)).save(str(root / "terrain" / "textures" / "terrain_bc.png"))
+    Image.fromarray(np.full((8, 8, 3), 128, np.uint8)).save(str(root / "rock_02" / "textures" / "rock_02_r.png"))
+    W, H, SD = 320, 180, 128
+    g = gpu_engine.Renderer(W, H, SD)
+    ids = assets.register_profabs(g, str(root))
+    assert sorted(ids) == ["rock_02", "terrain"]
+    wpath = tmp_path / "World.json"
+    wpath.write_text(json.dumps(scenes.sample_world()))
+    assets.world_load_file(g, str(wpath))
+    assert g.object_count() == 2                                # rock_01, grass_* have no directory: nothing drawn
+    g.render(); g.finish()
+    assets.world_save_file(g, str(tmp_path / "Saved.json"))
+    assert json.loads((tmp_path / "Saved.json").read_text())["Objects"][2]["ProfabName"] == "rock_02"
+    # oracle: same files, same instances
+    o = oracle_lib.Oracle(W, H, SD)
+    for i in range(g.object_count()):
+        mesh_id, inst = g.object_get_instances(i)
+        name = [n for n, m in ids.items() if m == [mesh_id]][0]
+        v, idx = assets.load_obj(str(root / name / "models" / (name + ".obj")))
+        tex = assets.find_profabs(str(root))[name][0][1]
+        mat, keep = abi.make_material([assets.load_image_rgba8(p) if p else None for p in tex])
+        o.object_add(o.mesh_create(v, idx), mat, inst)
+    o.set_frame(*g.get_frame())
+    o.render()
+    bad = {k: v for k, v in compare_all(o, g).items() if v}
+    assert not bad, bad
+    assert len(np.unique(g.gbuffer(4))) > 50                    # the checker texture reached the GBuffer
+
+
 def test_livelink_end_to_end(gpu_engine):
     """The reference client's bytes over TCP -> listener thread -> poll on the render thread -> new scene (ZE:1617-1710)."""
     g = gpu_engine.Renderer(128, 96, 64)
