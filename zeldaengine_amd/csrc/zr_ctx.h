@@ -76,7 +76,7 @@ struct zr_ctx {
     GBufferPtrs G = {};
     float* d_shadow = nullptr; uint32_t* d_color = nullptr; uint32_t* d_tiles = nullptr;
 
-    uint32_t *d_rects = nullptr, *d_tile_count = nullptr, *d_tile_offset = nullptr, *d_tile_cursor = nullptr, *d_bins = nullptr;
+    uint32_t *d_rects = nullptr, *d_tile_count = nullptr, *d_tile_offset = nullptr, *d_tile_cursor = nullptr; ZrBinEntry* d_bins = nullptr;
     uint32_t* d_chunk_offset = nullptr; unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048;
     uint32_t work_capacity = 0, bin_capacity = 0;
     ZrDevStats* d_stats = nullptr; ZrDevStats h_stats = {};

@@ -740,7 +740,7 @@ static void geometry_pass(zr_ctx* c, const ZrPass& P, int slot, uint32_t n_tiles
 {
     zr_launch_cull(P, c->d_objs, c->d_rects, c->d_tile_count, c->stream);
     zr_launch_scan(c->d_tile_count, c->d_tile_offset, c->d_tile_cursor, c->d_chunk_offset, n_tiles, c->bin_capacity, c->d_stats, slot, c->stream);
-    zr_launch_bin_fill(P, c->d_rects, c->d_tile_offset, c->d_tile_cursor, c->d_bins, c->d_stats, slot, c->stream);
+    zr_launch_bin_fill(P, c->d_objs, c->d_rects, c->d_tile_offset, c->d_tile_cursor, c->d_bins, c->d_stats, slot, c->stream);
     (void)hipEventRecord(after_bin, c->stream);
     zr_launch_raster_chunks(P, c->d_objs, c->d_tile_offset, c->d_chunk_offset, c->d_bins, c->d_stats, slot, c->d_vis,
                             (uint32_t*)c->d_shadow, c->raster_blocks, c->stream);

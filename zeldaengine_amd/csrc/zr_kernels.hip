@@ -273,9 +273,9 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
 
 // Scatter meshlet-instance ids into the per-tile lists.  Same LDS aggregation as k_bin_count: the workgroup reserves
 // a contiguous range per tile with one global atomic, then hands out slots from LDS.
-__global__ __launch_bounds__(1024) void k_bin_fill(ZrPass P, const uint32_t* __restrict__ rects,
+__global__ __launch_bounds__(1024) void k_bin_fill(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ rects,
                                                    const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
-                                                   uint32_t* __restrict__ bins, ZrDevStats* __restrict__ stats, int slot)
+                                                   ZrBinEntry* __restrict__ bins, ZrDevStats* __restrict__ stats, int slot)
 {
     extern __shared__ uint32_t hist[];
     __shared__ uint32_t tot;
@@ -299,14 +299,24 @@ __global__ __launch_bounds__(1024) void k_bin_fill(ZrPass P, const uint32_t* __r
         if (c) hist[i] = tile_offset[i] + atomicAdd(&tile_cursor[i], c);      // hist now holds the next free slot
     }
     __syncthreads();
-    if (r != ZR_RECT_CULLED)
+    if (r != ZR_RECT_CULLED) {
+        // decode the work id once; every tile of the rect gets the same self-contained record
+        const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w);
+        const uint32_t local = w - O->work_base;
+        const uint32_t inst_i = local / O->n_meshlets, m = local - inst_i * O->n_meshlets;
+        const XkMeshlet* __restrict__ ml = O->meshlets + m;
+        ZrBinEntry be;
+        be.mpos = O->mpos + ml->VertexOffset; be.mtri = O->mtri + ml->BindlessContext; be.inst = O->inst + inst_i;
+        be.counts = ml->VertexCount | ml->TriangleCount << 8 | (O->instanced ? 1u << 16 : 0u);
+        be.prim_base = O->prim_base + inst_i * O->n_tris;
         for (uint32_t ty = ty0; ty <= ty1; ++ty)
             for (uint32_t tx = tx0; tx <= tx1; ++tx) {
                 const uint32_t t = ty * P.tiles_x + tx;
                 if (t % P.tile_world != P.tile_rank) continue;
                 const uint32_t pos = atomicAdd(&hist[t], 1u);
-                if (pos < P.bin_capacity) bins[pos] = w;
+                if (pos < P.bin_capacity) bins[pos] = be;
             }
+    }
     const uint32_t cnt = (uint32_t)__popcll(__ballot(r != ZR_RECT_CULLED));
     if ((threadIdx.x & 63u) == 0 && cnt) atomicAdd(&tot, cnt);
     __syncthreads();
@@ -704,7 +714,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs,
                                                        const uint32_t* __restrict__ tile_offset,
                                                        const uint32_t* __restrict__ chunk_offset,
-                                                       const uint32_t* __restrict__ bins, ZrDevStats* __restrict__ stats, int slot,
+                                                       const ZrBinEntry* __restrict__ bins, ZrDevStats* __restrict__ stats, int slot,
                                                        unsigned long long* __restrict__ vis64, uint32_t* __restrict__ shadow_bits)
 {
     __shared__ unsigned long long keys64[MODE == ZR_MODE_GBUFFER ? TILE_PIX : 1];
@@ -736,27 +746,30 @@ __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject*
         T.px0 = (int)(tile % P.tiles_x) * TILE; T.py0 = (int)(tile / P.tiles_x) * TILE; T.W = (int)P.W; T.H = (int)P.H;
 
         uint32_t qhead = 0, qn = 0;
-        uint32_t w_next = beg + wv < end ? bins[beg + wv] : 0u;
+        // The next entry's 32-byte record is fetched (vector loads, vmcnt-ordered) while the current one is processed; every
+        // load of a meshlet then depends on that record alone.
+        const uint4* __restrict__ rec = (const uint4*)bins;
+        uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
+        if (beg + wv < end) { n0 = rec[2u * (beg + wv)]; n1 = rec[2u * (beg + wv) + 1u]; }
         for (uint32_t e = beg + wv; e < end; e += 4u) {
-            const uint32_t w = wave_uniform(w_next);
-            if (e + 4u < end) w_next = bins[e + 4u];      // next entry's id is in flight while this one is processed
-            const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w);
-            const uint32_t local = w - O->work_base;
-            const uint32_t nm = O->n_meshlets;
-            const uint32_t inst_i = local / nm, m = local - inst_i * nm;
-            const XkMeshlet ml = O->meshlets[m];
-            const ZrInstance I = O->inst[inst_i];
-            const bool instanced = O->instanced != 0;
+            const uint4 r0 = n0, r1 = n1;
+            if (e + 4u < end) { n0 = rec[2u * (e + 4u)]; n1 = rec[2u * (e + 4u) + 1u]; }
+            const float4* __restrict__ mp = (const float4*)(((unsigned long long)wave_uniform(r0.y) << 32) | wave_uniform(r0.x));
+            const uint2* __restrict__ tw = (const uint2*)(((unsigned long long)wave_uniform(r0.w) << 32) | wave_uniform(r0.z));
+            const ZrInstance* __restrict__ ip = (const ZrInstance*)(((unsigned long long)wave_uniform(r1.y) << 32) | wave_uniform(r1.x));
+            const uint32_t counts = wave_uniform(r1.z), pbase = wave_uniform(r1.w);
+            const uint32_t vcount = counts & 255u, tcount = (counts >> 8) & 255u;
+            const bool instanced = (counts >> 16) & 1u;
 
-            // both rounds' triangle words are requested before the vertex stage so their latency hides under it
-            const uint2* __restrict__ tw = O->mtri + ml.BindlessContext;
+            // both rounds' triangle words and the vertex are requested together, before anything waits
             uint2 tri_w[2];
-            tri_w[0] = lane < ml.TriangleCount ? tw[lane] : make_uint2(0u, 0u);
-            tri_w[1] = lane + WAVE < ml.TriangleCount ? tw[lane + WAVE] : make_uint2(0u, 0u);
+            tri_w[0] = lane < tcount ? tw[lane] : make_uint2(0u, 0u);
+            tri_w[1] = lane + WAVE < tcount ? tw[lane + WAVE] : make_uint2(0u, 0u);
+            const float4 pp = lane < vcount ? mp[lane] : make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            const ZrInstance I = *ip;
 
             lds_fence();   // this wave's previous readers are done with its staging area
-            if (lane < ml.VertexCount) {
-                const float4 pp = O->mpos[ml.VertexOffset + lane];
+            if (lane < vcount) {
                 const zf4 c = zr_mat4_point(P.PVM, vs_position(zr3(pp.x, pp.y, pp.z), I, instanced));
                 const uint32_t f = vertex_flags(c);
                 SV s; s.X = 0; s.Y = 0; s.z = 0.0f; s.rw = 0.0f;
@@ -767,16 +780,15 @@ __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject*
 
             // phase 1: every triangle gets the cheap tests; survivors are compacted into this wave's LDS ring so that
             // phase 2 (setup + pixel walk) always runs with full lanes, across meshlet boundaries
-            const uint32_t pbase = O->prim_base + inst_i * O->n_tris;
 #pragma unroll
             for (int round = 0; round < 2; ++round) {
                 const uint32_t t0 = (uint32_t)round * WAVE;
-                if (t0 >= ml.TriangleCount || P.debug_skip >= 2u) break;
+                if (t0 >= tcount || P.debug_skip >= 2u) break;
                 const uint32_t t = t0 + lane;
                 bool alive = false;
                 int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0;
                 const uint32_t prim = pbase + tri_w[round].y;
-                if (t < ml.TriangleCount) {
+                if (t < tcount) {
                     const uint32_t i0 = tri_w[round].x & 255u, i1 = (tri_w[round].x >> 8) & 255u, i2 = (tri_w[round].x >> 16) & 255u;
                     r0 = vstage[wv][i0]; r1 = vstage[wv][i1]; r2 = vstage[wv][i2];
                     const int cls = classify((uint32_t)r0.w, (uint32_t)r1.w, (uint32_t)r2.w);
@@ -786,8 +798,8 @@ __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject*
                         zf4 cc[3];
                         const uint32_t li[3] = { i0, i1, i2 };
                         for (int k = 0; k < 3; ++k) {
-                            const float4 pp = O->mpos[ml.VertexOffset + li[k]];
-                            cc[k] = zr_mat4_point(P.PVM, vs_position(zr3(pp.x, pp.y, pp.z), I, instanced));
+                            const float4 pk = mp[li[k]];
+                            cc[k] = zr_mat4_point(P.PVM, vs_position(zr3(pk.x, pk.y, pk.z), I, instanced));
                         }
                         raster_clipped<MODE>(cc[0], cc[1], cc[2], prim, T, P.hw, P.hh, keys64, keys32);
                     }
@@ -1152,12 +1164,12 @@ void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_
 {
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, chunk_offset, n, capacity, stats, slot);
 }
-void zr_launch_bin_fill(const ZrPass& P, const uint32_t* rects, const uint32_t* tile_offset, uint32_t* tile_cursor,
-                        uint32_t* bins, ZrDevStats* stats, int slot, hipStream_t s)
+void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* rects, const uint32_t* tile_offset,
+                        uint32_t* tile_cursor, ZrBinEntry* bins, ZrDevStats* stats, int slot, hipStream_t s)
 {
     if (P.n_work == 0) return;
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
-    hipLaunchKernelGGL(k_bin_fill, dim3((P.n_work + 1023) / 1024), dim3(1024), n_tiles * sizeof(uint32_t), s, P, rects, tile_offset,
+    hipLaunchKernelGGL(k_bin_fill, dim3((P.n_work + 1023) / 1024), dim3(1024), n_tiles * sizeof(uint32_t), s, P, objs, rects, tile_offset,
                        tile_cursor, bins, stats, slot);
 }
 void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s)
@@ -1169,7 +1181,7 @@ void zr_launch_fill64(unsigned long long* p, unsigned long long v, size_t n, hip
     hipLaunchKernelGGL(k_fill64, dim3(1024), dim3(256), 0, s, p, v, n);
 }
 void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint32_t* tile_offset, const uint32_t* chunk_offset,
-                             const uint32_t* bins, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t* shadow_bits,
+                             const ZrBinEntry* bins, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t* shadow_bits,
                              uint32_t n_blocks, hipStream_t s)
 {
     if (P.mode == ZR_MODE_GBUFFER)

@@ -51,6 +51,17 @@ struct ZrObject {
     uint32_t _pad;
 };
 
+// One (tile, meshlet-instance) entry of a bin list, self-contained: the rasteriser starts every load of a meshlet from
+// this record alone (one dependent round trip instead of bins -> draw table -> meshlet -> vertices).
+struct ZrBinEntry {
+    const float4*     mpos;          // first flattened vertex of the meshlet
+    const uint2*      mtri;          // first triangle word of the meshlet
+    const ZrInstance* inst;          // the instance record
+    uint32_t          counts;        // VertexCount | TriangleCount << 8 | instanced << 16
+    uint32_t          prim_base;     // primitive id of the instance's first triangle
+};
+static_assert(sizeof(ZrBinEntry) == 32, "ZrBinEntry");
+
 // Parameters of one geometry pass (camera or shadow), passed by value in the kernarg segment.
 struct ZrPass {
     float PVM[16];                   // proj * view * model
@@ -106,12 +117,12 @@ void zr_launch_instance_prep(const XkInstanceData* in, ZrInstance* out, uint32_t
 void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* rects, uint32_t* tile_count, hipStream_t s);
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint32_t n,
                     uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s);
-void zr_launch_bin_fill(const ZrPass& P, const uint32_t* rects, const uint32_t* tile_offset, uint32_t* tile_cursor,
-                        uint32_t* bins, ZrDevStats* stats, int slot, hipStream_t s);
+void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* rects, const uint32_t* tile_offset,
+                        uint32_t* tile_cursor, ZrBinEntry* bins, ZrDevStats* stats, int slot, hipStream_t s);
 void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s);
 void zr_launch_fill64(unsigned long long* p, unsigned long long v, size_t n, hipStream_t s);
 void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint32_t* tile_offset, const uint32_t* chunk_offset,
-                             const uint32_t* bins, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t* shadow_bits,
+                             const ZrBinEntry* bins, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t* shadow_bits,
                              uint32_t n_blocks, hipStream_t s);
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, ZrDevStats* stats, hipStream_t s);
