@@ -84,6 +84,7 @@ struct zr_ctx {
 
     std::vector<uint8_t*> d_cube; CubeDesc cube = {}; uint32_t cube_dim = 0, cube_levels = 0;
     float lut[256]; float* d_lut = nullptr;
+    float* d_unorm_lut = nullptr;        // [0..255] = c / 255, [256..1279] = c / 1023 (IEEE quotients, computed on the host)
 
     static constexpr int EV_RING = 64;     // per-pass hipEvents of the last EV_RING frames (bench averages over them)
     // skydome + background passes (ZE:2657-2744, 3681-3699)

@@ -90,6 +90,13 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     ok &= dev_alloc(&c->d_stats, 1) == hipSuccess;
     ok &= dev_alloc(&c->d_lut, 256) == hipSuccess;
     if (ok) ok &= hipMemcpy(c->d_lut, c->lut, sizeof c->lut, hipMemcpyHostToDevice) == hipSuccess;
+    {
+        std::vector<float> ul(1280);
+        for (int i = 0; i < 256; ++i) ul[(size_t)i] = (float)i / 255.0f;
+        for (int i = 0; i < 1024; ++i) ul[256 + (size_t)i] = (float)i / 1023.0f;
+        ok &= dev_alloc(&c->d_unorm_lut, ul.size()) == hipSuccess;
+        if (ok) ok &= hipMemcpy(c->d_unorm_lut, ul.data(), ul.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (ok) ok &= hipMemset(c->d_color, 0, n * 4) == hipSuccess;
 
     // screen tiles: camera target partitioned t % world == rank; the shadow map is rendered whole on every rank
@@ -150,7 +157,7 @@ extern "C" void zr_destroy(zr_ctx* c)
     free_mesh_buffers(c->sky_mesh); dev_free(c->sky_obj.d_inst); for (auto& t : c->sky_obj.d_tex) dev_free(t); dev_free(c->d_bg);
     for (auto p : c->d_cube) if (p) (void)hipFree(p);
     dev_free(c->G.depth); dev_free(c->G.scene_color); dev_free(c->G.gA); dev_free(c->G.gB); dev_free(c->G.gC); dev_free(c->G.gD); dev_free(c->G.overlay);
-    dev_free(c->d_color); dev_free(c->d_shadow); dev_free(c->d_view); dev_free(c->d_stats); dev_free(c->d_lut);
+    dev_free(c->d_color); dev_free(c->d_shadow); dev_free(c->d_view); dev_free(c->d_stats); dev_free(c->d_lut); dev_free(c->d_unorm_lut);
     dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles);
     dev_free(c->d_tile_count); dev_free(c->d_tile_offset); dev_free(c->d_tile_cursor); dev_free(c->d_chunk_offset); dev_free(c->d_vis); dev_free(c->d_rects); dev_free(c->d_bins);
     for (auto& fr : c->evr) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
@@ -445,6 +452,11 @@ static int finalize_scene(zr_ctx* c)
         d.n_inst = o.n_inst; d.instanced = o.instanced; d.flags = flags;
         d.work_base = (uint32_t)work; d.prim_base = (uint32_t)prim;
         memcpy(d.texel, o.texel, sizeof d.texel); memcpy(d.bc_linear, o.bc_linear, sizeof d.bc_linear);
+        for (int t = 0; t < 7; ++t)
+            for (int ch = 0; ch < 4; ++ch) {
+                const uint32_t v8 = (o.texel[t] >> (8 * ch)) & 255u;
+                d.texc[t][ch] = (t == 0 && ch < 3) ? c->lut[v8] : (float)v8 / 255.0f;
+            }
         for (int t = 0; t < 7; ++t) { d.tex[t].data = o.d_tex[t]; d.tex[t].w = o.tex_w[t]; d.tex[t].h = o.tex_h[t]; d.tex[t].levels = o.tex_levels[t]; d.tex[t]._pad = 0; }
         memcpy(d.mesh_center, m.center, sizeof d.mesh_center); d.mesh_radius = m.radius;
         work += (uint64_t)d.n_meshlets * d.n_inst; prim += (uint64_t)d.n_tris * d.n_inst;
@@ -784,9 +796,10 @@ extern "C" int zr_render(zr_ctx* c)
     L.W = c->W; L.H = c->H; L.SD = c->SD; L.tiles_x = c->tiles_x; L.debug_view = c->debug_view;
     L.cube_dim = c->cube_dim; L.cube_levels = c->cube_levels; L.tile_world = c->cfg.tile_world;
     L.packed_out = c->cfg.tile_world > 1 ? 1u : 0u;
+    { const char* dbg = getenv("ZR_DEBUG_SKIP_LIGHT"); L.debug_skip = dbg ? (uint32_t)atoi(dbg) : 0u; }
     L.bg_enabled = (c->bg_set && c->bg_enabled) ? 1u : 0u;
     L.bg.data = c->d_bg; L.bg.w = c->bg_w; L.bg.h = c->bg_h; L.bg.levels = c->bg_levels; L.bg._pad = 0;
-    zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, c->d_shadow, c->cube, c->d_lut,
+    zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, c->d_shadow, c->cube, c->d_lut, c->d_unorm_lut,
                        L.packed_out ? c->d_tiles : c->d_color, s);
     HIPCHK(c, hipEventRecord(ev[6], s));
     HIPCHK(c, hipGetLastError());

@@ -580,13 +580,11 @@ __device__ __forceinline__ zf4 tex_bilinear(const ZrTex& T, int level, float u, 
 }
 // Isotropic LOD from the quad derivatives, trilinear.  Anisotropic filtering (maxAnisotropy = device max, ZE:6540) is
 // implementation-defined and not reproduced.  A constant slot returns its texel.
-__device__ __forceinline__ zf4 tex_sample(const ZrTex& T, uint32_t texel, bool srgb, const float* __restrict__ lut,
+__device__ __forceinline__ zf4 tex_sample(const ZrTex& T, const float* __restrict__ constant, bool srgb, const float* __restrict__ lut,
                                           float u, float v, float dudx, float dvdx, float dudy, float dvdy)
 {
-    if (T.data == nullptr) {
-        zf4 r;
-        r.x = tex_decode(texel & 255u, srgb, lut); r.y = tex_decode((texel >> 8) & 255u, srgb, lut);
-        r.z = tex_decode((texel >> 16) & 255u, srgb, lut); r.w = tex_decode(texel >> 24, false, lut);
+    if (T.data == nullptr) {      // constant slot: decoded once on the host
+        zf4 r; r.x = constant[0]; r.y = constant[1]; r.z = constant[2]; r.w = constant[3];
         return r;
     }
     const float W = (float)T.w, H = (float)T.h;
@@ -657,7 +655,7 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
     const float s1 = (u0 - uh) * sx, t1 = (v0 - vh) * sx, s2 = (u0 - uv_) * sy, t2 = (v0 - vv) * sy;
 
     if (O->flags & ZR_OBJ_SKY) {    // Skydome.frag: texture(skydomeSampler, uv).rgb, gamma; the GBuffer keeps its clear values
-        const zf4 sk = tex_sample(O->tex[0], O->texel[0], true, lut, u0, v0, s1, t1, s2, t2);
+        const zf4 sk = tex_sample(O->tex[0], O->texc[0], true, lut, u0, v0, s1, t1, s2, t2);
         G.depth[p] = 1.0f; G.scene_color[p] = 0xFF000000u; G.gA[p] = 0u; G.gB[p] = 0xFF000000u; G.gC[p] = 0xFF000000u;
         G.gD[p] = make_uint2(0u, 0x3C000000u);
         G.overlay[p] = zr_unorm(zr_pow(sk.x, 0.4545f), 255.0f) | zr_unorm(zr_pow(sk.y, 0.4545f), 255.0f) << 8 |
@@ -666,13 +664,13 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
     }
     G.overlay[p] = 0u;
     // texture(samplerN, fragTexCoord), BaseScene.frag:30-36; slot 0 (base colour) is R8G8B8A8_SRGB (ZE:5878)
-    const zf4 tb = tex_sample(O->tex[0], O->texel[0], true, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tme = tex_sample(O->tex[1], O->texel[1], false, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tro = tex_sample(O->tex[2], O->texel[2], false, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tno = tex_sample(O->tex[3], O->texel[3], false, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tao = tex_sample(O->tex[4], O->texel[4], false, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tem = tex_sample(O->tex[5], O->texel[5], false, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tms = tex_sample(O->tex[6], O->texel[6], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tb = tex_sample(O->tex[0], O->texc[0], true, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tme = tex_sample(O->tex[1], O->texc[1], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tro = tex_sample(O->tex[2], O->texc[2], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tno = tex_sample(O->tex[3], O->texc[3], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tao = tex_sample(O->tex[4], O->texc[4], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tem = tex_sample(O->tex[5], O->texc[5], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tms = tex_sample(O->tex[6], O->texc[6], false, lut, u0, v0, s1, t1, s2, t2);
     const float Metallic = tme.x;
     const float Rough = __builtin_fmaxf(0.01f, tro.x);
     const zf3 texN = zr3(tno.x, tno.y, tno.z);
@@ -959,6 +957,8 @@ __device__ __forceinline__ float D_GGX(float NdotH, float r)                    
     return a2 / ((3.14159265359f * f) * f);
 }
 
+typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a 4-byte aligned address
+
 // ShadowDepthProject + texture(LINEAR, clamp-to-edge) of the D32 shadow map (SH/Common.glsl:307-319; sampler ZE:2532-2537)
 __device__ __forceinline__ float shadow_tap(const float* __restrict__ S, int SD, float sx, float sy, float sz, float sw, float ox, float oy)
 {
@@ -982,8 +982,15 @@ __device__ __forceinline__ float shadow_tap(const float* __restrict__ S, int SD,
 __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView* __restrict__ view,
                                                   const uint32_t* __restrict__ owned_tiles, GBufferPtrs G,
                                                   const float* __restrict__ shadowmap, CubeDesc C,
-                                                  const float* __restrict__ srgb_lut, uint32_t* __restrict__ out)
+                                                  const float* __restrict__ srgb_lut, const float* __restrict__ unorm_lut,
+                                                  uint32_t* __restrict__ out)
 {
+    // UNORM loads are IEEE quotients c / 255 and c / 1023: 14 per pixel, served from an LDS copy of the host-built table
+    __shared__ float u8[256];
+    __shared__ float u10[1024];
+    for (uint32_t i = threadIdx.x; i < 256u; i += 256u) u8[i] = unorm_lut[i];
+    for (uint32_t i = threadIdx.x; i < 1024u; i += 256u) u10[i] = unorm_lut[256u + i];
+    __syncthreads();
     const uint32_t tile = owned_tiles[blockIdx.x];
     const int tx0 = (int)(tile % L.tiles_x) * TILE, ty0 = (int)(tile / L.tiles_x) * TILE;
     const zf3 cam = zr3(view->CameraInfo[0], view->CameraInfo[1], view->CameraInfo[2]);
@@ -997,14 +1004,13 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
         const size_t p = (size_t)py * L.W + (size_t)px;
         const uint32_t sc = G.scene_color[p], A = G.gA[p], B = G.gB[p], Cc = G.gC[p];
         const uint2 D = G.gD[p];
-        const zf3 BaseColor = zr3((float)(Cc & 255u) / 255.0f, (float)((Cc >> 8) & 255u) / 255.0f, (float)((Cc >> 16) & 255u) / 255.0f);
-        const float Metallic = zr_saturate((float)(B & 255u) / 255.0f);
-        float Roughness = zr_saturate((float)((B >> 16) & 255u) / 255.0f);
-        const zf3 Normal = zr3(__builtin_fmaf((float)((A >> 20) & 1023u) / 1023.0f, 2.0f, -1.0f),
-                               __builtin_fmaf((float)((A >> 10) & 1023u) / 1023.0f, 2.0f, -1.0f),
-                               __builtin_fmaf((float)(A & 1023u) / 1023.0f, 2.0f, -1.0f));
-        const float AO = zr_saturate((float)(Cc >> 24) / 255.0f);
-        const float Mask = (float)(sc >> 24) / 255.0f;
+        const zf3 BaseColor = zr3(u8[Cc & 255u], u8[(Cc >> 8) & 255u], u8[(Cc >> 16) & 255u]);
+        const float Metallic = zr_saturate(u8[B & 255u]);
+        float Roughness = zr_saturate(u8[(B >> 16) & 255u]);
+        const zf3 Normal = zr3(__builtin_fmaf(u10[(A >> 20) & 1023u], 2.0f, -1.0f), __builtin_fmaf(u10[(A >> 10) & 1023u], 2.0f, -1.0f),
+                               __builtin_fmaf(u10[A & 1023u], 2.0f, -1.0f));
+        const float AO = zr_saturate(u8[Cc >> 24]);
+        const float Mask = u8[sc >> 24];
         Roughness = __builtin_fmaxf(0.01f, Roughness);
         const zf3 N = zr_normalize(Normal);
         const zf3 Pw = zr3(zr_f16_to_f32(D.x & 0xFFFFu), zr_f16_to_f32(D.x >> 16), zr_f16_to_f32(D.y & 0xFFFFu));
@@ -1013,16 +1019,72 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
 
         const zf4 s4 = zr_mat4_point(L.SB, Pw);
         const float sx = s4.x / s4.w, sy = s4.y / s4.w, sz = s4.z / s4.w, sw = s4.w / s4.w;
+        // ComputePCF r = 2 (SH/Common.glsl:323-342): 25 taps of ShadowDepthProject.  A tap's texel column / row and bilinear
+        // weight depend only on its x / y offset, so they are formed once per axis (5 + 5) instead of once per tap (25 + 25);
+        // every tap still evaluates fma(sx + ox, dim, -0.5) etc. with the same operands, i.e. the same bits.
         float sum = 0.0f;
-        for (int x = -2; x <= 2; ++x)
-            for (int y = -2; y <= 2; ++y)      // ComputePCF r = 2, SH/Common.glsl:323-342
-                sum += shadow_tap(shadowmap, (int)L.SD, sx, sy, sz, sw, dxy * (float)x, dxy * (float)y);
+        if (sz > -1.0f && sz < 1.0f && !(L.debug_skip & 1u)) {
+            const int SDi = (int)L.SD;
+            const float dim = (float)SDi;
+            int cx0[5], cx1[5], ry0[5], ry1[5]; float wa[5], wb[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const float off = dxy * (float)(k - 2);
+                const float u = __builtin_fmaf(sx + off, dim, -0.5f), v = __builtin_fmaf(sy + off, dim, -0.5f);
+                const float fu = __builtin_floorf(u), fv = __builtin_floorf(v);
+                wa[k] = u - fu; wb[k] = v - fv;
+                cx0[k] = idx_clamp(fu, SDi - 1); cx1[k] = idx_clamp(fu + 1.0f, SDi - 1);
+                ry0[k] = idx_clamp(fv, SDi - 1) * SDi; ry1[k] = idx_clamp(fv + 1.0f, SDi - 1) * SDi;
+            }
+            // Column pattern of the five x offsets (-3, -1.5, 0, 1.5, 3 texels) when nothing is clamped: pairs start at
+            // cb, cb+1|cb+2, cb+3, cb+4|cb+5, cb+6 - all inside an 8-texel span.  Then each tap row is TWO 16-byte loads per lane
+            // instead of ten 4-byte ones (the texture path processes ~4 lane addresses per clock whatever their width), and the
+            // taps pick their texels from registers.  Any deviation (map edge, a rounding oddity) takes the per-texel path.
+            const int cb = cx0[0];
+            const bool p1 = cx0[1] == cb + 2, p3 = cx0[3] == cb + 5;
+            const bool pattern = cx1[0] == cb + 1 && (cx0[1] == cb + 1 || p1) && cx1[1] == cx0[1] + 1 && cx0[2] == cb + 3 && cx1[2] == cb + 4 &&
+                                 (cx0[3] == cb + 4 || p3) && cx1[3] == cx0[3] + 1 && cx0[4] == cb + 6 && cx1[4] == cb + 7;
+            if (pattern) {
+                // taps accumulate in the reference's order (x outer, y inner): keep the 25 results, add afterwards
+                float tapv[5][5];
+#pragma unroll
+                for (int y = 0; y < 5; ++y) {
+                    const float4_u a0 = *(const float4_u*)(shadowmap + ry0[y] + cb), a1 = *(const float4_u*)(shadowmap + ry0[y] + cb + 4);
+                    const float4_u b0 = *(const float4_u*)(shadowmap + ry1[y] + cb), b1 = *(const float4_u*)(shadowmap + ry1[y] + cb + 4);
+                    const float t00[5] = { a0.x, p1 ? a0.z : a0.y, a0.w, p3 ? a1.y : a1.x, a1.z };
+                    const float t10[5] = { a0.y, p1 ? a0.w : a0.z, a1.x, p3 ? a1.z : a1.y, a1.w };
+                    const float t01[5] = { b0.x, p1 ? b0.z : b0.y, b0.w, p3 ? b1.y : b1.x, b1.z };
+                    const float t11[5] = { b0.y, p1 ? b0.w : b0.z, b1.x, p3 ? b1.z : b1.y, b1.w };
+#pragma unroll
+                    for (int x = 0; x < 5; ++x) {
+                        const float top = __builtin_fmaf(wa[x], t10[x] - t00[x], t00[x]), bot = __builtin_fmaf(wa[x], t11[x] - t01[x], t01[x]);
+                        const float dist = __builtin_fmaf(wb[y], bot - top, top);
+                        tapv[x][y] = (sw > 0.0f && dist < sz) ? 0.1f : 1.0f;
+                    }
+                }
+#pragma unroll
+                for (int x = 0; x < 5; ++x)
+#pragma unroll
+                    for (int y = 0; y < 5; ++y) sum += tapv[x][y];
+            } else {
+#pragma unroll
+                for (int x = 0; x < 5; ++x)
+#pragma unroll
+                    for (int y = 0; y < 5; ++y) {
+                        const float t00 = shadowmap[ry0[y] + cx0[x]], t10 = shadowmap[ry0[y] + cx1[x]];
+                        const float t01 = shadowmap[ry1[y] + cx0[x]], t11 = shadowmap[ry1[y] + cx1[x]];
+                        const float top = __builtin_fmaf(wa[x], t10 - t00, t00), bot = __builtin_fmaf(wa[x], t11 - t01, t01);
+                        const float dist = __builtin_fmaf(wb[y], bot - top, top);
+                        sum += (sw > 0.0f && dist < sz) ? 0.1f : 1.0f;
+                    }
+            }
+        } else sum = 25.0f;      // every tap returns 1.0: 25 exact additions
         const float ShadowFactor = sum / 25.0f;
 
         zf3 Direct = zr3(0.0f, 0.0f, 0.0f);
         const zf3 Nn = zr_normalize(N);                      // Apply*Light and refract() re-normalise N
         const zf3 DiffuseColor = BaseColor * (1.0f - Metallic);
-        for (uint32_t li = 0; li < nDir + nPoint; ++li) {
+        for (uint32_t li = 0; li < ((L.debug_skip & 2u) ? 0u : nDir + nPoint); ++li) {
             const bool isdir = li < nDir;
             const XkLight* __restrict__ Lt = isdir ? &view->DirectionalLights[li] : &view->PointLights[li - nDir];
             const zf3 lp = zr3(Lt->Position[0], Lt->Position[1], Lt->Position[2]);
@@ -1033,8 +1095,12 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
                                  __builtin_fabsf(Lt->Color[2]) <= 3.402823466e38f && __builtin_fabsf(Lt->Color[3]) <= 3.402823466e38f;
             float att = 1.0f;
             if (!isdir) {
-                const float dist = zr_length(lp - Pw);
                 const float falloff = Lt->Direction[3];
+                // far outside the radius (1e-6 relative margin on the squared distance covers every rounding in dist): the exact
+                // test below would give att == 0, so the square root and the quotient need not be formed
+                const zf3 dl = lp - Pw;
+                if (lfinite && falloff > 0.0f && zr_dot(dl, dl) > (falloff * falloff) * 1.000001f) continue;
+                const float dist = zr_length(dl);
                 att = 1.0f - zr_clamp(dist, 0.0f, falloff) / falloff;   // remap(dist, 0, falloff, 0, 1), SH/Common.glsl:43-47
                 if (lfinite && att == 0.0f) continue;
             }
@@ -1089,7 +1155,7 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
         }
         // ComputeReflectionMipFromRoughness, SH/Common.glsl:191-198
         const float MIPS = (maxmips - 1.0f) - __builtin_fmaf(-1.2f, zr_log2(__builtin_fmaxf(Roughness, 0.001f)), 1.0f);
-        const zf3 RL = cube_sample(C, srgb_lut, L.cube_dim, (int)L.cube_levels, R, MIPS) * 10.0f;
+        const zf3 RL = (L.debug_skip & 4u) ? zr3(0.0f, 0.0f, 0.0f) : cube_sample(C, srgb_lut, L.cube_dim, (int)L.cube_levels, R, MIPS) * 10.0f;
         const float RV = zr_saturate((zr_pow(NdotV + AO, Roughness * Roughness) - 1.0f) + AO);   // GetSpecularOcclusion :226
         const zf3 RefC = zr3((RL.x * RV) * RBRDF.x, (RL.y * RV) * RBRDF.y, (RL.z * RV) * RBRDF.z);
 
@@ -1118,7 +1184,8 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
             if (ov) rgba = ov;
             else if (L.bg_enabled && 1.0f <= G.depth[p]) {
                 const float u = ((float)px + 0.5f) / (float)L.W, v = ((float)py + 0.5f) / (float)L.H;
-                const zf4 bgc = tex_sample(L.bg, 0xFFFFFFFFu, true, srgb_lut, u, v, 1.0f / (float)L.W, 0.0f, 0.0f, 1.0f / (float)L.H);
+                const float one4[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
+                const zf4 bgc = tex_sample(L.bg, one4, true, srgb_lut, u, v, 1.0f / (float)L.W, 0.0f, 0.0f, 1.0f / (float)L.H);
                 rgba = zr_unorm(zr_pow(bgc.x, 0.4545f), 255.0f) | zr_unorm(zr_pow(bgc.y, 0.4545f), 255.0f) << 8 |
                        zr_unorm(zr_pow(bgc.z, 0.4545f), 255.0f) << 16 | 255u << 24;
             }
@@ -1200,10 +1267,11 @@ void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, h
     hipLaunchKernelGGL(k_count_shadow, dim3(256), dim3(256), 0, s, bits, n, stats);
 }
 void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32_t* owned_tiles, uint32_t n_owned,
-                        const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C, const float* lut, uint32_t* out, hipStream_t s)
+                        const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C, const float* lut, const float* unorm_lut,
+                        uint32_t* out, hipStream_t s)
 {
     if (n_owned == 0) return;
-    hipLaunchKernelGGL(k_lighting, dim3(n_owned), dim3(256), 0, s, L, view, owned_tiles, G, shadowmap, C, lut, out);
+    hipLaunchKernelGGL(k_lighting, dim3(n_owned), dim3(256), 0, s, L, view, owned_tiles, G, shadowmap, C, lut, unorm_lut, out);
 }
 void zr_launch_untile(const uint32_t* gathered, uint32_t* frame, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
                       uint32_t world, uint32_t slots_per_rank, hipStream_t s)

@@ -45,6 +45,7 @@ struct ZrObject {
     ZrTex    tex[7];                 // sampled material slots (data == nullptr: the slot is the constant `texel`)
     uint32_t texel[7];               // constant material: RGBA8 per PBR slot (bc, m, r, n, ao, ev, ms)
     float    bc_linear[3];           // sRGB-decoded base colour (slot 0 is R8G8B8A8_SRGB, ZE:5878)
+    float    texc[7][4];             // the constant texels decoded on the host (slot 0 rgb through the sRGB table, the rest c / 255)
     float    mesh_center[3];         // object-space bounding sphere of the whole mesh
     float    mesh_radius;
     uint32_t flags;                  // ZR_OBJ_*
@@ -100,6 +101,7 @@ struct ZrLightParams {
     uint32_t cube_dim, cube_levels;
     uint32_t packed_out;             // 1: write tile-major packed output (multi-GPU), 0: row-major frame
     uint32_t tile_world;
+    uint32_t debug_skip;             // diagnostics only (env ZR_DEBUG_SKIP_LIGHT bits: 1 PCF, 2 lights, 4 reflection)
     uint32_t bg_enabled;             // background quad (Background.vert/.frag) on
     ZrTex    bg;                     // its sRGB texture
 };
@@ -128,7 +130,7 @@ void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, ZrDevStats* stats, hipStream_t s);
 void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, hipStream_t s);
 void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32_t* owned_tiles, uint32_t n_owned,
-                        const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C, const float* lut, uint32_t* out,
-                        hipStream_t s);
+                        const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C, const float* lut, const float* unorm_lut,
+                        uint32_t* out, hipStream_t s);
 void zr_launch_untile(const uint32_t* gathered, uint32_t* frame, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
                       uint32_t world, uint32_t slots_per_rank, hipStream_t s);
