@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--instances", type=int, default=10000, help="config 3 instance count (default: the metric's 10k)")
+    ap.add_argument("--config", type=int, default=3, choices=[3, 4, 5],
+                    help="3: the metric's workload (default); 4: 1M instances at 3840x2160; 5: config 4 with 256 point lights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-instances", type=int, default=10000)
     args = ap.parse_args()
@@ -80,7 +82,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
-    cfg = scenes.config3(args.instances)
+    if args.config == 3:
+        cfg = scenes.config3(args.instances)
+    else:
+        cfg = scenes.config4(args.instances if args.instances != 10000 else 1000000, 256 if args.config == 5 else 16)
     W, H = cfg["width"], cfg["height"]
     dr = zdist.DistributedRenderer(W, H, 1024, device_index=local_rank, rank=rank, world=world)
     r = dr.r
@@ -139,8 +144,9 @@ def main():
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "config3: %d instanced 960-tri spheres (%d meshlet-instances), 1920x1080, 1 directional + 16 point "
-                                   "lights, 1024^2 shadow map + 5x5 PCF, cubemap IBL" % (args.instances, stats["work_items"][1]),
+            "config": {"workload": "config%d: %d instanced 960-tri spheres (%d meshlet-instances), %dx%d, 1 directional + %d point "
+                                   "lights, 1024^2 shadow map + 5x5 PCF, cubemap IBL" % (args.config, len(cfg["objects"][0]["instances"]),
+                                                                                          stats["work_items"][1], W, H, len(cfg["point"])),
                        "resolution": [W, H], "parallelism": "screen-tiles t%%%d" % world if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": KERNEL_OF_PASS[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
@@ -149,7 +155,7 @@ def main():
             "passes_gbs": {k: round(alg[k] / (times[k] * 1e-3) / 1e9, 2) for k in alg if times[k] > 0},
             "stats": stats,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == 3:     # defined on the metric's workload only
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_instances)
         print(json.dumps(line), flush=True)
     r.close()

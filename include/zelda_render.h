@@ -35,7 +35,9 @@ extern "C" {
 #define ZR_ERR_OVERFLOW -7
 #define ZR_ERR_UNSUPPORTED -8
 
-#define ZR_TILE 32            /* screen tile edge in pixels (raster + multi-GPU partition unit) */
+#ifndef ZR_TILE
+#define ZR_TILE 32            /* screen tile edge in pixels (raster + multi-GPU partition unit); 32 or 64 */
+#endif
 
 typedef struct zr_ctx zr_ctx;
 
@@ -88,6 +90,7 @@ void zr_destroy(zr_ctx* ctx);
 const char* zr_last_error(const zr_ctx* ctx);
 /* Render on a caller-owned hipStream_t (NULL = the context's own stream). */
 int  zr_set_stream(zr_ctx* ctx, void* hip_stream);
+int  zr_tile_size(void);                            /* the ZR_TILE this library was built with */
 
 /* --- scene submission (replaces CreateRenderObjectsFromProfabs ZE:4922-5000, CreateMeshVertexBuffers
  *     ZE:4725-4770, CreateInstancedBuffer ZE:4795-4824) --- */
@@ -154,6 +157,9 @@ int  zr_read_shadowmap(zr_ctx* ctx, float* dst, size_t bytes);        /* dim*dim
 /* --- multi-GPU screen-tile partition --- */
 /* Packed tile-major RGBA8 of the tiles this rank owns (device pointer, stable until zr_destroy). */
 int  zr_tiles_device_buffer(zr_ctx* ctx, void** dev_ptr, size_t* bytes_per_rank);
+/* Caller-owned packed buffer for the following frames (same size; NULL = the internal one).  Two alternating buffers let
+ * frame k's all-gather overlap frame k+1's rendering. */
+int  zr_set_tiles_buffer(zr_ctx* ctx, void* dev_ptr);
 int  zr_read_tiles(zr_ctx* ctx, uint8_t* dst, size_t bytes);             /* host copy of that buffer (tests) */
 /* Scatter the all-gathered buffer (tile_world * bytes_per_rank, rank-major, device pointer) into the frame. */
 int  zr_composite(zr_ctx* ctx, const void* gathered_dev);

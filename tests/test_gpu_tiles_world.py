@@ -36,6 +36,40 @@ def test_tile_partition_composites_to_the_single_gpu_frame(gpu_engine, world):
     assert sum(s["covered_pixels"] for s in st) == single.stats()["covered_pixels"]
 
 
+def test_pipelined_distributed_renderer_with_a_stand_in_collective(gpu_engine, monkeypatch):
+    """The two-stream, double-buffered frame loop of dist.DistributedRenderer for rank 0 of 2, with torch.distributed's
+    all-gather replaced by a local stand-in that supplies rank 1's packed tiles (one GPU here; RCCL itself is not under test)."""
+    import torch
+    import torch.distributed as tdist
+    cfg = scenes.config3(300, 416, 250)
+    single = gpu_engine.Renderer(cfg["width"], cfg["height"], 256)
+    gpu_engine.load_scene(single, cfg)
+    single.render()
+    want = single.color()
+    other = gpu_engine.Renderer(cfg["width"], cfg["height"], 256, tile_rank=1, tile_world=2)
+    gpu_engine.load_scene(other, cfg)
+    other.render()
+    other_tiles = torch.from_numpy(other.read_tiles().reshape(-1).copy()).cuda()
+    calls = []
+
+    def fake_all_gather(out, inp, group=None, async_op=False):
+        n = inp.numel()
+        out[:n].copy_(inp)              # on the current (collective) stream, like the real op
+        out[n:2 * n].copy_(other_tiles)
+        calls.append(torch.cuda.current_stream().cuda_stream)
+    monkeypatch.setattr(tdist, "all_gather_into_tensor", fake_all_gather)
+    dr = zdist.DistributedRenderer(cfg["width"], cfg["height"], 256, device_index=0, rank=0, world=2)
+    gpu_engine.load_scene(dr.r, cfg)
+    for _ in range(5):                  # exercises both halves of the double buffers
+        dr.frame()
+    dr.synchronize()
+    assert len(calls) == 5 and all(c == dr.comm_stream.cuda_stream for c in calls) and dr.comm_stream != dr.render_stream
+    assert np.array_equal(dr.r.color(), want)
+    assert np.array_equal(dr.tiles[0].cpu().numpy(), dr.tiles[1].cpu().numpy())
+    assert np.array_equal(dr.tiles[0].cpu().numpy().reshape(-1, 32, 32, 4), zdist.pack_tiles(want, 0, 2))
+    dr.close()
+
+
 def _register_sample_profabs(r):
     plane = r.mesh_create(*scenes.grid_plane(20.0, 4, 0.0))
     box = r.mesh_create(*scenes.box((0.5, 0.5, 0.5), (0, 0, 0.5)))

@@ -75,6 +75,7 @@ struct zr_ctx {
     uint32_t *d_owned = nullptr, *d_sowned = nullptr;
     GBufferPtrs G = {};
     float* d_shadow = nullptr; uint32_t* d_color = nullptr; uint32_t* d_tiles = nullptr;
+    uint32_t* d_tiles_ext = nullptr;     // caller-owned packed tile buffer for the next frames (zr_set_tiles_buffer), or null
 
     uint32_t *d_rects = nullptr, *d_tile_count = nullptr, *d_tile_offset = nullptr, *d_tile_cursor = nullptr; ZrBinEntry* d_bins = nullptr;
     uint32_t* d_chunk_offset = nullptr; unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048;

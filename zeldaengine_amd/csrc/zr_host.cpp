@@ -167,6 +167,8 @@ extern "C" void zr_destroy(zr_ctx* c)
 
 extern "C" const char* zr_last_error(const zr_ctx* c) { return c ? c->err.c_str() : "no context (no usable HIP device?)"; }
 
+extern "C" int zr_tile_size(void) { return ZR_TILE; }
+
 extern "C" int zr_set_stream(zr_ctx* c, void* s)
 {
     if (!c) return ZR_ERR_ARG;
@@ -800,7 +802,7 @@ extern "C" int zr_render(zr_ctx* c)
     L.bg_enabled = (c->bg_set && c->bg_enabled) ? 1u : 0u;
     L.bg.data = c->d_bg; L.bg.w = c->bg_w; L.bg.h = c->bg_h; L.bg.levels = c->bg_levels; L.bg._pad = 0;
     zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, c->d_shadow, c->cube, c->d_lut, c->d_unorm_lut,
-                       L.packed_out ? c->d_tiles : c->d_color, s);
+                       L.packed_out ? (c->d_tiles_ext ? c->d_tiles_ext : c->d_tiles) : c->d_color, s);
     HIPCHK(c, hipEventRecord(ev[6], s));
     HIPCHK(c, hipGetLastError());
     c->rendered = true; c->frame_no++;
@@ -908,13 +910,22 @@ extern "C" int zr_tiles_device_buffer(zr_ctx* c, void** p, size_t* bytes)
     *p = c->d_tiles; *bytes = (size_t)c->slots_per_rank * ZR_TILE * ZR_TILE * 4;
     return ZR_OK;
 }
+// Lets the caller own the packed tile buffer (e.g. a torch tensor handed to RCCL; two of them alternate so that frame k's
+// all-gather overlaps frame k+1's rendering).  ptr must hold zr_tiles_device_buffer's byte count; NULL = internal buffer.
+extern "C" int zr_set_tiles_buffer(zr_ctx* c, void* ptr)
+{
+    if (!c) return ZR_ERR_ARG;
+    c->d_tiles_ext = (uint32_t*)ptr;
+    return ZR_OK;
+}
+
 extern "C" int zr_read_tiles(zr_ctx* c, uint8_t* dst, size_t bytes)
 {
     if (!c) return ZR_ERR_ARG;
     ARGCHK(c, dst && bytes == (size_t)c->slots_per_rank * ZR_TILE * ZR_TILE * 4);
     int rc = zr_finish(c);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpy(dst, c->d_tiles, bytes, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(dst, c->d_tiles_ext ? c->d_tiles_ext : c->d_tiles, bytes, hipMemcpyDeviceToHost));
     return ZR_OK;
 }
 extern "C" int zr_composite(zr_ctx* c, const void* gathered)

@@ -22,6 +22,8 @@
 #define TILE ZR_TILE
 #define TILE_PIX (TILE * TILE)
 #define QCAP 128u
+#define RW (ZR_TILE >= 64 ? 8 : 4)          // waves per rasteriser workgroup: one 64x64 tile's keys (32 KB) are shared by 8 waves
+#define RTHREADS (RW * WAVE)
 
 // ------------------------------------------------------------------------------------------------ helpers
 
@@ -709,7 +711,7 @@ __global__ void k_fill64(unsigned long long* __restrict__ p, unsigned long long 
 //   GBUFFER: vis64[W*H] (depth bits << 32 | prim), resolved later by k_resolve_gbuffer
 //   SHADOW : the shadow map itself (float bits as uint): the merge IS the LESS_OR_EQUAL depth write
 template <int MODE>
-__global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs,
+__global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs,
                                                        const uint32_t* __restrict__ tile_offset,
                                                        const uint32_t* __restrict__ chunk_offset,
                                                        const ZrBinEntry* __restrict__ bins, ZrDevStats* __restrict__ stats, int slot,
@@ -717,8 +719,8 @@ __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject*
 {
     __shared__ unsigned long long keys64[MODE == ZR_MODE_GBUFFER ? TILE_PIX : 1];
     __shared__ uint32_t keys32[MODE == ZR_MODE_SHADOW ? TILE_PIX : 1];
-    __shared__ int4 vstage[4][WAVE];
-    __shared__ int queue[4][10][QCAP];      // per-wave ring of surviving triangles: 3 x (X, Y, z) + prim, SoA
+    __shared__ int4 vstage[RW][WAVE];
+    __shared__ int queue[RW][10][QCAP];      // per-wave ring of surviving triangles: 3 x (X, Y, z) + prim, SoA
     __shared__ uint32_t cur_chunk;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -727,7 +729,7 @@ __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject*
 
     for (;;) {
         if (tid == 0) cur_chunk = atomicAdd(&stats->chunk_counter[slot], 1u);
-        for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
+        for (uint32_t i = tid; i < TILE_PIX; i += RTHREADS) {
             if (MODE == ZR_MODE_GBUFFER) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
             else keys32[i] = 0x3F800000u;
         }
@@ -749,9 +751,9 @@ __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject*
         const uint4* __restrict__ rec = (const uint4*)bins;
         uint4 n0 = make_uint4(0, 0, 0, 0), n1 = n0;
         if (beg + wv < end) { n0 = rec[2u * (beg + wv)]; n1 = rec[2u * (beg + wv) + 1u]; }
-        for (uint32_t e = beg + wv; e < end; e += 4u) {
+        for (uint32_t e = beg + wv; e < end; e += RW) {
             const uint4 r0 = n0, r1 = n1;
-            if (e + 4u < end) { n0 = rec[2u * (e + 4u)]; n1 = rec[2u * (e + 4u) + 1u]; }
+            if (e + RW < end) { n0 = rec[2u * (e + RW)]; n1 = rec[2u * (e + RW) + 1u]; }
             const float4* __restrict__ mp = (const float4*)(((unsigned long long)wave_uniform(r0.y) << 32) | wave_uniform(r0.x));
             const uint2* __restrict__ tw = (const uint2*)(((unsigned long long)wave_uniform(r0.w) << 32) | wave_uniform(r0.z));
             const ZrInstance* __restrict__ ip = (const ZrInstance*)(((unsigned long long)wave_uniform(r1.y) << 32) | wave_uniform(r1.x));
@@ -840,7 +842,7 @@ __global__ __launch_bounds__(256) void k_raster_chunks(ZrPass P, const ZrObject*
         __syncthreads();
 
         // merge the touched keys into HBM
-        for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
+        for (uint32_t i = tid; i < TILE_PIX; i += RTHREADS) {
             const int px = T.px0 + (int)(i & (TILE - 1)), py = T.py0 + (int)(i / TILE);
             if (px >= T.W || py >= T.H) continue;
             const size_t p = (size_t)py * P.W + (size_t)px;
@@ -1252,9 +1254,9 @@ void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint32
                              uint32_t n_blocks, hipStream_t s)
 {
     if (P.mode == ZR_MODE_GBUFFER)
-        hipLaunchKernelGGL(k_raster_chunks<ZR_MODE_GBUFFER>, dim3(n_blocks), dim3(256), 0, s, P, objs, tile_offset, chunk_offset, bins, stats, slot, vis64, shadow_bits);
+        hipLaunchKernelGGL(k_raster_chunks<ZR_MODE_GBUFFER>, dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, tile_offset, chunk_offset, bins, stats, slot, vis64, shadow_bits);
     else
-        hipLaunchKernelGGL(k_raster_chunks<ZR_MODE_SHADOW>, dim3(n_blocks), dim3(256), 0, s, P, objs, tile_offset, chunk_offset, bins, stats, slot, vis64, shadow_bits);
+        hipLaunchKernelGGL(k_raster_chunks<ZR_MODE_SHADOW>, dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, tile_offset, chunk_offset, bins, stats, slot, vis64, shadow_bits);
 }
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, ZrDevStats* stats, hipStream_t s)

@@ -5,6 +5,9 @@ against its own tiles only, renders the (1024^2) shadow map redundantly, and lig
 RGBA8 buffer.  ONE collective per frame — an RCCL all-gather of those buffers over xGMI (4 B/pixel in total) — followed by
 an untile kernel gives every rank the full frame.  There is no other exchange step.
 
+Two HIP streams: the render stream produces frame k+1 while the collective stream gathers and composites frame k (packed
+and gathered buffers are double-buffered, ordering is by events), so the xGMI latency is hidden behind rendering.
+
 `pack_tiles` / `untile` are the numpy statement of the packed layout (what k_lighting writes and k_untile reads); the
 gloo tests use them, the GPU path uses the kernels.
 """
@@ -48,48 +51,63 @@ def untile(gathered, width, height):
     return frame
 
 
-class _DevBuf:
-    """Zero-copy view of a raw device pointer for torch.as_tensor (CUDA array interface v2)."""
-
-    def __init__(self, ptr, nbytes):
-        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
-
-
 class DistributedRenderer:
     """One rank of the screen-tile partition: Renderer + the per-frame all-gather + composite.
 
     world == 1 degenerates to the plain renderer (no collective).  The process group must already be initialised
-    (backend "nccl" = RCCL on ROCm) when world > 1.
+    (backend "nccl" = RCCL on ROCm) when world > 1.  All buffers RCCL touches are torch allocations; the library renders
+    straight into them (zr_set_tiles_buffer).
     """
 
-    def __init__(self, width, height, shadow_dim=1024, device_index=0, rank=0, world=1, flags=0):
+    def __init__(self, width, height, shadow_dim=1024, device_index=0, rank=0, world=1, flags=0, pipeline=True):
         import torch
         from . import engine
         self.torch = torch
         self.rank, self.world = rank, world
         self.device = torch.device("cuda", device_index)
         self.r = engine.Renderer(width, height, shadow_dim, device=device_index, tile_rank=rank, tile_world=world, flags=flags)
-        # one explicit stream carries render -> all-gather -> composite, so the collective is ordered after the lighting
-        # kernel that fills the packed tiles and before the untile kernel that reads the gathered buffer
-        self.stream = torch.cuda.Stream(self.device)
-        self.r.set_stream(self.stream.cuda_stream)
-        self.tiles = self.gathered = None
+        self.render_stream = torch.cuda.Stream(self.device)
+        self.comm_stream = torch.cuda.Stream(self.device) if (pipeline and world > 1) else self.render_stream
+        self.r.set_stream(self.render_stream.cuda_stream)
+        self.k = 0
         if world > 1:
-            ptr, nbytes = self.r.tiles_device_buffer()
-            self.tiles = torch.as_tensor(_DevBuf(ptr, nbytes), device=self.device)
-            self.gathered = torch.empty(nbytes * world, dtype=torch.uint8, device=self.device)
+            _, nbytes = self.r.tiles_device_buffer()
+            self.tiles = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
+            self.gathered = [torch.empty(nbytes * world, dtype=torch.uint8, device=self.device) for _ in range(2)]
+            self.rendered = [torch.cuda.Event() for _ in range(2)]      # tiles[b] is complete
+            self.consumed = [torch.cuda.Event() for _ in range(2)]      # tiles[b] has been gathered (may be overwritten)
+            for ev in self.consumed:
+                ev.record(self.comm_stream)
 
     def frame(self):
-        """Enqueue one full frame (asynchronous on self.stream)."""
-        with self.torch.cuda.stream(self.stream):
+        """Enqueue one full frame; returns immediately."""
+        torch = self.torch
+        if self.world == 1:
+            with torch.cuda.stream(self.render_stream):
+                self.r.render()
+            return
+        import torch.distributed as dist
+        b = self.k & 1
+        self.k += 1
+        # render stream: wait until buffer b's previous contents were gathered, then render into it
+        self.render_stream.wait_event(self.consumed[b])
+        self.r.set_tiles_buffer(self.tiles[b].data_ptr())
+        with torch.cuda.stream(self.render_stream):
             self.r.render()
-            if self.world > 1:
-                import torch.distributed as dist
-                dist.all_gather_into_tensor(self.gathered, self.tiles)
-                self.r.composite(self.gathered.data_ptr())
+            self.rendered[b].record(self.render_stream)
+        # collective stream: gather + composite frame k while the render stream starts frame k + 1
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(self.rendered[b])
+            dist.all_gather_into_tensor(self.gathered[b], self.tiles[b])
+            self.consumed[b].record(self.comm_stream)
+            self.r.set_stream(self.comm_stream.cuda_stream)
+            self.r.composite(self.gathered[b].data_ptr())
+            self.r.set_stream(self.render_stream.cuda_stream)
 
     def synchronize(self):
-        self.stream.synchronize()
+        self.render_stream.synchronize()
+        self.comm_stream.synchronize()
 
     def close(self):
+        self.synchronize()
         self.r.close()

@@ -70,6 +70,8 @@ def lib():
         "zr_tiles_device_buffer": [vp, C.POINTER(vp), C.POINTER(sz)],
         "zr_composite": [vp, vp],
         "zr_read_tiles": [vp, vp, sz],
+        "zr_set_tiles_buffer": [vp, vp],
+        "zr_tile_size": [],
         "zr_color_device_ptr": [vp, C.POINTER(vp)],
         "zr_profab_register": [vp, C.c_char_p, u32, vp],
         "zr_world_load_json": [vp, C.c_char_p, sz],
@@ -316,6 +318,9 @@ class Renderer:
         p, n = C.c_void_p(), C.c_size_t()
         self._chk(self.L.zr_tiles_device_buffer(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def set_tiles_buffer(self, dev_ptr):
+        self._chk(self.L.zr_set_tiles_buffer(self.h, C.c_void_p(dev_ptr) if dev_ptr else None))
 
     def read_tiles(self):
         _, nbytes = self.tiles_device_buffer()
