@@ -142,6 +142,11 @@ int  zr_set_debug_view(zr_ctx* ctx, uint32_t spec_constants);
 /* --- the frame (replaces RecordCommandBuffer ZE:3160-3744 + vkQueueSubmit ZE:2014) ---
  * cull -> shadow -> cull -> gbuffer -> lighting [-> composite].  Asynchronous on the render stream. */
 int  zr_render(zr_ctx* ctx);
+/* The same frame in three stages (zr_render = all three, in this order), so that a multi-GPU host can place its
+ * collectives between them: shadow pass | deferred-scene pass (cull, raster, GBuffer write) | deferred-lighting pass. */
+int  zr_render_shadow(zr_ctx* ctx);
+int  zr_render_gbuffer(zr_ctx* ctx);
+int  zr_render_lighting(zr_ctx* ctx);
 int  zr_finish(zr_ctx* ctx);                        /* stream sync + overflow check */
 int  zr_get_pass_times(zr_ctx* ctx, float ms[ZR_PASS_COUNT]);              /* last frame */
 int  zr_get_pass_times_avg(zr_ctx* ctx, uint32_t last_n, float ms[ZR_PASS_COUNT]);  /* mean of the last n <= 64 frames */
@@ -155,6 +160,11 @@ int  zr_read_gbuffer(zr_ctx* ctx, int target, void* dst, size_t bytes);
 int  zr_read_shadowmap(zr_ctx* ctx, float* dst, size_t bytes);        /* dim*dim*4 */
 
 /* --- multi-GPU screen-tile partition --- */
+/* Shadow pass split: this context draws instances i % world == rank into its shadow map; the caller min-reduces the maps
+ * (depth test LESS_OR_EQUAL = min) between zr_render_shadow and zr_render_lighting.  Default 0 / 1 = everything. */
+int  zr_set_shadow_partition(zr_ctx* ctx, uint32_t rank, uint32_t world);
+/* Caller-owned shadow map, float[shadow_dim^2] device memory (NULL = internal). */
+int  zr_set_shadow_buffer(zr_ctx* ctx, void* dev_ptr);
 /* Packed tile-major RGBA8 of the tiles this rank owns (device pointer, stable until zr_destroy). */
 int  zr_tiles_device_buffer(zr_ctx* ctx, void** dev_ptr, size_t* bytes_per_rank);
 /* Caller-owned packed buffer for the following frames (same size; NULL = the internal one).  Two alternating buffers let

@@ -52,7 +52,16 @@ def _rank_main(rank, world, port, W, H, q):
     dist.all_gather_into_tensor(gathered, mine)
     lay = zdist.tile_layout(W, H, world)
     frame = zdist.untile(gathered.numpy().reshape(world, lay["slots_per_rank"], 32, 32, 4), W, H)
-    q.put((rank, bool(np.array_equal(frame, full)), int(mine.numel())))
+    # shadow pass split: this rank draws instances i % world == rank; MIN all-reduce of the maps = the whole shadow map
+    part = pyoracle.Oracle(W, H, 128)
+    pcfg = dict(cfg)
+    pcfg["objects"] = [{"mesh": cfg["objects"][0]["mesh"], "instances": cfg["objects"][0]["instances"][rank::world]}]
+    pyoracle.load_scene(part, pcfg)
+    part.render(0, 1)
+    sh = torch.from_numpy(part.shadowmap().reshape(-1).copy())
+    dist.all_reduce(sh, op=dist.ReduceOp.MIN)
+    shadow_ok = bool(np.array_equal(sh.numpy().view(np.uint32), o.shadowmap().reshape(-1).view(np.uint32)))
+    q.put((rank, bool(np.array_equal(frame, full)) and shadow_ok, int(mine.numel())))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -181,6 +181,32 @@ def test_many_lights_config5_style(oracle_lib, gpu_engine):
     _identical(o, g, "256 lights")
 
 
+def test_staged_frame_and_shadow_instance_partition(oracle_lib, gpu_engine):
+    """zr_render_shadow/gbuffer/lighting == zr_render; per-rank shadow shares min-reduce to the full shadow map."""
+    cfg = scenes.config3(500, 320, 200)
+    full = gpu_engine.Renderer(cfg["width"], cfg["height"], 512)
+    gpu_engine.load_scene(full, cfg)
+    full.render()
+    want_color, want_shadow = full.color(), full.shadowmap()
+    shares = []
+    for world in (1, 3):
+        maps = []
+        for rank in range(world):
+            g = gpu_engine.Renderer(cfg["width"], cfg["height"], 512)
+            gpu_engine.load_scene(g, cfg)
+            g.set_shadow_partition(rank, world)
+            g.render_shadow()
+            with pytest.raises(gpu_engine.ZeldaRenderError):
+                g.render_lighting()                      # stages must run in order
+            g.render_gbuffer(); g.render_lighting(); g.finish()
+            maps.append(g.shadowmap())
+            if world == 1:
+                assert np.array_equal(g.color(), want_color)
+        shares.append(np.minimum.reduce(maps))
+        assert np.array_equal(shares[-1].view(np.uint32), want_shadow.view(np.uint32))
+    assert (maps[0] != want_shadow).any()                # a single share really is partial
+
+
 def test_errors_are_reported_not_swallowed(gpu_engine):
     g = gpu_engine.Renderer(64, 64, 64)
     with pytest.raises(gpu_engine.ZeldaRenderError) as e:

@@ -52,19 +52,34 @@ def test_pipelined_distributed_renderer_with_a_stand_in_collective(gpu_engine, m
     other_tiles = torch.from_numpy(other.read_tiles().reshape(-1).copy()).cuda()
     calls = []
 
+    other.set_shadow_partition(1, 2)     # rank 1's share of the shadow casters (its lit tiles above used the full map)
+    other.render_shadow()
+    other_shadow = torch.from_numpy(other.shadowmap().reshape(-1).copy()).cuda()
+    other.render_gbuffer(); other.render_lighting()
+    assert (other.shadowmap() >= single.shadowmap()).all() and (other.shadowmap() > single.shadowmap()).any()
+
     def fake_all_gather(out, inp, group=None, async_op=False):
         n = inp.numel()
         out[:n].copy_(inp)              # on the current (collective) stream, like the real op
         out[n:2 * n].copy_(other_tiles)
         calls.append(torch.cuda.current_stream().cuda_stream)
+
+    def fake_all_reduce(t, op=None, group=None, async_op=False):
+        assert op == tdist.ReduceOp.MIN
+        torch.minimum(t, other_shadow, out=t)
+        calls.append(-1)
     monkeypatch.setattr(tdist, "all_gather_into_tensor", fake_all_gather)
+    monkeypatch.setattr(tdist, "all_reduce", fake_all_reduce)
     dr = zdist.DistributedRenderer(cfg["width"], cfg["height"], 256, device_index=0, rank=0, world=2)
     gpu_engine.load_scene(dr.r, cfg)
     for _ in range(5):                  # exercises both halves of the double buffers
         dr.frame()
     dr.synchronize()
-    assert len(calls) == 5 and all(c == dr.comm_stream.cuda_stream for c in calls) and dr.comm_stream != dr.render_stream
+    gathers = [c for c in calls if c != -1]
+    assert len(gathers) == 5 and calls.count(-1) == 5 and all(c == dr.comm_stream.cuda_stream for c in gathers)
+    assert dr.comm_stream != dr.render_stream
     assert np.array_equal(dr.r.color(), want)
+    assert np.array_equal(dr.r.shadowmap().view(np.uint32), single.shadowmap().view(np.uint32))     # min of the two shares = the whole map
     assert np.array_equal(dr.tiles[0].cpu().numpy(), dr.tiles[1].cpu().numpy())
     assert np.array_equal(dr.tiles[0].cpu().numpy().reshape(-1, 32, 32, 4), zdist.pack_tiles(want, 0, 2))
     dr.close()

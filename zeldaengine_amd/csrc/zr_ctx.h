@@ -75,6 +75,8 @@ struct zr_ctx {
     uint32_t *d_owned = nullptr, *d_sowned = nullptr;
     GBufferPtrs G = {};
     float* d_shadow = nullptr; uint32_t* d_color = nullptr; uint32_t* d_tiles = nullptr;
+    float* d_shadow_ext = nullptr;       // caller-owned shadow map (zr_set_shadow_buffer), or null
+    uint32_t shadow_rank = 0, shadow_world = 1; int stage = 0;   // stage: 0 idle, 1 shadow done, 2 gbuffer done
     uint32_t* d_tiles_ext = nullptr;     // caller-owned packed tile buffer for the next frames (zr_set_tiles_buffer), or null
 
     uint32_t *d_rects = nullptr, *d_tile_count = nullptr, *d_tile_offset = nullptr, *d_tile_cursor = nullptr; ZrBinEntry* d_bins = nullptr;

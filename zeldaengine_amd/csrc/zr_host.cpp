@@ -710,6 +710,7 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
     P->hw = 0.5f * (float)P->W; P->hh = 0.5f * (float)P->H;
     P->tiles_x = mode == ZR_MODE_SHADOW ? c->stiles_x : c->tiles_x; P->tiles_y = mode == ZR_MODE_SHADOW ? c->stiles_y : c->tiles_y;
     P->tile_rank = mode == ZR_MODE_SHADOW ? 0 : c->cfg.tile_rank; P->tile_world = mode == ZR_MODE_SHADOW ? 1 : c->cfg.tile_world;
+    P->inst_rank = mode == ZR_MODE_SHADOW ? c->shadow_rank : 0; P->inst_world = mode == ZR_MODE_SHADOW ? c->shadow_world : 1;
     P->n_objects = c->n_objs; P->n_work = c->n_work; P->bin_capacity = c->bin_capacity;
     { const char* dbg = getenv("ZR_DEBUG_SKIP"); P->debug_skip = dbg ? (uint32_t)atoi(dbg) : 0u; }
     if (!finite16(P->PVM)) return false;
@@ -757,14 +758,21 @@ static void geometry_pass(zr_ctx* c, const ZrPass& P, int slot, uint32_t n_tiles
     zr_launch_bin_fill(P, c->d_objs, c->d_rects, c->d_tile_offset, c->d_tile_cursor, c->d_bins, c->d_stats, slot, c->stream);
     (void)hipEventRecord(after_bin, c->stream);
     zr_launch_raster_chunks(P, c->d_objs, c->d_tile_offset, c->d_chunk_offset, c->d_bins, c->d_stats, slot, c->d_vis,
-                            (uint32_t*)c->d_shadow, c->raster_blocks, c->stream);
+                            (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), c->raster_blocks, c->stream);
 }
 
-// RecordCommandBuffer (ZE:3160-3744) + vkQueueSubmit (ZE:2014): shadow -> deferred scene -> deferred lighting
-extern "C" int zr_render(zr_ctx* c)
+static inline float* shadow_buf(zr_ctx* c) { return c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow; }
+
+// The frame in three stages so that a multi-GPU host can put collectives between them (zeldaengine_amd/dist.py):
+//   zr_render_shadow    shadow pass (ZE:3239-3393) of this rank's share of the instances
+//   zr_render_gbuffer   deferred-scene pass (ZE:3417-3480): cull + bin + raster + resolve of the owned tiles
+//   zr_render_lighting  deferred-lighting pass (ZE:3531-3540) [+ skydome / background overlay]
+// zr_render = all three.
+extern "C" int zr_render_shadow(zr_ctx* c)
 {
     if (!c) return ZR_ERR_ARG;
     if (!c->frame_valid) return zr_fail(c, ZR_ERR_STATE, "no frame uniforms: call zr_update_uniforms or zr_set_frame first");
+    if (c->stage != 0) return zr_fail(c, ZR_ERR_STATE, "zr_render_shadow out of order");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = finalize_scene(c);
     if (rc) return rc;
@@ -774,24 +782,45 @@ extern "C" int zr_render(zr_ctx* c)
     HIPCHK(c, hipEventRecord(ev[0], s));
     HIPCHK(c, hipMemsetAsync(c->d_stats, 0, sizeof(ZrDevStats), s));
     HIPCHK(c, hipMemcpyAsync(c->d_view, &c->view, sizeof(XkView), hipMemcpyHostToDevice, s));
-
     ZrPass P;
-    // shadow pass (ZE:3239-3393): every object, light-space, whole map on every rank
-    bool live = build_pass(c, c->shadow, ZR_MODE_SHADOW, &P);
+    const bool live = build_pass(c, c->shadow, ZR_MODE_SHADOW, &P);
     if (!live) P.n_work = 0;      // no finite vertex: the pass is its clear
     c->last_work[0] = P.n_work;
-    zr_launch_fill32((uint32_t*)c->d_shadow, 0x3F800000u, (size_t)c->SD * c->SD, s);      // clear depth 1.0, ZE:3248
+    zr_launch_fill32((uint32_t*)shadow_buf(c), 0x3F800000u, (size_t)c->SD * c->SD, s);      // clear depth 1.0, ZE:3248
     geometry_pass(c, P, 0, c->sn_tiles, ev[1]);
     HIPCHK(c, hipEventRecord(ev[2], s));
-    // deferred-scene pass (ZE:3417-3480)
-    live = build_pass(c, c->cam, ZR_MODE_GBUFFER, &P);
+    HIPCHK(c, hipGetLastError());
+    c->stage = 1;
+    return ZR_OK;
+}
+
+extern "C" int zr_render_gbuffer(zr_ctx* c)
+{
+    if (!c) return ZR_ERR_ARG;
+    if (c->stage != 1) return zr_fail(c, ZR_ERR_STATE, "zr_render_gbuffer out of order");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    hipEvent_t* ev = c->evr[c->frame_no % zr_ctx::EV_RING];
+    ZrPass P;
+    const bool live = build_pass(c, c->cam, ZR_MODE_GBUFFER, &P);
     if (!live) P.n_work = 0;
     c->last_work[1] = P.n_work;
     geometry_pass(c, P, 1, c->n_tiles, ev[3]);
     HIPCHK(c, hipEventRecord(ev[4], s));
     zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_lut, c->d_stats, s);
     HIPCHK(c, hipEventRecord(ev[5], s));
-    // deferred-lighting pass (ZE:3531-3540)
+    HIPCHK(c, hipGetLastError());
+    c->stage = 2;
+    return ZR_OK;
+}
+
+extern "C" int zr_render_lighting(zr_ctx* c)
+{
+    if (!c) return ZR_ERR_ARG;
+    if (c->stage != 2) return zr_fail(c, ZR_ERR_STATE, "zr_render_lighting out of order");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    hipEvent_t* ev = c->evr[c->frame_no % zr_ctx::EV_RING];
     ZrLightParams L; memset(&L, 0, sizeof L);
     static const float Bias[16] = { 0.5f, 0, 0, 0, 0, 0.5f, 0, 0, 0, 0, 1, 0, 0.5f, 0.5f, 0, 1 };
     zr_mat4_mul(Bias, c->view.ShadowmapSpace, L.SB);
@@ -801,11 +830,39 @@ extern "C" int zr_render(zr_ctx* c)
     { const char* dbg = getenv("ZR_DEBUG_SKIP_LIGHT"); L.debug_skip = dbg ? (uint32_t)atoi(dbg) : 0u; }
     L.bg_enabled = (c->bg_set && c->bg_enabled) ? 1u : 0u;
     L.bg.data = c->d_bg; L.bg.w = c->bg_w; L.bg.h = c->bg_h; L.bg.levels = c->bg_levels; L.bg._pad = 0;
-    zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, c->d_shadow, c->cube, c->d_lut, c->d_unorm_lut,
+    zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, shadow_buf(c), c->cube, c->d_lut, c->d_unorm_lut,
                        L.packed_out ? (c->d_tiles_ext ? c->d_tiles_ext : c->d_tiles) : c->d_color, s);
     HIPCHK(c, hipEventRecord(ev[6], s));
     HIPCHK(c, hipGetLastError());
-    c->rendered = true; c->frame_no++;
+    c->rendered = true; c->frame_no++; c->stage = 0;
+    return ZR_OK;
+}
+
+// RecordCommandBuffer (ZE:3160-3744) + vkQueueSubmit (ZE:2014): shadow -> deferred scene -> deferred lighting
+extern "C" int zr_render(zr_ctx* c)
+{
+    int rc = zr_render_shadow(c);
+    if (rc == ZR_OK) rc = zr_render_gbuffer(c);
+    if (rc == ZR_OK) rc = zr_render_lighting(c);
+    if (rc != ZR_OK && c) c->stage = 0;
+    return rc;
+}
+
+// Multi-GPU shadow pass: this context draws instances i with i % world == rank (non-instanced draws count as instance 0).
+// The per-rank shadow maps must be min-reduced before zr_render_lighting.  rank 0 / world 1 = the whole scene (default).
+extern "C" int zr_set_shadow_partition(zr_ctx* c, uint32_t rank, uint32_t world)
+{
+    if (!c) return ZR_ERR_ARG;
+    ARGCHK(c, world >= 1 && rank < world);
+    c->shadow_rank = rank; c->shadow_world = world;
+    return ZR_OK;
+}
+
+// Caller-owned shadow map (float[shadow_dim^2], e.g. a torch tensor RCCL reduces in place); NULL = the internal one.
+extern "C" int zr_set_shadow_buffer(zr_ctx* c, void* ptr)
+{
+    if (!c) return ZR_ERR_ARG;
+    c->d_shadow_ext = (float*)ptr;
     return ZR_OK;
 }
 
@@ -858,7 +915,7 @@ extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out)
         ZrDevStats z; (void)hipMemcpy(&z, c->d_stats, sizeof z, hipMemcpyDeviceToHost);
         uint32_t zero = 0;
         (void)hipMemcpy(&c->d_stats->covered_shadow, &zero, 4, hipMemcpyHostToDevice);
-        zr_launch_count_shadow((const uint32_t*)c->d_shadow, (size_t)c->SD * c->SD, c->d_stats, c->stream);
+        zr_launch_count_shadow((const uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), (size_t)c->SD * c->SD, c->d_stats, c->stream);
         (void)hipStreamSynchronize(c->stream);
         (void)hipMemcpy(&c->h_stats, c->d_stats, sizeof(ZrDevStats), hipMemcpyDeviceToHost);
     }
@@ -898,7 +955,7 @@ extern "C" int zr_read_shadowmap(zr_ctx* c, float* dst, size_t bytes)
     ARGCHK(c, dst && bytes == (size_t)c->SD * c->SD * 4);
     int rc = zr_finish(c);
     if (rc) return rc;
-    HIPCHK(c, hipMemcpy(dst, c->d_shadow, bytes, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(dst, c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow, bytes, hipMemcpyDeviceToHost));
     return ZR_OK;
 }
 

@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
     const XkMeshlet ml = O->meshlets[m];
     const ZrInstance I = O->inst[inst_i];
     const bool instanced = O->instanced != 0;
-    if (MODE == ZR_MODE_SHADOW && (O->flags & ZR_OBJ_SKY)) {       // the skydome is not a shadow caster (ZE:4709-4720)
+    // the skydome is not a shadow caster (ZE:4709-4720); with N GPUs each draws every N-th instance into its own copy of
+    // the shadow map and the copies are min-reduced (depth test LESS_OR_EQUAL is a min, so the split is exact)
+    if (MODE == ZR_MODE_SHADOW && ((O->flags & ZR_OBJ_SKY) || inst_i % P.inst_world != P.inst_rank)) {
         if (lane == 0) rects[w] = ZR_RECT_CULLED;
         return;
     }

@@ -74,6 +74,7 @@ struct ZrPass {
     uint32_t W, H;                   // target extent
     uint32_t tiles_x, tiles_y;
     uint32_t tile_rank, tile_world;  // this device owns tiles with t % tile_world == tile_rank
+    uint32_t inst_rank, inst_world;  // shadow pass only: this device draws instances with i % inst_world == inst_rank
     uint32_t n_objects, n_work;
     uint32_t mode;                   // ZR_MODE_*
     uint32_t frustum_ok, cone_ok;    // culling enabled (cone_ok also needs a standard perspective eye)

@@ -1,9 +1,13 @@
 """Screen-tile data parallelism across the GPUs of one node.
 
 The frame is cut into 32x32 tiles; tile t belongs to rank t % world.  Every rank holds the whole scene, culls and bins
-against its own tiles only, renders the (1024^2) shadow map redundantly, and lights its tiles into a packed, tile-major
-RGBA8 buffer.  ONE collective per frame — an RCCL all-gather of those buffers over xGMI (4 B/pixel in total) — followed by
-an untile kernel gives every rank the full frame.  There is no other exchange step.
+against its own tiles only, and lights its tiles into a packed, tile-major RGBA8 buffer.  Per frame there are two RCCL
+collectives over xGMI:
+
+* shadow map: rank r rasterises instances i % world == r into its own 1024^2 map and the maps are all-reduced with MIN
+  (4 MB; the depth test LESS_OR_EQUAL is a min, so the split is exact).  It runs on the collective stream while the render
+  stream does the camera cull + raster + GBuffer write, which do not need the shadow map;
+* composite: an all-gather of the packed tiles (4 B/pixel in total) followed by an untile kernel gives every rank the frame.
 
 Two HIP streams: the render stream produces frame k+1 while the collective stream gathers and composites frame k (packed
 and gathered buffers are double-buffered, ordering is by events), so the xGMI latency is hidden behind rendering.
@@ -59,7 +63,8 @@ class DistributedRenderer:
     straight into them (zr_set_tiles_buffer).
     """
 
-    def __init__(self, width, height, shadow_dim=1024, device_index=0, rank=0, world=1, flags=0, pipeline=True):
+    def __init__(self, width, height, shadow_dim=1024, device_index=0, rank=0, world=1, flags=0, pipeline=True,
+                 split_shadow=True):
         import torch
         from . import engine
         self.torch = torch
@@ -78,6 +83,12 @@ class DistributedRenderer:
             self.consumed = [torch.cuda.Event() for _ in range(2)]      # tiles[b] has been gathered (may be overwritten)
             for ev in self.consumed:
                 ev.record(self.comm_stream)
+            self.split_shadow = bool(split_shadow)
+            if self.split_shadow:
+                self.shadow = torch.ones(shadow_dim * shadow_dim, dtype=torch.float32, device=self.device)
+                self.r.set_shadow_buffer(self.shadow.data_ptr())
+                self.r.set_shadow_partition(rank, world)
+                self.shadow_done, self.shadow_reduced = torch.cuda.Event(), torch.cuda.Event()
 
     def frame(self):
         """Enqueue one full frame; returns immediately."""
@@ -93,7 +104,18 @@ class DistributedRenderer:
         self.render_stream.wait_event(self.consumed[b])
         self.r.set_tiles_buffer(self.tiles[b].data_ptr())
         with torch.cuda.stream(self.render_stream):
-            self.r.render()
+            if self.split_shadow:
+                self.r.render_shadow()                          # this rank's share of the shadow casters
+                self.shadow_done.record(self.render_stream)
+                with torch.cuda.stream(self.comm_stream):       # min-reduce the maps while the camera passes run
+                    self.comm_stream.wait_event(self.shadow_done)
+                    dist.all_reduce(self.shadow, op=dist.ReduceOp.MIN)
+                    self.shadow_reduced.record(self.comm_stream)
+                self.r.render_gbuffer()
+                self.render_stream.wait_event(self.shadow_reduced)
+                self.r.render_lighting()
+            else:
+                self.r.render()
             self.rendered[b].record(self.render_stream)
         # collective stream: gather + composite frame k while the render stream starts frame k + 1
         with torch.cuda.stream(self.comm_stream):

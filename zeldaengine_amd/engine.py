@@ -60,6 +60,8 @@ def lib():
         "zr_get_frame": [vp, vp, vp, vp],
         "zr_set_debug_view": [vp, u32],
         "zr_render": [vp],
+        "zr_render_shadow": [vp], "zr_render_gbuffer": [vp], "zr_render_lighting": [vp],
+        "zr_set_shadow_partition": [vp, u32, u32], "zr_set_shadow_buffer": [vp, vp],
         "zr_finish": [vp],
         "zr_get_pass_times": [vp, vp],
         "zr_get_pass_times_avg": [vp, u32, vp],
@@ -281,6 +283,21 @@ class Renderer:
         if debug_view is not None:
             self.set_debug_view(debug_view)
         self._chk(self.L.zr_render(self.h))
+
+    def render_shadow(self):
+        self._chk(self.L.zr_render_shadow(self.h))
+
+    def render_gbuffer(self):
+        self._chk(self.L.zr_render_gbuffer(self.h))
+
+    def render_lighting(self):
+        self._chk(self.L.zr_render_lighting(self.h))
+
+    def set_shadow_partition(self, rank, world):
+        self._chk(self.L.zr_set_shadow_partition(self.h, rank, world))
+
+    def set_shadow_buffer(self, dev_ptr):
+        self._chk(self.L.zr_set_shadow_buffer(self.h, C.c_void_p(dev_ptr) if dev_ptr else None))
 
     def finish(self):
         self._chk(self.L.zr_finish(self.h))
