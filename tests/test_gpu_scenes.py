@@ -207,6 +207,21 @@ def test_staged_frame_and_shadow_instance_partition(oracle_lib, gpu_engine):
     assert (maps[0] != want_shadow).any()                # a single share really is partial
 
 
+def test_instance_level_precull_path(oracle_lib, gpu_engine):
+    """>= 65536 instances switch on the two-level cull (instance spheres, then meshlets of the survivors): same frame."""
+    v, idx = scenes.uv_sphere(8, 4, 0.5)                      # 48 triangles: keeps the oracle quick
+    inst = scenes.generate_instances(70000, 2.0, 40.0, 0.1, 0.5, seed=21)
+
+    def build(r):
+        r.set_cubemap(None)
+        r.object_add(r.mesh_create(v, idx), None, inst)
+        r.object_add(r.mesh_create(*scenes.grid_plane(100.0, 4, -0.3)))
+    o, g = _both(oracle_lib, gpu_engine, 320, 180, 256, build, _std_frame(abi.make_camera((9.0, 9.0, 4.0), (0.0, 0.0, 0.0))))
+    _identical(o, g, "instance-level pre-cull")
+    st = g.stats()
+    assert st["work_items"][1] >= 70000 and st["survivors"][1] < 0.6 * st["work_items"][1]
+
+
 def test_errors_are_reported_not_swallowed(gpu_engine):
     g = gpu_engine.Renderer(64, 64, 64)
     with pytest.raises(gpu_engine.ZeldaRenderError) as e:

@@ -80,6 +80,7 @@ struct zr_ctx {
     uint32_t* d_tiles_ext = nullptr;     // caller-owned packed tile buffer for the next frames (zr_set_tiles_buffer), or null
 
     uint32_t *d_rects = nullptr, *d_tile_count = nullptr, *d_tile_offset = nullptr, *d_tile_cursor = nullptr; ZrBinEntry* d_bins = nullptr;
+    uint32_t* d_work = nullptr; uint32_t n_inst_total = 0;
     uint32_t* d_chunk_offset = nullptr; unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048;
     uint32_t work_capacity = 0, bin_capacity = 0;
     ZrDevStats* d_stats = nullptr; ZrDevStats h_stats = {};

@@ -159,7 +159,7 @@ extern "C" void zr_destroy(zr_ctx* c)
     dev_free(c->G.depth); dev_free(c->G.scene_color); dev_free(c->G.gA); dev_free(c->G.gB); dev_free(c->G.gC); dev_free(c->G.gD); dev_free(c->G.overlay);
     dev_free(c->d_color); dev_free(c->d_shadow); dev_free(c->d_view); dev_free(c->d_stats); dev_free(c->d_lut); dev_free(c->d_unorm_lut);
     dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles);
-    dev_free(c->d_tile_count); dev_free(c->d_tile_offset); dev_free(c->d_tile_cursor); dev_free(c->d_chunk_offset); dev_free(c->d_vis); dev_free(c->d_rects); dev_free(c->d_bins);
+    dev_free(c->d_tile_count); dev_free(c->d_tile_offset); dev_free(c->d_tile_cursor); dev_free(c->d_chunk_offset); dev_free(c->d_vis); dev_free(c->d_rects); dev_free(c->d_bins); dev_free(c->d_work);
     for (auto& fr : c->evr) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -445,14 +445,15 @@ static int finalize_scene(zr_ctx* c)
     const bool sky = c->sky_set && c->sky_enabled;
     if (sky) { int rc = upload_mesh(c, c->sky_mesh); if (rc) return rc; }
     std::vector<ZrObject> tab;
-    uint64_t work = 0, prim = 0;
+    uint64_t work = 0, prim = 0, inst_total = 0;
     auto emit = [&](const ZrSceneObject& o, const ZrMesh& m, uint32_t flags) {
         ZrObject d; memset(&d, 0, sizeof d);
         d.verts = m.d_v; d.indices = m.d_idx; d.meshlets = m.d_meshlets; d.mpos = m.d_mpos; d.mtri = m.d_mtri;
         d.inst = o.d_inst;
         d.n_meshlets = (uint32_t)m.ms.meshlets.size(); d.n_tris = (uint32_t)(m.idx.size() / 3);
         d.n_inst = o.n_inst; d.instanced = o.instanced; d.flags = flags;
-        d.work_base = (uint32_t)work; d.prim_base = (uint32_t)prim;
+        d.work_base = (uint32_t)work; d.prim_base = (uint32_t)prim; d.inst_base = (uint32_t)inst_total;
+        inst_total += d.n_inst;
         memcpy(d.texel, o.texel, sizeof d.texel); memcpy(d.bc_linear, o.bc_linear, sizeof d.bc_linear);
         for (int t = 0; t < 7; ++t)
             for (int ch = 0; ch < 4; ++ch) {
@@ -471,13 +472,14 @@ static int finalize_scene(zr_ctx* c)
     if (work >= 0xFFFFFFFFull || prim >= 0xFFFFFFFFull) return zr_fail(c, ZR_ERR_OVERFLOW, "scene exceeds 2^32 meshlet-instances or primitives");
     dev_free(c->d_objs);
     HIPCHK(c, upload(&c->d_objs, tab));
-    c->n_objs = (uint32_t)tab.size(); c->n_work = (uint32_t)work;
+    c->n_objs = (uint32_t)tab.size(); c->n_work = (uint32_t)work; c->n_inst_total = (uint32_t)inst_total;
     if (c->n_work > c->work_capacity) {
-        dev_free(c->d_rects); dev_free(c->d_bins);
+        dev_free(c->d_rects); dev_free(c->d_bins); dev_free(c->d_work);
         c->work_capacity = c->n_work;
         const uint64_t cap = std::max<uint64_t>(1u << 20, 8ull * c->n_work);
         c->bin_capacity = (uint32_t)std::min<uint64_t>(cap, 0x3FFFFFFFull);
         HIPCHK(c, dev_alloc(&c->d_rects, c->work_capacity));
+        HIPCHK(c, dev_alloc(&c->d_work, c->work_capacity));
         HIPCHK(c, dev_alloc(&c->d_bins, c->bin_capacity));
     }
     c->scene_dirty = false;
@@ -711,7 +713,9 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
     P->tiles_x = mode == ZR_MODE_SHADOW ? c->stiles_x : c->tiles_x; P->tiles_y = mode == ZR_MODE_SHADOW ? c->stiles_y : c->tiles_y;
     P->tile_rank = mode == ZR_MODE_SHADOW ? 0 : c->cfg.tile_rank; P->tile_world = mode == ZR_MODE_SHADOW ? 1 : c->cfg.tile_world;
     P->inst_rank = mode == ZR_MODE_SHADOW ? c->shadow_rank : 0; P->inst_world = mode == ZR_MODE_SHADOW ? c->shadow_world : 1;
-    P->n_objects = c->n_objs; P->n_work = c->n_work; P->bin_capacity = c->bin_capacity;
+    P->n_objects = c->n_objs; P->n_work = c->n_work; P->n_inst_total = c->n_inst_total; P->bin_capacity = c->bin_capacity;
+    // the instance-level pre-pass pays for itself on big scenes; small ones go straight to one wave per meshlet-instance
+    P->use_worklist = c->n_inst_total >= 65536u ? 1u : 0u;
     { const char* dbg = getenv("ZR_DEBUG_SKIP"); P->debug_skip = dbg ? (uint32_t)atoi(dbg) : 0u; }
     if (!finite16(P->PVM)) return false;
     // frustum planes of proj*view in world space (sphere centres are taken to world space by M in the kernel)
@@ -753,9 +757,9 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
 
 static void geometry_pass(zr_ctx* c, const ZrPass& P, int slot, uint32_t n_tiles, hipEvent_t after_bin)
 {
-    zr_launch_cull(P, c->d_objs, c->d_rects, c->d_tile_count, c->stream);
+    zr_launch_cull(P, c->d_objs, c->d_work, c->d_rects, c->d_tile_count, c->d_stats, slot, c->raster_blocks * 4u, c->stream);
     zr_launch_scan(c->d_tile_count, c->d_tile_offset, c->d_tile_cursor, c->d_chunk_offset, n_tiles, c->bin_capacity, c->d_stats, slot, c->stream);
-    zr_launch_bin_fill(P, c->d_objs, c->d_rects, c->d_tile_offset, c->d_tile_cursor, c->d_bins, c->d_stats, slot, c->stream);
+    zr_launch_bin_fill(P, c->d_objs, c->d_work, c->d_rects, c->d_tile_offset, c->d_tile_cursor, c->d_bins, c->d_stats, slot, c->stream);
     (void)hipEventRecord(after_bin, c->stream);
     zr_launch_raster_chunks(P, c->d_objs, c->d_tile_offset, c->d_chunk_offset, c->d_bins, c->d_stats, slot, c->d_vis,
                             (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), c->raster_blocks, c->stream);

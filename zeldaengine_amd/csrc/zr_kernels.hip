@@ -18,6 +18,8 @@
 #include "zr_math.h"
 #include "zr_types.h"
 
+#include <algorithm>
+
 #define WAVE 64
 #define TILE ZR_TILE
 #define TILE_PIX (TILE * TILE)
@@ -137,15 +139,62 @@ __device__ __forceinline__ int wave_max(int v) { for (int o = 32; o > 0; o >>= 1
 __device__ __forceinline__ uint32_t wave_or(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o); return v; }
 __device__ __forceinline__ uint32_t wave_and(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v &= (uint32_t)__shfl_xor((int)v, o); return v; }
 
-// One wavefront per meshlet-instance.  Writes rects[w] (packed tile rect or ZR_RECT_CULLED).  Every rejection here is exact or conservative:
+__device__ __forceinline__ int find_object_inst(const ZrObject* __restrict__ objs, int n, uint32_t g)
+{
+    int lo = 0, hi = n - 1;
+    while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (objs[mid].inst_base <= g) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+// Level 1 of the cull hierarchy: one lane per instance, whole-mesh bounding sphere against the frustum (same inflated
+// bounds as the meshlet test, so it is conservative).  The meshlet-instances of the surviving instances are appended to
+// work[]; one atomic per wave reserves the range.  Also applies the shadow-pass filters (skydome, instance partition).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_cull_instances(ZrPass P, const ZrObject* __restrict__ objs, uint32_t* __restrict__ work,
+                                                        ZrDevStats* __restrict__ stats, int slot)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+    uint32_t nm = 0, wbase = 0;
+    if (g < P.n_inst_total) {
+        const ZrObject* __restrict__ O = objs + find_object_inst(objs, (int)P.n_objects, g);
+        const uint32_t inst_i = g - O->inst_base;
+        bool vis = true;
+        // the skydome is not a shadow caster (ZE:4709-4720); with N GPUs each draws every N-th instance into its own copy of
+        // the shadow map and the copies are min-reduced (depth test LESS_OR_EQUAL is a min, so the split is exact)
+        if (MODE == ZR_MODE_SHADOW && ((O->flags & ZR_OBJ_SKY) || inst_i % P.inst_world != P.inst_rank)) vis = false;
+        if (vis && P.frustum_ok) {
+            const ZrInstance I = O->inst[inst_i];
+            const bool instanced = O->instanced != 0;
+            const zf3 co = vs_position(zr3(O->mesh_center[0], O->mesh_center[1], O->mesh_center[2]), I, instanced);
+            const zf4 cw4 = zr_mat4_point(P.M, co);
+            float rw = O->mesh_radius * (instanced ? __builtin_fabsf(I.s) : 1.0f) * P.m_scale;
+            rw = __builtin_fmaf(rw, 1.001f, 1e-5f * (__builtin_fabsf(cw4.x) + __builtin_fabsf(cw4.y) + __builtin_fabsf(cw4.z) + 1.0f));
+            for (int k = 0; k < 6; ++k) {
+                const float d = __builtin_fmaf(P.planes[k][0], cw4.x, __builtin_fmaf(P.planes[k][1], cw4.y,
+                                __builtin_fmaf(P.planes[k][2], cw4.z, P.planes[k][3])));
+                if (d < -rw) vis = false;
+            }
+        }
+        if (vis) { nm = O->n_meshlets; wbase = O->work_base + inst_i * nm; }
+    }
+    // wave-aggregated reservation
+    uint32_t incl = nm;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if ((int)lane >= o) incl += v; }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    uint32_t base = 0;
+    if (lane == 63 && total) base = atomicAdd(&stats->n_vis_work[slot], total);
+    base = (uint32_t)__shfl((int)base, 63);
+    const uint32_t off = base + incl - nm;
+    for (uint32_t m = 0; m < nm; ++m) work[off + m] = wbase + m;
+}
+
+// Level 2: one wavefront per surviving meshlet-instance (persistent waves stride over work[]).  Writes rects[k] (packed tile
+// rect or ZR_RECT_CULLED).  Every rejection here is exact or conservative:
 //   sphere-vs-frustum and the normal-cone test use inflated bounds;
 //   "all vertices outside one clip plane" and "snapped bbox holds no pixel centre" are exact.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restrict__ objs, uint32_t* __restrict__ rects)
+__device__ __forceinline__ uint32_t cull_meshlet(const ZrPass& P, const ZrObject* __restrict__ objs, uint32_t w, uint32_t lane)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t w = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
-    if (w >= P.n_work) return;
     const int oi = find_object_work(objs, (int)P.n_objects, w);
     const ZrObject* __restrict__ O = objs + oi;
     const uint32_t local = w - O->work_base;
@@ -154,12 +203,8 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
     const XkMeshlet ml = O->meshlets[m];
     const ZrInstance I = O->inst[inst_i];
     const bool instanced = O->instanced != 0;
-    // the skydome is not a shadow caster (ZE:4709-4720); with N GPUs each draws every N-th instance into its own copy of
-    // the shadow map and the copies are min-reduced (depth test LESS_OR_EQUAL is a min, so the split is exact)
-    if (MODE == ZR_MODE_SHADOW && ((O->flags & ZR_OBJ_SKY) || inst_i % P.inst_world != P.inst_rank)) {
-        if (lane == 0) rects[w] = ZR_RECT_CULLED;
-        return;
-    }
+    // shadow-pass filters (already applied per instance when the work list is in use; repeated here for the direct path)
+    if (MODE == ZR_MODE_SHADOW && ((O->flags & ZR_OBJ_SKY) || inst_i % P.inst_world != P.inst_rank)) return ZR_RECT_CULLED;
 
     if (P.frustum_ok | P.cone_ok) {
         zf3 co = vs_position(zr3(ml.BoundsCenter[0], ml.BoundsCenter[1], ml.BoundsCenter[2]), I, instanced);
@@ -187,7 +232,7 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
             float L = zr_length(d);
             if (zr_dot(d, aw) >= __builtin_fmaf(ml.ConeCutoff + 0.02f, L, rw)) culled = true;
         }
-        if (culled) { if (lane == 0) rects[w] = ZR_RECT_CULLED; return; }
+        if (culled) return ZR_RECT_CULLED;
     }
 
     // lane-per-vertex transform, exactly as the rasteriser will redo it
@@ -201,28 +246,50 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
         if (!(f & 129u)) { SV s = project(c, P.hw, P.hh); X0 = X1 = s.X; Y0 = Y1 = s.Y; }
     }
     f_or = wave_or(f_or); f_and = wave_and(f_and);
-    if (!(f_or & 1u) && (f_and & 0x7Eu)) { if (lane == 0) rects[w] = ZR_RECT_CULLED; return; }
+    if (!(f_or & 1u) && (f_and & 0x7Eu)) return ZR_RECT_CULLED;
     int px0 = 0, py0 = 0, px1 = (int)P.W - 1, py1 = (int)P.H - 1;
     if (!(f_or & 129u)) {
         X0 = wave_min(X0); X1 = wave_max(X1); Y0 = wave_min(Y0); Y1 = wave_max(Y1);
         px0 = max(px0, (X0 - 128 + 255) >> 8); px1 = min(px1, (X1 - 128) >> 8);
         py0 = max(py0, (Y0 - 128 + 255) >> 8); py1 = min(py1, (Y1 - 128) >> 8);
-        if (px0 > px1 || py0 > py1) { if (lane == 0) rects[w] = ZR_RECT_CULLED; return; }
+        if (px0 > px1 || py0 > py1) return ZR_RECT_CULLED;
     }
     const int tx0 = px0 / TILE, tx1 = px1 / TILE, ty0 = py0 / TILE, ty1 = py1 / TILE;
-    if (lane == 0) rects[w] = (uint32_t)tx0 | (uint32_t)ty0 << 8 | (uint32_t)tx1 << 16 | (uint32_t)ty1 << 24;
+    return (uint32_t)tx0 | (uint32_t)ty0 << 8 | (uint32_t)tx1 << 16 | (uint32_t)ty1 << 24;
+}
+
+template <int MODE, bool WORKLIST>
+__global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
+                                              uint32_t* __restrict__ rects, const ZrDevStats* __restrict__ stats, int slot)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    if (WORKLIST) {                 // persistent waves stride over the compacted list
+        const uint32_t n = stats->n_vis_work[slot], stride = gridDim.x * 4u;
+        for (uint32_t k = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6)); k < n; k += stride) {
+            const uint32_t r = cull_meshlet<MODE>(P, objs, wave_uniform(work[k]), lane);
+            if (lane == 0) rects[k] = r;
+        }
+    } else {                        // one wave per meshlet-instance, work item k = k
+        const uint32_t k = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
+        if (k >= P.n_work) return;
+        const uint32_t r = cull_meshlet<MODE>(P, objs, k, lane);
+        if (lane == 0) rects[k] = r;
+    }
 }
 
 // Per-tile entry counts from the rects.  Counting goes through an LDS histogram per 1024 work items so that a hot
 // tile costs one global atomic per workgroup instead of one per meshlet-instance (same-address atomics serialise).
-__global__ __launch_bounds__(1024) void k_bin_count(ZrPass P, const uint32_t* __restrict__ rects, uint32_t* __restrict__ tile_count)
+__global__ __launch_bounds__(1024) void k_bin_count(ZrPass P, const uint32_t* __restrict__ rects, uint32_t* __restrict__ tile_count,
+                                                    const ZrDevStats* __restrict__ stats, int slot)
 {
     extern __shared__ uint32_t hist[];
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    const uint32_t n_vis = P.use_worklist ? stats->n_vis_work[slot] : P.n_work;
+    if (blockIdx.x * 1024u >= n_vis) return;            // the grid is sized for every meshlet-instance of the scene
     for (uint32_t i = threadIdx.x; i < n_tiles; i += 1024u) hist[i] = 0;
     __syncthreads();
     const uint32_t w = blockIdx.x * 1024u + threadIdx.x;
-    if (w < P.n_work) {
+    if (w < n_vis) {
         const uint32_t r = rects[w];
         if (r != ZR_RECT_CULLED) {
             const uint32_t tx0 = r & 255u, ty0 = (r >> 8) & 255u, tx1 = (r >> 16) & 255u, ty1 = r >> 24;
@@ -277,19 +344,22 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
 
 // Scatter meshlet-instance ids into the per-tile lists.  Same LDS aggregation as k_bin_count: the workgroup reserves
 // a contiguous range per tile with one global atomic, then hands out slots from LDS.
-__global__ __launch_bounds__(1024) void k_bin_fill(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ rects,
+__global__ __launch_bounds__(1024) void k_bin_fill(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
+                                                   const uint32_t* __restrict__ rects,
                                                    const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
                                                    ZrBinEntry* __restrict__ bins, ZrDevStats* __restrict__ stats, int slot)
 {
     extern __shared__ uint32_t hist[];
     __shared__ uint32_t tot;
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    const uint32_t n_vis = P.use_worklist ? stats->n_vis_work[slot] : P.n_work;
+    if (blockIdx.x * 1024u >= n_vis) return;
     for (uint32_t i = threadIdx.x; i < n_tiles; i += 1024u) hist[i] = 0;
     if (threadIdx.x == 0) tot = 0;
     __syncthreads();
-    const uint32_t w = blockIdx.x * 1024u + threadIdx.x;
-    uint32_t r = ZR_RECT_CULLED;
-    if (w < P.n_work) r = rects[w];
+    const uint32_t k = blockIdx.x * 1024u + threadIdx.x;
+    uint32_t r = ZR_RECT_CULLED, w = 0;
+    if (k < n_vis) { r = rects[k]; w = P.use_worklist ? work[k] : k; }
     const uint32_t tx0 = r & 255u, ty0 = (r >> 8) & 255u, tx1 = (r >> 16) & 255u, ty1 = r >> 24;
     if (r != ZR_RECT_CULLED)
         for (uint32_t ty = ty0; ty <= ty1; ++ty)
@@ -1221,27 +1291,39 @@ void zr_launch_instance_prep(const XkInstanceData* in, ZrInstance* out, uint32_t
 {
     hipLaunchKernelGGL(k_instance_prep, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n, instanced);
 }
-void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* rects, uint32_t* tile_count, hipStream_t s)
+void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, uint32_t* tile_count, ZrDevStats* stats,
+                    int slot, uint32_t n_waves, hipStream_t s)
 {
     if (P.n_work == 0) return;
-    const dim3 g((P.n_work + 3) / 4), b(256);
-    if (P.mode == ZR_MODE_GBUFFER) hipLaunchKernelGGL(k_cull<ZR_MODE_GBUFFER>, g, b, 0, s, P, objs, rects);
-    else hipLaunchKernelGGL(k_cull<ZR_MODE_SHADOW>, g, b, 0, s, P, objs, rects);
+    const dim3 gi((P.n_inst_total + 255) / 256), b(256);
+    const uint32_t all = (uint32_t)(((uint64_t)P.n_work + 3) / 4);
+    const uint32_t blocks = P.use_worklist ? std::min<uint32_t>(all, std::max<uint32_t>(1u, n_waves / 4u)) : all;
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
-    hipLaunchKernelGGL(k_bin_count, dim3((P.n_work + 1023) / 1024), dim3(1024), n_tiles * sizeof(uint32_t), s, P, rects, tile_count);
+    if (P.mode == ZR_MODE_GBUFFER) {
+        if (P.use_worklist) {
+            hipLaunchKernelGGL(k_cull_instances<ZR_MODE_GBUFFER>, gi, b, 0, s, P, objs, work, stats, slot);
+            hipLaunchKernelGGL((k_cull<ZR_MODE_GBUFFER, true>), dim3(blocks), b, 0, s, P, objs, work, rects, stats, slot);
+        } else hipLaunchKernelGGL((k_cull<ZR_MODE_GBUFFER, false>), dim3(blocks), b, 0, s, P, objs, work, rects, stats, slot);
+    } else {
+        if (P.use_worklist) {
+            hipLaunchKernelGGL(k_cull_instances<ZR_MODE_SHADOW>, gi, b, 0, s, P, objs, work, stats, slot);
+            hipLaunchKernelGGL((k_cull<ZR_MODE_SHADOW, true>), dim3(blocks), b, 0, s, P, objs, work, rects, stats, slot);
+        } else hipLaunchKernelGGL((k_cull<ZR_MODE_SHADOW, false>), dim3(blocks), b, 0, s, P, objs, work, rects, stats, slot);
+    }
+    hipLaunchKernelGGL(k_bin_count, dim3((P.n_work + 1023) / 1024), dim3(1024), n_tiles * sizeof(uint32_t), s, P, rects, tile_count, stats, slot);
 }
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint32_t n,
                     uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s)
 {
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, chunk_offset, n, capacity, stats, slot);
 }
-void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* rects, const uint32_t* tile_offset,
+void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
                         uint32_t* tile_cursor, ZrBinEntry* bins, ZrDevStats* stats, int slot, hipStream_t s)
 {
     if (P.n_work == 0) return;
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
-    hipLaunchKernelGGL(k_bin_fill, dim3((P.n_work + 1023) / 1024), dim3(1024), n_tiles * sizeof(uint32_t), s, P, objs, rects, tile_offset,
-                       tile_cursor, bins, stats, slot);
+    hipLaunchKernelGGL(k_bin_fill, dim3((P.n_work + 1023) / 1024), dim3(1024), n_tiles * sizeof(uint32_t), s, P, objs, work, rects,
+                       tile_offset, tile_cursor, bins, stats, slot);
 }
 void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s)
 {

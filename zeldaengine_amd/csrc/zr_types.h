@@ -42,6 +42,7 @@ struct ZrObject {
     uint32_t n_meshlets, n_tris, n_inst, instanced;
     uint32_t work_base;              // first meshlet-instance id of this draw
     uint32_t prim_base;              // first primitive id of this draw
+    uint32_t inst_base;              // instances in earlier draws (global instance ordinal of instance 0)
     ZrTex    tex[7];                 // sampled material slots (data == nullptr: the slot is the constant `texel`)
     uint32_t texel[7];               // constant material: RGBA8 per PBR slot (bc, m, r, n, ao, ev, ms)
     float    bc_linear[3];           // sRGB-decoded base colour (slot 0 is R8G8B8A8_SRGB, ZE:5878)
@@ -76,6 +77,8 @@ struct ZrPass {
     uint32_t tile_rank, tile_world;  // this device owns tiles with t % tile_world == tile_rank
     uint32_t inst_rank, inst_world;  // shadow pass only: this device draws instances with i % inst_world == inst_rank
     uint32_t n_objects, n_work;
+    uint32_t n_inst_total;           // instances over all draws
+    uint32_t use_worklist;           // 1: instance-level pre-cull compacts the work items into work[]; 0: work item k = k
     uint32_t mode;                   // ZR_MODE_*
     uint32_t frustum_ok, cone_ok;    // culling enabled (cone_ok also needs a standard perspective eye)
     uint32_t bin_capacity;
@@ -91,6 +94,7 @@ struct ZrDevStats {
     uint32_t overflow;
     uint32_t n_chunks[2];
     uint32_t chunk_counter[2];
+    uint32_t n_vis_work[2];          // meshlet-instances of the instances that passed the instance-level frustum test
 };
 
 // Uniforms of the lighting pass that are not in XkView.
@@ -117,10 +121,11 @@ struct CubeDesc { const uint8_t* levels[16]; };
 
 // launchers defined in zr_kernels.hip
 void zr_launch_instance_prep(const XkInstanceData* in, ZrInstance* out, uint32_t n, uint32_t instanced, hipStream_t s);
-void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* rects, uint32_t* tile_count, hipStream_t s);
+void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, uint32_t* tile_count, ZrDevStats* stats,
+                    int slot, uint32_t n_waves, hipStream_t s);
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint32_t n,
                     uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s);
-void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* rects, const uint32_t* tile_offset,
+void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
                         uint32_t* tile_cursor, ZrBinEntry* bins, ZrDevStats* stats, int slot, hipStream_t s);
 void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s);
 void zr_launch_fill64(unsigned long long* p, unsigned long long v, size_t n, hipStream_t s);
