@@ -45,6 +45,7 @@ typedef struct zr_ctx zr_ctx;
 #define ZR_FLAG_NO_FRUSTUM_CULL 1u  /* disable meshlet frustum culling (parity A/B) */
 #define ZR_FLAG_NO_CONE_CULL    2u  /* disable meshlet cone culling   (parity A/B) */
 #define ZR_FLAG_SKIP_COMPOSITE  4u  /* tile_world>1: caller gathers packed tiles itself */
+#define ZR_FLAG_NO_HIZ          8u  /* disable two-pass Hi-Z occlusion culling of the camera pass (parity A/B) */
 
 typedef struct zr_config {
     uint32_t width, height;   /* swapchain extent, ZE:78-79 (default 1920x1080) */
@@ -81,7 +82,8 @@ typedef struct zr_stats {
     uint64_t covered_pixels;    /* GBuffer pixels with geometry */
     uint64_t covered_shadow_texels; /* shadow-map texels with depth < 1 */
     uint32_t overflow;          /* nonzero: a bin list overflowed; frame invalid */
-    uint32_t _pad;
+    uint32_t hiz_culled;        /* camera meshlet-instances rejected by the Hi-Z occlusion test (0 on a scene's first frame) */
+    uint64_t round1_survivors;  /* of survivors[1]: drawn in round 1 (visible last frame); 0 when the frame ran in one round */
 } zr_stats;
 
 /* --- lifetime (replaces InitVulkan/Cleanup, ZE:1714, 3747) --- */

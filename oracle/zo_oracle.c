@@ -524,6 +524,7 @@ typedef struct {
     int tl[3];
     float a1, b1, a2, b2;       /* barycentric gradients per sub-pixel unit */
     float z0, gx, gy;
+    float zlo, zhi;             /* depth range of the three vertices */
     int32_t minX, maxX, minY, maxY;
 } zo_setup;
 
@@ -551,6 +552,8 @@ static int zo_tri_setup(const zo_sv v[3], int cull_back, zo_setup* s)
     s->z0 = v[0].z;
     s->gx = fmaf(s->a2, dz2, s->a1 * dz1);
     s->gy = fmaf(s->b2, dz2, s->b1 * dz1);
+    s->zlo = fminf(fminf(v[0].z, v[1].z), v[2].z);
+    s->zhi = fmaxf(fmaxf(v[0].z, v[1].z), v[2].z);
     s->minX = v[0].X < v[1].X ? (v[0].X < v[2].X ? v[0].X : v[2].X) : (v[1].X < v[2].X ? v[1].X : v[2].X);
     s->maxX = v[0].X > v[1].X ? (v[0].X > v[2].X ? v[0].X : v[2].X) : (v[1].X > v[2].X ? v[1].X : v[2].X);
     s->minY = v[0].Y < v[1].Y ? (v[0].Y < v[2].Y ? v[0].Y : v[2].Y) : (v[1].Y < v[2].Y ? v[1].Y : v[2].Y);
@@ -572,6 +575,9 @@ static float zo_depth_at(const zo_setup* s, int32_t Px, int32_t Py)
 {
     float fx = (float)(Px - s->X0), fy = (float)(Py - s->Y0);
     float z = fmaf(s->gy, fy, fmaf(s->gx, fx, s->z0));
+    /* the exact interpolant lies within the vertex depths; keep the rounded plane equation there too (a stated rule of
+       this restatement: it bounds every fragment of a triangle by its vertices, which occlusion culling relies on) */
+    z = fminf(fmaxf(z, s->zlo), s->zhi);
     return z + 0.0f;
 }
 

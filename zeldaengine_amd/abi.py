@@ -53,7 +53,8 @@ class Config(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("work_items", C.c_uint64 * 2), ("survivors", C.c_uint64 * 2), ("bin_entries", C.c_uint64 * 2),
-                ("covered_pixels", C.c_uint64), ("covered_shadow_texels", C.c_uint64), ("overflow", C.c_uint32), ("_pad", C.c_uint32)]
+                ("covered_pixels", C.c_uint64), ("covered_shadow_texels", C.c_uint64), ("overflow", C.c_uint32), ("hiz_culled", C.c_uint32),
+                ("round1_survivors", C.c_uint64)]
 
 
 PASS_NAMES = ["cull_shadow", "shadow", "cull_camera", "gbuffer", "resolve", "lighting", "composite", "total"]
@@ -62,6 +63,7 @@ GBUFFER_DTYPES = [np.dtype("<f4"), np.dtype("<u4"), np.dtype("<u4"), np.dtype("<
 FLAG_NO_FRUSTUM_CULL = 1
 FLAG_NO_CONE_CULL = 2
 FLAG_SKIP_COMPOSITE = 4
+FLAG_NO_HIZ = 8
 
 
 def make_light(position=(0, 0, 0), type_=0, color=(1, 1, 1), intensity=1.0, direction=(0, 0, 1), radius=0.0,

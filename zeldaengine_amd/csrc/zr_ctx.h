@@ -18,7 +18,7 @@ struct ZrMesh {
     bool has_meshlets = false, uploaded = false;
     float center[3] = { 0, 0, 0 }; float radius = 0;
     XkVertex* d_v = nullptr; uint32_t* d_idx = nullptr; XkMeshlet* d_meshlets = nullptr;
-    float4* d_mpos = nullptr; uint2* d_mtri = nullptr;
+    float4* d_mpos = nullptr; uint2* d_mtri = nullptr; uint32_t* d_tri_meshlet = nullptr;
 };
 
 // Host form of one material: per slot either a constant texel or an RGBA8 image (mips are built at zr_object_add).
@@ -83,6 +83,10 @@ struct zr_ctx {
     uint32_t* d_work = nullptr; uint32_t n_inst_total = 0;
     uint32_t* d_chunk_offset = nullptr; unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048;
     uint32_t work_capacity = 0, bin_capacity = 0;
+    // two-pass Hi-Z occlusion culling of the camera pass: per work item pixel bbox + least depth (written by the cull),
+    // visibility of the previous / current frame (one byte per meshlet-instance, marked by the resolve), the pyramid
+    uint2* d_pxrect = nullptr; float* d_zmin = nullptr; uint8_t* d_visflag[2] = { nullptr, nullptr };
+    float* d_hiz = nullptr; ZrHiz hiz = {}; int vis_cur = 0; bool vis_history = false, last_two_round = false;
     ZrDevStats* d_stats = nullptr; ZrDevStats h_stats = {};
     uint64_t last_work[2] = { 0, 0 };
 

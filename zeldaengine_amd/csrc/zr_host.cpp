@@ -123,6 +123,13 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     if (ok) { zr_launch_fill64(c->d_vis, (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM, n, c->stream); ok &= hipStreamSynchronize(c->stream) == hipSuccess; }
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->raster_blocks = (uint32_t)prop.multiProcessorCount * 8u; }
     if (ok) ok &= hipMemset(c->d_tile_count, 0, mt * 4) == hipSuccess;
+    {   // Hi-Z pyramid: level l = max depth per (8 << l)^2 pixel block
+        size_t tot = 0;
+        for (int l = 0; l < 4; ++l) { c->hiz.hw[l] = (c->W + (8u << l) - 1) / (8u << l); c->hiz.hh[l] = (c->H + (8u << l) - 1) / (8u << l); tot += (size_t)c->hiz.hw[l] * c->hiz.hh[l]; }
+        ok &= dev_alloc(&c->d_hiz, tot) == hipSuccess;
+        float* p = c->d_hiz;
+        for (int l = 0; l < 4; ++l) { c->hiz.lvl[l] = p; p += (size_t)c->hiz.hw[l] * c->hiz.hh[l]; }
+    }
     if (!ok) { zr_destroy(c); return ZR_ERR_DEVICE; }
     if (zr_set_cubemap(c, nullptr, 0) != ZR_OK) { zr_destroy(c); return ZR_ERR_DEVICE; }
     *out = c;
@@ -131,7 +138,7 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
 
 static void free_mesh_buffers(ZrMesh& m)
 {
-    dev_free(m.d_v); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mtri);
+    dev_free(m.d_v); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mtri); dev_free(m.d_tri_meshlet);
     m.uploaded = false;
 }
 
@@ -140,7 +147,7 @@ static void free_scene(zr_ctx* c)
     for (auto& o : c->objects) { dev_free(o.d_inst); for (auto& t : o.d_tex) dev_free(t); }
     c->objects.clear();
     for (auto& m : c->meshes) {
-        dev_free(m.d_v); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mtri);
+        dev_free(m.d_v); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mtri); dev_free(m.d_tri_meshlet);
     }
     c->meshes.clear();
     c->profabs.clear();
@@ -160,6 +167,7 @@ extern "C" void zr_destroy(zr_ctx* c)
     dev_free(c->d_color); dev_free(c->d_shadow); dev_free(c->d_view); dev_free(c->d_stats); dev_free(c->d_lut); dev_free(c->d_unorm_lut);
     dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles);
     dev_free(c->d_tile_count); dev_free(c->d_tile_offset); dev_free(c->d_tile_cursor); dev_free(c->d_chunk_offset); dev_free(c->d_vis); dev_free(c->d_rects); dev_free(c->d_bins); dev_free(c->d_work);
+    dev_free(c->d_pxrect); dev_free(c->d_zmin); dev_free(c->d_visflag[0]); dev_free(c->d_visflag[1]); dev_free(c->d_hiz);
     for (auto& fr : c->evr) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -431,7 +439,16 @@ static int upload_mesh(zr_ctx* c, ZrMesh& m)
                                                       m.ms.tri_order[ml.BindlessContext + t]);
         }
     HIPCHK(c, upload(&m.d_v, m.v)); HIPCHK(c, upload(&m.d_idx, m.idx)); HIPCHK(c, upload(&m.d_meshlets, m.ms.meshlets));
-    HIPCHK(c, upload(&m.d_mpos, mpos)); HIPCHK(c, upload(&m.d_mtri, mtri));
+    // draw-order triangle -> meshlet (the resolve marks the meshlet-instances that own a pixel)
+    std::vector<uint32_t> tri_meshlet(std::max<size_t>(1, m.idx.size() / 3), 0u);
+    for (size_t mi = 0; mi < m.ms.meshlets.size(); ++mi) {
+        const XkMeshlet& ml = m.ms.meshlets[mi];
+        for (uint32_t t = 0; t < ml.TriangleCount; ++t) {
+            const uint32_t tri = m.ms.tri_order[ml.BindlessContext + t];
+            if (tri < tri_meshlet.size()) tri_meshlet[tri] = (uint32_t)mi;
+        }
+    }
+    HIPCHK(c, upload(&m.d_mpos, mpos)); HIPCHK(c, upload(&m.d_mtri, mtri)); HIPCHK(c, upload(&m.d_tri_meshlet, tri_meshlet));
     m.uploaded = true;
     return ZR_OK;
 }
@@ -448,7 +465,7 @@ static int finalize_scene(zr_ctx* c)
     uint64_t work = 0, prim = 0, inst_total = 0;
     auto emit = [&](const ZrSceneObject& o, const ZrMesh& m, uint32_t flags) {
         ZrObject d; memset(&d, 0, sizeof d);
-        d.verts = m.d_v; d.indices = m.d_idx; d.meshlets = m.d_meshlets; d.mpos = m.d_mpos; d.mtri = m.d_mtri;
+        d.verts = m.d_v; d.indices = m.d_idx; d.meshlets = m.d_meshlets; d.mpos = m.d_mpos; d.mtri = m.d_mtri; d.tri_meshlet = m.d_tri_meshlet;
         d.inst = o.d_inst;
         d.n_meshlets = (uint32_t)m.ms.meshlets.size(); d.n_tris = (uint32_t)(m.idx.size() / 3);
         d.n_inst = o.n_inst; d.instanced = o.instanced; d.flags = flags;
@@ -475,13 +492,17 @@ static int finalize_scene(zr_ctx* c)
     c->n_objs = (uint32_t)tab.size(); c->n_work = (uint32_t)work; c->n_inst_total = (uint32_t)inst_total;
     if (c->n_work > c->work_capacity) {
         dev_free(c->d_rects); dev_free(c->d_bins); dev_free(c->d_work);
+        dev_free(c->d_pxrect); dev_free(c->d_zmin); dev_free(c->d_visflag[0]); dev_free(c->d_visflag[1]);
         c->work_capacity = c->n_work;
         const uint64_t cap = std::max<uint64_t>(1u << 20, 8ull * c->n_work);
         c->bin_capacity = (uint32_t)std::min<uint64_t>(cap, 0x3FFFFFFFull);
         HIPCHK(c, dev_alloc(&c->d_rects, c->work_capacity));
         HIPCHK(c, dev_alloc(&c->d_work, c->work_capacity));
         HIPCHK(c, dev_alloc(&c->d_bins, c->bin_capacity));
+        HIPCHK(c, dev_alloc(&c->d_pxrect, c->work_capacity)); HIPCHK(c, dev_alloc(&c->d_zmin, c->work_capacity));
+        HIPCHK(c, dev_alloc(&c->d_visflag[0], c->work_capacity)); HIPCHK(c, dev_alloc(&c->d_visflag[1], c->work_capacity));
     }
+    c->vis_history = false;         // work item numbering changed: last frame's visibility says nothing about this scene
     c->scene_dirty = false;
     return ZR_OK;
 }
@@ -755,12 +776,15 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
 
 // ------------------------------------------------------------------------------------------------ the frame
 
-static void geometry_pass(zr_ctx* c, const ZrPass& P, int slot, uint32_t n_tiles, hipEvent_t after_bin)
+// cull -> count -> scan -> fill -> raster of one pass.  Z.phase selects the share of the camera pass drawn (0 = all of it).
+static void bin_and_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, uint32_t n_tiles)
 {
-    zr_launch_cull(P, c->d_objs, c->d_work, c->d_rects, c->d_tile_count, c->d_stats, slot, c->raster_blocks * 4u, c->stream);
+    zr_launch_bin_count(P, c->d_work, c->d_rects, c->d_tile_count, Z, c->d_stats, slot, c->stream);
     zr_launch_scan(c->d_tile_count, c->d_tile_offset, c->d_tile_cursor, c->d_chunk_offset, n_tiles, c->bin_capacity, c->d_stats, slot, c->stream);
-    zr_launch_bin_fill(P, c->d_objs, c->d_work, c->d_rects, c->d_tile_offset, c->d_tile_cursor, c->d_bins, c->d_stats, slot, c->stream);
-    (void)hipEventRecord(after_bin, c->stream);
+    zr_launch_bin_fill(P, c->d_objs, c->d_work, c->d_rects, c->d_tile_offset, c->d_tile_cursor, c->d_bins, Z, c->d_stats, slot, c->stream);
+}
+static void raster(zr_ctx* c, const ZrPass& P, int slot)
+{
     zr_launch_raster_chunks(P, c->d_objs, c->d_tile_offset, c->d_chunk_offset, c->d_bins, c->d_stats, slot, c->d_vis,
                             (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), c->raster_blocks, c->stream);
 }
@@ -791,7 +815,11 @@ extern "C" int zr_render_shadow(zr_ctx* c)
     if (!live) P.n_work = 0;      // no finite vertex: the pass is its clear
     c->last_work[0] = P.n_work;
     zr_launch_fill32((uint32_t*)shadow_buf(c), 0x3F800000u, (size_t)c->SD * c->SD, s);      // clear depth 1.0, ZE:3248
-    geometry_pass(c, P, 0, c->sn_tiles, ev[1]);
+    ZrHiz Z; memset(&Z, 0, sizeof Z);
+    zr_launch_cull(P, c->d_objs, c->d_work, c->d_rects, Z, c->d_stats, 0, c->raster_blocks * 4u, s);
+    bin_and_raster(c, P, Z, 0, c->sn_tiles);
+    HIPCHK(c, hipEventRecord(ev[1], s));
+    raster(c, P, 0);
     HIPCHK(c, hipEventRecord(ev[2], s));
     HIPCHK(c, hipGetLastError());
     c->stage = 1;
@@ -809,9 +837,34 @@ extern "C" int zr_render_gbuffer(zr_ctx* c)
     const bool live = build_pass(c, c->cam, ZR_MODE_GBUFFER, &P);
     if (!live) P.n_work = 0;
     c->last_work[1] = P.n_work;
-    geometry_pass(c, P, 1, c->n_tiles, ev[3]);
+    // Two-pass occlusion culling: round 1 draws the meshlet-instances that owned a pixel last frame, a Hi-Z pyramid of the
+    // result rejects what it hides, round 2 draws the rest.  The depth test decides every pixel either way, so the frame does
+    // not depend on the history; without one (first frame of a scene) or with ZR_FLAG_NO_HIZ everything is drawn at once.
+    const bool hiz_on = !(c->cfg.flags & ZR_FLAG_NO_HIZ) && P.n_work != 0;
+    ZrHiz Z = c->hiz;
+    Z.pxrect = hiz_on ? c->d_pxrect : nullptr; Z.zmin = hiz_on ? c->d_zmin : nullptr;
+    Z.vis_prev = c->d_visflag[c->vis_cur ^ 1]; Z.vis_now = hiz_on ? c->d_visflag[c->vis_cur] : nullptr;
+    Z.phase = 0;
+    zr_launch_cull(P, c->d_objs, c->d_work, c->d_rects, Z, c->d_stats, 1, c->raster_blocks * 4u, s);
+    if (hiz_on) HIPCHK(c, hipMemsetAsync(c->d_visflag[c->vis_cur], 0, c->n_work, s));
+    c->last_two_round = hiz_on && c->vis_history;
+    if (c->last_two_round) {
+        Z.phase = 1;
+        bin_and_raster(c, P, Z, 1, c->n_tiles);
+        HIPCHK(c, hipEventRecord(ev[3], s));        // cull_camera ends where the first raster starts
+        raster(c, P, 1);
+        zr_launch_hiz_build(c->d_vis, c->W, c->H, Z, s);
+        Z.phase = 2;
+        bin_and_raster(c, P, Z, 2, c->n_tiles);
+        raster(c, P, 2);
+    } else {
+        bin_and_raster(c, P, Z, 1, c->n_tiles);
+        HIPCHK(c, hipEventRecord(ev[3], s));
+        raster(c, P, 1);
+    }
     HIPCHK(c, hipEventRecord(ev[4], s));
-    zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_lut, c->d_stats, s);
+    zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_lut, Z.vis_now, c->d_stats, s);
+    if (hiz_on) { c->vis_history = true; c->vis_cur ^= 1; } else c->vis_history = false;
     HIPCHK(c, hipEventRecord(ev[5], s));
     HIPCHK(c, hipGetLastError());
     c->stage = 2;
@@ -927,6 +980,8 @@ extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out)
     for (int i = 0; i < 2; ++i) {
         out->work_items[i] = c->last_work[i]; out->survivors[i] = c->h_stats.survivors[i]; out->bin_entries[i] = c->h_stats.bin_entries[i];
     }
+    out->survivors[1] += c->h_stats.survivors[2]; out->bin_entries[1] += c->h_stats.bin_entries[2];    // both rounds of the camera pass
+    out->hiz_culled = c->h_stats.hiz_culled; out->round1_survivors = c->last_two_round ? c->h_stats.survivors[1] : 0;
     out->covered_pixels = c->h_stats.covered; out->covered_shadow_texels = c->h_stats.covered_shadow; out->overflow = c->h_stats.overflow;
     return rc;
 }

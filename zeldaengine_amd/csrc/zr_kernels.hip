@@ -193,8 +193,10 @@ __global__ __launch_bounds__(256) void k_cull_instances(ZrPass P, const ZrObject
 //   sphere-vs-frustum and the normal-cone test use inflated bounds;
 //   "all vertices outside one clip plane" and "snapped bbox holds no pixel centre" are exact.
 template <int MODE>
-__device__ __forceinline__ uint32_t cull_meshlet(const ZrPass& P, const ZrObject* __restrict__ objs, uint32_t w, uint32_t lane)
+__device__ __forceinline__ uint32_t cull_meshlet(const ZrPass& P, const ZrObject* __restrict__ objs, uint32_t w, uint32_t lane,
+                                                 uint2& pxrect, float& zmin)
 {
+    pxrect = make_uint2(0u, 0u); zmin = -1.0f;
     const int oi = find_object_work(objs, (int)P.n_objects, w);
     const ZrObject* __restrict__ O = objs + oi;
     const uint32_t local = w - O->work_base;
@@ -238,12 +240,13 @@ __device__ __forceinline__ uint32_t cull_meshlet(const ZrPass& P, const ZrObject
     // lane-per-vertex transform, exactly as the rasteriser will redo it
     uint32_t f_or = 0, f_and = 0xFFu;
     int X0 = 0x7FFFFFFF, X1 = (int)0x80000000, Y0 = 0x7FFFFFFF, Y1 = (int)0x80000000;
+    int zb = 0x7FFFFFFF;           // least NDC depth over the vertices, as ordered int bits (depths here are >= 0)
     if (lane < ml.VertexCount) {
         const float4 pp = O->mpos[ml.VertexOffset + lane];
         zf4 c = zr_mat4_point(P.PVM, vs_position(zr3(pp.x, pp.y, pp.z), I, instanced));
         uint32_t f = vertex_flags(c);
         f_or = f; f_and = f;
-        if (!(f & 129u)) { SV s = project(c, P.hw, P.hh); X0 = X1 = s.X; Y0 = Y1 = s.Y; }
+        if (!(f & 129u)) { SV s = project(c, P.hw, P.hh); X0 = X1 = s.X; Y0 = Y1 = s.Y; zb = (int)zr_f2u(s.z + 0.0f); }
     }
     f_or = wave_or(f_or); f_and = wave_and(f_and);
     if (!(f_or & 1u) && (f_and & 0x7Eu)) return ZR_RECT_CULLED;
@@ -253,6 +256,10 @@ __device__ __forceinline__ uint32_t cull_meshlet(const ZrPass& P, const ZrObject
         px0 = max(px0, (X0 - 128 + 255) >> 8); px1 = min(px1, (X1 - 128) >> 8);
         py0 = max(py0, (Y0 - 128 + 255) >> 8); py1 = min(py1, (Y1 - 128) >> 8);
         if (px0 > px1 || py0 > py1) return ZR_RECT_CULLED;
+        if (MODE == ZR_MODE_GBUFFER) {      // unclipped meshlet (so every z >= 0): usable for the Hi-Z test
+            zmin = zr_u2f((uint32_t)wave_min(zb));
+            pxrect = make_uint2((uint32_t)px0 | (uint32_t)py0 << 16, (uint32_t)px1 | (uint32_t)py1 << 16);
+        }
     }
     const int tx0 = px0 / TILE, tx1 = px1 / TILE, ty0 = py0 / TILE, ty1 = py1 / TILE;
     return (uint32_t)tx0 | (uint32_t)ty0 << 8 | (uint32_t)tx1 << 16 | (uint32_t)ty1 << 24;
@@ -260,37 +267,112 @@ __device__ __forceinline__ uint32_t cull_meshlet(const ZrPass& P, const ZrObject
 
 template <int MODE, bool WORKLIST>
 __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
-                                              uint32_t* __restrict__ rects, const ZrDevStats* __restrict__ stats, int slot)
+                                              uint32_t* __restrict__ rects, uint2* __restrict__ pxrect, float* __restrict__ zmin,
+                                              const ZrDevStats* __restrict__ stats, int slot)
 {
     const uint32_t lane = threadIdx.x & 63u;
+    uint2 pr; float zm;
     if (WORKLIST) {                 // persistent waves stride over the compacted list
         const uint32_t n = stats->n_vis_work[slot], stride = gridDim.x * 4u;
         for (uint32_t k = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6)); k < n; k += stride) {
-            const uint32_t r = cull_meshlet<MODE>(P, objs, wave_uniform(work[k]), lane);
-            if (lane == 0) rects[k] = r;
+            const uint32_t r = cull_meshlet<MODE>(P, objs, wave_uniform(work[k]), lane, pr, zm);
+            if (lane == 0) { rects[k] = r; if (MODE == ZR_MODE_GBUFFER && pxrect) { pxrect[k] = pr; zmin[k] = zm; } }
         }
     } else {                        // one wave per meshlet-instance, work item k = k
         const uint32_t k = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
         if (k >= P.n_work) return;
-        const uint32_t r = cull_meshlet<MODE>(P, objs, k, lane);
-        if (lane == 0) rects[k] = r;
+        const uint32_t r = cull_meshlet<MODE>(P, objs, k, lane, pr, zm);
+        if (lane == 0) { rects[k] = r; if (MODE == ZR_MODE_GBUFFER && pxrect) { pxrect[k] = pr; zmin[k] = zm; } }
     }
 }
 
+// Hi-Z pyramid of the key buffer: level 0 = max depth per 8x8 pixel block (1.0 where a pixel is still empty), each further
+// level the max over 2x2 blocks of the previous one.  One workgroup per 64x64 pixel region builds all four levels in LDS.
+__global__ __launch_bounds__(256) void k_hiz_build(const unsigned long long* __restrict__ vis64, uint32_t W, uint32_t H, ZrHiz Z)
+{
+    __shared__ float l0[8][8];
+    const uint32_t rx = blockIdx.x, ry = blockIdx.y, tid = threadIdx.x;
+    // 256 threads: thread t handles pixel-block (t & 7, (t >> 3) & 7) quarter (t >> 6): 4 threads per 8x8 block, 16 pixels each
+    const uint32_t bx = tid & 7u, by = (tid >> 3) & 7u, q = tid >> 6;
+    float m = 0.0f;
+    bool any = false;
+    for (uint32_t i = 0; i < 16u; ++i) {
+        const uint32_t px = rx * 64u + bx * 8u + (i & 7u), py = ry * 64u + by * 8u + q * 2u + (i >> 3);
+        if (px < W && py < H) { m = __builtin_fmaxf(m, zr_u2f((uint32_t)(vis64[(size_t)py * W + px] >> 32))); any = true; }
+    }
+    if (!any) m = 0.0f;
+    // combine the 4 quarters (lanes tid, tid+64, tid+128, tid+192) through LDS
+    __shared__ float part[4][64];
+    part[q][tid & 63u] = m;
+    __syncthreads();
+    if (tid < 64u) {
+        const float v = __builtin_fmaxf(__builtin_fmaxf(part[0][tid], part[1][tid]), __builtin_fmaxf(part[2][tid], part[3][tid]));
+        l0[by][bx] = v;
+        const uint32_t gx = rx * 8u + bx, gy = ry * 8u + by;
+        if (gx < Z.hw[0] && gy < Z.hh[0]) Z.lvl[0][(size_t)gy * Z.hw[0] + gx] = v;
+    }
+    __syncthreads();
+    if (tid < 16u) {            // level 1: 4x4 per region
+        const uint32_t x = tid & 3u, y = tid >> 2;
+        const float v = __builtin_fmaxf(__builtin_fmaxf(l0[2 * y][2 * x], l0[2 * y][2 * x + 1]), __builtin_fmaxf(l0[2 * y + 1][2 * x], l0[2 * y + 1][2 * x + 1]));
+        const uint32_t gx = rx * 4u + x, gy = ry * 4u + y;
+        if (gx < Z.hw[1] && gy < Z.hh[1]) Z.lvl[1][(size_t)gy * Z.hw[1] + gx] = v;
+    }
+    if (tid >= 64u && tid < 68u) {   // level 2: 2x2 per region
+        const uint32_t x = (tid - 64u) & 1u, y = (tid - 64u) >> 1;
+        float v = 0.0f;
+        for (uint32_t j = 0; j < 4u; ++j) for (uint32_t i = 0; i < 4u; ++i) v = __builtin_fmaxf(v, l0[4 * y + j][4 * x + i]);
+        const uint32_t gx = rx * 2u + x, gy = ry * 2u + y;
+        if (gx < Z.hw[2] && gy < Z.hh[2]) Z.lvl[2][(size_t)gy * Z.hw[2] + gx] = v;
+    }
+    if (tid == 128u) {               // level 3: the region
+        float v = 0.0f;
+        for (uint32_t j = 0; j < 8u; ++j) for (uint32_t i = 0; i < 8u; ++i) v = __builtin_fmaxf(v, l0[j][i]);
+        if (rx < Z.hw[3] && ry < Z.hh[3]) Z.lvl[3][(size_t)ry * Z.hw[3] + rx] = v;
+    }
+}
+
+// Conservative occlusion test of one meshlet-instance against the pyramid: true when every pixel of its snapped bounding box
+// already holds a depth smaller than the least depth the meshlet can produce, i.e. its fragments would all fail LESS.
+__device__ __forceinline__ bool hiz_occluded(const ZrHiz& Z, uint2 pr, float zmin)
+{
+    if (!(zmin >= 0.0f)) return false;
+    const uint32_t x0 = pr.x & 0xFFFFu, y0 = pr.x >> 16, x1 = pr.y & 0xFFFFu, y1 = pr.y >> 16;
+    const uint32_t ext = max(x1 - x0, y1 - y0);
+    uint32_t l = 0;
+    while (l < 3u && (ext >> (3u + l)) >= 3u) ++l;        // at most ~4x4 texels of the chosen level
+    const uint32_t sh = 3u + l;
+    float hmax = 0.0f;
+    for (uint32_t ty = y0 >> sh; ty <= (y1 >> sh); ++ty)
+        for (uint32_t tx = x0 >> sh; tx <= (x1 >> sh); ++tx)
+            hmax = __builtin_fmaxf(hmax, Z.lvl[l][(size_t)ty * Z.hw[l] + tx]);
+    // fragment depths are clamped to their triangle's vertex depths (shade_key), so zmin bounds them exactly
+    return zmin > hmax;
+}
+
+
 // Per-tile entry counts from the rects.  Counting goes through an LDS histogram per 1024 work items so that a hot
 // tile costs one global atomic per workgroup instead of one per meshlet-instance (same-address atomics serialise).
-__global__ __launch_bounds__(1024) void k_bin_count(ZrPass P, const uint32_t* __restrict__ rects, uint32_t* __restrict__ tile_count,
-                                                    const ZrDevStats* __restrict__ stats, int slot)
+__global__ __launch_bounds__(1024) void k_bin_count(ZrPass P, const uint32_t* __restrict__ work, uint32_t* __restrict__ rects,
+                                                    uint32_t* __restrict__ tile_count, ZrHiz Z, ZrDevStats* __restrict__ stats, int slot)
 {
     extern __shared__ uint32_t hist[];
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
-    const uint32_t n_vis = P.use_worklist ? stats->n_vis_work[slot] : P.n_work;
+    const int vslot = slot > 1 ? 1 : slot;               // camera rounds 1 and 2 share the cull results of slot 1
+    const uint32_t n_vis = P.use_worklist ? stats->n_vis_work[vslot] : P.n_work;
     if (blockIdx.x * 1024u >= n_vis) return;            // the grid is sized for every meshlet-instance of the scene
     for (uint32_t i = threadIdx.x; i < n_tiles; i += 1024u) hist[i] = 0;
     __syncthreads();
     const uint32_t w = blockIdx.x * 1024u + threadIdx.x;
+    uint32_t occluded = 0;
     if (w < n_vis) {
-        const uint32_t r = rects[w];
+        uint32_t r = rects[w];
+        if (r != ZR_RECT_CULLED && Z.phase) {            // two-pass occlusion culling: who is drawn in this round?
+            const bool was_visible = Z.vis_prev[P.use_worklist ? work[w] : w] != 0;
+            if (Z.phase == 1u) { if (!was_visible) r = ZR_RECT_CULLED; }
+            else if (was_visible) r = ZR_RECT_CULLED;     // drawn in round 1
+            else if (hiz_occluded(Z, Z.pxrect[w], Z.zmin[w])) { r = ZR_RECT_CULLED; rects[w] = r; occluded = 1; }
+        }
         if (r != ZR_RECT_CULLED) {
             const uint32_t tx0 = r & 255u, ty0 = (r >> 8) & 255u, tx1 = (r >> 16) & 255u, ty1 = r >> 24;
             for (uint32_t ty = ty0; ty <= ty1; ++ty)
@@ -302,6 +384,8 @@ __global__ __launch_bounds__(1024) void k_bin_count(ZrPass P, const uint32_t* __
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_tiles; i += 1024u) { const uint32_t c = hist[i]; if (c) atomicAdd(&tile_count[i], c); }
+    const uint32_t nocc = (uint32_t)__popcll(__ballot(occluded != 0));
+    if ((threadIdx.x & 63u) == 0 && nocc) atomicAdd(&stats->hiz_culled, nocc);
 }
 
 // Exclusive scan of tile_count[0..n) into tile_offset[0..n] and of the per-tile chunk counts ceil(count / ZR_CHUNK)
@@ -347,19 +431,26 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
 __global__ __launch_bounds__(1024) void k_bin_fill(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
                                                    const uint32_t* __restrict__ rects,
                                                    const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
-                                                   ZrBinEntry* __restrict__ bins, ZrDevStats* __restrict__ stats, int slot)
+                                                   ZrBinEntry* __restrict__ bins, ZrHiz Z, ZrDevStats* __restrict__ stats, int slot)
 {
     extern __shared__ uint32_t hist[];
     __shared__ uint32_t tot;
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
-    const uint32_t n_vis = P.use_worklist ? stats->n_vis_work[slot] : P.n_work;
+    const int vslot = slot > 1 ? 1 : slot;
+    const uint32_t n_vis = P.use_worklist ? stats->n_vis_work[vslot] : P.n_work;
     if (blockIdx.x * 1024u >= n_vis) return;
     for (uint32_t i = threadIdx.x; i < n_tiles; i += 1024u) hist[i] = 0;
     if (threadIdx.x == 0) tot = 0;
     __syncthreads();
     const uint32_t k = blockIdx.x * 1024u + threadIdx.x;
     uint32_t r = ZR_RECT_CULLED, w = 0;
-    if (k < n_vis) { r = rects[k]; w = P.use_worklist ? work[k] : k; }
+    if (k < n_vis) {
+        r = rects[k]; w = P.use_worklist ? work[k] : k;
+        if (r != ZR_RECT_CULLED && Z.phase) {            // same split as k_bin_count (round 2's occluded items were marked CULLED there)
+            const bool was_visible = Z.vis_prev[w] != 0;
+            if ((Z.phase == 1u) != was_visible) r = ZR_RECT_CULLED;
+        }
+    }
     const uint32_t tx0 = r & 255u, ty0 = (r >> 8) & 255u, tx1 = (r >> 16) & 255u, ty1 = r >> 24;
     if (r != ZR_RECT_CULLED)
         for (uint32_t ty = ty0; ty <= ty1; ++ty)
@@ -418,11 +509,12 @@ __device__ __forceinline__ bool tri_prefilter(int X0, int Y0, int X1, int Y1, in
 }
 
 template <int MODE>
-__device__ __forceinline__ void shade_key(int x, int y, float fy, const SV& v0, float gx, float gy, float bias, uint32_t prim,
-                                          const TileCtx& T, unsigned long long* __restrict__ keys64, uint32_t* __restrict__ keys32)
+__device__ __forceinline__ void shade_key(int x, int y, float fy, const SV& v0, float gx, float gy, float zlo, float zhi,
+                                          float bias, uint32_t prim, const TileCtx& T, unsigned long long* __restrict__ keys64, uint32_t* __restrict__ keys32)
 {
     const float fx = (float)(x * 256 + 128 - v0.X);
     float z = __builtin_fmaf(gy, fy, __builtin_fmaf(gx, fx, v0.z));
+    z = __builtin_fminf(__builtin_fmaxf(z, zlo), zhi);      // fragments stay within their vertices' depths (Hi-Z relies on it)
     z = z + 0.0f;
     const int li = (y - T.py0) * TILE + (x - T.px0);
     if (MODE == ZR_MODE_GBUFFER) {
@@ -472,6 +564,7 @@ __device__ __forceinline__ void raster_sub(const SV& v0, const SV& v1, const SV&
     const float a2 = (float)(v0.Y - v1.Y) * invA, b2 = (float)(v1.X - v0.X) * invA;
     const float dz1 = v1.z - v0.z, dz2 = v2.z - v0.z;
     const float gx = __builtin_fmaf(a2, dz2, a1 * dz1), gy = __builtin_fmaf(b2, dz2, b1 * dz1);
+    const float zlo = __builtin_fminf(__builtin_fminf(v0.z, v1.z), v2.z), zhi = __builtin_fmaxf(__builtin_fmaxf(v0.z, v1.z), v2.z);
     float bias = 0.0f;
     if (MODE == ZR_MODE_SHADOW) {
         // vkCmdSetDepthBias(1.25, 0, 7.5) on D32 (ZE:3280-3287): o = m * slope + r * constant, r = 2^(e - 23)
@@ -494,7 +587,7 @@ __device__ __forceinline__ void raster_sub(const SV& v0, const SV& v1, const SV&
             int r0 = e0, r1 = e1, r2 = e2;
             const float fy = (float)(y * 256 + 128 - v0.Y);
             for (int x = x0; x <= x1; ++x) {
-                if ((r0 | r1 | r2) >= 0) shade_key<MODE>(x, y, fy, v0, gx, gy, bias, prim, T, keys64, keys32);
+                if ((r0 | r1 | r2) >= 0) shade_key<MODE>(x, y, fy, v0, gx, gy, zlo, zhi, bias, prim, T, keys64, keys32);
                 r0 += sx0; r1 += sx1; r2 += sx2;
             }
             e0 += sy0; e1 += sy1; e2 += sy2;
@@ -506,7 +599,7 @@ __device__ __forceinline__ void raster_sub(const SV& v0, const SV& v1, const SV&
             long long r0 = E0, r1 = E1, r2 = E2;
             const float fy = (float)(y * 256 + 128 - v0.Y);
             for (int x = x0; x <= x1; ++x) {
-                if ((r0 | r1 | r2) >= 0) shade_key<MODE>(x, y, fy, v0, gx, gy, bias, prim, T, keys64, keys32);
+                if ((r0 | r1 | r2) >= 0) shade_key<MODE>(x, y, fy, v0, gx, gy, zlo, zhi, bias, prim, T, keys64, keys32);
                 r0 += sx0; r1 += sx1; r2 += sx2;
             }
             E0 += sy0; E1 += sy1; E2 += sy2;
@@ -679,7 +772,8 @@ __device__ __forceinline__ zf4 tex_sample(const ZrTex& T, const float* __restric
 // BaseScene.frag:26-48 for the pixel (px, py) whose winning primitive is `prim`
 // returns true when the pixel holds scene geometry (not empty, not sky)
 __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* __restrict__ objs, uint32_t prim, float depth,
-                                              int px, int py, const GBufferPtrs& G, const float* __restrict__ lut)
+                                              int px, int py, const GBufferPtrs& G, const float* __restrict__ lut,
+                                              uint8_t* __restrict__ vis_now)
 {
     const size_t p = (size_t)py * P.W + (size_t)px;
     if (prim == ZR_EMPTY_PRIM) {   // clears, ZE:3427-3433
@@ -693,6 +787,8 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
     const uint32_t inst_i = local / O->n_tris, tri = local - inst_i * O->n_tris;
     const bool instanced = O->instanced != 0;
     const ZrInstance I = O->inst[inst_i];
+    // visibility history for next frame's round 1: this meshlet-instance owns a pixel
+    if (vis_now) vis_now[O->work_base + inst_i * O->n_meshlets + O->tri_meshlet[tri]] = 1;
     zf4 clip[3]; zf3 WP[3], WN[3]; float U[3], V[3]; uint32_t fl[3];
     for (int k = 0; k < 3; ++k) {
         const XkVertex* __restrict__ vtx = O->verts + O->indices[3u * tri + (uint32_t)k];
@@ -799,15 +895,15 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
     const uint32_t n_chunks = stats->n_chunks[slot];
 
+    // the first chunk of a workgroup is its own index (no atomic: an empty pass costs nothing), later ones come from the counter
+    uint32_t chunk = blockIdx.x;
     for (;;) {
-        if (tid == 0) cur_chunk = atomicAdd(&stats->chunk_counter[slot], 1u);
+        if (chunk >= n_chunks) break;
         for (uint32_t i = tid; i < TILE_PIX; i += RTHREADS) {
             if (MODE == ZR_MODE_GBUFFER) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
             else keys32[i] = 0x3F800000u;
         }
         __syncthreads();
-        const uint32_t chunk = cur_chunk;
-        if (chunk >= n_chunks) break;
         // tile = last t with chunk_offset[t] <= chunk (tiles without entries have zero-width ranges and are skipped)
         uint32_t lo = 0, hi = n_tiles;
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (chunk_offset[mid] <= chunk) lo = mid; else hi = mid; }
@@ -926,7 +1022,9 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
                 if (k < shadow_bits[p]) atomicMin(&shadow_bits[p], k);
             }
         }
+        if (tid == 0) cur_chunk = gridDim.x + atomicAdd(&stats->chunk_counter[slot], 1u);
         __syncthreads();   // keys are re-cleared at the top of the loop
+        chunk = cur_chunk;
     }
 }
 
@@ -934,7 +1032,8 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
 __global__ __launch_bounds__(256) void k_resolve_gbuffer(ZrPass P, const ZrObject* __restrict__ objs,
                                                          const uint32_t* __restrict__ owned_tiles,
                                                          unsigned long long* __restrict__ vis64, GBufferPtrs G,
-                                                         const float* __restrict__ srgb_lut, ZrDevStats* __restrict__ stats)
+                                                         const float* __restrict__ srgb_lut, uint8_t* __restrict__ vis_now,
+                                                         ZrDevStats* __restrict__ stats)
 {
     __shared__ uint32_t covered_s;
     const uint32_t tid = threadIdx.x;
@@ -950,7 +1049,7 @@ __global__ __launch_bounds__(256) void k_resolve_gbuffer(ZrPass P, const ZrObjec
         const size_t p = (size_t)py * P.W + (size_t)px;
         const unsigned long long k = vis64[p];
         vis64[p] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
-        ncov += resolve_pixel(P, objs, (uint32_t)k, zr_u2f((uint32_t)(k >> 32)), px, py, G, srgb_lut) ? 1u : 0u;
+        ncov += resolve_pixel(P, objs, (uint32_t)k, zr_u2f((uint32_t)(k >> 32)), px, py, G, srgb_lut, vis_now) ? 1u : 0u;
     }
     if (ncov) atomicAdd(&covered_s, ncov);
     __syncthreads();
@@ -1291,26 +1390,35 @@ void zr_launch_instance_prep(const XkInstanceData* in, ZrInstance* out, uint32_t
 {
     hipLaunchKernelGGL(k_instance_prep, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n, instanced);
 }
-void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, uint32_t* tile_count, ZrDevStats* stats,
+void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, const ZrHiz& Z, ZrDevStats* stats,
                     int slot, uint32_t n_waves, hipStream_t s)
 {
     if (P.n_work == 0) return;
     const dim3 gi((P.n_inst_total + 255) / 256), b(256);
     const uint32_t all = (uint32_t)(((uint64_t)P.n_work + 3) / 4);
     const uint32_t blocks = P.use_worklist ? std::min<uint32_t>(all, std::max<uint32_t>(1u, n_waves / 4u)) : all;
-    const uint32_t n_tiles = P.tiles_x * P.tiles_y;
     if (P.mode == ZR_MODE_GBUFFER) {
         if (P.use_worklist) {
             hipLaunchKernelGGL(k_cull_instances<ZR_MODE_GBUFFER>, gi, b, 0, s, P, objs, work, stats, slot);
-            hipLaunchKernelGGL((k_cull<ZR_MODE_GBUFFER, true>), dim3(blocks), b, 0, s, P, objs, work, rects, stats, slot);
-        } else hipLaunchKernelGGL((k_cull<ZR_MODE_GBUFFER, false>), dim3(blocks), b, 0, s, P, objs, work, rects, stats, slot);
+            hipLaunchKernelGGL((k_cull<ZR_MODE_GBUFFER, true>), dim3(blocks), b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, stats, slot);
+        } else hipLaunchKernelGGL((k_cull<ZR_MODE_GBUFFER, false>), dim3(blocks), b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, stats, slot);
     } else {
         if (P.use_worklist) {
             hipLaunchKernelGGL(k_cull_instances<ZR_MODE_SHADOW>, gi, b, 0, s, P, objs, work, stats, slot);
-            hipLaunchKernelGGL((k_cull<ZR_MODE_SHADOW, true>), dim3(blocks), b, 0, s, P, objs, work, rects, stats, slot);
-        } else hipLaunchKernelGGL((k_cull<ZR_MODE_SHADOW, false>), dim3(blocks), b, 0, s, P, objs, work, rects, stats, slot);
+            hipLaunchKernelGGL((k_cull<ZR_MODE_SHADOW, true>), dim3(blocks), b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, stats, slot);
+        } else hipLaunchKernelGGL((k_cull<ZR_MODE_SHADOW, false>), dim3(blocks), b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, stats, slot);
     }
-    hipLaunchKernelGGL(k_bin_count, dim3((P.n_work + 1023) / 1024), dim3(1024), n_tiles * sizeof(uint32_t), s, P, rects, tile_count, stats, slot);
+}
+void zr_launch_bin_count(const ZrPass& P, const uint32_t* work, uint32_t* rects, uint32_t* tile_count, const ZrHiz& Z, ZrDevStats* stats,
+                         int slot, hipStream_t s)
+{
+    if (P.n_work == 0) return;
+    const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    hipLaunchKernelGGL(k_bin_count, dim3((P.n_work + 1023) / 1024), dim3(1024), n_tiles * sizeof(uint32_t), s, P, work, rects, tile_count, Z, stats, slot);
+}
+void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H, const ZrHiz& Z, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_hiz_build, dim3((W + 63) / 64, (H + 63) / 64), dim3(256), 0, s, vis64, W, H, Z);
 }
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint32_t n,
                     uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s)
@@ -1318,12 +1426,12 @@ void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, chunk_offset, n, capacity, stats, slot);
 }
 void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
-                        uint32_t* tile_cursor, ZrBinEntry* bins, ZrDevStats* stats, int slot, hipStream_t s)
+                        uint32_t* tile_cursor, ZrBinEntry* bins, const ZrHiz& Z, ZrDevStats* stats, int slot, hipStream_t s)
 {
     if (P.n_work == 0) return;
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
     hipLaunchKernelGGL(k_bin_fill, dim3((P.n_work + 1023) / 1024), dim3(1024), n_tiles * sizeof(uint32_t), s, P, objs, work, rects,
-                       tile_offset, tile_cursor, bins, stats, slot);
+                       tile_offset, tile_cursor, bins, Z, stats, slot);
 }
 void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s)
 {
@@ -1343,10 +1451,11 @@ void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint32
         hipLaunchKernelGGL(k_raster_chunks<ZR_MODE_SHADOW>, dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, tile_offset, chunk_offset, bins, stats, slot, vis64, shadow_bits);
 }
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
-                               unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, ZrDevStats* stats, hipStream_t s)
+                               unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, uint8_t* vis_now,
+                               ZrDevStats* stats, hipStream_t s)
 {
     if (n_owned == 0) return;
-    hipLaunchKernelGGL(k_resolve_gbuffer, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, stats);
+    hipLaunchKernelGGL(k_resolve_gbuffer, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, vis_now, stats);
 }
 void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, hipStream_t s)
 {

@@ -36,6 +36,7 @@ struct ZrObject {
     const XkMeshlet*  meshlets;      // device copy; BindlessContext = tri_base (triangles in earlier meshlets)
     const float4*     mpos;          // flattened meshlet vertices: mpos[VertexOffset + k] = position of meshlet vertex k
                                      // (CreateMeshVertexBuffers<XkMeshIndirect> flattens the same way, ZE:4733-4756)
+    const uint32_t*   tri_meshlet;   // draw-order triangle -> meshlet index (visibility history for the Hi-Z pass)
     const uint2*      mtri;          // per meshlet triangle slot (tri_base + t): x = corners i0 | i1 << 8 | i2 << 16,
                                      // y = draw-order triangle index (primitive id within the instance)
     const ZrInstance* inst;
@@ -87,14 +88,27 @@ struct ZrPass {
 
 // Frame statistics block in device memory (one per pass slot: [shadow, camera]).
 struct ZrDevStats {
-    uint32_t survivors[2];
-    uint32_t bin_entries[2];
+    uint32_t survivors[3];           // slots: 0 shadow pass, 1 camera pass (round 1), 2 camera pass round 2 (after Hi-Z)
+    uint32_t bin_entries[3];
     uint32_t covered;
     uint32_t covered_shadow;
     uint32_t overflow;
-    uint32_t n_chunks[2];
-    uint32_t chunk_counter[2];
+    uint32_t n_chunks[3];
+    uint32_t chunk_counter[3];
     uint32_t n_vis_work[2];          // meshlet-instances of the instances that passed the instance-level frustum test
+    uint32_t hiz_culled;             // meshlet-instances rejected by the Hi-Z test
+};
+
+// Two-pass Hi-Z occlusion culling of the camera pass (config 5; conservative).
+// Hi-Z level l holds, per (8 << l) x (8 << l) pixel block, the MAX depth currently in the key buffer (1.0 where empty).
+struct ZrHiz {
+    float*    lvl[4];                // device arrays, level l is hw[l] x hh[l]
+    uint32_t  hw[4], hh[4];
+    uint2*    pxrect;                // per work item: snapped pixel bbox (x0 | y0 << 16, x1 | y1 << 16)
+    float*    zmin;                  // per work item: least NDC depth of the meshlet's vertices, < 0: do not occlusion-test
+    const uint8_t* vis_prev;         // per meshlet-instance: owned a pixel of the previous frame
+    uint8_t*  vis_now;               // marked by the resolve
+    uint32_t  phase;                 // 0: no Hi-Z (one round); 1: round 1 = last frame's visible set; 2: round 2 = the rest, Hi-Z tested
 };
 
 // Uniforms of the lighting pass that are not in XkView.
@@ -121,19 +135,23 @@ struct CubeDesc { const uint8_t* levels[16]; };
 
 // launchers defined in zr_kernels.hip
 void zr_launch_instance_prep(const XkInstanceData* in, ZrInstance* out, uint32_t n, uint32_t instanced, hipStream_t s);
-void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, uint32_t* tile_count, ZrDevStats* stats,
+void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, const ZrHiz& Z, ZrDevStats* stats,
                     int slot, uint32_t n_waves, hipStream_t s);
+void zr_launch_bin_count(const ZrPass& P, const uint32_t* work, uint32_t* rects, uint32_t* tile_count, const ZrHiz& Z, ZrDevStats* stats,
+                         int slot, hipStream_t s);
+void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H, const ZrHiz& Z, hipStream_t s);
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint32_t n,
                     uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s);
 void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
-                        uint32_t* tile_cursor, ZrBinEntry* bins, ZrDevStats* stats, int slot, hipStream_t s);
+                        uint32_t* tile_cursor, ZrBinEntry* bins, const ZrHiz& Z, ZrDevStats* stats, int slot, hipStream_t s);
 void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s);
 void zr_launch_fill64(unsigned long long* p, unsigned long long v, size_t n, hipStream_t s);
 void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint32_t* tile_offset, const uint32_t* chunk_offset,
                              const ZrBinEntry* bins, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t* shadow_bits,
                              uint32_t n_blocks, hipStream_t s);
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
-                               unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, ZrDevStats* stats, hipStream_t s);
+                               unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, uint8_t* vis_now,
+                               ZrDevStats* stats, hipStream_t s);
 void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, hipStream_t s);
 void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32_t* owned_tiles, uint32_t n_owned,
                         const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C, const float* lut, const float* unorm_lut,
