@@ -100,6 +100,7 @@ struct zr_ctx {
     uint8_t* d_bg = nullptr; uint32_t bg_w = 0, bg_h = 0, bg_levels = 0; bool bg_set = false, bg_enabled = true;
 
     hipEvent_t evr[EV_RING][7] = {}; uint64_t frame_no = 0; bool rendered = false;
+    uint32_t timing_interval = 1; bool timing_now = true; uint64_t sample_no = 0;    // pass events every interval-th frame
 
     // world + livelink
     ZrWorld world;

@@ -783,10 +783,10 @@ static void bin_and_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot,
     zr_launch_scan(c->d_tile_count, c->d_tile_offset, c->d_tile_cursor, c->d_chunk_offset, n_tiles, c->bin_capacity, c->d_stats, slot, c->stream);
     zr_launch_bin_fill(P, c->d_objs, c->d_work, c->d_rects, c->d_tile_offset, c->d_tile_cursor, c->d_bins, Z, c->d_stats, slot, c->stream);
 }
-static void raster(zr_ctx* c, const ZrPass& P, int slot)
+static void raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot)
 {
     zr_launch_raster_chunks(P, c->d_objs, c->d_tile_offset, c->d_chunk_offset, c->d_bins, c->d_stats, slot, c->d_vis,
-                            (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), c->raster_blocks, c->stream);
+                            (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), c->raster_blocks, Z, c->stream);
 }
 
 static inline float* shadow_buf(zr_ctx* c) { return c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow; }
@@ -806,8 +806,9 @@ extern "C" int zr_render_shadow(zr_ctx* c)
     if (rc) return rc;
     c->view.LightsCount[3] = (int32_t)c->cube_levels;
     hipStream_t s = c->stream;
-    hipEvent_t* ev = c->evr[c->frame_no % zr_ctx::EV_RING];
-    HIPCHK(c, hipEventRecord(ev[0], s));
+    c->timing_now = c->timing_interval != 0 && c->frame_no % c->timing_interval == 0;     // pass events cost ~6 us of stream bubble each
+    hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
+    if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
     HIPCHK(c, hipMemsetAsync(c->d_stats, 0, sizeof(ZrDevStats), s));
     HIPCHK(c, hipMemcpyAsync(c->d_view, &c->view, sizeof(XkView), hipMemcpyHostToDevice, s));
     ZrPass P;
@@ -818,9 +819,9 @@ extern "C" int zr_render_shadow(zr_ctx* c)
     ZrHiz Z; memset(&Z, 0, sizeof Z);
     zr_launch_cull(P, c->d_objs, c->d_work, c->d_rects, Z, c->d_stats, 0, c->raster_blocks * 4u, s);
     bin_and_raster(c, P, Z, 0, c->sn_tiles);
-    HIPCHK(c, hipEventRecord(ev[1], s));
-    raster(c, P, 0);
-    HIPCHK(c, hipEventRecord(ev[2], s));
+    if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
+    raster(c, P, Z, 0);
+    if (ev) HIPCHK(c, hipEventRecord(ev[2], s));
     HIPCHK(c, hipGetLastError());
     c->stage = 1;
     return ZR_OK;
@@ -832,7 +833,7 @@ extern "C" int zr_render_gbuffer(zr_ctx* c)
     if (c->stage != 1) return zr_fail(c, ZR_ERR_STATE, "zr_render_gbuffer out of order");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    hipEvent_t* ev = c->evr[c->frame_no % zr_ctx::EV_RING];
+    hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
     ZrPass P;
     const bool live = build_pass(c, c->cam, ZR_MODE_GBUFFER, &P);
     if (!live) P.n_work = 0;
@@ -851,21 +852,21 @@ extern "C" int zr_render_gbuffer(zr_ctx* c)
     if (c->last_two_round) {
         Z.phase = 1;
         bin_and_raster(c, P, Z, 1, c->n_tiles);
-        HIPCHK(c, hipEventRecord(ev[3], s));        // cull_camera ends where the first raster starts
-        raster(c, P, 1);
+        if (ev) HIPCHK(c, hipEventRecord(ev[3], s));        // cull_camera ends where the first raster starts
+        raster(c, P, Z, 1);
         zr_launch_hiz_build(c->d_vis, c->W, c->H, Z, s);
         Z.phase = 2;
         bin_and_raster(c, P, Z, 2, c->n_tiles);
-        raster(c, P, 2);
+        raster(c, P, Z, 2);
     } else {
         bin_and_raster(c, P, Z, 1, c->n_tiles);
-        HIPCHK(c, hipEventRecord(ev[3], s));
-        raster(c, P, 1);
+        if (ev) HIPCHK(c, hipEventRecord(ev[3], s));
+        raster(c, P, Z, 1);
     }
-    HIPCHK(c, hipEventRecord(ev[4], s));
+    if (ev) HIPCHK(c, hipEventRecord(ev[4], s));
     zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_lut, Z.vis_now, c->d_stats, s);
     if (hiz_on) { c->vis_history = true; c->vis_cur ^= 1; } else c->vis_history = false;
-    HIPCHK(c, hipEventRecord(ev[5], s));
+    if (ev) HIPCHK(c, hipEventRecord(ev[5], s));
     HIPCHK(c, hipGetLastError());
     c->stage = 2;
     return ZR_OK;
@@ -877,7 +878,7 @@ extern "C" int zr_render_lighting(zr_ctx* c)
     if (c->stage != 2) return zr_fail(c, ZR_ERR_STATE, "zr_render_lighting out of order");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    hipEvent_t* ev = c->evr[c->frame_no % zr_ctx::EV_RING];
+    hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
     ZrLightParams L; memset(&L, 0, sizeof L);
     static const float Bias[16] = { 0.5f, 0, 0, 0, 0, 0.5f, 0, 0, 0, 0, 1, 0, 0.5f, 0.5f, 0, 1 };
     zr_mat4_mul(Bias, c->view.ShadowmapSpace, L.SB);
@@ -889,8 +890,9 @@ extern "C" int zr_render_lighting(zr_ctx* c)
     L.bg.data = c->d_bg; L.bg.w = c->bg_w; L.bg.h = c->bg_h; L.bg.levels = c->bg_levels; L.bg._pad = 0;
     zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, shadow_buf(c), c->cube, c->d_lut, c->d_unorm_lut,
                        L.packed_out ? (c->d_tiles_ext ? c->d_tiles_ext : c->d_tiles) : c->d_color, s);
-    HIPCHK(c, hipEventRecord(ev[6], s));
+    if (ev) HIPCHK(c, hipEventRecord(ev[6], s));
     HIPCHK(c, hipGetLastError());
+    if (c->timing_now) c->sample_no++;
     c->rendered = true; c->frame_no++; c->stage = 0;
     return ZR_OK;
 }
@@ -945,10 +947,11 @@ extern "C" int zr_get_pass_times_avg(zr_ctx* c, uint32_t last_n, float ms[ZR_PAS
     if (rc && rc != ZR_ERR_OVERFLOW) return rc;
     if (last_n == 0) last_n = 1;
     if (last_n > (uint32_t)zr_ctx::EV_RING) last_n = zr_ctx::EV_RING;
-    if ((uint64_t)last_n > c->frame_no) last_n = (uint32_t)c->frame_no;
+    if (c->sample_no == 0) return zr_fail(c, ZR_ERR_STATE, "no timed frame yet (zr_set_timing_interval)");
+    if ((uint64_t)last_n > c->sample_no) last_n = (uint32_t)c->sample_no;
     double acc[ZR_PASS_COUNT] = { 0 };
     for (uint32_t k = 0; k < last_n; ++k) {
-        hipEvent_t* ev = c->evr[(c->frame_no - 1 - k) % zr_ctx::EV_RING];
+        hipEvent_t* ev = c->evr[(c->sample_no - 1 - k) % zr_ctx::EV_RING];
         float t[ZR_PASS_COUNT] = { 0 };
         (void)hipEventElapsedTime(&t[ZR_PASS_CULL_SHADOW], ev[0], ev[1]);
         (void)hipEventElapsedTime(&t[ZR_PASS_SHADOW], ev[1], ev[2]);
@@ -963,6 +966,15 @@ extern "C" int zr_get_pass_times_avg(zr_ctx* c, uint32_t last_n, float ms[ZR_PAS
     return ZR_OK;
 }
 extern "C" int zr_get_pass_times(zr_ctx* c, float ms[ZR_PASS_COUNT]) { return zr_get_pass_times_avg(c, 1, ms); }
+
+// Per-pass hipEvents are recorded on every interval-th frame (default 1 = every frame, 0 = never).  Each record is a small
+// bubble on the render stream (~6 us on MI355X, six per frame), so a host that only wants throughput samples sparsely.
+extern "C" int zr_set_timing_interval(zr_ctx* c, uint32_t interval)
+{
+    if (!c) return ZR_ERR_ARG;
+    c->timing_interval = interval;
+    return ZR_OK;
+}
 
 extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out)
 {

@@ -340,16 +340,34 @@ __device__ __forceinline__ bool hiz_occluded(const ZrHiz& Z, uint2 pr, float zmi
     const uint32_t x0 = pr.x & 0xFFFFu, y0 = pr.x >> 16, x1 = pr.y & 0xFFFFu, y1 = pr.y >> 16;
     const uint32_t ext = max(x1 - x0, y1 - y0);
     uint32_t l = 0;
-    while (l < 3u && (ext >> (3u + l)) >= 3u) ++l;        // at most ~4x4 texels of the chosen level
+    while (l < 3u && (ext >> (3u + l)) >= 3u) ++l;        // the box then spans at most 4 texels of level l per axis
     const uint32_t sh = 3u + l;
+    const uint32_t tx0 = x0 >> sh, ty0 = y0 >> sh, tx1 = x1 >> sh, ty1 = y1 >> sh;
+    if (tx1 - tx0 > 3u || ty1 - ty0 > 3u) return false;     // wider than 4x4 texels of the coarsest level: not tested
+    const float* __restrict__ L = Z.lvl[l];
+    const uint32_t hw = Z.hw[l];
+    // 16 independent loads (clamped repeats at the far edges) instead of a data-dependent loop: one memory latency, not sixteen
     float hmax = 0.0f;
-    for (uint32_t ty = y0 >> sh; ty <= (y1 >> sh); ++ty)
-        for (uint32_t tx = x0 >> sh; tx <= (x1 >> sh); ++tx)
-            hmax = __builtin_fmaxf(hmax, Z.lvl[l][(size_t)ty * Z.hw[l] + tx]);
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j)
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i)
+            hmax = __builtin_fmaxf(hmax, L[(size_t)min(ty0 + j, ty1) * hw + min(tx0 + i, tx1)]);
     // fragment depths are clamped to their triangle's vertex depths (shade_key), so zmin bounds them exactly
     return zmin > hmax;
 }
 
+// Round 2, per (meshlet-instance, tile) pair: the pyramid level whose texels are the raster tiles tells whether the whole
+// tile is already nearer than anything the meshlet can produce.  k_bin_count and k_bin_fill must agree: both call these.
+__device__ __forceinline__ float tile_test_depth(const ZrHiz& Z, uint32_t k)
+{
+    if (TILE != 32 || Z.phase != 2u) return -1.0f;
+    return Z.zmin[k];                                   // < 0: the meshlet is not occlusion-tested
+}
+__device__ __forceinline__ bool tile_hides(const ZrHiz& Z, float zt, uint32_t tile)
+{
+    return zt >= 0.0f && zt > Z.lvl[2][tile];           // level 2 = 32 x 32 pixel blocks = tiles, same row pitch (tiles_x)
+}
 
 // Per-tile entry counts from the rects.  Counting goes through an LDS histogram per 1024 work items so that a hot
 // tile costs one global atomic per workgroup instead of one per meshlet-instance (same-address atomics serialise).
@@ -375,17 +393,24 @@ __global__ __launch_bounds__(1024) void k_bin_count(ZrPass P, const uint32_t* __
         }
         if (r != ZR_RECT_CULLED) {
             const uint32_t tx0 = r & 255u, ty0 = (r >> 8) & 255u, tx1 = (r >> 16) & 255u, ty1 = r >> 24;
+            const float zt = tile_test_depth(Z, w);
             for (uint32_t ty = ty0; ty <= ty1; ++ty)
                 for (uint32_t tx = tx0; tx <= tx1; ++tx) {
                     const uint32_t t = ty * P.tiles_x + tx;
-                    if (t % P.tile_world == P.tile_rank) atomicAdd(&hist[t], 1u);
+                    if (t % P.tile_world == P.tile_rank && !tile_hides(Z, zt, t)) atomicAdd(&hist[t], 1u);
                 }
         }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_tiles; i += 1024u) { const uint32_t c = hist[i]; if (c) atomicAdd(&tile_count[i], c); }
+    // statistics: one global atomic per workgroup (same-address atomics serialise)
+    __shared__ uint32_t tally;
+    if (threadIdx.x == 0) tally = 0;
+    __syncthreads();
     const uint32_t nocc = (uint32_t)__popcll(__ballot(occluded != 0));
-    if ((threadIdx.x & 63u) == 0 && nocc) atomicAdd(&stats->hiz_culled, nocc);
+    if ((threadIdx.x & 63u) == 0 && nocc) atomicAdd(&tally, nocc);
+    __syncthreads();
+    if (threadIdx.x == 0 && tally) atomicAdd(&stats->hiz_culled, tally);
 }
 
 // Exclusive scan of tile_count[0..n) into tile_offset[0..n] and of the per-tile chunk counts ceil(count / ZR_CHUNK)
@@ -452,12 +477,14 @@ __global__ __launch_bounds__(1024) void k_bin_fill(ZrPass P, const ZrObject* __r
         }
     }
     const uint32_t tx0 = r & 255u, ty0 = (r >> 8) & 255u, tx1 = (r >> 16) & 255u, ty1 = r >> 24;
-    if (r != ZR_RECT_CULLED)
+    if (r != ZR_RECT_CULLED) {
+        const float zt = tile_test_depth(Z, k);
         for (uint32_t ty = ty0; ty <= ty1; ++ty)
             for (uint32_t tx = tx0; tx <= tx1; ++tx) {
                 const uint32_t t = ty * P.tiles_x + tx;
-                if (t % P.tile_world == P.tile_rank) atomicAdd(&hist[t], 1u);
+                if (t % P.tile_world == P.tile_rank && !tile_hides(Z, zt, t)) atomicAdd(&hist[t], 1u);
             }
+    }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_tiles; i += 1024u) {
         const uint32_t c = hist[i];
@@ -474,10 +501,11 @@ __global__ __launch_bounds__(1024) void k_bin_fill(ZrPass P, const ZrObject* __r
         be.mpos = O->mpos + ml->VertexOffset; be.mtri = O->mtri + ml->BindlessContext; be.inst = O->inst + inst_i;
         be.counts = ml->VertexCount | ml->TriangleCount << 8 | (O->instanced ? 1u << 16 : 0u);
         be.prim_base = O->prim_base + inst_i * O->n_tris;
+        const float zt = tile_test_depth(Z, k);
         for (uint32_t ty = ty0; ty <= ty1; ++ty)
             for (uint32_t tx = tx0; tx <= tx1; ++tx) {
                 const uint32_t t = ty * P.tiles_x + tx;
-                if (t % P.tile_world != P.tile_rank) continue;
+                if (t % P.tile_world != P.tile_rank || tile_hides(Z, zt, t)) continue;
                 const uint32_t pos = atomicAdd(&hist[t], 1u);
                 if (pos < P.bin_capacity) bins[pos] = be;
             }
@@ -497,15 +525,27 @@ struct TileCtx {
 
 // Cheap per-triangle rejection, identical in effect to the early-outs of raster_sub: degenerate, back-facing
 // (GBUFFER only), or no pixel centre of this tile inside the snapped bounding box.
-template <int MODE>
-__device__ __forceinline__ bool tri_prefilter(int X0, int Y0, int X1, int Y1, int X2, int Y2, const TileCtx& T)
+// HIZ (camera pass, round 2): hz[] holds the tile's 4 x 4 pyramid texels (max depth per 8 x 8 pixel block after round 1); a
+// triangle whose least vertex depth lies behind every block its clipped box touches cannot win a pixel (fragment depths
+// are clamped to the vertex depths).
+template <int MODE, bool HIZ = false>
+__device__ __forceinline__ bool tri_prefilter(int X0, int Y0, int X1, int Y1, int X2, int Y2, const TileCtx& T,
+                                              float zmin = 0.0f, const float* __restrict__ hz = nullptr)
 {
     const long long A = (long long)(X1 - X0) * (Y2 - Y0) - (long long)(X2 - X0) * (Y1 - Y0);
     if (A == 0) return false;
     if (MODE == ZR_MODE_GBUFFER && A > 0) return false;
     const int x0 = max((imin3(X0, X1, X2) - 128 + 255) >> 8, T.px0), x1 = min((imax3(X0, X1, X2) - 128) >> 8, min(T.px0 + TILE - 1, T.W - 1));
     const int y0 = max((imin3(Y0, Y1, Y2) - 128 + 255) >> 8, T.py0), y1 = min((imax3(Y0, Y1, Y2) - 128) >> 8, min(T.py0 + TILE - 1, T.H - 1));
-    return x0 <= x1 && y0 <= y1;
+    if (!(x0 <= x1 && y0 <= y1)) return false;
+    if (HIZ) {
+        const int bx0 = (x0 - T.px0) >> 3, bx1 = (x1 - T.px0) >> 3, by0 = (y0 - T.py0) >> 3, by1 = (y1 - T.py0) >> 3;
+        float h = 0.0f;
+        for (int by = by0; by <= by1; ++by)
+            for (int bx = bx0; bx <= bx1; ++bx) h = __builtin_fmaxf(h, hz[by * (TILE / 8) + bx]);
+        if (zmin > h) return false;
+    }
+    return true;
 }
 
 template <int MODE>
@@ -878,13 +918,15 @@ __global__ void k_fill64(unsigned long long* __restrict__ p, unsigned long long 
 // the frame-sized key buffer in HBM with global atomic min (skipped when the resident key already wins).
 //   GBUFFER: vis64[W*H] (depth bits << 32 | prim), resolved later by k_resolve_gbuffer
 //   SHADOW : the shadow map itself (float bits as uint): the merge IS the LESS_OR_EQUAL depth write
-template <int MODE>
+template <int MODE, bool HIZ>
 __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs,
                                                        const uint32_t* __restrict__ tile_offset,
                                                        const uint32_t* __restrict__ chunk_offset,
                                                        const ZrBinEntry* __restrict__ bins, ZrDevStats* __restrict__ stats, int slot,
-                                                       unsigned long long* __restrict__ vis64, uint32_t* __restrict__ shadow_bits)
+                                                       unsigned long long* __restrict__ vis64, uint32_t* __restrict__ shadow_bits,
+                                                       const float* __restrict__ hiz0, uint32_t hiz0_w, uint32_t hiz0_h)
 {
+    __shared__ float hz[HIZ ? (TILE / 8) * (TILE / 8) : 1];
     __shared__ unsigned long long keys64[MODE == ZR_MODE_GBUFFER ? TILE_PIX : 1];
     __shared__ uint32_t keys32[MODE == ZR_MODE_SHADOW ? TILE_PIX : 1];
     __shared__ int4 vstage[RW][WAVE];
@@ -912,6 +954,13 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
         const uint32_t end = min(min(beg + ZR_CHUNK, tile_offset[tile + 1]), P.bin_capacity);
         TileCtx T;
         T.px0 = (int)(tile % P.tiles_x) * TILE; T.py0 = (int)(tile / P.tiles_x) * TILE; T.W = (int)P.W; T.H = (int)P.H;
+        if (HIZ) {      // this tile's finest pyramid texels (blocks past the target's edge hold no pixel: 0 = "hides everything")
+            if (tid < (TILE / 8) * (TILE / 8)) {
+                const uint32_t bx = (uint32_t)T.px0 / 8u + tid % (TILE / 8), by = (uint32_t)T.py0 / 8u + tid / (TILE / 8);
+                hz[tid] = (bx < hiz0_w && by < hiz0_h) ? hiz0[(size_t)by * hiz0_w + bx] : 0.0f;
+            }
+            __syncthreads();
+        }
 
         uint32_t qhead = 0, qn = 0;
         // The next entry's 32-byte record is fetched (vector loads, vmcnt-ordered) while the current one is processed; every
@@ -961,7 +1010,8 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
                     r0 = vstage[wv][i0]; r1 = vstage[wv][i1]; r2 = vstage[wv][i2];
                     const int cls = classify((uint32_t)r0.w, (uint32_t)r1.w, (uint32_t)r2.w);
                     if (cls == 1) {
-                        alive = tri_prefilter<MODE>(r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, T);
+                        const float tz = HIZ ? __builtin_fminf(__builtin_fminf(zr_u2f((uint32_t)r0.z), zr_u2f((uint32_t)r1.z)), zr_u2f((uint32_t)r2.z)) : 0.0f;
+                        alive = tri_prefilter<MODE, HIZ>(r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, T, tz, hz);
                     } else if (cls == 2) {
                         zf4 cc[3];
                         const uint32_t li[3] = { i0, i1, i2 };
@@ -1443,12 +1493,15 @@ void zr_launch_fill64(unsigned long long* p, unsigned long long v, size_t n, hip
 }
 void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint32_t* tile_offset, const uint32_t* chunk_offset,
                              const ZrBinEntry* bins, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t* shadow_bits,
-                             uint32_t n_blocks, hipStream_t s)
+                             uint32_t n_blocks, const ZrHiz& Z, hipStream_t s)
 {
-    if (P.mode == ZR_MODE_GBUFFER)
-        hipLaunchKernelGGL(k_raster_chunks<ZR_MODE_GBUFFER>, dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, tile_offset, chunk_offset, bins, stats, slot, vis64, shadow_bits);
+    const float* none = nullptr;
+    if (P.mode == ZR_MODE_GBUFFER && Z.phase == 2u)
+        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_GBUFFER, true>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, tile_offset, chunk_offset, bins, stats, slot, vis64, shadow_bits, (const float*)Z.lvl[0], Z.hw[0], Z.hh[0]);
+    else if (P.mode == ZR_MODE_GBUFFER)
+        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_GBUFFER, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, tile_offset, chunk_offset, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u);
     else
-        hipLaunchKernelGGL(k_raster_chunks<ZR_MODE_SHADOW>, dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, tile_offset, chunk_offset, bins, stats, slot, vis64, shadow_bits);
+        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, tile_offset, chunk_offset, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u);
 }
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, uint8_t* vis_now,

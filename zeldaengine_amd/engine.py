@@ -65,6 +65,7 @@ def lib():
         "zr_finish": [vp],
         "zr_get_pass_times": [vp, vp],
         "zr_get_pass_times_avg": [vp, u32, vp],
+        "zr_set_timing_interval": [vp, u32],
         "zr_get_stats": [vp, C.POINTER(abi.Stats)],
         "zr_read_color": [vp, vp, sz],
         "zr_read_gbuffer": [vp, C.c_int, vp, sz],
@@ -302,8 +303,12 @@ class Renderer:
     def finish(self):
         self._chk(self.L.zr_finish(self.h))
 
+    def set_timing_interval(self, interval):
+        """Record the per-pass hipEvents on every interval-th frame only (each record is a ~6 us bubble on the stream)."""
+        self._chk(self.L.zr_set_timing_interval(self.h, interval))
+
     def pass_times(self, last_n=1):
-        """Mean GPU milliseconds per pass over the last `last_n` (<= 64) frames."""
+        """Mean GPU milliseconds per pass over the last `last_n` (<= 64) timed frames."""
         ms = (C.c_float * len(abi.PASS_NAMES))()
         self._chk(self.L.zr_get_pass_times_avg(self.h, last_n, ms))
         return dict(zip(abi.PASS_NAMES, [float(x) for x in ms]))
