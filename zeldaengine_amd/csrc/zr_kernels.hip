@@ -134,10 +134,23 @@ __global__ void k_instance_prep(const XkInstanceData* __restrict__ in, ZrInstanc
 
 // ------------------------------------------------------------------------------------------------ cull + bin
 
-__device__ __forceinline__ int wave_min(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return v; }
-__device__ __forceinline__ int wave_max(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
-__device__ __forceinline__ uint32_t wave_or(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v |= (uint32_t)__shfl_xor((int)v, o); return v; }
-__device__ __forceinline__ uint32_t wave_and(uint32_t v) { for (int o = 32; o > 0; o >>= 1) v &= (uint32_t)__shfl_xor((int)v, o); return v; }
+// Wave-wide reductions on the DPP network (no LDS round trips): an inclusive scan over each row of 16 lanes (row_shr 1, 2, 4,
+// 8), then row_bcast15 / row_bcast31 fold the rows; lane 63 holds the result, which is broadcast through an SGPR.
+// `idn` is the operation's identity (what lanes without a source contribute).
+#define ZR_DPP_STEP(OP, ctrl, rmask) r = OP(r, __builtin_amdgcn_update_dpp(idn, r, ctrl, rmask, 0xF, false))
+#define ZR_WAVE_REDUCE(OP)                                                                 \
+    int r = v;                                                                              \
+    ZR_DPP_STEP(OP, 0x111, 0xF); ZR_DPP_STEP(OP, 0x112, 0xF); ZR_DPP_STEP(OP, 0x114, 0xF);   \
+    ZR_DPP_STEP(OP, 0x118, 0xF); ZR_DPP_STEP(OP, 0x142, 0xA); ZR_DPP_STEP(OP, 0x143, 0xC);   \
+    return __builtin_amdgcn_readlane(r, 63)
+__device__ __forceinline__ int op_min(int a, int b) { return min(a, b); }
+__device__ __forceinline__ int op_max(int a, int b) { return max(a, b); }
+__device__ __forceinline__ int op_or(int a, int b) { return a | b; }
+__device__ __forceinline__ int op_and(int a, int b) { return a & b; }
+__device__ __forceinline__ int wave_min(int v) { const int idn = 0x7FFFFFFF; ZR_WAVE_REDUCE(op_min); }
+__device__ __forceinline__ int wave_max(int v) { const int idn = (int)0x80000000; ZR_WAVE_REDUCE(op_max); }
+__device__ __forceinline__ uint32_t wave_or(uint32_t u) { const int idn = 0, v = (int)u; ZR_WAVE_REDUCE(op_or); }
+__device__ __forceinline__ uint32_t wave_and(uint32_t u) { const int idn = -1, v = (int)u; ZR_WAVE_REDUCE(op_and); }
 
 __device__ __forceinline__ int find_object_inst(const ZrObject* __restrict__ objs, int n, uint32_t g)
 {
@@ -188,82 +201,24 @@ __global__ __launch_bounds__(256) void k_cull_instances(ZrPass P, const ZrObject
     for (uint32_t m = 0; m < nm; ++m) work[off + m] = wbase + m;
 }
 
-// Level 2: one wavefront per surviving meshlet-instance (persistent waves stride over work[]).  Writes rects[k] (packed tile
-// rect or ZR_RECT_CULLED).  Every rejection here is exact or conservative:
-//   sphere-vs-frustum and the normal-cone test use inflated bounds;
-//   "all vertices outside one clip plane" and "snapped bbox holds no pixel centre" are exact.
-template <int MODE>
-__device__ __forceinline__ uint32_t cull_meshlet(const ZrPass& P, const ZrObject* __restrict__ objs, uint32_t w, uint32_t lane,
-                                                 uint2& pxrect, float& zmin)
-{
-    pxrect = make_uint2(0u, 0u); zmin = -1.0f;
-    const int oi = find_object_work(objs, (int)P.n_objects, w);
-    const ZrObject* __restrict__ O = objs + oi;
-    const uint32_t local = w - O->work_base;
-    const uint32_t nm = O->n_meshlets;
-    const uint32_t inst_i = local / nm, m = local - inst_i * nm;
-    const XkMeshlet ml = O->meshlets[m];
-    const ZrInstance I = O->inst[inst_i];
-    const bool instanced = O->instanced != 0;
-    // shadow-pass filters (already applied per instance when the work list is in use; repeated here for the direct path)
-    if (MODE == ZR_MODE_SHADOW && ((O->flags & ZR_OBJ_SKY) || inst_i % P.inst_world != P.inst_rank)) return ZR_RECT_CULLED;
-
-    if (P.frustum_ok | P.cone_ok) {
-        zf3 co = vs_position(zr3(ml.BoundsCenter[0], ml.BoundsCenter[1], ml.BoundsCenter[2]), I, instanced);
-        zf4 cw4 = zr_mat4_point(P.M, co);
-        zf3 cw = zr3(cw4.x, cw4.y, cw4.z);
-        float rw = ml.BoundsRadius * (instanced ? __builtin_fabsf(I.s) : 1.0f) * P.m_scale;
-        rw = __builtin_fmaf(rw, 1.001f, 1e-5f * (__builtin_fabsf(cw.x) + __builtin_fabsf(cw.y) + __builtin_fabsf(cw.z) + 1.0f));
-        bool culled = false;
-        if (P.frustum_ok) {
-            for (int k = 0; k < 6; ++k) {
-                float d = __builtin_fmaf(P.planes[k][0], cw.x, __builtin_fmaf(P.planes[k][1], cw.y,
-                          __builtin_fmaf(P.planes[k][2], cw.z, P.planes[k][3])));
-                if (d < -rw) culled = true;
-            }
-        }
-        if (MODE == ZR_MODE_GBUFFER && P.cone_ok && ml.ConeCutoff < 1.0f && (!instanced || I.s > 0.0f)) {
-            // meshoptimizer's bounding-sphere cone test, widened by ~1 degree (0.02 L): every triangle of the
-            // cluster is back-facing for this eye  <=  dot(c - eye, axis) >= cutoff*|c - eye| + radius
-            zf3 ax = zr3(ml.ConeAxis[0], ml.ConeAxis[1], ml.ConeAxis[2]);
-            if (instanced) ax = zr_rowvec_mat3(ax, I.R);
-            zf3 aw = zr3(__builtin_fmaf(P.M[8], ax.z, __builtin_fmaf(P.M[4], ax.y, P.M[0] * ax.x)),
-                         __builtin_fmaf(P.M[9], ax.z, __builtin_fmaf(P.M[5], ax.y, P.M[1] * ax.x)),
-                         __builtin_fmaf(P.M[10], ax.z, __builtin_fmaf(P.M[6], ax.y, P.M[2] * ax.x)));
-            zf3 d = cw - zr3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
-            float L = zr_length(d);
-            if (zr_dot(d, aw) >= __builtin_fmaf(ml.ConeCutoff + 0.02f, L, rw)) culled = true;
-        }
-        if (culled) return ZR_RECT_CULLED;
-    }
-
-    // lane-per-vertex transform, exactly as the rasteriser will redo it
-    uint32_t f_or = 0, f_and = 0xFFu;
-    int X0 = 0x7FFFFFFF, X1 = (int)0x80000000, Y0 = 0x7FFFFFFF, Y1 = (int)0x80000000;
-    int zb = 0x7FFFFFFF;           // least NDC depth over the vertices, as ordered int bits (depths here are >= 0)
-    if (lane < ml.VertexCount) {
-        const float4 pp = O->mpos[ml.VertexOffset + lane];
-        zf4 c = zr_mat4_point(P.PVM, vs_position(zr3(pp.x, pp.y, pp.z), I, instanced));
-        uint32_t f = vertex_flags(c);
-        f_or = f; f_and = f;
-        if (!(f & 129u)) { SV s = project(c, P.hw, P.hh); X0 = X1 = s.X; Y0 = Y1 = s.Y; zb = (int)zr_f2u(s.z + 0.0f); }
-    }
-    f_or = wave_or(f_or); f_and = wave_and(f_and);
-    if (!(f_or & 1u) && (f_and & 0x7Eu)) return ZR_RECT_CULLED;
-    int px0 = 0, py0 = 0, px1 = (int)P.W - 1, py1 = (int)P.H - 1;
-    if (!(f_or & 129u)) {
-        X0 = wave_min(X0); X1 = wave_max(X1); Y0 = wave_min(Y0); Y1 = wave_max(Y1);
-        px0 = max(px0, (X0 - 128 + 255) >> 8); px1 = min(px1, (X1 - 128) >> 8);
-        py0 = max(py0, (Y0 - 128 + 255) >> 8); py1 = min(py1, (Y1 - 128) >> 8);
-        if (px0 > px1 || py0 > py1) return ZR_RECT_CULLED;
-        if (MODE == ZR_MODE_GBUFFER) {      // unclipped meshlet (so every z >= 0): usable for the Hi-Z test
-            zmin = zr_u2f((uint32_t)wave_min(zb));
-            pxrect = make_uint2((uint32_t)px0 | (uint32_t)py0 << 16, (uint32_t)px1 | (uint32_t)py1 << 16);
-        }
-    }
-    const int tx0 = px0 / TILE, tx1 = px1 / TILE, ty0 = py0 / TILE, ty1 = py1 / TILE;
-    return (uint32_t)tx0 | (uint32_t)ty0 << 8 | (uint32_t)tx1 << 16 | (uint32_t)ty1 << 24;
-}
+// Level 2, in two stages inside one wavefront that owns ZR_CULL_GROUP consecutive work items (every rejection is exact or conservative:
+// sphere-vs-frustum and the normal-cone test use inflated bounds; "all vertices outside one clip plane"
+// and "snapped bounding box holds no pixel centre" are exact):
+//   A  lane per meshlet-instance: decode, load the meshlet record and the instance, shadow-pass filters, bounding sphere
+//      against the frustum, normal cone against the eye;
+//   B  wave per survivor, ZR_CULL_BATCH of them at a time: the batch's vertex loads are issued together, then each survivor
+//      gets the lane-per-vertex transform exactly as the rasteriser will redo it, its clip flags and its snapped bounding box.
+// A wave therefore waits for memory a few times per group instead of three times per meshlet.
+// Outputs per work item k: rects[k] (packed tile rect or ZR_RECT_CULLED) and, for the camera pass, the pixel box and the least
+// vertex depth the Hi-Z test uses (zmin < 0: not testable).
+#ifndef ZR_CULL_BATCH
+#define ZR_CULL_BATCH 2
+#endif
+#ifndef ZR_CULL_GROUP
+#define ZR_CULL_GROUP 8u                     // work items per wave (stage A uses that many lanes): enough waves to fill the chip
+#endif
+__device__ __forceinline__ float lane_bcast(float v, uint32_t src) { return zr_u2f((uint32_t)__builtin_amdgcn_readlane((int)zr_f2u(v), (int)src)); }
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
 
 template <int MODE, bool WORKLIST>
 __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
@@ -271,18 +226,119 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
                                               const ZrDevStats* __restrict__ stats, int slot)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    uint2 pr; float zm;
-    if (WORKLIST) {                 // persistent waves stride over the compacted list
-        const uint32_t n = stats->n_vis_work[slot], stride = gridDim.x * 4u;
-        for (uint32_t k = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6)); k < n; k += stride) {
-            const uint32_t r = cull_meshlet<MODE>(P, objs, wave_uniform(work[k]), lane, pr, zm);
-            if (lane == 0) { rects[k] = r; if (MODE == ZR_MODE_GBUFFER && pxrect) { pxrect[k] = pr; zmin[k] = zm; } }
+    const uint32_t n = WORKLIST ? stats->n_vis_work[slot] : P.n_work;
+    const uint32_t wave0 = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6)), n_waves = gridDim.x * 4u;
+    for (uint32_t base = wave0 * ZR_CULL_GROUP; base < n; base += n_waves * ZR_CULL_GROUP) {
+        const uint32_t k = base + lane;
+        // ---------------------------------------------------------------- stage A: lane per meshlet-instance
+        const bool mine = lane < ZR_CULL_GROUP && k < n;
+        bool alive = mine;
+        const float4* mposv = nullptr;              // first vertex of the meshlet in the flattened position array
+        uint32_t vcount = 0, instanced = 0;
+        ZrInstance I;
+        for (int i = 0; i < 9; ++i) I.R[i] = 0.0f;
+        I.t[0] = I.t[1] = I.t[2] = 0.0f; I.s = 1.0f;
+        if (alive) {
+            const uint32_t w = WORKLIST ? work[k] : k;
+            const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w);
+            const uint32_t local = w - O->work_base, nm = O->n_meshlets;
+            const uint32_t inst_i = local / nm, m = local - inst_i * nm;
+            const XkMeshlet* __restrict__ mlp = O->meshlets + m;
+            // the 64-byte record as aligned 16-byte words: [16] centre.xyz radius  [32] apex.xyz axis.x  [48] axis.yz cutoff
+            const float4* __restrict__ mq = (const float4*)mlp;
+            const float4 bs = mq[1], q2 = mq[2], q3 = mq[3];
+            const float4 cn = make_float4(q2.w, q3.x, q3.y, q3.z);      // axis.xyz, cutoff
+            mposv = O->mpos + mlp->VertexOffset; vcount = mlp->VertexCount;
+            I = O->inst[inst_i];
+            instanced = O->instanced != 0 ? 1u : 0u;
+            // the skydome is not a shadow caster (ZE:4709-4720); with N GPUs each draws every N-th instance (see k_cull_instances)
+            if (MODE == ZR_MODE_SHADOW && ((O->flags & ZR_OBJ_SKY) || inst_i % P.inst_world != P.inst_rank)) alive = false;
+            if (alive && (P.frustum_ok | P.cone_ok)) {
+                const zf3 co = vs_position(zr3(bs.x, bs.y, bs.z), I, instanced != 0);
+                const zf4 cw4 = zr_mat4_point(P.M, co);
+                const zf3 cw = zr3(cw4.x, cw4.y, cw4.z);
+                float rw = bs.w * (instanced ? __builtin_fabsf(I.s) : 1.0f) * P.m_scale;
+                rw = __builtin_fmaf(rw, 1.001f, 1e-5f * (__builtin_fabsf(cw.x) + __builtin_fabsf(cw.y) + __builtin_fabsf(cw.z) + 1.0f));
+                if (P.frustum_ok) {
+                    for (int q = 0; q < 6; ++q) {
+                        const float d = __builtin_fmaf(P.planes[q][0], cw.x, __builtin_fmaf(P.planes[q][1], cw.y,
+                                        __builtin_fmaf(P.planes[q][2], cw.z, P.planes[q][3])));
+                        if (d < -rw) alive = false;
+                    }
+                }
+                if (MODE == ZR_MODE_GBUFFER && P.cone_ok && cn.w < 1.0f && (!instanced || I.s > 0.0f)) {
+                    // meshoptimizer's bounding-sphere cone test, widened by ~1 degree (0.02 L): every triangle of the
+                    // cluster is back-facing for this eye  <=  dot(c - eye, axis) >= cutoff*|c - eye| + radius
+                    zf3 ax = zr3(cn.x, cn.y, cn.z);
+                    if (instanced) ax = zr_rowvec_mat3(ax, I.R);
+                    const zf3 aw = zr3(__builtin_fmaf(P.M[8], ax.z, __builtin_fmaf(P.M[4], ax.y, P.M[0] * ax.x)),
+                                       __builtin_fmaf(P.M[9], ax.z, __builtin_fmaf(P.M[5], ax.y, P.M[1] * ax.x)),
+                                       __builtin_fmaf(P.M[10], ax.z, __builtin_fmaf(P.M[6], ax.y, P.M[2] * ax.x)));
+                    const zf3 d = cw - zr3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+                    const float L = zr_length(d);
+                    if (zr_dot(d, aw) >= __builtin_fmaf(cn.w + 0.02f, L, rw)) alive = false;
+                }
+            }
         }
-    } else {                        // one wave per meshlet-instance, work item k = k
-        const uint32_t k = wave_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
-        if (k >= P.n_work) return;
-        const uint32_t r = cull_meshlet<MODE>(P, objs, k, lane, pr, zm);
-        if (lane == 0) { rects[k] = r; if (MODE == ZR_MODE_GBUFFER && pxrect) { pxrect[k] = pr; zmin[k] = zm; } }
+        uint32_t out_rect = ZR_RECT_CULLED; uint2 out_px = make_uint2(0u, 0u); float out_z = -1.0f;
+        const uint32_t mp_lo = (uint32_t)(unsigned long long)mposv, mp_hi = (uint32_t)((unsigned long long)mposv >> 32);
+
+        // ---------------------------------------------------------------- stage B: wave per survivor, batched
+        unsigned long long live = __ballot(alive);
+        while (live) {
+            uint32_t src[ZR_CULL_BATCH]; float4 pp[ZR_CULL_BATCH];
+#pragma unroll
+            for (int c = 0; c < ZR_CULL_BATCH; ++c) {
+                src[c] = 64u;
+                if (live) { src[c] = (uint32_t)__builtin_ctzll(live); live &= live - 1ull; }
+                pp[c] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+                if (src[c] < 64u) {
+                    const float4* __restrict__ mp = (const float4*)(((unsigned long long)lane_bcast(mp_hi, src[c]) << 32) | lane_bcast(mp_lo, src[c]));
+                    if (lane < lane_bcast(vcount, src[c])) pp[c] = mp[lane];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < ZR_CULL_BATCH; ++c) {
+                if (src[c] >= 64u) break;
+                ZrInstance J;
+                for (int i = 0; i < 9; ++i) J.R[i] = lane_bcast(I.R[i], src[c]);
+                J.t[0] = lane_bcast(I.t[0], src[c]); J.t[1] = lane_bcast(I.t[1], src[c]); J.t[2] = lane_bcast(I.t[2], src[c]);
+                J.s = lane_bcast(I.s, src[c]);
+                const bool inst = lane_bcast(instanced, src[c]) != 0u;
+                const uint32_t vc = lane_bcast(vcount, src[c]);
+                uint32_t f_or = 0, f_and = 0xFFu;
+                int X0 = 0x7FFFFFFF, X1 = (int)0x80000000, Y0 = 0x7FFFFFFF, Y1 = (int)0x80000000;
+                int zb = 0x7FFFFFFF;           // least NDC depth over the vertices, as ordered int bits (depths here are >= 0)
+                if (lane < vc) {
+                    const zf4 cl = zr_mat4_point(P.PVM, vs_position(zr3(pp[c].x, pp[c].y, pp[c].z), J, inst));
+                    const uint32_t f = vertex_flags(cl);
+                    f_or = f; f_and = f;
+                    if (!(f & 129u)) { const SV sv = project(cl, P.hw, P.hh); X0 = X1 = sv.X; Y0 = Y1 = sv.Y; zb = (int)zr_f2u(sv.z + 0.0f); }
+                }
+                f_or = wave_or(f_or); f_and = wave_and(f_and);
+                uint32_t r = ZR_RECT_CULLED; uint2 pr = make_uint2(0u, 0u); float zm = -1.0f;
+                if ((f_or & 1u) || !(f_and & 0x7Eu)) {
+                    int px0 = 0, py0 = 0, px1 = (int)P.W - 1, py1 = (int)P.H - 1;
+                    bool any = true;
+                    if (!(f_or & 129u)) {
+                        X0 = wave_min(X0); X1 = wave_max(X1); Y0 = wave_min(Y0); Y1 = wave_max(Y1);
+                        px0 = max(px0, (X0 - 128 + 255) >> 8); px1 = min(px1, (X1 - 128) >> 8);
+                        py0 = max(py0, (Y0 - 128 + 255) >> 8); py1 = min(py1, (Y1 - 128) >> 8);
+                        any = px0 <= px1 && py0 <= py1;
+                        if (any && MODE == ZR_MODE_GBUFFER) {      // unclipped meshlet (so every z >= 0): usable for the Hi-Z test
+                            zm = zr_u2f((uint32_t)wave_min(zb));
+                            pr = make_uint2((uint32_t)px0 | (uint32_t)py0 << 16, (uint32_t)px1 | (uint32_t)py1 << 16);
+                        }
+                    }
+                    if (any) r = (uint32_t)(px0 / TILE) | (uint32_t)(py0 / TILE) << 8 | (uint32_t)(px1 / TILE) << 16 | (uint32_t)(py1 / TILE) << 24;
+                }
+                if (lane == src[c]) { out_rect = r; out_px = pr; out_z = zm; }
+            }
+        }
+        if (mine) {
+            rects[k] = out_rect;
+            if (MODE == ZR_MODE_GBUFFER && pxrect) { pxrect[k] = out_px; zmin[k] = out_z; }
+        }
     }
 }
 
@@ -1445,7 +1501,8 @@ void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint3
 {
     if (P.n_work == 0) return;
     const dim3 gi((P.n_inst_total + 255) / 256), b(256);
-    const uint32_t all = (uint32_t)(((uint64_t)P.n_work + 3) / 4);
+    // one wave per ZR_CULL_GROUP work items; with the work list the count is only known on the device: a fixed grid strides over it
+    const uint32_t all = (uint32_t)(((uint64_t)P.n_work + 4u * ZR_CULL_GROUP - 1) / (4u * ZR_CULL_GROUP));
     const uint32_t blocks = P.use_worklist ? std::min<uint32_t>(all, std::max<uint32_t>(1u, n_waves / 4u)) : all;
     if (P.mode == ZR_MODE_GBUFFER) {
         if (P.use_worklist) {
