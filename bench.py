@@ -4,7 +4,8 @@
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 A step is one full frame of the hot path on synthetic, HBM-resident input:
-    meshlet cull+bin (shadow) -> shadow raster -> meshlet cull+bin (camera) -> tile raster + GBuffer write
+    meshlet cull+bin (shadow) -> shadow raster -> meshlet cull+bin (camera) -> tile raster of last frame's visible set
+    -> Hi-Z pyramid -> bin + tile raster of the rest (occlusion-tested) -> GBuffer write (resolve)
     -> deferred PBR + PCF lighting [-> RCCL all-gather of the packed RGBA8 tiles + untile, N > 1].
 N > 1 partitions the SAME frame by screen tiles (tile t is rendered by rank t % N), so scaling is "strong".
 value = W*H*steps / max-over-ranks(wall time of the K steps).
@@ -40,14 +41,16 @@ def algorithmic_bytes(stats, cfg, n_tiles_owned_px):
         "cull_shadow": 64 * stats["work_items"][0] + 4 * stats["survivors"][0],
         "shadow": geo * stats["survivors"][0] + 4 * SD * SD + 4 * stats["covered_shadow_texels"],
         "cull_camera": 64 * stats["work_items"][1] + 4 * stats["survivors"][1],
-        "gbuffer": geo * stats["survivors"][1] + 8 * stats["covered_pixels"],
+        "gbuffer": geo * stats["round1_survivors"] + 8 * stats["covered_pixels"] if stats["round1_survivors"] else
+                   geo * stats["survivors"][1] + 8 * stats["covered_pixels"],
+        "gbuffer2": geo * (stats["survivors"][1] - stats["round1_survivors"]) if stats["round1_survivors"] else 0,
         "resolve": 28 * n_tiles_owned_px + 28 * stats["covered_pixels"],
         "lighting": 28 * n_tiles_owned_px + 35068 + 4 * SD * SD,
     }
 
 
-KERNEL_OF_PASS = {"cull_shadow": "k_cull<SHADOW>+k_scan+k_bin_fill", "shadow": "k_raster<SHADOW>",
-                  "cull_camera": "k_cull<GBUFFER>+k_scan+k_bin_fill", "gbuffer": "k_raster<GBUFFER>",
+# passes that are ONE kernel launch (the roofline object is quoted on the longest of these); the cull / hiz passes are groups
+KERNEL_OF_PASS = {"shadow": "k_raster<SHADOW>", "gbuffer": "k_raster<GBUFFER>", "gbuffer2": "k_raster<GBUFFER,HiZ>",
                   "resolve": "k_resolve_gbuffer", "lighting": "k_lighting"}
 
 

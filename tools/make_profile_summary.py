@@ -19,17 +19,19 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-shutil.copy(glob.glob(stats_dir + "/*/*kernel_stats.csv")[0], os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"))
+shutil.copy(glob.glob(stats_dir + "/**/*kernel_stats.csv", recursive=True)[0], os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"))
 
 
 def short(name):
     n = name.split("(")[0].replace("void ", "").strip()
-    return {"k_raster_chunks<0>": "k_raster<GBUFFER>", "k_raster_chunks<1>": "k_raster<SHADOW>"}.get(n, n)
+    return {"k_raster_chunks<0, false>": "k_raster<GBUFFER>", "k_raster_chunks<0, true>": "k_raster<GBUFFER,HiZ>",
+            "k_raster_chunks<1, false>": "k_raster<SHADOW>", "k_cull<0, false>": "k_cull<GBUFFER>", "k_cull<1, false>": "k_cull<SHADOW>",
+            "k_cull<0, true>": "k_cull<GBUFFER,worklist>", "k_cull<1, true>": "k_cull<SHADOW,worklist>"}.get(n, n)
 
 
 def mean_counter(d, counter):
     acc = defaultdict(list)
-    for f in glob.glob(d + "/*/*counter_collection.csv"):
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
@@ -43,7 +45,5 @@ for k in sorted(set(fetch) | set(write)):
               "hbm_bytes_per_launch": int((2 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024)}
 json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_pmc.json"), "w"), indent=1)
 traffic = {k: v["hbm_bytes_per_launch"] for k, v in out.items()}
-traffic["k_cull<SHADOW>+k_scan+k_bin_fill"] = sum(traffic.get(k, 0) for k in ("k_cull<1>", "k_bin_count", "k_scan", "k_bin_fill"))
-traffic["k_cull<GBUFFER>+k_scan+k_bin_fill"] = sum(traffic.get(k, 0) for k in ("k_cull<0>", "k_bin_count", "k_scan", "k_bin_fill"))
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -57,7 +57,7 @@ class Stats(C.Structure):
                 ("round1_survivors", C.c_uint64)]
 
 
-PASS_NAMES = ["cull_shadow", "shadow", "cull_camera", "gbuffer", "resolve", "lighting", "composite", "total"]
+PASS_NAMES = ["cull_shadow", "shadow", "cull_camera", "gbuffer", "hiz", "gbuffer2", "resolve", "lighting", "composite", "total"]
 GBUFFER_DTYPES = [np.dtype("<f4"), np.dtype("<u4"), np.dtype("<u4"), np.dtype("<u4"), np.dtype("<u4"), np.dtype("<u8")]
 
 FLAG_NO_FRUSTUM_CULL = 1

@@ -94,12 +94,12 @@ struct zr_ctx {
     float lut[256]; float* d_lut = nullptr;
     float* d_unorm_lut = nullptr;        // [0..255] = c / 255, [256..1279] = c / 1023 (IEEE quotients, computed on the host)
 
-    static constexpr int EV_RING = 64;     // per-pass hipEvents of the last EV_RING frames (bench averages over them)
+    static constexpr int EV_RING = 64;     // per-pass hipEvents of the last EV_RING timed frames (bench averages over them)
     // skydome + background passes (ZE:2657-2744, 3681-3699)
     ZrMesh sky_mesh; ZrSceneObject sky_obj; bool sky_set = false, sky_enabled = true;
     uint8_t* d_bg = nullptr; uint32_t bg_w = 0, bg_h = 0, bg_levels = 0; bool bg_set = false, bg_enabled = true;
 
-    hipEvent_t evr[EV_RING][7] = {}; uint64_t frame_no = 0; bool rendered = false;
+    hipEvent_t evr[EV_RING][9] = {}; uint64_t frame_no = 0; bool rendered = false;
     uint32_t timing_interval = 1; bool timing_now = true; uint64_t sample_no = 0;    // pass events every interval-th frame
 
     // world + livelink

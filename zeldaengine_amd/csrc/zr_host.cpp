@@ -852,21 +852,24 @@ extern "C" int zr_render_gbuffer(zr_ctx* c)
     if (c->last_two_round) {
         Z.phase = 1;
         bin_and_raster(c, P, Z, 1, c->n_tiles);
-        if (ev) HIPCHK(c, hipEventRecord(ev[3], s));        // cull_camera ends where the first raster starts
+        if (ev) HIPCHK(c, hipEventRecord(ev[3], s));
         raster(c, P, Z, 1);
+        if (ev) HIPCHK(c, hipEventRecord(ev[4], s));
         zr_launch_hiz_build(c->d_vis, c->W, c->H, Z, s);
         Z.phase = 2;
         bin_and_raster(c, P, Z, 2, c->n_tiles);
+        if (ev) HIPCHK(c, hipEventRecord(ev[5], s));
         raster(c, P, Z, 2);
     } else {
         bin_and_raster(c, P, Z, 1, c->n_tiles);
         if (ev) HIPCHK(c, hipEventRecord(ev[3], s));
         raster(c, P, Z, 1);
+        if (ev) { HIPCHK(c, hipEventRecord(ev[4], s)); HIPCHK(c, hipEventRecord(ev[5], s)); }
     }
-    if (ev) HIPCHK(c, hipEventRecord(ev[4], s));
+    if (ev) HIPCHK(c, hipEventRecord(ev[6], s));
     zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_lut, Z.vis_now, c->d_stats, s);
+    if (ev) HIPCHK(c, hipEventRecord(ev[7], s));
     if (hiz_on) { c->vis_history = true; c->vis_cur ^= 1; } else c->vis_history = false;
-    if (ev) HIPCHK(c, hipEventRecord(ev[5], s));
     HIPCHK(c, hipGetLastError());
     c->stage = 2;
     return ZR_OK;
@@ -890,7 +893,7 @@ extern "C" int zr_render_lighting(zr_ctx* c)
     L.bg.data = c->d_bg; L.bg.w = c->bg_w; L.bg.h = c->bg_h; L.bg.levels = c->bg_levels; L.bg._pad = 0;
     zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, shadow_buf(c), c->cube, c->d_lut, c->d_unorm_lut,
                        L.packed_out ? (c->d_tiles_ext ? c->d_tiles_ext : c->d_tiles) : c->d_color, s);
-    if (ev) HIPCHK(c, hipEventRecord(ev[6], s));
+    if (ev) HIPCHK(c, hipEventRecord(ev[8], s));
     HIPCHK(c, hipGetLastError());
     if (c->timing_now) c->sample_no++;
     c->rendered = true; c->frame_no++; c->stage = 0;
@@ -957,9 +960,11 @@ extern "C" int zr_get_pass_times_avg(zr_ctx* c, uint32_t last_n, float ms[ZR_PAS
         (void)hipEventElapsedTime(&t[ZR_PASS_SHADOW], ev[1], ev[2]);
         (void)hipEventElapsedTime(&t[ZR_PASS_CULL_CAMERA], ev[2], ev[3]);
         (void)hipEventElapsedTime(&t[ZR_PASS_GBUFFER], ev[3], ev[4]);
-        (void)hipEventElapsedTime(&t[ZR_PASS_RESOLVE], ev[4], ev[5]);
-        (void)hipEventElapsedTime(&t[ZR_PASS_LIGHTING], ev[5], ev[6]);
-        (void)hipEventElapsedTime(&t[ZR_PASS_TOTAL], ev[0], ev[6]);
+        (void)hipEventElapsedTime(&t[ZR_PASS_HIZ], ev[4], ev[5]);
+        (void)hipEventElapsedTime(&t[ZR_PASS_GBUFFER2], ev[5], ev[6]);
+        (void)hipEventElapsedTime(&t[ZR_PASS_RESOLVE], ev[6], ev[7]);
+        (void)hipEventElapsedTime(&t[ZR_PASS_LIGHTING], ev[7], ev[8]);
+        (void)hipEventElapsedTime(&t[ZR_PASS_TOTAL], ev[0], ev[8]);
         for (int i = 0; i < ZR_PASS_COUNT; ++i) acc[i] += t[i];
     }
     for (int i = 0; i < ZR_PASS_COUNT; ++i) ms[i] = (float)(acc[i] / last_n);
