@@ -910,6 +910,110 @@ static float zo_shadow_tap(const zo_ctx* c, float sx, float sy, float sz, float 
     return f;
 }
 
+/* ------------------------------------------------------------------ GBufferVis, BaseLighting.frag:42-145 (SPEC_CONSTANTS 9)
+ *
+ * The lighting quad samples every GBuffer target again at UV = fragTexCoord * 3 / (1 - EmptyRatio) through the LINEAR / REPEAT
+ * samplers of ZE:2811-2847 and shows a 3 x 3 mosaic; the centre cell and everything outside the cells keep FinalColor.
+ * Choice made here (Vulkan leaves the weight precision to the implementation): the bilinear weights are snapped to 8 fractional
+ * bits, as sampling hardware does; with EmptyRatio = 0 every sample then lands exactly on texel (3x + 1, 3y + 1) mod (W, H).
+ */
+typedef struct { float sc[4], a[4], b[4], c[4], d[4]; } zo_gtexel;
+
+static void zo_gbuffer_texel(const zo_ctx* c, int x, int y, zo_gtexel* t)
+{
+    size_t p = (size_t)y * c->W + (size_t)x;
+    uint32_t sc = c->scene_color[p], A = c->gA[p], B = c->gB[p], C = c->gC[p]; uint64_t D = c->gD[p];
+    for (int k = 0; k < 4; ++k) {
+        t->sc[k] = (float)((sc >> (8 * k)) & 255u) / 255.0f;
+        t->b[k] = (float)((B >> (8 * k)) & 255u) / 255.0f;
+        t->c[k] = (float)((C >> (8 * k)) & 255u) / 255.0f;
+        t->d[k] = zo_f16_to_f32((uint16_t)(D >> (16 * k)));
+    }
+    /* A2R10G10B10_UNORM_PACK32: r = bits 20-29, g = 10-19, b = 0-9, a = 30-31 */
+    t->a[0] = (float)((A >> 20) & 1023u) / 1023.0f; t->a[1] = (float)((A >> 10) & 1023u) / 1023.0f;
+    t->a[2] = (float)(A & 1023u) / 1023.0f; t->a[3] = (float)(A >> 30) / 3.0f;
+}
+
+static int zo_wrap(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+
+static void zo_gbuffer_sample(const zo_ctx* c, float u, float v, zo_gtexel* out)
+{
+    float x = fmaf(u, (float)c->W, -0.5f), y = fmaf(v, (float)c->H, -0.5f);
+    if (!(fabsf(x) < 1.0e9f)) x = 0.0f;
+    if (!(fabsf(y) < 1.0e9f)) y = 0.0f;
+    float fx = floorf(x), fy = floorf(y);
+    float ax = floorf(fmaf(x - fx, 256.0f, 0.5f)) / 256.0f, ay = floorf(fmaf(y - fy, 256.0f, 0.5f)) / 256.0f;
+    int x0 = zo_wrap((int)fx, (int)c->W), x1 = zo_wrap((int)fx + 1, (int)c->W);
+    int y0 = zo_wrap((int)fy, (int)c->H), y1 = zo_wrap((int)fy + 1, (int)c->H);
+    zo_gtexel t00, t10, t01, t11;
+    zo_gbuffer_texel(c, x0, y0, &t00); zo_gbuffer_texel(c, x1, y0, &t10);
+    zo_gbuffer_texel(c, x0, y1, &t01); zo_gbuffer_texel(c, x1, y1, &t11);
+    const float* s00 = t00.sc; const float* s10 = t10.sc; const float* s01 = t01.sc; const float* s11 = t11.sc;
+    float* o = out->sc;
+    for (int k = 0; k < 20; ++k) {          /* the five vec4s are contiguous */
+        float top = fmaf(ax, s10[k] - s00[k], s00[k]), bot = fmaf(ax, s11[k] - s01[k], s01[k]);
+        o[k] = fmaf(ay, bot - top, top);
+    }
+}
+
+static float zo_pcf(const zo_ctx* c, const float* SB, zo_v3 P, float dxy)
+{
+    zo_v4 s4 = zo_mat4_point(SB, P);
+    float sx = s4.x / s4.w, sy = s4.y / s4.w, sz = s4.z / s4.w, sw = s4.w / s4.w;
+    float sum = 0.0f;
+    for (int x = -2; x <= 2; ++x) for (int y = -2; y <= 2; ++y)               /* ComputePCF r=2, :323-342 */
+        sum += zo_shadow_tap(c, sx, sy, sz, sw, dxy * (float)x, dxy * (float)y);
+    return sum / 25.0f;
+}
+
+static zo_v3 zo_gbuffer_vis(const zo_ctx* c, uint32_t px, uint32_t py, zo_v3 FinalColor, const float* SB, zo_v3 cam, float dxy)
+{
+    const XkView* V = &c->view;
+    float ERx = V->ViewportInfo[2] / V->ViewportInfo[0], ERy = V->ViewportInfo[3] / V->ViewportInfo[1];
+    float tx = ((float)px + 0.5f) / (float)c->W, ty = ((float)py + 0.5f) / (float)c->H;       /* fragTexCoord */
+    float UVx = (tx * 3.0f) / (1.0f - ERx), UVy = (ty * 3.0f) / (1.0f - ERy);
+    float Sx = (1.0f - ERx) / 3.0f, Sy = (1.0f - ERy) / 3.0f;                                   /* Step */
+    int cell = -1; float bx = 0.0f, by = 0.0f;      /* which branch of :74-143, and its white-border thresholds */
+    if (tx < Sx && ty < Sy) { cell = 0; bx = 1.0f; by = 1.0f; }
+    else if (tx < Sx * 2.0f && ty < Sy) { cell = 1; bx = 2.0f; by = 1.0f; }
+    else if (tx < Sx * 3.0f && ty < Sy) { cell = 2; bx = 3.0f; by = 1.0f; }
+    else if (tx < Sx && ty < Sy * 2.0f) { cell = 3; bx = 1.0f; by = 2.0f; }
+    else if (tx < 1.0f && ty < Sy * 2.0f && tx > Sx * 2.0f) { cell = 4; bx = 3.0f; by = 2.0f; }
+    else if (tx < Sx && ty < Sx * 3.0f) { cell = 5; bx = 1.0f; by = 3.0f; }                     /* Step.x * 3 is the shader's own */
+    else if (tx < Sx * 2.0f && tx > Sx && ty < Sy * 3.0f && ty > Sy * 2.0f) { cell = 6; bx = 2.0f; by = 3.0f; }
+    else if (tx < Sx * 3.0f && tx > Sx * 2.0f && ty < Sy * 3.0f && ty > Sy * 2.0f) { cell = 7; bx = 3.0f; by = 3.0f; }
+    if (cell < 0) return FinalColor;
+    if (tx > Sx * (bx - ERx) || ty > Sy * (by - ERy)) return zo_v3make(1.0f, 1.0f, 1.0f);
+    zo_gtexel g; zo_gbuffer_sample(c, UVx, UVy, &g);
+    zo_v3 BaseColor = zo_v3make(g.c[0], g.c[1], g.c[2]);
+    float Metallic = zo_saturate(g.b[0]);
+    float Roughness = fmaxf(0.01f, zo_saturate(g.b[2]));
+    zo_v3 Normal = zo_v3make(fmaf(g.a[0], 2.0f, -1.0f), fmaf(g.a[1], 2.0f, -1.0f), fmaf(g.a[2], 2.0f, -1.0f));
+    float AO = zo_saturate(g.c[3]);
+    zo_v3 N = zo_normalize(Normal);
+    zo_v3 P = zo_v3make(g.d[0], g.d[1], g.d[2]);
+    switch (cell) {
+    case 0: return zo_v3make(zo_powf(BaseColor.x, 0.4545f), zo_powf(BaseColor.y, 0.4545f), zo_powf(BaseColor.z, 0.4545f));
+    case 1: return zo_v3make(Metallic, Metallic, Metallic);
+    case 2: return zo_v3make(Roughness, Roughness, Roughness);
+    case 3: return N;
+    case 4: return zo_v3make(AO, AO, AO);
+    case 5: return zo_v3make(0.0f, 0.0f, 0.0f);
+    case 6: {
+        zo_v3 Vv = zo_normalize(zo_sub(cam, P));
+        zo_v3 Nn = zo_normalize(N);
+        float eta = 1.00f / 1.52f;
+        float dNI = zo_dot(Nn, Vv);
+        float kk = fmaf(-(eta * eta), fmaf(-dNI, dNI, 1.0f), 1.0f);
+        zo_v3 R;
+        if (kk < 0.0f) R = zo_v3make(0, 0, 0);
+        else { float q = fmaf(eta, dNI, sqrtf(kk)); R = zo_v3make(fmaf(eta, Vv.x, -(q * Nn.x)), fmaf(eta, Vv.y, -(q * Nn.y)), fmaf(eta, Vv.z, -(q * Nn.z))); }
+        return zo_scale(zo_cube_sample(c, R, 0.0f), 10.0f);
+    }
+    default: { float sf = zo_pcf(c, SB, P, dxy); return zo_v3make(sf, sf, sf); }
+    }
+}
+
 static void zo_lighting(zo_ctx* c, uint32_t debug_view)
 {
     const XkView* V = &c->view;
@@ -938,12 +1042,7 @@ static void zo_lighting(zo_ctx* c, uint32_t debug_view)
         zo_v3 Vv = zo_normalize(zo_sub(cam, P));
         float NdotV = zo_saturate(zo_dot(N, Vv));
 
-        zo_v4 s4 = zo_mat4_point(SB, P);
-        float sx = s4.x / s4.w, sy = s4.y / s4.w, sz = s4.z / s4.w, sw = s4.w / s4.w;
-        float sum = 0.0f;
-        for (int x = -2; x <= 2; ++x) for (int y = -2; y <= 2; ++y)               /* ComputePCF r=2, :323-342 */
-            sum += zo_shadow_tap(c, sx, sy, sz, sw, dxy * (float)x, dxy * (float)y);
-        float ShadowFactor = sum / 25.0f;
+        float ShadowFactor = zo_pcf(c, SB, P, dxy);
 
         zo_v3 Direct = zo_v3make(0, 0, 0);
         zo_v3 Nn = zo_normalize(N);                  /* Apply*Light and refract() re-normalise N */
@@ -1020,7 +1119,8 @@ static void zo_lighting(zo_ctx* c, uint32_t debug_view)
             out = v >= u ? zo_v3make(1.0f - v, u, v - u) : zo_v3make(1.0f - u, v, u - v);
             break;
         }
-        default: out = zo_scale(Final, ShadowFactor); break;   /* 9 (GBufferVis mosaic) is not restated: DESIGN.md */
+        case 9: out = zo_gbuffer_vis(c, px, py, Final, SB, cam, dxy); break;
+        default: out = zo_scale(Final, ShadowFactor); break;
         }
         uint8_t* o = c->color + p * 4;
         o[0] = (uint8_t)zo_unorm(out.x, 255.0f); o[1] = (uint8_t)zo_unorm(out.y, 255.0f);

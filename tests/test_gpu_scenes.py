@@ -121,6 +121,35 @@ def test_debug_views(oracle_lib, gpu_engine, view):
     assert np.array_equal(o.color(), g.color())
 
 
+def test_debug_view_9_gbuffer_mosaic(oracle_lib, gpu_engine):
+    """SPEC_CONSTANTS 9 (BaseLighting.frag:42-145): 3x3 mosaic of the GBuffer re-sampled at 3x the texture coordinate."""
+    W, H = 192, 129          # 192 = 3 * 64: the cell borders fall on pixel edges; 129 = 3 * 43
+    o, g = _both(oracle_lib, gpu_engine, W, H, 128, _mixed_scene, _std_frame(), debug_view=9)
+    mosaic = g.color()
+    assert np.array_equal(o.color(), mosaic)
+    # the centre cell keeps the lit frame, the bottom-left one is black, the top-left one is the gamma-encoded base colour
+    o0, g0 = _both(oracle_lib, gpu_engine, W, H, 128, _mixed_scene, _std_frame(), debug_view=0)
+    lit = g0.color()
+    assert np.array_equal(mosaic[43:86, 64:128], lit[43:86, 64:128])
+    assert (mosaic[86:, :64, :3] == 0).all()
+    o1, g1 = _both(oracle_lib, gpu_engine, W, H, 128, _mixed_scene, _std_frame(), debug_view=1)
+    assert np.array_equal(mosaic[:43, :64], g1.color()[1::3, 1::3][:43, :64])      # texel (3x + 1, 3y + 1)
+
+
+def test_debug_view_9_with_editor_bars(oracle_lib, gpu_engine):
+    """ViewportInfo.zw = the space ImGui's right / bottom bars take (ZE:4636): cells shrink, samples fall between texels
+    (LINEAR filtering) and the cells get their white frames."""
+    def frame(r):
+        _std_frame()(r)
+        cam, sh, view = r.get_frame()
+        view["ViewportInfo"][2] = 37.0
+        view["ViewportInfo"][3] = 21.0
+        r.set_frame(cam, sh, view)
+    o, g = _both(oracle_lib, gpu_engine, 200, 120, 64, _mixed_scene, frame, debug_view=9)
+    assert np.array_equal(o.color(), g.color())
+    assert (g.color()[..., :3] == 255).all(axis=2).sum() > 100            # the white frames exist
+
+
 def test_skydome_and_background_passes(oracle_lib, gpu_engine):
     """N3: skydome mesh (unlit, depth LESS vs the deferred depth) + background quad at z = 1 (LESS_OR_EQUAL), view 0 only."""
     bg = scenes.synthetic_sky_image(90, 60)[:, ::-1].copy()

@@ -161,3 +161,27 @@ def test_oracle_frame_is_stable(oracle_lib):
     if not os.path.exists(path):
         pytest.fail("golden hash missing; generate with tests/golden/make_golden_oracle.py: %s" % h)
     assert open(path).read().strip() == h
+
+
+def test_debug_view_9_is_a_mosaic_of_the_other_views(oracle_lib):
+    """GBufferVis (BaseLighting.frag:42-145) with no editor bars: cell (i, j) shows texel (3x + 1, 3y + 1) of one GBuffer
+    quantity, the centre cell keeps the lit frame, the bottom-left cell is black."""
+    W, H = 96, 66
+    cfg = scenes.config3(40, W, H)
+    o = oracle_lib.Oracle(W, H, 128)
+    oracle_lib.load_scene(o, cfg)
+    views = {}
+    for v in (0, 1, 2, 3, 5, 8, 9):
+        o.render(v)
+        views[v] = o.color()
+    m, cw, ch = views[9], W // 3, H // 3
+
+    def sub(img):            # what a cell shows: every third texel starting at 1, wrapped
+        return img[1::3, 1::3]
+    assert np.array_equal(m[:ch, :cw], sub(views[1])[:ch, :cw])                       # base colour
+    assert np.array_equal(m[:ch, cw:2 * cw], sub(views[2])[:ch, :cw])                 # metallic
+    assert np.array_equal(m[:ch, 2 * cw:], sub(views[3])[:ch, :cw])                   # roughness
+    assert np.array_equal(m[ch:2 * ch, 2 * cw:], sub(views[5])[:ch, :cw])             # ambient occlusion
+    assert np.array_equal(m[ch:2 * ch, cw:2 * cw], views[0][ch:2 * ch, cw:2 * cw])    # centre: FinalColor
+    assert (m[2 * ch:, :cw, :3] == 0).all()
+    assert np.array_equal(m[2 * ch:, 2 * cw:], sub(views[8])[:ch, :cw])               # shadow factor

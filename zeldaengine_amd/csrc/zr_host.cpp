@@ -801,6 +801,8 @@ extern "C" int zr_render_shadow(zr_ctx* c)
     if (!c) return ZR_ERR_ARG;
     if (!c->frame_valid) return zr_fail(c, ZR_ERR_STATE, "no frame uniforms: call zr_update_uniforms or zr_set_frame first");
     if (c->stage != 0) return zr_fail(c, ZR_ERR_STATE, "zr_render_shadow out of order");
+    if (c->debug_view == 9u && c->cfg.tile_world > 1u)
+        return zr_fail(c, ZR_ERR_STATE, "debug view 9 (GBufferVis) re-samples the whole GBuffer: not available on a tile-partitioned context");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = finalize_scene(c);
     if (rc) return rc;
@@ -893,6 +895,8 @@ extern "C" int zr_render_lighting(zr_ctx* c)
     L.bg.data = c->d_bg; L.bg.w = c->bg_w; L.bg.h = c->bg_h; L.bg.levels = c->bg_levels; L.bg._pad = 0;
     zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, shadow_buf(c), c->cube, c->d_lut, c->d_unorm_lut,
                        L.packed_out ? (c->d_tiles_ext ? c->d_tiles_ext : c->d_tiles) : c->d_color, s);
+    if (c->debug_view == 9u)        // GBufferVis mosaic over the lit frame (needs the whole GBuffer: single-rank contexts only)
+        zr_launch_gbuffer_vis(L, c->d_view, c->G, shadow_buf(c), c->cube, c->d_lut, c->d_color, s);
     if (ev) HIPCHK(c, hipEventRecord(ev[8], s));
     HIPCHK(c, hipGetLastError());
     if (c->timing_now) c->sample_no++;

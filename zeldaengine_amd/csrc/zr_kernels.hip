@@ -1450,6 +1450,7 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
         case 5: o = zr3(AO, AO, AO); break;
         case 7: o = RefC; break;
         case 8: o = zr3(ShadowFactor, ShadowFactor, ShadowFactor); break;
+        case 9: o = Final; break;       // GBufferVis: k_gbuffer_vis then overwrites the eight mosaic cells
         case 6: {   // fragColor of the full-screen quad: Background.vert:10-17 vertex colours over its two triangles
             const float u = ((float)px + 0.5f) / (float)L.W, v = ((float)py + 0.5f) / (float)L.H;
             o = v >= u ? zr3(1.0f - v, u, v - u) : zr3(1.0f - u, v, u - v);
@@ -1472,6 +1473,115 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
         if (L.packed_out) out[(size_t)blockIdx.x * TILE_PIX + i] = rgba;
         else out[p] = rgba;
     }
+}
+
+// GBufferVis (SH/BaseLighting.frag:42-145, SPEC_CONSTANTS 9).  Runs after k_lighting has written FinalColor everywhere: the
+// lighting quad samples every GBuffer target again at UV = fragTexCoord * 3 / (1 - EmptyRatio) through LINEAR / REPEAT samplers
+// (ZE:2811-2847) and shows a 3 x 3 mosaic; the centre cell and whatever lies outside the cells keep FinalColor.  Bilinear
+// weights are snapped to 8 fractional bits (a stated choice, like sampling hardware): with EmptyRatio = 0 every sample is
+// exactly texel (3x + 1, 3y + 1) mod (W, H).
+struct GTexel { float v[20]; };     // SceneColor, GBufferA, B, C, D as five vec4
+__device__ __forceinline__ GTexel gbuffer_texel(const GBufferPtrs& G, uint32_t W, int x, int y)
+{
+    const size_t p = (size_t)y * W + (size_t)x;
+    const uint32_t sc = G.scene_color[p], A = G.gA[p], B = G.gB[p], C = G.gC[p];
+    const uint2 D = G.gD[p];
+    GTexel t;
+    for (int k = 0; k < 4; ++k) {
+        t.v[k] = (float)((sc >> (8 * k)) & 255u) / 255.0f;
+        t.v[8 + k] = (float)((B >> (8 * k)) & 255u) / 255.0f;
+        t.v[12 + k] = (float)((C >> (8 * k)) & 255u) / 255.0f;
+    }
+    t.v[4] = (float)((A >> 20) & 1023u) / 1023.0f; t.v[5] = (float)((A >> 10) & 1023u) / 1023.0f;
+    t.v[6] = (float)(A & 1023u) / 1023.0f; t.v[7] = (float)(A >> 30) / 3.0f;
+    t.v[16] = zr_f16_to_f32(D.x & 0xFFFFu); t.v[17] = zr_f16_to_f32(D.x >> 16);
+    t.v[18] = zr_f16_to_f32(D.y & 0xFFFFu); t.v[19] = zr_f16_to_f32(D.y >> 16);
+    return t;
+}
+__device__ __forceinline__ int wrap_index(int i, int n) { const int m = i % n; return m < 0 ? m + n : m; }
+
+__global__ __launch_bounds__(256) void k_gbuffer_vis(ZrLightParams L, const XkView* __restrict__ view, GBufferPtrs G,
+                                                     const float* __restrict__ shadowmap, CubeDesc C,
+                                                     const float* __restrict__ srgb_lut, uint32_t* __restrict__ out)
+{
+    const uint32_t px = blockIdx.x * 16u + (threadIdx.x & 15u), py = blockIdx.y * 16u + (threadIdx.x >> 4);
+    if (px >= L.W || py >= L.H) return;
+    const float ERx = view->ViewportInfo[2] / view->ViewportInfo[0], ERy = view->ViewportInfo[3] / view->ViewportInfo[1];
+    const float tx = ((float)px + 0.5f) / (float)L.W, ty = ((float)py + 0.5f) / (float)L.H;        // fragTexCoord
+    const float UVx = (tx * 3.0f) / (1.0f - ERx), UVy = (ty * 3.0f) / (1.0f - ERy);
+    const float Sx = (1.0f - ERx) / 3.0f, Sy = (1.0f - ERy) / 3.0f;                                 // Step
+    int cell = -1; float bx = 0.0f, by = 0.0f;
+    if (tx < Sx && ty < Sy) { cell = 0; bx = 1.0f; by = 1.0f; }
+    else if (tx < Sx * 2.0f && ty < Sy) { cell = 1; bx = 2.0f; by = 1.0f; }
+    else if (tx < Sx * 3.0f && ty < Sy) { cell = 2; bx = 3.0f; by = 1.0f; }
+    else if (tx < Sx && ty < Sy * 2.0f) { cell = 3; bx = 1.0f; by = 2.0f; }
+    else if (tx < 1.0f && ty < Sy * 2.0f && tx > Sx * 2.0f) { cell = 4; bx = 3.0f; by = 2.0f; }
+    else if (tx < Sx && ty < Sx * 3.0f) { cell = 5; bx = 1.0f; by = 3.0f; }                         // Step.x * 3: as the shader has it
+    else if (tx < Sx * 2.0f && tx > Sx && ty < Sy * 3.0f && ty > Sy * 2.0f) { cell = 6; bx = 2.0f; by = 3.0f; }
+    else if (tx < Sx * 3.0f && tx > Sx * 2.0f && ty < Sy * 3.0f && ty > Sy * 2.0f) { cell = 7; bx = 3.0f; by = 3.0f; }
+    if (cell < 0) return;                                                                           // FinalColor stays
+    zf3 o;
+    if (tx > Sx * (bx - ERx) || ty > Sy * (by - ERy)) o = zr3(1.0f, 1.0f, 1.0f);                      // the cells' white frames
+    else {
+        // texture(sampler2D, UV): one mip level, LINEAR, REPEAT
+        float x = __builtin_fmaf(UVx, (float)L.W, -0.5f), y = __builtin_fmaf(UVy, (float)L.H, -0.5f);
+        if (!(__builtin_fabsf(x) < 1.0e9f)) x = 0.0f;
+        if (!(__builtin_fabsf(y) < 1.0e9f)) y = 0.0f;
+        const float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
+        const float ax = __builtin_floorf(__builtin_fmaf(x - fx, 256.0f, 0.5f)) / 256.0f;
+        const float ay = __builtin_floorf(__builtin_fmaf(y - fy, 256.0f, 0.5f)) / 256.0f;
+        const int x0 = wrap_index((int)fx, (int)L.W), x1 = wrap_index((int)fx + 1, (int)L.W);
+        const int y0 = wrap_index((int)fy, (int)L.H), y1 = wrap_index((int)fy + 1, (int)L.H);
+        const GTexel t00 = gbuffer_texel(G, L.W, x0, y0), t10 = gbuffer_texel(G, L.W, x1, y0);
+        const GTexel t01 = gbuffer_texel(G, L.W, x0, y1), t11 = gbuffer_texel(G, L.W, x1, y1);
+        float g[20];
+        for (int k = 0; k < 20; ++k) {
+            const float top = __builtin_fmaf(ax, t10.v[k] - t00.v[k], t00.v[k]), bot = __builtin_fmaf(ax, t11.v[k] - t01.v[k], t01.v[k]);
+            g[k] = __builtin_fmaf(ay, bot - top, top);
+        }
+        const zf3 BaseColor = zr3(g[12], g[13], g[14]);
+        const float Metallic = zr_saturate(g[8]);
+        const float Roughness = __builtin_fmaxf(0.01f, zr_saturate(g[10]));
+        const zf3 Normal = zr3(__builtin_fmaf(g[4], 2.0f, -1.0f), __builtin_fmaf(g[5], 2.0f, -1.0f), __builtin_fmaf(g[6], 2.0f, -1.0f));
+        const float AO = zr_saturate(g[15]);
+        const zf3 N = zr_normalize(Normal);
+        const zf3 Pw = zr3(g[16], g[17], g[18]);
+        switch (cell) {
+        case 0: o = zr3(zr_pow(BaseColor.x, 0.4545f), zr_pow(BaseColor.y, 0.4545f), zr_pow(BaseColor.z, 0.4545f)); break;
+        case 1: o = zr3(Metallic, Metallic, Metallic); break;
+        case 2: o = zr3(Roughness, Roughness, Roughness); break;
+        case 3: o = N; break;
+        case 4: o = zr3(AO, AO, AO); break;
+        case 5: o = zr3(0.0f, 0.0f, 0.0f); break;
+        case 6: {
+            const zf3 cam = zr3(view->CameraInfo[0], view->CameraInfo[1], view->CameraInfo[2]);
+            const zf3 Vv = zr_normalize(cam - Pw), Nn = zr_normalize(N);
+            const float eta = 1.00f / 1.52f;
+            const float dNI = zr_dot(Nn, Vv);
+            const float kk = __builtin_fmaf(-(eta * eta), __builtin_fmaf(-dNI, dNI, 1.0f), 1.0f);
+            zf3 R;
+            if (kk < 0.0f) R = zr3(0.0f, 0.0f, 0.0f);
+            else {
+                const float q = __builtin_fmaf(eta, dNI, __builtin_sqrtf(kk));
+                R = zr3(__builtin_fmaf(eta, Vv.x, -(q * Nn.x)), __builtin_fmaf(eta, Vv.y, -(q * Nn.y)), __builtin_fmaf(eta, Vv.z, -(q * Nn.z)));
+            }
+            o = cube_sample(C, srgb_lut, L.cube_dim, (int)L.cube_levels, R, 0.0f) * 10.0f;
+            break;
+        }
+        default: {
+            const zf4 s4 = zr_mat4_point(L.SB, Pw);
+            const float sx = s4.x / s4.w, sy = s4.y / s4.w, sz = s4.z / s4.w, sw = s4.w / s4.w;
+            const float dxy = 1.5f * 1.0f / (float)L.SD;
+            float sum = 0.0f;
+            for (int xo = -2; xo <= 2; ++xo)
+                for (int yo = -2; yo <= 2; ++yo) sum += shadow_tap(shadowmap, (int)L.SD, sx, sy, sz, sw, dxy * (float)xo, dxy * (float)yo);
+            const float sf = sum / 25.0f;
+            o = zr3(sf, sf, sf);
+            break;
+        }
+        }
+    }
+    out[(size_t)py * L.W + px] = zr_unorm(o.x, 255.0f) | zr_unorm(o.y, 255.0f) << 8 | zr_unorm(o.z, 255.0f) << 16 | 255u << 24;
 }
 
 // Multi-GPU composite: gathered[rank][slot][TILE_PIX] (slot = tile / world for tiles with tile % world == rank) -> frame
@@ -1577,6 +1687,11 @@ void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32
 {
     if (n_owned == 0) return;
     hipLaunchKernelGGL(k_lighting, dim3(n_owned), dim3(256), 0, s, L, view, owned_tiles, G, shadowmap, C, lut, unorm_lut, out);
+}
+void zr_launch_gbuffer_vis(const ZrLightParams& L, const XkView* view, const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C,
+                           const float* lut, uint32_t* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_gbuffer_vis, dim3((L.W + 15) / 16, (L.H + 15) / 16), dim3(256), 0, s, L, view, G, shadowmap, C, lut, out);
 }
 void zr_launch_untile(const uint32_t* gathered, uint32_t* frame, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
                       uint32_t world, uint32_t slots_per_rank, hipStream_t s)

@@ -156,5 +156,7 @@ void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, h
 void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32_t* owned_tiles, uint32_t n_owned,
                         const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C, const float* lut, const float* unorm_lut,
                         uint32_t* out, hipStream_t s);
+void zr_launch_gbuffer_vis(const ZrLightParams& L, const XkView* view, const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C,
+                           const float* lut, uint32_t* out, hipStream_t s);
 void zr_launch_untile(const uint32_t* gathered, uint32_t* frame, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
                       uint32_t world, uint32_t slots_per_rank, hipStream_t s);
