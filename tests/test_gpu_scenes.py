@@ -210,6 +210,31 @@ def test_many_lights_config5_style(oracle_lib, gpu_engine):
     _identical(o, g, "256 lights")
 
 
+def test_tile_light_lists_scattered_and_odd_lights(oracle_lib, gpu_engine):
+    """300 point lights spread over the scene with small radii (most tiles see few of them), plus lights the tile test must
+    not drop: zero / negative radius, non-finite colour, non-finite position.  Sky pixels (Mask = 0) are in the frame too."""
+    rng = np.random.default_rng(11)
+    w = scenes.sample_world()
+    d, _, s = scenes.lights_from_world(w)
+    n = 300
+    p = np.zeros(n, dtype=abi.XkLight)
+    for i in range(n):
+        pos = (rng.uniform(-9, 9), rng.uniform(-9, 9), rng.uniform(0.1, 2.5))
+        p[i] = abi.make_light(pos, 1, tuple(rng.uniform(0.1, 1.0, 3)), rng.uniform(2.0, 12.0), (0.0, 0.0, 1.0), rng.uniform(0.3, 2.5))
+    p[7] = abi.make_light((1.0, 1.0, 1.0), 1, (1.0, 0.5, 0.2), 5.0, (0, 0, 1), 0.0)            # radius 0: 0/0
+    p[19] = abi.make_light((-2.0, 1.0, 0.5), 1, (1.0, 0.5, 0.2), 5.0, (0, 0, 1), -1.0)
+    p[33] = abi.make_light((50.0, 50.0, 1.0), 1, (float("nan"), 0.5, 0.2), 5.0, (0, 0, 1), 0.5)  # far away but NaN colour
+    p[64] = abi.make_light((float("inf"), 0.0, 1.0), 1, (1.0, 0.5, 0.2), 5.0, (0, 0, 1), 1.0)
+    p[65] = abi.make_light((float("nan"), 0.0, 1.0), 1, (1.0, 0.5, 0.2), 5.0, (0, 0, 1), 1.0)
+    p[299] = abi.make_light((0.0, 0.0, 1.0), 1, (0.2, 0.9, 0.2), float("inf"), (0, 0, 1), 3.0)
+
+    def frame(r):
+        r.update_uniforms(abi.make_camera((7.0, -9.0, 4.0), (0.0, 0.0, 0.6), fov=55.0, zfar=80.0), d, p, s, 0.2, 0.0, 1.0)
+    o, g = _both(oracle_lib, gpu_engine, 320, 192, 128, _mixed_scene, frame)
+    assert (o.gbuffer(0) == 1.0).sum() > 1000            # sky pixels present
+    _identical(o, g, "300 scattered lights")
+
+
 def test_staged_frame_and_shadow_instance_partition(oracle_lib, gpu_engine):
     """zr_render_shadow/gbuffer/lighting == zr_render; per-rank shadow shares min-reduce to the full shadow map."""
     cfg = scenes.config3(500, 320, 200)

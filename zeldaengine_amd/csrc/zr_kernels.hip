@@ -26,6 +26,9 @@
 #define QCAP 128u
 #define RW (ZR_TILE >= 64 ? 8 : 4)          // waves per rasteriser workgroup: one 64x64 tile's keys (32 KB) are shared by 8 waves
 #define RTHREADS (RW * WAVE)
+#ifndef ZR_LIGHT_LIST_MIN
+#define ZR_LIGHT_LIST_MIN 32u                 // point lights from which k_lighting builds a per-tile light list
+#endif
 
 // ------------------------------------------------------------------------------------------------ helpers
 
@@ -151,6 +154,10 @@ __device__ __forceinline__ int wave_min(int v) { const int idn = 0x7FFFFFFF; ZR_
 __device__ __forceinline__ int wave_max(int v) { const int idn = (int)0x80000000; ZR_WAVE_REDUCE(op_max); }
 __device__ __forceinline__ uint32_t wave_or(uint32_t u) { const int idn = 0, v = (int)u; ZR_WAVE_REDUCE(op_or); }
 __device__ __forceinline__ uint32_t wave_and(uint32_t u) { const int idn = -1, v = (int)u; ZR_WAVE_REDUCE(op_and); }
+__device__ __forceinline__ int op_fmin(int a, int b) { return (int)zr_f2u(__builtin_fminf(zr_u2f((uint32_t)a), zr_u2f((uint32_t)b))); }
+__device__ __forceinline__ int op_fmax(int a, int b) { return (int)zr_f2u(__builtin_fmaxf(zr_u2f((uint32_t)a), zr_u2f((uint32_t)b))); }
+__device__ __forceinline__ float wave_fmin(float f) { const int idn = 0x7F800000, v = (int)zr_f2u(f); return zr_u2f((uint32_t)[&]() { ZR_WAVE_REDUCE(op_fmin); }()); }
+__device__ __forceinline__ float wave_fmax(float f) { const int idn = (int)0xFF800000, v = (int)zr_f2u(f); return zr_u2f((uint32_t)[&]() { ZR_WAVE_REDUCE(op_fmax); }()); }
 
 __device__ __forceinline__ int find_object_inst(const ZrObject* __restrict__ objs, int n, uint32_t g)
 {
@@ -1277,6 +1284,60 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
     const float maxmips = (float)(uint32_t)view->LightsCount[3];
     const float dxy = 1.5f * 1.0f / (float)L.SD;
 
+    // Tile light list (many point lights): a light whose sphere of influence misses the bounding box of the tile's world
+    // positions would be skipped by every pixel's own exact test below (|lp - P| >= the box distance per axis, and the squared
+    // sums are monotonic), so it is dropped for the whole tile.  The list is a bitmask, walked in ascending order: the
+    // accumulation order over lights is unchanged.  Pixels with Mask = 0 do not count: their colour is (...) * 0 -> stored 0.
+    __shared__ float bbp[4][6];
+    __shared__ uint32_t lmask[XK_MAX_POINT_LIGHTS_NUM / 32];
+    const bool use_mask = nPoint >= ZR_LIGHT_LIST_MIN && nPoint <= XK_MAX_POINT_LIGHTS_NUM;
+    if (use_mask) {
+        float lo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, hi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
+        bool odd = false;                    // a non-finite position: keep every light
+        for (uint32_t i = threadIdx.x; i < TILE_PIX; i += 256u) {
+            const int px = tx0 + (int)(i & (TILE - 1)), py = ty0 + (int)(i / TILE);
+            if (px >= (int)L.W || py >= (int)L.H) continue;
+            const size_t p = (size_t)py * L.W + (size_t)px;
+            if ((G.scene_color[p] >> 24) == 0u) continue;
+            const uint2 D = G.gD[p];
+            const float q[3] = { zr_f16_to_f32(D.x & 0xFFFFu), zr_f16_to_f32(D.x >> 16), zr_f16_to_f32(D.y & 0xFFFFu) };
+            for (int a = 0; a < 3; ++a) {
+                if (!(__builtin_fabsf(q[a]) <= 3.402823466e38f)) odd = true;
+                lo[a] = __builtin_fminf(lo[a], q[a]); hi[a] = __builtin_fmaxf(hi[a], q[a]);
+            }
+        }
+        for (int a = 0; a < 3; ++a) { lo[a] = wave_fmin(lo[a]); hi[a] = wave_fmax(hi[a]); }
+        const bool wodd = __ballot(odd) != 0ull;
+        if ((threadIdx.x & 63u) == 0u) {
+            float* o = bbp[threadIdx.x >> 6];
+            o[0] = wodd ? -__builtin_inff() : lo[0]; o[1] = wodd ? -__builtin_inff() : lo[1]; o[2] = wodd ? -__builtin_inff() : lo[2];
+            o[3] = wodd ? __builtin_inff() : hi[0]; o[4] = wodd ? __builtin_inff() : hi[1]; o[5] = wodd ? __builtin_inff() : hi[2];
+        }
+        for (uint32_t i = threadIdx.x; i < XK_MAX_POINT_LIGHTS_NUM / 32; i += 256u) lmask[i] = 0u;
+        __syncthreads();
+        float blo[3], bhi[3];
+        for (int a = 0; a < 3; ++a) {
+            blo[a] = __builtin_fminf(__builtin_fminf(bbp[0][a], bbp[1][a]), __builtin_fminf(bbp[2][a], bbp[3][a]));
+            bhi[a] = __builtin_fmaxf(__builtin_fmaxf(bbp[0][3 + a], bbp[1][3 + a]), __builtin_fmaxf(bbp[2][3 + a], bbp[3][3 + a]));
+        }
+        for (uint32_t li = threadIdx.x; li < nPoint; li += 256u) {
+            const XkLight* __restrict__ Lt = &view->PointLights[li];
+            const bool lfinite = __builtin_fabsf(Lt->Color[0]) <= 3.402823466e38f && __builtin_fabsf(Lt->Color[1]) <= 3.402823466e38f &&
+                                 __builtin_fabsf(Lt->Color[2]) <= 3.402823466e38f && __builtin_fabsf(Lt->Color[3]) <= 3.402823466e38f;
+            const float falloff = Lt->Direction[3];
+            bool keep = true;
+            if (lfinite && falloff > 0.0f) {
+                zf3 e;      // per axis: how far the light lies outside the box (0 inside); |lp - P| is at least that for every P in it
+                e.x = __builtin_fmaxf(0.0f, __builtin_fmaxf(blo[0] - Lt->Position[0], Lt->Position[0] - bhi[0]));
+                e.y = __builtin_fmaxf(0.0f, __builtin_fmaxf(blo[1] - Lt->Position[1], Lt->Position[1] - bhi[1]));
+                e.z = __builtin_fmaxf(0.0f, __builtin_fmaxf(blo[2] - Lt->Position[2], Lt->Position[2] - bhi[2]));
+                if (zr_dot(e, e) > (falloff * falloff) * 1.000001f) keep = false;
+            }
+            if (keep) atomicOr(&lmask[li >> 5], 1u << (li & 31u));
+        }
+        __syncthreads();
+    }
+
     for (uint32_t i = threadIdx.x; i < TILE_PIX; i += 256u) {
         const int px = tx0 + (int)(i & (TILE - 1)), py = ty0 + (int)(i / TILE);
         if (px >= (int)L.W || py >= (int)L.H) continue;
@@ -1363,7 +1424,18 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
         zf3 Direct = zr3(0.0f, 0.0f, 0.0f);
         const zf3 Nn = zr_normalize(N);                      // Apply*Light and refract() re-normalise N
         const zf3 DiffuseColor = BaseColor * (1.0f - Metallic);
-        for (uint32_t li = 0; li < ((L.debug_skip & 2u) ? 0u : nDir + nPoint); ++li) {
+        // lights in the shader's order: directional, then point (with a tile list: only its set bits, ascending)
+        const uint32_t n_lights = (L.debug_skip & 2u) ? 0u : nDir + nPoint;
+        uint32_t mword = 0u, mnext = 0u;       // remaining bits of the current mask word, index of the next word
+        for (uint32_t li = 0; li < n_lights; ++li) {
+            if (use_mask && li >= nDir) {
+                while (mword == 0u && mnext * 32u < nPoint) mword = lmask[mnext++];
+                if (mword == 0u) break;
+                const uint32_t b = (uint32_t)__builtin_ctz(mword);
+                mword &= mword - 1u;
+                li = nDir + (mnext - 1u) * 32u + b;
+                if (li >= n_lights) break;
+            }
             const bool isdir = li < nDir;
             const XkLight* __restrict__ Lt = isdir ? &view->DirectionalLights[li] : &view->PointLights[li - nDir];
             const zf3 lp = zr3(Lt->Position[0], Lt->Position[1], Lt->Position[2]);
