@@ -892,6 +892,8 @@ extern "C" int zr_render_lighting(zr_ctx* c)
     L.packed_out = c->cfg.tile_world > 1 ? 1u : 0u;
     { const char* dbg = getenv("ZR_DEBUG_SKIP_LIGHT"); L.debug_skip = dbg ? (uint32_t)atoi(dbg) : 0u; }
     L.bg_enabled = (c->bg_set && c->bg_enabled) ? 1u : 0u;
+    { const char* e = getenv("ZR_LIGHT_LIST_MIN"); const int32_t lmin = e ? atoi(e) : 4;      // env: A/B only
+      const int32_t np = c->view.LightsCount[1]; L.light_list = (np >= lmin && np <= XK_MAX_POINT_LIGHTS_NUM) ? 1u : 0u; }
     L.bg.data = c->d_bg; L.bg.w = c->bg_w; L.bg.h = c->bg_h; L.bg.levels = c->bg_levels; L.bg._pad = 0;
     zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, shadow_buf(c), c->cube, c->d_lut, c->d_unorm_lut,
                        L.packed_out ? (c->d_tiles_ext ? c->d_tiles_ext : c->d_tiles) : c->d_color, s);

@@ -26,9 +26,6 @@
 #define QCAP 128u
 #define RW (ZR_TILE >= 64 ? 8 : 4)          // waves per rasteriser workgroup: one 64x64 tile's keys (32 KB) are shared by 8 waves
 #define RTHREADS (RW * WAVE)
-#ifndef ZR_LIGHT_LIST_MIN
-#define ZR_LIGHT_LIST_MIN 32u                 // point lights from which k_lighting builds a per-tile light list
-#endif
 
 // ------------------------------------------------------------------------------------------------ helpers
 
@@ -1265,6 +1262,7 @@ __device__ __forceinline__ float shadow_tap(const float* __restrict__ S, int SD,
 }
 
 // BaseLighting.frag:147-254 for every pixel of the owned tiles (the full-screen quad of ZE:3531-3540)
+template <bool LIGHT_LIST>
 __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView* __restrict__ view,
                                                   const uint32_t* __restrict__ owned_tiles, GBufferPtrs G,
                                                   const float* __restrict__ shadowmap, CubeDesc C,
@@ -1284,14 +1282,14 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
     const float maxmips = (float)(uint32_t)view->LightsCount[3];
     const float dxy = 1.5f * 1.0f / (float)L.SD;
 
-    // Tile light list (many point lights): a light whose sphere of influence misses the bounding box of the tile's world
+    // Tile light list (LIGHT_LIST: four or more point lights): a light whose sphere of influence misses the bounding box of the tile's world
     // positions would be skipped by every pixel's own exact test below (|lp - P| >= the box distance per axis, and the squared
     // sums are monotonic), so it is dropped for the whole tile.  The list is a bitmask, walked in ascending order: the
     // accumulation order over lights is unchanged.  Pixels with Mask = 0 do not count: their colour is (...) * 0 -> stored 0.
-    __shared__ float bbp[4][6];
-    __shared__ uint32_t lmask[XK_MAX_POINT_LIGHTS_NUM / 32];
-    const bool use_mask = nPoint >= ZR_LIGHT_LIST_MIN && nPoint <= XK_MAX_POINT_LIGHTS_NUM;
-    if (use_mask) {
+    __shared__ float bbp[LIGHT_LIST ? 4 : 1][6];
+    __shared__ uint32_t lmask[LIGHT_LIST ? XK_MAX_POINT_LIGHTS_NUM / 32 : 1];
+    constexpr bool use_mask = LIGHT_LIST;
+    if constexpr (LIGHT_LIST) {
         float lo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, hi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
         bool odd = false;                    // a non-finite position: keep every light
         for (uint32_t i = threadIdx.x; i < TILE_PIX; i += 256u) {
@@ -1758,7 +1756,9 @@ void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32
                         uint32_t* out, hipStream_t s)
 {
     if (n_owned == 0) return;
-    hipLaunchKernelGGL(k_lighting, dim3(n_owned), dim3(256), 0, s, L, view, owned_tiles, G, shadowmap, C, lut, unorm_lut, out);
+    // with several point lights each tile first builds its light list (L.light_list: decided on the host from the light count)
+    if (L.light_list) hipLaunchKernelGGL(k_lighting<true>, dim3(n_owned), dim3(256), 0, s, L, view, owned_tiles, G, shadowmap, C, lut, unorm_lut, out);
+    else hipLaunchKernelGGL(k_lighting<false>, dim3(n_owned), dim3(256), 0, s, L, view, owned_tiles, G, shadowmap, C, lut, unorm_lut, out);
 }
 void zr_launch_gbuffer_vis(const ZrLightParams& L, const XkView* view, const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C,
                            const float* lut, uint32_t* out, hipStream_t s)

@@ -122,6 +122,7 @@ struct ZrLightParams {
     uint32_t tile_world;
     uint32_t debug_skip;             // diagnostics only (env ZR_DEBUG_SKIP_LIGHT bits: 1 PCF, 2 lights, 4 reflection)
     uint32_t bg_enabled;             // background quad (Background.vert/.frag) on
+    uint32_t light_list;             // 1: per-tile point-light lists
     ZrTex    bg;                     // its sRGB texture
 };
 
