@@ -151,6 +151,13 @@ __device__ __forceinline__ int wave_min(int v) { const int idn = 0x7FFFFFFF; ZR_
 __device__ __forceinline__ int wave_max(int v) { const int idn = (int)0x80000000; ZR_WAVE_REDUCE(op_max); }
 __device__ __forceinline__ uint32_t wave_or(uint32_t u) { const int idn = 0, v = (int)u; ZR_WAVE_REDUCE(op_or); }
 __device__ __forceinline__ uint32_t wave_and(uint32_t u) { const int idn = -1, v = (int)u; ZR_WAVE_REDUCE(op_and); }
+typedef short short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int op_pkmin(int a, int b) { short2_t x, y; __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4); x = __builtin_elementwise_min(x, y); int r; __builtin_memcpy(&r, &x, 4); return r; }
+__device__ __forceinline__ int op_pkmax(int a, int b) { short2_t x, y; __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4); x = __builtin_elementwise_max(x, y); int r; __builtin_memcpy(&r, &x, 4); return r; }
+// two int16 lanes per register: one reduction for (x, y) pairs
+__device__ __forceinline__ int wave_pkmin16(int v) { const int idn = 0x7FFF7FFF; ZR_WAVE_REDUCE(op_pkmin); }
+__device__ __forceinline__ int wave_pkmax16(int v) { const int idn = (int)0x80008000; ZR_WAVE_REDUCE(op_pkmax); }
+__device__ __forceinline__ int clamp16(int v) { return min(max(v, -32768), 32767); }
 __device__ __forceinline__ int op_fmin(int a, int b) { return (int)zr_f2u(__builtin_fminf(zr_u2f((uint32_t)a), zr_u2f((uint32_t)b))); }
 __device__ __forceinline__ int op_fmax(int a, int b) { return (int)zr_f2u(__builtin_fmaxf(zr_u2f((uint32_t)a), zr_u2f((uint32_t)b))); }
 __device__ __forceinline__ float wave_fmin(float f) { const int idn = 0x7F800000, v = (int)zr_f2u(f); return zr_u2f((uint32_t)[&]() { ZR_WAVE_REDUCE(op_fmin); }()); }
@@ -310,24 +317,33 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
                 J.s = lane_bcast(I.s, src[c]);
                 const bool inst = lane_bcast(instanced, src[c]) != 0u;
                 const uint32_t vc = lane_bcast(vcount, src[c]);
-                uint32_t f_or = 0, f_and = 0xFFu;
-                int X0 = 0x7FFFFFFF, X1 = (int)0x80000000, Y0 = 0x7FFFFFFF, Y1 = (int)0x80000000;
+                // per lane: clip flags, and for an unflagged vertex the first / last pixel centre its snapped position can bound
+                // ((X - 128 + 255) >> 8 and (X - 128) >> 8 are monotonic, so min / max commute with them); the four box sides travel
+                // as two packed int16 pairs and the OR / AND of the flags as one word: 3 wave reductions (+ 1 for the depth)
+                uint32_t fbits = 0u;           // f | (~f & 0xFF) << 8
+                int lo2 = 0x7FFF7FFF, hi2 = (int)0x80008000;
                 int zb = 0x7FFFFFFF;           // least NDC depth over the vertices, as ordered int bits (depths here are >= 0)
                 if (lane < vc) {
                     const zf4 cl = zr_mat4_point(P.PVM, vs_position(zr3(pp[c].x, pp[c].y, pp[c].z), J, inst));
                     const uint32_t f = vertex_flags(cl);
-                    f_or = f; f_and = f;
-                    if (!(f & 129u)) { const SV sv = project(cl, P.hw, P.hh); X0 = X1 = sv.X; Y0 = Y1 = sv.Y; zb = (int)zr_f2u(sv.z + 0.0f); }
+                    fbits = f | ((~f & 0xFFu) << 8);
+                    if (!(f & 129u)) {
+                        const SV sv = project(cl, P.hw, P.hh);
+                        lo2 = (clamp16((sv.X - 128 + 255) >> 8) & 0xFFFF) | (clamp16((sv.Y - 128 + 255) >> 8) << 16);
+                        hi2 = (clamp16((sv.X - 128) >> 8) & 0xFFFF) | (clamp16((sv.Y - 128) >> 8) << 16);
+                        zb = (int)zr_f2u(sv.z + 0.0f);
+                    }
                 }
-                f_or = wave_or(f_or); f_and = wave_and(f_and);
+                fbits = wave_or(fbits);
+                const uint32_t f_or = fbits & 0xFFu, f_and = ~(fbits >> 8) & 0xFFu;
                 uint32_t r = ZR_RECT_CULLED; uint2 pr = make_uint2(0u, 0u); float zm = -1.0f;
                 if ((f_or & 1u) || !(f_and & 0x7Eu)) {
                     int px0 = 0, py0 = 0, px1 = (int)P.W - 1, py1 = (int)P.H - 1;
                     bool any = true;
                     if (!(f_or & 129u)) {
-                        X0 = wave_min(X0); X1 = wave_max(X1); Y0 = wave_min(Y0); Y1 = wave_max(Y1);
-                        px0 = max(px0, (X0 - 128 + 255) >> 8); px1 = min(px1, (X1 - 128) >> 8);
-                        py0 = max(py0, (Y0 - 128 + 255) >> 8); py1 = min(py1, (Y1 - 128) >> 8);
+                        const int lo = wave_pkmin16(lo2), hi = wave_pkmax16(hi2);
+                        px0 = max(px0, (int)(short)(lo & 0xFFFF)); py0 = max(py0, lo >> 16);
+                        px1 = min(px1, (int)(short)(hi & 0xFFFF)); py1 = min(py1, hi >> 16);
                         any = px0 <= px1 && py0 <= py1;
                         if (any && MODE == ZR_MODE_GBUFFER) {      // unclipped meshlet (so every z >= 0): usable for the Hi-Z test
                             zm = zr_u2f((uint32_t)wave_min(zb));
