@@ -46,6 +46,7 @@ typedef struct zr_ctx zr_ctx;
 #define ZR_FLAG_NO_CONE_CULL    2u  /* disable meshlet cone culling   (parity A/B) */
 #define ZR_FLAG_SKIP_COMPOSITE  4u  /* tile_world>1: caller gathers packed tiles itself */
 #define ZR_FLAG_NO_HIZ          8u  /* disable two-pass Hi-Z occlusion culling of the camera pass (parity A/B) */
+#define ZR_FLAG_SERIAL_PASSES   16u /* zr_render: shadow and camera pipelines on the one stream instead of side by side */
 
 typedef struct zr_config {
     uint32_t width, height;   /* swapchain extent, ZE:78-79 (default 1920x1080) */

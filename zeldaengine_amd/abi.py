@@ -64,6 +64,7 @@ FLAG_NO_FRUSTUM_CULL = 1
 FLAG_NO_CONE_CULL = 2
 FLAG_SKIP_COMPOSITE = 4
 FLAG_NO_HIZ = 8
+FLAG_SERIAL_PASSES = 16
 
 
 def make_light(position=(0, 0, 0), type_=0, color=(1, 1, 1), intensity=1.0, direction=(0, 0, 1), radius=0.0,

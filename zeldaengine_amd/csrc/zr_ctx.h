@@ -79,9 +79,13 @@ struct zr_ctx {
     uint32_t shadow_rank = 0, shadow_world = 1; int stage = 0;   // stage: 0 idle, 1 shadow done, 2 gbuffer done
     uint32_t* d_tiles_ext = nullptr;     // caller-owned packed tile buffer for the next frames (zr_set_tiles_buffer), or null
 
-    uint32_t *d_rects = nullptr, *d_tile_count = nullptr, *d_tile_offset = nullptr, *d_tile_cursor = nullptr; ZrBinEntry* d_bins = nullptr;
-    uint32_t* d_work = nullptr; uint32_t n_inst_total = 0;
-    uint32_t* d_chunk_offset = nullptr; unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048;
+    // cull / bin scratch, one set per geometry pass (0 shadow, 1 camera) so that the two pipelines can run on two streams
+    struct Scratch { uint32_t *rects = nullptr, *tile_count = nullptr, *tile_offset = nullptr, *tile_cursor = nullptr, *chunk_offset = nullptr,
+                     *work = nullptr; ZrBinEntry* bins = nullptr; } sc[2];
+    uint32_t n_inst_total = 0;
+    hipStream_t aux = nullptr;           // zr_render: the shadow pipeline runs here, next to the camera pipeline on `stream`
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048;
     uint32_t work_capacity = 0, bin_capacity = 0;
     // two-pass Hi-Z occlusion culling of the camera pass: per work item pixel bbox + least depth (written by the cull),
     // visibility of the previous / current frame (one byte per meshlet-instance, marked by the resolve), the pyramid
@@ -99,7 +103,7 @@ struct zr_ctx {
     ZrMesh sky_mesh; ZrSceneObject sky_obj; bool sky_set = false, sky_enabled = true;
     uint8_t* d_bg = nullptr; uint32_t bg_w = 0, bg_h = 0, bg_levels = 0; bool bg_set = false, bg_enabled = true;
 
-    hipEvent_t evr[EV_RING][9] = {}; uint64_t frame_no = 0; bool rendered = false;
+    hipEvent_t evr[EV_RING][10] = {}; uint64_t frame_no = 0; bool rendered = false;
     uint32_t timing_interval = 1; bool timing_now = true; uint64_t sample_no = 0;    // pass events every interval-th frame
 
     // world + livelink

@@ -115,14 +115,19 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     if (ok) ok &= hipMemcpy(c->d_sowned, sowned.data(), sowned.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     if (ok) ok &= hipMemset(c->d_tiles, 0, (size_t)c->slots_per_rank * ZR_TILE * ZR_TILE * 4) == hipSuccess;
     const uint32_t mt = (c->n_tiles > c->sn_tiles ? c->n_tiles : c->sn_tiles) + 1;
-    ok &= dev_alloc(&c->d_tile_count, mt) == hipSuccess;
-    ok &= dev_alloc(&c->d_tile_offset, mt) == hipSuccess;
-    ok &= dev_alloc(&c->d_tile_cursor, mt) == hipSuccess;
-    ok &= dev_alloc(&c->d_chunk_offset, mt) == hipSuccess;
+    for (auto& sc : c->sc) {
+        ok &= dev_alloc(&sc.tile_count, mt) == hipSuccess;
+        ok &= dev_alloc(&sc.tile_offset, mt) == hipSuccess;
+        ok &= dev_alloc(&sc.tile_cursor, mt) == hipSuccess;
+        ok &= dev_alloc(&sc.chunk_offset, mt) == hipSuccess;
+        if (ok) ok &= hipMemset(sc.tile_count, 0, mt * 4) == hipSuccess;
+    }
+    ok &= hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) == hipSuccess;
+    ok &= hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+    ok &= hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     ok &= dev_alloc(&c->d_vis, n) == hipSuccess;
     if (ok) { zr_launch_fill64(c->d_vis, (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM, n, c->stream); ok &= hipStreamSynchronize(c->stream) == hipSuccess; }
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->raster_blocks = (uint32_t)prop.multiProcessorCount * 8u; }
-    if (ok) ok &= hipMemset(c->d_tile_count, 0, mt * 4) == hipSuccess;
     {   // Hi-Z pyramid: level l = max depth per (8 << l)^2 pixel block
         size_t tot = 0;
         for (int l = 0; l < 4; ++l) { c->hiz.hw[l] = (c->W + (8u << l) - 1) / (8u << l); c->hiz.hh[l] = (c->H + (8u << l) - 1) / (8u << l); tot += (size_t)c->hiz.hw[l] * c->hiz.hh[l]; }
@@ -166,7 +171,14 @@ extern "C" void zr_destroy(zr_ctx* c)
     dev_free(c->G.depth); dev_free(c->G.scene_color); dev_free(c->G.gA); dev_free(c->G.gB); dev_free(c->G.gC); dev_free(c->G.gD); dev_free(c->G.overlay);
     dev_free(c->d_color); dev_free(c->d_shadow); dev_free(c->d_view); dev_free(c->d_stats); dev_free(c->d_lut); dev_free(c->d_unorm_lut);
     dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles);
-    dev_free(c->d_tile_count); dev_free(c->d_tile_offset); dev_free(c->d_tile_cursor); dev_free(c->d_chunk_offset); dev_free(c->d_vis); dev_free(c->d_rects); dev_free(c->d_bins); dev_free(c->d_work);
+    for (auto& sc : c->sc) {
+        dev_free(sc.tile_count); dev_free(sc.tile_offset); dev_free(sc.tile_cursor); dev_free(sc.chunk_offset);
+        dev_free(sc.rects); dev_free(sc.bins); dev_free(sc.work);
+    }
+    if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    dev_free(c->d_vis);
     dev_free(c->d_pxrect); dev_free(c->d_zmin); dev_free(c->d_visflag[0]); dev_free(c->d_visflag[1]); dev_free(c->d_hiz);
     for (auto& fr : c->evr) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -491,14 +503,16 @@ static int finalize_scene(zr_ctx* c)
     HIPCHK(c, upload(&c->d_objs, tab));
     c->n_objs = (uint32_t)tab.size(); c->n_work = (uint32_t)work; c->n_inst_total = (uint32_t)inst_total;
     if (c->n_work > c->work_capacity) {
-        dev_free(c->d_rects); dev_free(c->d_bins); dev_free(c->d_work);
+        for (auto& sc : c->sc) { dev_free(sc.rects); dev_free(sc.bins); dev_free(sc.work); }
         dev_free(c->d_pxrect); dev_free(c->d_zmin); dev_free(c->d_visflag[0]); dev_free(c->d_visflag[1]);
         c->work_capacity = c->n_work;
         const uint64_t cap = std::max<uint64_t>(1u << 20, 8ull * c->n_work);
         c->bin_capacity = (uint32_t)std::min<uint64_t>(cap, 0x3FFFFFFFull);
-        HIPCHK(c, dev_alloc(&c->d_rects, c->work_capacity));
-        HIPCHK(c, dev_alloc(&c->d_work, c->work_capacity));
-        HIPCHK(c, dev_alloc(&c->d_bins, c->bin_capacity));
+        for (auto& sc : c->sc) {
+            HIPCHK(c, dev_alloc(&sc.rects, c->work_capacity));
+            HIPCHK(c, dev_alloc(&sc.work, c->work_capacity));
+            HIPCHK(c, dev_alloc(&sc.bins, c->bin_capacity));
+        }
         HIPCHK(c, dev_alloc(&c->d_pxrect, c->work_capacity)); HIPCHK(c, dev_alloc(&c->d_zmin, c->work_capacity));
         HIPCHK(c, dev_alloc(&c->d_visflag[0], c->work_capacity)); HIPCHK(c, dev_alloc(&c->d_visflag[1], c->work_capacity));
     }
@@ -777,16 +791,18 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
 // ------------------------------------------------------------------------------------------------ the frame
 
 // cull -> count -> scan -> fill -> raster of one pass.  Z.phase selects the share of the camera pass drawn (0 = all of it).
-static void bin_and_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, uint32_t n_tiles)
+static void bin_and_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, uint32_t n_tiles, hipStream_t s)
 {
-    zr_launch_bin_count(P, c->d_work, c->d_rects, c->d_tile_count, Z, c->d_stats, slot, c->stream);
-    zr_launch_scan(c->d_tile_count, c->d_tile_offset, c->d_tile_cursor, c->d_chunk_offset, n_tiles, c->bin_capacity, c->d_stats, slot, c->stream);
-    zr_launch_bin_fill(P, c->d_objs, c->d_work, c->d_rects, c->d_tile_offset, c->d_tile_cursor, c->d_bins, Z, c->d_stats, slot, c->stream);
+    const zr_ctx::Scratch& sc = c->sc[slot ? 1 : 0];
+    zr_launch_bin_count(P, sc.work, sc.rects, sc.tile_count, Z, c->d_stats, slot, s);
+    zr_launch_scan(sc.tile_count, sc.tile_offset, sc.tile_cursor, sc.chunk_offset, n_tiles, c->bin_capacity, c->d_stats, slot, s);
+    zr_launch_bin_fill(P, c->d_objs, sc.work, sc.rects, sc.tile_offset, sc.tile_cursor, sc.bins, Z, c->d_stats, slot, s);
 }
-static void raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot)
+static void raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s)
 {
-    zr_launch_raster_chunks(P, c->d_objs, c->d_tile_offset, c->d_chunk_offset, c->d_bins, c->d_stats, slot, c->d_vis,
-                            (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), c->raster_blocks, Z, c->stream);
+    const zr_ctx::Scratch& sc = c->sc[slot ? 1 : 0];
+    zr_launch_raster_chunks(P, c->d_objs, sc.tile_offset, sc.chunk_offset, sc.bins, c->d_stats, slot, c->d_vis,
+                            (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), c->raster_blocks, Z, s);
 }
 
 static inline float* shadow_buf(zr_ctx* c) { return c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow; }
@@ -796,9 +812,8 @@ static inline float* shadow_buf(zr_ctx* c) { return c->d_shadow_ext ? c->d_shado
 //   zr_render_gbuffer   deferred-scene pass (ZE:3417-3480): cull + bin + raster + resolve of the owned tiles
 //   zr_render_lighting  deferred-lighting pass (ZE:3531-3540) [+ skydome / background overlay]
 // zr_render = all three.
-extern "C" int zr_render_shadow(zr_ctx* c)
+static int frame_begin(zr_ctx* c)
 {
-    if (!c) return ZR_ERR_ARG;
     if (!c->frame_valid) return zr_fail(c, ZR_ERR_STATE, "no frame uniforms: call zr_update_uniforms or zr_set_frame first");
     if (c->stage != 0) return zr_fail(c, ZR_ERR_STATE, "zr_render_shadow out of order");
     if (c->debug_view == 9u && c->cfg.tile_world > 1u)
@@ -813,29 +828,33 @@ extern "C" int zr_render_shadow(zr_ctx* c)
     if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
     HIPCHK(c, hipMemsetAsync(c->d_stats, 0, sizeof(ZrDevStats), s));
     HIPCHK(c, hipMemcpyAsync(c->d_view, &c->view, sizeof(XkView), hipMemcpyHostToDevice, s));
+    return ZR_OK;
+}
+
+// shadow pass (ZE:3239-3393) of this rank's share of the instances, on stream s
+static int shadow_pass(zr_ctx* c, hipStream_t s)
+{
+    hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
     ZrPass P;
     const bool live = build_pass(c, c->shadow, ZR_MODE_SHADOW, &P);
     if (!live) P.n_work = 0;      // no finite vertex: the pass is its clear
     c->last_work[0] = P.n_work;
     zr_launch_fill32((uint32_t*)shadow_buf(c), 0x3F800000u, (size_t)c->SD * c->SD, s);      // clear depth 1.0, ZE:3248
     ZrHiz Z; memset(&Z, 0, sizeof Z);
-    zr_launch_cull(P, c->d_objs, c->d_work, c->d_rects, Z, c->d_stats, 0, c->raster_blocks * 4u, s);
-    bin_and_raster(c, P, Z, 0, c->sn_tiles);
+    zr_launch_cull(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, c->raster_blocks * 4u, s);
+    bin_and_raster(c, P, Z, 0, c->sn_tiles, s);
     if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
-    raster(c, P, Z, 0);
+    raster(c, P, Z, 0, s);
     if (ev) HIPCHK(c, hipEventRecord(ev[2], s));
     HIPCHK(c, hipGetLastError());
-    c->stage = 1;
     return ZR_OK;
 }
 
-extern "C" int zr_render_gbuffer(zr_ctx* c)
+// deferred-scene pass (ZE:3417-3480): cull + bin + raster + resolve of the owned tiles, on stream s
+static int gbuffer_pass(zr_ctx* c, hipStream_t s)
 {
-    if (!c) return ZR_ERR_ARG;
-    if (c->stage != 1) return zr_fail(c, ZR_ERR_STATE, "zr_render_gbuffer out of order");
-    HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
     hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
+    if (ev) HIPCHK(c, hipEventRecord(ev[9], s));
     ZrPass P;
     const bool live = build_pass(c, c->cam, ZR_MODE_GBUFFER, &P);
     if (!live) P.n_work = 0;
@@ -848,24 +867,24 @@ extern "C" int zr_render_gbuffer(zr_ctx* c)
     Z.pxrect = hiz_on ? c->d_pxrect : nullptr; Z.zmin = hiz_on ? c->d_zmin : nullptr;
     Z.vis_prev = c->d_visflag[c->vis_cur ^ 1]; Z.vis_now = hiz_on ? c->d_visflag[c->vis_cur] : nullptr;
     Z.phase = 0;
-    zr_launch_cull(P, c->d_objs, c->d_work, c->d_rects, Z, c->d_stats, 1, c->raster_blocks * 4u, s);
+    zr_launch_cull(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, c->raster_blocks * 4u, s);
     if (hiz_on) HIPCHK(c, hipMemsetAsync(c->d_visflag[c->vis_cur], 0, c->n_work, s));
     c->last_two_round = hiz_on && c->vis_history;
     if (c->last_two_round) {
         Z.phase = 1;
-        bin_and_raster(c, P, Z, 1, c->n_tiles);
+        bin_and_raster(c, P, Z, 1, c->n_tiles, s);
         if (ev) HIPCHK(c, hipEventRecord(ev[3], s));
-        raster(c, P, Z, 1);
+        raster(c, P, Z, 1, s);
         if (ev) HIPCHK(c, hipEventRecord(ev[4], s));
         zr_launch_hiz_build(c->d_vis, c->W, c->H, Z, s);
         Z.phase = 2;
-        bin_and_raster(c, P, Z, 2, c->n_tiles);
+        bin_and_raster(c, P, Z, 2, c->n_tiles, s);
         if (ev) HIPCHK(c, hipEventRecord(ev[5], s));
-        raster(c, P, Z, 2);
+        raster(c, P, Z, 2, s);
     } else {
-        bin_and_raster(c, P, Z, 1, c->n_tiles);
+        bin_and_raster(c, P, Z, 1, c->n_tiles, s);
         if (ev) HIPCHK(c, hipEventRecord(ev[3], s));
-        raster(c, P, Z, 1);
+        raster(c, P, Z, 1, s);
         if (ev) { HIPCHK(c, hipEventRecord(ev[4], s)); HIPCHK(c, hipEventRecord(ev[5], s)); }
     }
     if (ev) HIPCHK(c, hipEventRecord(ev[6], s));
@@ -873,8 +892,26 @@ extern "C" int zr_render_gbuffer(zr_ctx* c)
     if (ev) HIPCHK(c, hipEventRecord(ev[7], s));
     if (hiz_on) { c->vis_history = true; c->vis_cur ^= 1; } else c->vis_history = false;
     HIPCHK(c, hipGetLastError());
-    c->stage = 2;
     return ZR_OK;
+}
+
+extern "C" int zr_render_shadow(zr_ctx* c)
+{
+    if (!c) return ZR_ERR_ARG;
+    int rc = frame_begin(c);
+    if (rc == ZR_OK) rc = shadow_pass(c, c->stream);
+    if (rc == ZR_OK) c->stage = 1;
+    return rc;
+}
+
+extern "C" int zr_render_gbuffer(zr_ctx* c)
+{
+    if (!c) return ZR_ERR_ARG;
+    if (c->stage != 1) return zr_fail(c, ZR_ERR_STATE, "zr_render_gbuffer out of order");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = gbuffer_pass(c, c->stream);
+    if (rc == ZR_OK) c->stage = 2;
+    return rc;
 }
 
 extern "C" int zr_render_lighting(zr_ctx* c)
@@ -906,13 +943,31 @@ extern "C" int zr_render_lighting(zr_ctx* c)
     return ZR_OK;
 }
 
-// RecordCommandBuffer (ZE:3160-3744) + vkQueueSubmit (ZE:2014): shadow -> deferred scene -> deferred lighting
+// RecordCommandBuffer (ZE:3160-3744) + vkQueueSubmit (ZE:2014): shadow -> deferred scene -> deferred lighting.
+// The shadow pass and the deferred-scene pass do not depend on each other (the reference serialises them with subpass
+// barriers it does not need): here the shadow pipeline runs on an internal second stream next to the camera pipeline, and the
+// lighting pass joins them.  Their kernels are bound by different things at different moments (VALU issue, memory latency,
+// the small launch-bound binning kernels), so together they fill the machine better than one after the other.
+// ZR_FLAG_SERIAL_PASSES keeps everything on the one stream (as the staged entry points always do).
 extern "C" int zr_render(zr_ctx* c)
 {
-    int rc = zr_render_shadow(c);
-    if (rc == ZR_OK) rc = zr_render_gbuffer(c);
-    if (rc == ZR_OK) rc = zr_render_lighting(c);
-    if (rc != ZR_OK && c) c->stage = 0;
+    if (!c) return ZR_ERR_ARG;
+    int rc = frame_begin(c);
+    if (rc != ZR_OK) return rc;
+    const bool overlap = !(c->cfg.flags & ZR_FLAG_SERIAL_PASSES) && c->aux != nullptr && !getenv("ZR_SERIAL_PASSES");    // env: A/B only
+    if (overlap) {
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        rc = shadow_pass(c, c->aux);
+        if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
+        if (rc == ZR_OK) rc = gbuffer_pass(c, c->stream);
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    } else {
+        rc = shadow_pass(c, c->stream);
+        if (rc == ZR_OK) rc = gbuffer_pass(c, c->stream);
+    }
+    if (rc == ZR_OK) { c->stage = 2; rc = zr_render_lighting(c); }
+    if (rc != ZR_OK) c->stage = 0;
     return rc;
 }
 
@@ -964,7 +1019,7 @@ extern "C" int zr_get_pass_times_avg(zr_ctx* c, uint32_t last_n, float ms[ZR_PAS
         float t[ZR_PASS_COUNT] = { 0 };
         (void)hipEventElapsedTime(&t[ZR_PASS_CULL_SHADOW], ev[0], ev[1]);
         (void)hipEventElapsedTime(&t[ZR_PASS_SHADOW], ev[1], ev[2]);
-        (void)hipEventElapsedTime(&t[ZR_PASS_CULL_CAMERA], ev[2], ev[3]);
+        (void)hipEventElapsedTime(&t[ZR_PASS_CULL_CAMERA], ev[9], ev[3]);
         (void)hipEventElapsedTime(&t[ZR_PASS_GBUFFER], ev[3], ev[4]);
         (void)hipEventElapsedTime(&t[ZR_PASS_HIZ], ev[4], ev[5]);
         (void)hipEventElapsedTime(&t[ZR_PASS_GBUFFER2], ev[5], ev[6]);
