@@ -69,6 +69,7 @@ def lib():
         L.zo_kat_lookat.argtypes = [C.c_void_p] * 4
         L.zo_kat_sincos.argtypes = [C.c_float, C.c_void_p]
         L.zo_kat_rotmat.argtypes = [C.c_void_p, C.c_void_p]
+        L.zo_kat_aniso.argtypes = [C.c_float] * 4 + [C.c_int, C.c_void_p]
         _lib = L
     return _lib
 

@@ -729,22 +729,56 @@ static void zo_tex_bilinear(const zo_ctx* c, const zo_tex* t, int srgb, int leve
         out[ch] = fmaf(b, bot - top, top);
     }
 }
-/* texture(sampler2D, uv) in the fragment stage: isotropic LOD from the quad derivatives, trilinear.  Anisotropic filtering
- * (maxAnisotropy = device max, ZE:6540) is implementation-defined and NOT reproduced: documented deviation. */
-static void zo_tex_sample(const zo_ctx* c, const zo_tex* t, int srgb, float u, float v, float dudx, float dvdx, float dudy, float dvdy, float out[4])
+/* texture(sampler2D, uv) in the fragment stage.  The samplers are LINEAR / LINEAR-mip / REPEAT with anisotropyEnable and
+ * maxAnisotropy = the device limit (ZE:6523-6557; 16 on the target class of hardware).  Vulkan leaves the anisotropic scheme to
+ * the implementation; this restatement takes the one the specification itself describes ("Texel Anisotropic Filtering"):
+ *   Pmax, Pmin = longer / shorter of the two screen-axis footprints in texels,  N = min(ceil(Pmax / Pmin), maxAniso),
+ *   lambda = log2(Pmax / N),  result = 1/N * sum_{i=1..N} trilinear(uv + (i / (N+1) - 1/2) * duv/d(major axis)).
+ * N = 1 (isotropic footprint) is plain trilinear filtering with lambda = log2(Pmax). */
+#define ZO_MAX_ANISO 16
+static void zo_tex_trilinear(const zo_ctx* c, const zo_tex* t, int srgb, float lambda, float u, float v, float out[4])
 {
-    if (t->constant) { zo_tex_fetch(c, t, srgb, 0, 0, 0, out); return; }
-    float W = (float)t->w, H = (float)t->h;
-    float ax = dudx * W, ay = dvdx * H, bx = dudy * W, by = dvdy * H;
-    float rho2 = fmaxf(fmaf(ax, ax, ay * ay), fmaf(bx, bx, by * by));
-    float lambda = 0.5f * zo_log2f(rho2);
-    lambda = fminf(fmaxf(lambda, 0.0f), (float)(t->levels - 1));
     float fl = floorf(lambda);
     int l0 = (int)fl, l1 = l0 + 1 < t->levels ? l0 + 1 : t->levels - 1;
     float f = lambda - fl;
     float c0[4], c1[4];
     zo_tex_bilinear(c, t, srgb, l0, u, v, c0); zo_tex_bilinear(c, t, srgb, l1, u, v, c1);
     for (int ch = 0; ch < 4; ++ch) out[ch] = fmaf(f, c1[ch] - c0[ch], c0[ch]);
+}
+/* tap count, level of detail and major axis for the footprint (ax, ay) / (bx, by) in texels of level 0 */
+static void zo_aniso_setup(float ax, float ay, float bx, float by, int levels, int* Nout, float* lambda_out, int* xmajor_out)
+{
+    float rx2 = fmaf(ax, ax, ay * ay), ry2 = fmaf(bx, bx, by * by);
+    float rmax2 = fmaxf(rx2, ry2), rmin2 = fminf(rx2, ry2);
+    int N = 1;                                            /* least N with N^2 * Pmin^2 >= Pmax^2, at most maxAniso */
+    while (N < ZO_MAX_ANISO && (float)(N * N) * rmin2 < rmax2) ++N;
+    float lambda = 0.5f * zo_log2f(rmax2);
+    if (N > 1) lambda = lambda - zo_log2f((float)N);
+    *lambda_out = fminf(fmaxf(lambda, 0.0f), (float)(levels - 1));
+    *Nout = N; *xmajor_out = rx2 >= ry2;
+}
+void zo_kat_aniso(float ax, float ay, float bx, float by, int levels, float out[3])
+{
+    int N, xm; float l;
+    zo_aniso_setup(ax, ay, bx, by, levels, &N, &l, &xm);
+    out[0] = (float)N; out[1] = l; out[2] = (float)xm;
+}
+static void zo_tex_sample(const zo_ctx* c, const zo_tex* t, int srgb, float u, float v, float dudx, float dvdx, float dudy, float dvdy, float out[4])
+{
+    if (t->constant) { zo_tex_fetch(c, t, srgb, 0, 0, 0, out); return; }
+    float W = (float)t->w, H = (float)t->h;
+    int N, xmajor; float lambda;
+    zo_aniso_setup(dudx * W, dvdx * H, dudy * W, dvdy * H, t->levels, &N, &lambda, &xmajor);
+    if (N == 1) { zo_tex_trilinear(c, t, srgb, lambda, u, v, out); return; }
+    float du = xmajor ? dudx : dudy, dv = xmajor ? dvdx : dvdy;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i = 1; i <= N; ++i) {
+        float off = (float)i / (float)(N + 1) - 0.5f;
+        float s[4];
+        zo_tex_trilinear(c, t, srgb, lambda, fmaf(du, off, u), fmaf(dv, off, v), s);
+        for (int ch = 0; ch < 4; ++ch) acc[ch] += s[ch];
+    }
+    for (int ch = 0; ch < 4; ++ch) out[ch] = acc[ch] / (float)N;
 }
 
 /* ComputeNormal(fragPosition, fragTexCoord, fragNormal, texNormal), SH/Common.glsl:113-127 */

@@ -65,6 +65,7 @@ float zo_kat_log2(float x);
 float zo_kat_pow(float x, float y);
 uint16_t zo_kat_f32_to_f16(float x);
 void  zo_kat_rotmat(const float euler[3], float out9[9]);
+void  zo_kat_aniso(float ax, float ay, float bx, float by, int levels, float out[3]);   /* N, lambda, x-major */
 
 #ifdef __cplusplus
 }

@@ -323,3 +323,24 @@ def test_textured_materials_trilinear_repeat_srgb(oracle_lib, gpu_engine):
     o, g = _both(oracle_lib, gpu_engine, 400, 240, 256, build, _std_frame(abi.make_camera((5.0, 4.0, 2.5), (0.0, 0.0, 0.3))))
     assert len(np.unique(o.gbuffer(4))) > 200                  # base colour really varies
     _identical(o, g, "textured")
+
+
+def test_anisotropic_filtering_at_grazing_angles(oracle_lib, gpu_engine):
+    """Samplers have anisotropy on at the device maximum (ZE:6540): a striped ground plane seen almost edge-on gives footprints
+    from 1:1 near the camera to beyond 16:1 at the horizon, i.e. every tap count of the scheme."""
+    def build(r):
+        r.set_cubemap(None)
+        img = np.zeros((64, 64, 4), dtype=np.uint8)
+        img[..., 3] = 255
+        img[:, ::2, :3] = 255                                   # one-texel stripes: the harshest case for minification
+        img[::8, :, 0] = 40
+        mat, keep = abi.make_material([img, None, None, None, None, None, None])
+        r._keepalive = keep
+        v, idx = scenes.grid_plane(60.0, 4, 0.0)
+        v = v.copy(); v["TexCoord"] *= 3.0
+        r.object_add(r.mesh_create(v, idx), mat)
+    cam = abi.make_camera((0.0, -20.0, 0.35), (0.0, 20.0, 0.0), fov=50.0, znear=0.05, zfar=200.0)
+    o, g = _both(oracle_lib, gpu_engine, 320, 200, 64, build, _std_frame(cam, n_point=2))
+    bc = o.gbuffer(4)
+    assert len(np.unique(bc)) > 50                             # filtered greys, not just the two stripe colours
+    _identical(o, g, "anisotropic")

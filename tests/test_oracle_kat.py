@@ -94,3 +94,26 @@ def test_rot_matrix_conventions(L):
     c, s = math.cos(0.5), math.sin(0.5)
     assert np.allclose(R, [[c, s, 0], [-s, c, 0], [0, 0, 1]], atol=1e-6)
     assert np.allclose(R @ R.T, np.eye(3), atol=1e-6)
+
+
+def test_anisotropic_tap_count_and_lod(oracle_lib):
+    """Vulkan's described anisotropic scheme: N = min(ceil(Pmax / Pmin), 16), lambda = log2(Pmax / N), clamped to the chain."""
+    L = oracle_lib.lib()
+
+    def q(ax, ay, bx, by, levels=8):
+        out = np.zeros(3, dtype=np.float32)
+        L.zo_kat_aniso(ax, ay, bx, by, levels, out.ctypes.data)
+        return int(out[0]), float(out[1]), int(out[2])
+    assert q(1, 0, 0, 1) == (1, 0.0, 1)                       # isotropic, magnification boundary
+    assert q(4, 0, 0, 4) == (1, 2.0, 1)                       # isotropic minification: plain trilinear at log2(4)
+    assert q(8, 0, 0, 1) == (8, 0.0, 1)                       # 8:1 along x: 8 taps of the base level
+    assert q(0, 1, 8, 0) == (8, 0.0, 0)                       # the same along y
+    n, l, _ = q(32, 0, 0, 1)
+    assert n == 16 and abs(l - 1.0) < 1e-6                    # capped at 16 taps, the rest goes to the LOD
+    n, l, _ = q(3.5, 0, 0, 1)
+    assert n == 4 and l == 0.0                                # log2(3.5 / 4) < 0 clamps to the base level
+    n, l, _ = q(6, 0, 0, 2)
+    assert n == 3 and abs(l - 1.0) < 1e-6                     # Pmax / N = 2 texels
+    assert q(5, 0, 0, 0)[0] == 16                             # degenerate minor axis
+    assert q(0, 0, 0, 0) == (1, 0.0, 1)                       # no footprint at all (log2 0 = -inf clamps to level 0)
+    assert q(1000, 0, 0, 1000, levels=4)[1] == 3.0            # clamped to the last level

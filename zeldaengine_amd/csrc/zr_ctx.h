@@ -86,7 +86,7 @@ struct zr_ctx {
     hipStream_t aux = nullptr;           // zr_render: the shadow pipeline runs here, next to the camera pipeline on `stream`
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048;
-    uint32_t work_capacity = 0, bin_capacity = 0;
+    uint32_t work_capacity = 0, bin_capacity = 0; bool any_images = false;
     // two-pass Hi-Z occlusion culling of the camera pass: per work item pixel bbox + least depth (written by the cull),
     // visibility of the previous / current frame (one byte per meshlet-instance, marked by the resolve), the pyramid
     uint2* d_pxrect = nullptr; float* d_zmin = nullptr; uint8_t* d_visflag[2] = { nullptr, nullptr };

@@ -516,6 +516,8 @@ static int finalize_scene(zr_ctx* c)
         HIPCHK(c, dev_alloc(&c->d_pxrect, c->work_capacity)); HIPCHK(c, dev_alloc(&c->d_zmin, c->work_capacity));
         HIPCHK(c, dev_alloc(&c->d_visflag[0], c->work_capacity)); HIPCHK(c, dev_alloc(&c->d_visflag[1], c->work_capacity));
     }
+    c->any_images = false;
+    for (const ZrObject& d : tab) for (int t = 0; t < 7; ++t) if (d.tex[t].data) c->any_images = true;
     c->vis_history = false;         // work item numbering changed: last frame's visibility says nothing about this scene
     c->scene_dirty = false;
     return ZR_OK;
@@ -748,6 +750,7 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
     P->tiles_x = mode == ZR_MODE_SHADOW ? c->stiles_x : c->tiles_x; P->tiles_y = mode == ZR_MODE_SHADOW ? c->stiles_y : c->tiles_y;
     P->tile_rank = mode == ZR_MODE_SHADOW ? 0 : c->cfg.tile_rank; P->tile_world = mode == ZR_MODE_SHADOW ? 1 : c->cfg.tile_world;
     P->inst_rank = mode == ZR_MODE_SHADOW ? c->shadow_rank : 0; P->inst_world = mode == ZR_MODE_SHADOW ? c->shadow_world : 1;
+    P->images = c->any_images ? 1u : 0u;
     P->n_objects = c->n_objs; P->n_work = c->n_work; P->n_inst_total = c->n_inst_total; P->bin_capacity = c->bin_capacity;
     // the instance-level pre-pass pays for itself on big scenes; small ones go straight to one wave per meshlet-instance
     P->use_worklist = c->n_inst_total >= 65536u ? 1u : 0u;

@@ -863,18 +863,9 @@ __device__ __forceinline__ zf4 tex_bilinear(const ZrTex& T, int level, float u, 
 }
 // Isotropic LOD from the quad derivatives, trilinear.  Anisotropic filtering (maxAnisotropy = device max, ZE:6540) is
 // implementation-defined and not reproduced.  A constant slot returns its texel.
-__device__ __forceinline__ zf4 tex_sample(const ZrTex& T, const float* __restrict__ constant, bool srgb, const float* __restrict__ lut,
-                                          float u, float v, float dudx, float dvdx, float dudy, float dvdy)
+// trilinear between the two mip levels around lambda (already clamped to the chain)
+__device__ __forceinline__ zf4 tex_trilinear(const ZrTex& T, float lambda, float u, float v, bool srgb, const float* __restrict__ lut)
 {
-    if (T.data == nullptr) {      // constant slot: decoded once on the host
-        zf4 r; r.x = constant[0]; r.y = constant[1]; r.z = constant[2]; r.w = constant[3];
-        return r;
-    }
-    const float W = (float)T.w, H = (float)T.h;
-    const float ax = dudx * W, ay = dvdx * H, bx = dudy * W, by = dvdy * H;
-    const float rho2 = __builtin_fmaxf(__builtin_fmaf(ax, ax, ay * ay), __builtin_fmaf(bx, bx, by * by));
-    float lambda = 0.5f * zr_log2(rho2);
-    lambda = __builtin_fminf(__builtin_fmaxf(lambda, 0.0f), (float)(T.levels - 1u));
     const float fl = __builtin_floorf(lambda);
     const int l0 = (int)fl, l1 = min(l0 + 1, (int)T.levels - 1);
     const float f = lambda - fl;
@@ -884,9 +875,50 @@ __device__ __forceinline__ zf4 tex_sample(const ZrTex& T, const float* __restric
     r.z = __builtin_fmaf(f, c1.z - c0.z, c0.z); r.w = __builtin_fmaf(f, c1.w - c0.w, c0.w);
     return r;
 }
+// texture(sampler2D, uv): LINEAR, LINEAR mips, REPEAT, anisotropy on with the device's maximum (ZE:6523-6557).  The anisotropic
+// scheme is the one the Vulkan specification describes: N = min(ceil(Pmax / Pmin), 16) trilinear taps spread along the major
+// screen axis at lambda = log2(Pmax / N), averaged; N = 1 is plain trilinear filtering.
+#define ZR_MAX_ANISO 16
+__device__ __forceinline__ zf4 tex_sample_image(const ZrTex& T, bool srgb, const float* __restrict__ lut,
+                                             float u, float v, float dudx, float dvdx, float dudy, float dvdy)
+{
+    const float W = (float)T.w, H = (float)T.h;
+    const float ax = dudx * W, ay = dvdx * H, bx = dudy * W, by = dvdy * H;
+    const float rx2 = __builtin_fmaf(ax, ax, ay * ay), ry2 = __builtin_fmaf(bx, bx, by * by);
+    const bool xmajor = rx2 >= ry2;
+    const float rmax2 = __builtin_fmaxf(rx2, ry2), rmin2 = __builtin_fminf(rx2, ry2);
+    int N = 1;                                            // least N with N^2 * Pmin^2 >= Pmax^2, at most the limit
+    while (N < ZR_MAX_ANISO && (float)(N * N) * rmin2 < rmax2) ++N;
+    float lambda = 0.5f * zr_log2(rmax2);
+    if (N > 1) lambda = lambda - zr_log2((float)N);
+    lambda = __builtin_fminf(__builtin_fmaxf(lambda, 0.0f), (float)(T.levels - 1u));
+    if (N == 1) return tex_trilinear(T, lambda, u, v, srgb, lut);
+    const float du = xmajor ? dudx : dudy, dv = xmajor ? dvdx : dvdy;
+    zf4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
+    for (int i = 1; i <= N; ++i) {
+        const float off = (float)i / (float)(N + 1) - 0.5f;
+        const zf4 s = tex_trilinear(T, lambda, __builtin_fmaf(du, off, u), __builtin_fmaf(dv, off, v), srgb, lut);
+        acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
+    }
+    zf4 r; r.x = acc.x / (float)N; r.y = acc.y / (float)N; r.z = acc.z / (float)N; r.w = acc.w / (float)N;
+    return r;
+}
+// IMAGES = false: the caller knows that no slot of the scene holds an image (every material constant, the common synthetic
+// case): the filter is not even instantiated, which keeps eight inlined copies of it out of the kernel's registers.
+template <bool IMAGES>
+__device__ __forceinline__ zf4 tex_sample(const ZrTex& T, const float* __restrict__ constant, bool srgb, const float* __restrict__ lut,
+                                          float u, float v, float dudx, float dvdx, float dudy, float dvdy)
+{
+    if (!IMAGES || T.data == nullptr) {      // constant slot: decoded once on the host
+        zf4 r; r.x = constant[0]; r.y = constant[1]; r.z = constant[2]; r.w = constant[3];
+        return r;
+    }
+    return tex_sample_image(T, srgb, lut, u, v, dudx, dvdx, dudy, dvdy);
+}
 
 // BaseScene.frag:26-48 for the pixel (px, py) whose winning primitive is `prim`
 // returns true when the pixel holds scene geometry (not empty, not sky)
+template <bool IMAGES>
 __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* __restrict__ objs, uint32_t prim, float depth,
                                               int px, int py, const GBufferPtrs& G, const float* __restrict__ lut,
                                               uint8_t* __restrict__ vis_now)
@@ -941,7 +973,7 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
     const float s1 = (u0 - uh) * sx, t1 = (v0 - vh) * sx, s2 = (u0 - uv_) * sy, t2 = (v0 - vv) * sy;
 
     if (O->flags & ZR_OBJ_SKY) {    // Skydome.frag: texture(skydomeSampler, uv).rgb, gamma; the GBuffer keeps its clear values
-        const zf4 sk = tex_sample(O->tex[0], O->texc[0], true, lut, u0, v0, s1, t1, s2, t2);
+        const zf4 sk = tex_sample<IMAGES>(O->tex[0], O->texc[0], true, lut, u0, v0, s1, t1, s2, t2);
         G.depth[p] = 1.0f; G.scene_color[p] = 0xFF000000u; G.gA[p] = 0u; G.gB[p] = 0xFF000000u; G.gC[p] = 0xFF000000u;
         G.gD[p] = make_uint2(0u, 0x3C000000u);
         G.overlay[p] = zr_unorm(zr_pow(sk.x, 0.4545f), 255.0f) | zr_unorm(zr_pow(sk.y, 0.4545f), 255.0f) << 8 |
@@ -950,13 +982,13 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
     }
     G.overlay[p] = 0u;
     // texture(samplerN, fragTexCoord), BaseScene.frag:30-36; slot 0 (base colour) is R8G8B8A8_SRGB (ZE:5878)
-    const zf4 tb = tex_sample(O->tex[0], O->texc[0], true, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tme = tex_sample(O->tex[1], O->texc[1], false, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tro = tex_sample(O->tex[2], O->texc[2], false, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tno = tex_sample(O->tex[3], O->texc[3], false, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tao = tex_sample(O->tex[4], O->texc[4], false, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tem = tex_sample(O->tex[5], O->texc[5], false, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tms = tex_sample(O->tex[6], O->texc[6], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tb = tex_sample<IMAGES>(O->tex[0], O->texc[0], true, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tme = tex_sample<IMAGES>(O->tex[1], O->texc[1], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tro = tex_sample<IMAGES>(O->tex[2], O->texc[2], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tno = tex_sample<IMAGES>(O->tex[3], O->texc[3], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tao = tex_sample<IMAGES>(O->tex[4], O->texc[4], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tem = tex_sample<IMAGES>(O->tex[5], O->texc[5], false, lut, u0, v0, s1, t1, s2, t2);
+    const zf4 tms = tex_sample<IMAGES>(O->tex[6], O->texc[6], false, lut, u0, v0, s1, t1, s2, t2);
     const float Metallic = tme.x;
     const float Rough = __builtin_fmaxf(0.01f, tro.x);
     const zf3 texN = zr3(tno.x, tno.y, tno.z);
@@ -1155,6 +1187,7 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
 }
 
 // BaseScene.frag for every pixel of the owned tiles, from the frame's key buffer; resets the keys for the next frame.
+template <bool IMAGES>
 __global__ __launch_bounds__(256) void k_resolve_gbuffer(ZrPass P, const ZrObject* __restrict__ objs,
                                                          const uint32_t* __restrict__ owned_tiles,
                                                          unsigned long long* __restrict__ vis64, GBufferPtrs G,
@@ -1175,7 +1208,7 @@ __global__ __launch_bounds__(256) void k_resolve_gbuffer(ZrPass P, const ZrObjec
         const size_t p = (size_t)py * P.W + (size_t)px;
         const unsigned long long k = vis64[p];
         vis64[p] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
-        ncov += resolve_pixel(P, objs, (uint32_t)k, zr_u2f((uint32_t)(k >> 32)), px, py, G, srgb_lut, vis_now) ? 1u : 0u;
+        ncov += resolve_pixel<IMAGES>(P, objs, (uint32_t)k, zr_u2f((uint32_t)(k >> 32)), px, py, G, srgb_lut, vis_now) ? 1u : 0u;
     }
     if (ncov) atomicAdd(&covered_s, ncov);
     __syncthreads();
@@ -1278,7 +1311,7 @@ __device__ __forceinline__ float shadow_tap(const float* __restrict__ S, int SD,
 }
 
 // BaseLighting.frag:147-254 for every pixel of the owned tiles (the full-screen quad of ZE:3531-3540)
-template <bool LIGHT_LIST>
+template <bool LIGHT_LIST, bool BACKGROUND>
 __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView* __restrict__ view,
                                                   const uint32_t* __restrict__ owned_tiles, GBufferPtrs G,
                                                   const float* __restrict__ shadowmap, CubeDesc C,
@@ -1548,10 +1581,10 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
         if (L.debug_view == 0u) {      // skydome, then background quad at z = 1 (LESS_OR_EQUAL): drawn over the lit quad (ZE:3681-3699)
             const uint32_t ov = G.overlay[p];
             if (ov) rgba = ov;
-            else if (L.bg_enabled && 1.0f <= G.depth[p]) {
+            else if (BACKGROUND && L.bg_enabled && 1.0f <= G.depth[p]) {
                 const float u = ((float)px + 0.5f) / (float)L.W, v = ((float)py + 0.5f) / (float)L.H;
                 const float one4[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
-                const zf4 bgc = tex_sample(L.bg, one4, true, srgb_lut, u, v, 1.0f / (float)L.W, 0.0f, 0.0f, 1.0f / (float)L.H);
+                const zf4 bgc = tex_sample<true>(L.bg, one4, true, srgb_lut, u, v, 1.0f / (float)L.W, 0.0f, 0.0f, 1.0f / (float)L.H);
                 rgba = zr_unorm(zr_pow(bgc.x, 0.4545f), 255.0f) | zr_unorm(zr_pow(bgc.y, 0.4545f), 255.0f) << 8 |
                        zr_unorm(zr_pow(bgc.z, 0.4545f), 255.0f) << 16 | 255u << 24;
             }
@@ -1761,7 +1794,8 @@ void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint
                                ZrDevStats* stats, hipStream_t s)
 {
     if (n_owned == 0) return;
-    hipLaunchKernelGGL(k_resolve_gbuffer, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, vis_now, stats);
+    if (P.images) hipLaunchKernelGGL(k_resolve_gbuffer<true>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, vis_now, stats);
+    else hipLaunchKernelGGL(k_resolve_gbuffer<false>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, vis_now, stats);
 }
 void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, hipStream_t s)
 {
@@ -1773,8 +1807,10 @@ void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32
 {
     if (n_owned == 0) return;
     // with several point lights each tile first builds its light list (L.light_list: decided on the host from the light count)
-    if (L.light_list) hipLaunchKernelGGL(k_lighting<true>, dim3(n_owned), dim3(256), 0, s, L, view, owned_tiles, G, shadowmap, C, lut, unorm_lut, out);
-    else hipLaunchKernelGGL(k_lighting<false>, dim3(n_owned), dim3(256), 0, s, L, view, owned_tiles, G, shadowmap, C, lut, unorm_lut, out);
+#define ZR_LAUNCH_LIGHTING(LL, BG) hipLaunchKernelGGL((k_lighting<LL, BG>), dim3(n_owned), dim3(256), 0, s, L, view, owned_tiles, G, shadowmap, C, lut, unorm_lut, out)
+    if (L.light_list) { if (L.bg_enabled) ZR_LAUNCH_LIGHTING(true, true); else ZR_LAUNCH_LIGHTING(true, false); }
+    else { if (L.bg_enabled) ZR_LAUNCH_LIGHTING(false, true); else ZR_LAUNCH_LIGHTING(false, false); }
+#undef ZR_LAUNCH_LIGHTING
 }
 void zr_launch_gbuffer_vis(const ZrLightParams& L, const XkView* view, const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C,
                            const float* lut, uint32_t* out, hipStream_t s)

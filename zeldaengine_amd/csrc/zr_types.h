@@ -83,6 +83,7 @@ struct ZrPass {
     uint32_t mode;                   // ZR_MODE_*
     uint32_t frustum_ok, cone_ok;    // culling enabled (cone_ok also needs a standard perspective eye)
     uint32_t bin_capacity;
+    uint32_t images;                 // some material slot (or the skydome) holds an image: the resolve needs the texture filter
     uint32_t debug_skip;             // diagnostics only (env ZR_DEBUG_SKIP): 1 skip pixel walk, 2 skip triangle phase too
 };
 
