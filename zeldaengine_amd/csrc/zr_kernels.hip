@@ -599,7 +599,7 @@ struct TileCtx {
     int W, H;                     // target extent
 };
 
-// Cheap per-triangle rejection, identical in effect to the early-outs of raster_sub: degenerate, back-facing
+// Cheap per-triangle rejection, identical in effect to the early-outs of raster_sub: degenerate or back-facing
 // (GBUFFER only), or no pixel centre of this tile inside the snapped bounding box.
 // HIZ (camera pass, round 2): hz[] holds the tile's 4 x 4 pyramid texels (max depth per 8 x 8 pixel block after round 1); a
 // triangle whose least vertex depth lies behind every block its clipped box touches cannot win a pixel (fragment depths
@@ -608,9 +608,10 @@ template <int MODE, bool HIZ = false>
 __device__ __forceinline__ bool tri_prefilter(int X0, int Y0, int X1, int Y1, int X2, int Y2, const TileCtx& T,
                                               float zmin = 0.0f, const float* __restrict__ hz = nullptr)
 {
-    const long long A = (long long)(X1 - X0) * (Y2 - Y0) - (long long)(X2 - X0) * (Y1 - Y0);
-    if (A == 0) return false;
-    if (MODE == ZR_MODE_GBUFFER && A > 0) return false;
+    if (MODE == ZR_MODE_GBUFFER) {      // the shadow pass is two-sided: its (rare) degenerate triangles are left to raster_sub
+        const long long A = (long long)(X1 - X0) * (Y2 - Y0) - (long long)(X2 - X0) * (Y1 - Y0);
+        if (A >= 0) return false;
+    }
     const int x0 = max((imin3(X0, X1, X2) - 128 + 255) >> 8, T.px0), x1 = min((imax3(X0, X1, X2) - 128) >> 8, min(T.px0 + TILE - 1, T.W - 1));
     const int y0 = max((imin3(Y0, Y1, Y2) - 128 + 255) >> 8, T.py0), y1 = min((imax3(Y0, Y1, Y2) - 128) >> 8, min(T.py0 + TILE - 1, T.H - 1));
     if (!(x0 <= x1 && y0 <= y1)) return false;
@@ -654,7 +655,14 @@ __device__ __forceinline__ void raster_sub(const SV& v0, const SV& v1, const SV&
                                            unsigned long long* __restrict__ keys64, uint32_t* __restrict__ keys32)
 {
     const int dX1 = v1.X - v0.X, dY1 = v1.Y - v0.Y, dX2 = v2.X - v0.X, dY2 = v2.Y - v0.Y;
-    const long long A = (long long)dX1 * dY2 - (long long)dX2 * dY1;
+    // Small triangles (every edge component below 2^12 sub-pixel units = 16 px) keep the whole setup in 32 bits: products stay
+    // below 2^27 and every edge value met in the walk below 2^28.  The test is made wave-uniform so that the 64-bit code is
+    // skipped altogether; both routes produce the same integers.
+    const int ext = max(max(abs(dX1), abs(dY1)), max(abs(dX2), abs(dY2)));
+    const bool all_small = __ballot(ext >= (1 << 12)) == 0ull;
+    long long A;
+    if (all_small) A = (long long)(dX1 * dY2 - dX2 * dY1);
+    else A = (long long)dX1 * dY2 - (long long)dX2 * dY1;
     if (A == 0) return;
     // Vulkan facing: a = -A/2 in framebuffer coordinates; COUNTER_CLOCKWISE front  <=>  A < 0 (ZE:5113-5123)
     if (MODE == ZR_MODE_GBUFFER && A > 0) return;
@@ -670,9 +678,8 @@ __device__ __forceinline__ void raster_sub(const SV& v0, const SV& v1, const SV&
     const int ex1 = sgn * (v0.X - v2.X), ey1 = sgn * (v0.Y - v2.Y);
     const int ex2 = sgn * (v1.X - v0.X), ey2 = sgn * (v1.Y - v0.Y);
     const int Px0 = x0 * 256 + 128, Py0 = y0 * 256 + 128;
-    long long E0 = (long long)ex0 * (Py0 - v1.Y) - (long long)ey0 * (Px0 - v1.X) - (((ey0 < 0) || (ey0 == 0 && ex0 > 0)) ? 0 : 1);
-    long long E1 = (long long)ex1 * (Py0 - v2.Y) - (long long)ey1 * (Px0 - v2.X) - (((ey1 < 0) || (ey1 == 0 && ex1 > 0)) ? 0 : 1);
-    long long E2 = (long long)ex2 * (Py0 - v0.Y) - (long long)ey2 * (Px0 - v0.X) - (((ey2 < 0) || (ey2 == 0 && ex2 > 0)) ? 0 : 1);
+    const int tl0 = ((ey0 < 0) || (ey0 == 0 && ex0 > 0)) ? 0 : 1, tl1 = ((ey1 < 0) || (ey1 == 0 && ex1 > 0)) ? 0 : 1;
+    const int tl2 = ((ey2 < 0) || (ey2 == 0 && ex2 > 0)) ? 0 : 1;
 
     // depth plane anchored at vertex 0, gradients per sub-pixel unit
     const float invA = 1.0f / (float)A;
@@ -690,14 +697,28 @@ __device__ __forceinline__ void raster_sub(const SV& v0, const SV& v1, const SV&
         const float r = (e > (23u << 23) && e < 0x7F800000u) ? zr_u2f(e - (23u << 23)) : 0.0f;
         bias = __builtin_fmaf(m, 7.5f, r * 1.25f);
     }
-    // |E| anywhere in the walk <= |E at the origin| + nx*|sx| + ny*|sy|
-    const long long nx = x1 - x0 + 1, ny = y1 - y0 + 1;
-    const long long lim = 0x3FFFFFFFll;
-    const long long m0 = (E0 < 0 ? -E0 : E0) + 256 * (nx * (ey0 < 0 ? -(long long)ey0 : ey0) + ny * (ex0 < 0 ? -(long long)ex0 : ex0));
-    const long long m1 = (E1 < 0 ? -E1 : E1) + 256 * (nx * (ey1 < 0 ? -(long long)ey1 : ey1) + ny * (ex1 < 0 ? -(long long)ex1 : ex1));
-    const long long m2 = (E2 < 0 ? -E2 : E2) + 256 * (nx * (ey2 < 0 ? -(long long)ey2 : ey2) + ny * (ex2 < 0 ? -(long long)ex2 : ex2));
-    if (m0 < lim && m1 < lim && m2 < lim) {
-        int e0 = (int)E0, e1 = (int)E1, e2 = (int)E2;
+    int e0 = 0, e1 = 0, e2 = 0;
+    long long E0 = 0, E1 = 0, E2 = 0;
+    bool fits;
+    if (all_small) {
+        e0 = ex0 * (Py0 - v1.Y) - ey0 * (Px0 - v1.X) - tl0;
+        e1 = ex1 * (Py0 - v2.Y) - ey1 * (Px0 - v2.X) - tl1;
+        e2 = ex2 * (Py0 - v0.Y) - ey2 * (Px0 - v0.X) - tl2;
+        fits = true;
+    } else {
+        E0 = (long long)ex0 * (Py0 - v1.Y) - (long long)ey0 * (Px0 - v1.X) - tl0;
+        E1 = (long long)ex1 * (Py0 - v2.Y) - (long long)ey1 * (Px0 - v2.X) - tl1;
+        E2 = (long long)ex2 * (Py0 - v0.Y) - (long long)ey2 * (Px0 - v0.X) - tl2;
+        // |E| anywhere in the walk <= |E at the origin| + nx*|sx| + ny*|sy|
+        const long long nx = x1 - x0 + 1, ny = y1 - y0 + 1;
+        const long long lim = 0x3FFFFFFFll;
+        const long long m0 = (E0 < 0 ? -E0 : E0) + 256 * (nx * (ey0 < 0 ? -(long long)ey0 : ey0) + ny * (ex0 < 0 ? -(long long)ex0 : ex0));
+        const long long m1 = (E1 < 0 ? -E1 : E1) + 256 * (nx * (ey1 < 0 ? -(long long)ey1 : ey1) + ny * (ex1 < 0 ? -(long long)ex1 : ex1));
+        const long long m2 = (E2 < 0 ? -E2 : E2) + 256 * (nx * (ey2 < 0 ? -(long long)ey2 : ey2) + ny * (ex2 < 0 ? -(long long)ex2 : ex2));
+        fits = m0 < lim && m1 < lim && m2 < lim;
+        if (fits) { e0 = (int)E0; e1 = (int)E1; e2 = (int)E2; }
+    }
+    if (fits) {
         const int sx0 = -ey0 * 256, sx1 = -ey1 * 256, sx2 = -ey2 * 256, sy0 = ex0 * 256, sy1 = ex1 * 256, sy2 = ex2 * 256;
         for (int y = y0; y <= y1; ++y) {
             int r0 = e0, r1 = e1, r2 = e2;
@@ -1432,8 +1453,8 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
             const bool pattern = cx1[0] == cb + 1 && (cx0[1] == cb + 1 || p1) && cx1[1] == cx0[1] + 1 && cx0[2] == cb + 3 && cx1[2] == cb + 4 &&
                                  (cx0[3] == cb + 4 || p3) && cx1[3] == cx0[3] + 1 && cx0[4] == cb + 6 && cx1[4] == cb + 7;
             if (pattern) {
-                // taps accumulate in the reference's order (x outer, y inner): keep the 25 results, add afterwards
-                float tapv[5][5];
+                // taps accumulate in the reference's order (x outer, y inner): keep the 25 outcomes (one bit each), add afterwards
+                uint32_t lit = 0u;
 #pragma unroll
                 for (int y = 0; y < 5; ++y) {
                     const float4_u a0 = *(const float4_u*)(shadowmap + ry0[y] + cb), a1 = *(const float4_u*)(shadowmap + ry0[y] + cb + 4);
@@ -1446,13 +1467,13 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
                     for (int x = 0; x < 5; ++x) {
                         const float top = __builtin_fmaf(wa[x], t10[x] - t00[x], t00[x]), bot = __builtin_fmaf(wa[x], t11[x] - t01[x], t01[x]);
                         const float dist = __builtin_fmaf(wb[y], bot - top, top);
-                        tapv[x][y] = (sw > 0.0f && dist < sz) ? 0.1f : 1.0f;
+                        if (sw > 0.0f && dist < sz) lit |= 1u << (x * 5 + y);
                     }
                 }
 #pragma unroll
                 for (int x = 0; x < 5; ++x)
 #pragma unroll
-                    for (int y = 0; y < 5; ++y) sum += tapv[x][y];
+                    for (int y = 0; y < 5; ++y) sum += ((lit >> (x * 5 + y)) & 1u) ? 0.1f : 1.0f;
             } else {
 #pragma unroll
                 for (int x = 0; x < 5; ++x)
