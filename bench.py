@@ -63,8 +63,9 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=[3, 4, 5],
                     help="3: the metric's workload (default); 4: 1M instances at 3840x2160; 5: config 4 with 256 point lights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--timing-interval", type=int, default=8,
-                    help="per-kernel hipEvents are recorded on every n-th timed frame (each record is a ~6 us stream bubble)")
+    ap.add_argument("--timing-interval", type=int, default=0,
+                    help="per-kernel hipEvents are recorded on every n-th timed frame (each record is a ~6 us stream bubble); "
+                         "0 = steps // 6 clamped to 1..16, i.e. at least six timed frames")
     ap.add_argument("--cpu-sample-instances", type=int, default=10000)
     args = ap.parse_args()
 
@@ -96,7 +97,8 @@ def main():
     r = dr.r
     engine.load_scene(r, cfg)
     step = dr.frame        # render [+ ONE RCCL all-gather of the packed RGBA8 tiles + untile when world > 1]
-    interval = max(1, min(args.timing_interval, args.steps))
+    interval = args.timing_interval if args.timing_interval > 0 else max(1, min(16, args.steps // 6))
+    interval = max(1, min(interval, args.steps))
     r.set_timing_interval(interval)
 
     for _ in range(args.warmup):
