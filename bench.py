@@ -125,6 +125,15 @@ def main():
     # per-kernel means over the timed frames, from hipEvents recorded on the render stream
     times = r.pass_times(max(1, min(args.steps // interval, 64)))
     stats = r.stats()
+    # Informative only (never `value`): the rate when the host reads every frame back over PCIe (zr_read_color), N = 1
+    pcie_rate = None
+    if world == 1:
+        n_rb = max(5, min(20, args.steps))
+        t1 = time.perf_counter()
+        for _ in range(n_rb):
+            step()
+            r.color()
+        pcie_rate = W * H * n_rb / (time.perf_counter() - t1) / 1e6
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = W * H * args.steps / elapsed / 1e6
@@ -166,6 +175,7 @@ def main():
             "passes_timing": "hipEvents on the render stream, every %d-th timed frame" % interval,
             "passes_gbs": {k: round(alg[k] / (times[k] * 1e-3) / 1e9, 2) for k in alg if times[k] > 0},
             "stats": stats,
+            "pcie_inclusive_mpixels_s": None if pcie_rate is None else round(pcie_rate, 1),
         }
         if world == 1 and not args.no_cpu_baseline and args.config == 3:     # defined on the metric's workload only
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_instances)
