@@ -83,6 +83,8 @@ struct zr_ctx {
     struct Scratch { uint32_t *rects = nullptr, *tile_count = nullptr, *tile_offset = nullptr, *tile_cursor = nullptr, *chunk_offset = nullptr,
                      *work = nullptr; ZrBinEntry* bins = nullptr; } sc[2];
     uint32_t n_inst_total = 0;
+    // one pixel holding the clear value of every GBuffer target, and the colour the lighting shader gives it this frame
+    uint8_t* d_clear_px = nullptr; GBufferPtrs Gclear = {}; uint32_t* d_empty_rgba = nullptr; bool empty_ready = false;
     hipStream_t aux = nullptr;           // zr_render: the shadow pipeline runs here, next to the camera pipeline on `stream`
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048;

@@ -122,6 +122,19 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         ok &= dev_alloc(&sc.chunk_offset, mt) == hipSuccess;
         if (ok) ok &= hipMemset(sc.tile_count, 0, mt * 4) == hipSuccess;
     }
+    {   // the clear values of ZE:3427-3433, as resolve_pixel writes them for an empty pixel
+        ok &= dev_alloc(&c->d_clear_px, 64) == hipSuccess;
+        ok &= dev_alloc(&c->d_empty_rgba, 1) == hipSuccess;
+        uint32_t px[16] = { 0 };
+        px[0] = 0x3F800000u;                    // depth 1.0
+        px[1] = 0xFF000000u; px[2] = 0u; px[3] = 0xFF000000u; px[4] = 0xFF000000u;   // SceneColor, A, B, C
+        px[6] = 0u; px[7] = 0x3C000000u;        // D = (0, 0, 0, 1) as fp16
+        px[8] = 0u;                             // overlay
+        if (ok) ok &= hipMemcpy(c->d_clear_px, px, sizeof px, hipMemcpyHostToDevice) == hipSuccess;
+        uint32_t* w = (uint32_t*)c->d_clear_px;
+        c->Gclear.depth = (float*)w; c->Gclear.scene_color = w + 1; c->Gclear.gA = w + 2; c->Gclear.gB = w + 3; c->Gclear.gC = w + 4;
+        c->Gclear.gD = (uint2*)(w + 6); c->Gclear.overlay = w + 8;
+    }
     ok &= hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) == hipSuccess;
     ok &= hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok &= hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
@@ -175,6 +188,7 @@ extern "C" void zr_destroy(zr_ctx* c)
         dev_free(sc.tile_count); dev_free(sc.tile_offset); dev_free(sc.tile_cursor); dev_free(sc.chunk_offset);
         dev_free(sc.rects); dev_free(sc.bins); dev_free(sc.work);
     }
+    dev_free(c->d_clear_px); dev_free(c->d_empty_rgba);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -917,14 +931,9 @@ extern "C" int zr_render_gbuffer(zr_ctx* c)
     return rc;
 }
 
-extern "C" int zr_render_lighting(zr_ctx* c)
+static void light_params(const zr_ctx* c, ZrLightParams* Lp)
 {
-    if (!c) return ZR_ERR_ARG;
-    if (c->stage != 2) return zr_fail(c, ZR_ERR_STATE, "zr_render_lighting out of order");
-    HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
-    ZrLightParams L; memset(&L, 0, sizeof L);
+    ZrLightParams& L = *Lp; memset(&L, 0, sizeof L);
     static const float Bias[16] = { 0.5f, 0, 0, 0, 0, 0.5f, 0, 0, 0, 0, 1, 0, 0.5f, 0.5f, 0, 1 };
     zr_mat4_mul(Bias, c->view.ShadowmapSpace, L.SB);
     L.W = c->W; L.H = c->H; L.SD = c->SD; L.tiles_x = c->tiles_x; L.debug_view = c->debug_view;
@@ -935,6 +944,29 @@ extern "C" int zr_render_lighting(zr_ctx* c)
     { const char* e = getenv("ZR_LIGHT_LIST_MIN"); const int32_t lmin = e ? atoi(e) : 4;      // env: A/B only
       const int32_t np = c->view.LightsCount[1]; L.light_list = (np >= lmin && np <= XK_MAX_POINT_LIGHTS_NUM) ? 1u : 0u; }
     L.bg.data = c->d_bg; L.bg.w = c->bg_w; L.bg.h = c->bg_h; L.bg.levels = c->bg_levels; L.bg._pad = 0;
+}
+
+// The lighting shader's colour for a pixel that still holds every target's clear value: one launch of the lighting kernel over a
+// one-pixel GBuffer.  It needs the finished shadow map (PCF at world position 0) and the frame's uniforms, nothing else.  View 6
+// (the quad's interpolated vertex colour) depends on the pixel position, so it goes without.
+static int empty_pixel_pass(zr_ctx* c, hipStream_t s)
+{
+    c->empty_ready = false;
+    if (c->debug_view == 6u || getenv("ZR_NO_EMPTY_PIXEL")) return ZR_OK;      // env: A/B only
+    ZrLightParams L; light_params(c, &L);
+    L.W = 1; L.H = 1; L.tiles_x = 1; L.packed_out = 0; L.bg_enabled = 0;
+    zr_launch_lighting(L, c->d_view, c->d_sowned, 1, c->Gclear, shadow_buf(c), c->cube, c->d_lut, c->d_unorm_lut, c->d_empty_rgba, s);
+    HIPCHK(c, hipGetLastError());
+    c->empty_ready = true;
+    return ZR_OK;
+}
+
+static int lighting_pass(zr_ctx* c)
+{
+    hipStream_t s = c->stream;
+    hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
+    ZrLightParams L; light_params(c, &L);
+    L.empty_rgba = c->empty_ready ? c->d_empty_rgba : nullptr;
     zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, shadow_buf(c), c->cube, c->d_lut, c->d_unorm_lut,
                        L.packed_out ? (c->d_tiles_ext ? c->d_tiles_ext : c->d_tiles) : c->d_color, s);
     if (c->debug_view == 9u)        // GBufferVis mosaic over the lit frame (needs the whole GBuffer: single-rank contexts only)
@@ -944,6 +976,16 @@ extern "C" int zr_render_lighting(zr_ctx* c)
     if (c->timing_now) c->sample_no++;
     c->rendered = true; c->frame_no++; c->stage = 0;
     return ZR_OK;
+}
+
+extern "C" int zr_render_lighting(zr_ctx* c)
+{
+    if (!c) return ZR_ERR_ARG;
+    if (c->stage != 2) return zr_fail(c, ZR_ERR_STATE, "zr_render_lighting out of order");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = empty_pixel_pass(c, c->stream);       // staged frame: the shadow map (possibly reduced over ranks) is final only now
+    if (rc == ZR_OK) rc = lighting_pass(c);
+    return rc;
 }
 
 // RecordCommandBuffer (ZE:3160-3744) + vkQueueSubmit (ZE:2014): shadow -> deferred scene -> deferred lighting.
@@ -962,14 +1004,16 @@ extern "C" int zr_render(zr_ctx* c)
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
         rc = shadow_pass(c, c->aux);
+        if (rc == ZR_OK) rc = empty_pixel_pass(c, c->aux);
         if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
         if (rc == ZR_OK) rc = gbuffer_pass(c, c->stream);
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     } else {
         rc = shadow_pass(c, c->stream);
+        if (rc == ZR_OK) rc = empty_pixel_pass(c, c->stream);
         if (rc == ZR_OK) rc = gbuffer_pass(c, c->stream);
     }
-    if (rc == ZR_OK) { c->stage = 2; rc = zr_render_lighting(c); }
+    if (rc == ZR_OK) { c->stage = 2; HIPCHK(c, hipSetDevice(c->device)); rc = lighting_pass(c); }
     if (rc != ZR_OK) c->stage = 0;
     return rc;
 }

@@ -1412,6 +1412,28 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
         const size_t p = (size_t)py * L.W + (size_t)px;
         const uint32_t sc = G.scene_color[p], A = G.gA[p], B = G.gB[p], Cc = G.gC[p];
         const uint2 D = G.gD[p];
+        // what every path ends with: the skydome / background drawn over the lit quad in view 0 (ZE:3681-3699), then the store
+        auto emit = [&](uint32_t rgba) {
+            if (L.debug_view == 0u) {
+                const uint32_t ov = G.overlay[p];
+                if (ov) rgba = ov;
+                else if (BACKGROUND && L.bg_enabled && 1.0f <= G.depth[p]) {
+                    const float u = ((float)px + 0.5f) / (float)L.W, v = ((float)py + 0.5f) / (float)L.H;
+                    const float one4[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
+                    const zf4 bgc = tex_sample<true>(L.bg, one4, true, srgb_lut, u, v, 1.0f / (float)L.W, 0.0f, 0.0f, 1.0f / (float)L.H);
+                    rgba = zr_unorm(zr_pow(bgc.x, 0.4545f), 255.0f) | zr_unorm(zr_pow(bgc.y, 0.4545f), 255.0f) << 8 |
+                           zr_unorm(zr_pow(bgc.z, 0.4545f), 255.0f) << 16 | 255u << 24;
+                }
+            }
+            if (L.packed_out) out[(size_t)blockIdx.x * TILE_PIX + i] = rgba;
+            else out[p] = rgba;
+        };
+        // A pixel nothing was drawn to holds the clear values of every target (ZE:3427-3433), so the shader computes the same
+        // colour for all of them: it was computed once (zr_launch_lighting's one-pixel pre-launch of this very kernel).
+        if (L.empty_rgba != nullptr && sc == 0xFF000000u && A == 0u && B == 0xFF000000u && Cc == 0xFF000000u && D.x == 0u && D.y == 0x3C000000u) {
+            emit(*L.empty_rgba);
+            continue;
+        }
         const zf3 BaseColor = zr3(u8[Cc & 255u], u8[(Cc >> 8) & 255u], u8[(Cc >> 16) & 255u]);
         const float Metallic = zr_saturate(u8[B & 255u]);
         float Roughness = zr_saturate(u8[(B >> 16) & 255u]);
@@ -1598,20 +1620,7 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
         }
         default: o = Final * ShadowFactor; break;
         }
-        uint32_t rgba = zr_unorm(o.x, 255.0f) | zr_unorm(o.y, 255.0f) << 8 | zr_unorm(o.z, 255.0f) << 16 | 255u << 24;
-        if (L.debug_view == 0u) {      // skydome, then background quad at z = 1 (LESS_OR_EQUAL): drawn over the lit quad (ZE:3681-3699)
-            const uint32_t ov = G.overlay[p];
-            if (ov) rgba = ov;
-            else if (BACKGROUND && L.bg_enabled && 1.0f <= G.depth[p]) {
-                const float u = ((float)px + 0.5f) / (float)L.W, v = ((float)py + 0.5f) / (float)L.H;
-                const float one4[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
-                const zf4 bgc = tex_sample<true>(L.bg, one4, true, srgb_lut, u, v, 1.0f / (float)L.W, 0.0f, 0.0f, 1.0f / (float)L.H);
-                rgba = zr_unorm(zr_pow(bgc.x, 0.4545f), 255.0f) | zr_unorm(zr_pow(bgc.y, 0.4545f), 255.0f) << 8 |
-                       zr_unorm(zr_pow(bgc.z, 0.4545f), 255.0f) << 16 | 255u << 24;
-            }
-        }
-        if (L.packed_out) out[(size_t)blockIdx.x * TILE_PIX + i] = rgba;
-        else out[p] = rgba;
+        emit(zr_unorm(o.x, 255.0f) | zr_unorm(o.y, 255.0f) << 8 | zr_unorm(o.z, 255.0f) << 16 | 255u << 24);
     }
 }
 

@@ -124,6 +124,7 @@ struct ZrLightParams {
     uint32_t debug_skip;             // diagnostics only (env ZR_DEBUG_SKIP_LIGHT bits: 1 PCF, 2 lights, 4 reflection)
     uint32_t bg_enabled;             // background quad (Background.vert/.frag) on
     uint32_t light_list;             // 1: per-tile point-light lists
+    const uint32_t* empty_rgba;      // the lit colour of a pixel holding the GBuffer's clear values (same for all of them), or null
     ZrTex    bg;                     // its sRGB texture
 };
 
