@@ -111,3 +111,26 @@ def test_full_size_config3_second_frame(oracle_lib, gpu_engine, tmp_path):
     st = g.stats()
     assert st["hiz_culled"] > 10000, st
     assert st["round1_survivors"] < 0.5 * (st["survivors"][1] + st["hiz_culled"]), st
+
+
+def test_tile_partitioned_ranks_keep_their_own_history(oracle_lib, gpu_engine):
+    """Two rank contexts (tiles t % 2) on one GPU over a moving sequence: each rank's occlusion history covers its own tiles
+    only, and the two packed halves still assemble to the oracle's frame on every frame."""
+    from zeldaengine_amd import dist as zdist
+    W, H, SD = 352, 208, 128
+    o = oracle_lib.Oracle(W, H, SD)
+    ranks = [gpu_engine.Renderer(W, H, SD, tile_rank=r, tile_world=2) for r in range(2)]
+    for r in [o] + ranks:
+        _crowd(r, 400, 3)
+    d, p, s = _lights()
+    for i, (pos, look) in enumerate(CAMS[:4]):
+        cam = abi.make_camera(pos, look, fov=50.0)
+        for r in [o] + ranks:
+            r.update_uniforms(cam, d, p, s, 0.05 * i, 0.0, 1.0)
+        o.render(0)
+        want = o.color()
+        for k, g in enumerate(ranks):
+            g.render(); g.finish()
+            assert np.array_equal(g.read_tiles(), zdist.pack_tiles(want, k, 2)), "frame %d rank %d" % (i, k)
+        if i:
+            assert all(g.stats()["round1_survivors"] > 0 for g in ranks)
