@@ -85,6 +85,12 @@ struct zr_ctx {
     uint32_t n_inst_total = 0;
     // one pixel holding the clear value of every GBuffer target, and the colour the lighting shader gives it this frame
     uint8_t* d_clear_px = nullptr; GBufferPtrs Gclear = {}; uint32_t* d_empty_rgba = nullptr; bool empty_ready = false;
+    // diagnostics / A-B switches read from the environment once, at zr_create (never needed for a correct frame)
+    uint32_t env_skip = 0, env_skip_light = 0; int32_t env_light_list_min = 4; bool env_no_empty_px = false, env_serial = false;
+    // XkView upload: a pageable-memory hipMemcpyAsync blocks the host until the stream has drained (~0.3 ms per frame here),
+    // so the uniforms go through a small ring of pinned copies, and only when they changed
+    static constexpr int VIEW_RING = 4;
+    XkView* h_view_ring = nullptr; hipEvent_t view_ev[VIEW_RING] = {}; uint32_t view_slot = 0; bool view_dirty = true;
     hipStream_t aux = nullptr;           // zr_render: the shadow pipeline runs here, next to the camera pipeline on `stream`
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048;

@@ -135,6 +135,16 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         c->Gclear.depth = (float*)w; c->Gclear.scene_color = w + 1; c->Gclear.gA = w + 2; c->Gclear.gB = w + 3; c->Gclear.gC = w + 4;
         c->Gclear.gD = (uint2*)(w + 6); c->Gclear.overlay = w + 8;
     }
+    {   // environment switches for diagnostics and A/B timing, read once
+        const char* e;
+        if ((e = getenv("ZR_DEBUG_SKIP"))) c->env_skip = (uint32_t)atoi(e);                 // 1: no pixel walk, 2: no triangle phase
+        if ((e = getenv("ZR_DEBUG_SKIP_LIGHT"))) c->env_skip_light = (uint32_t)atoi(e);     // bits: 1 PCF, 2 lights, 4 reflection
+        if ((e = getenv("ZR_LIGHT_LIST_MIN"))) c->env_light_list_min = atoi(e);
+        c->env_no_empty_px = getenv("ZR_NO_EMPTY_PIXEL") != nullptr;
+        c->env_serial = getenv("ZR_SERIAL_PASSES") != nullptr;
+    }
+    ok &= hipHostMalloc((void**)&c->h_view_ring, sizeof(XkView) * zr_ctx::VIEW_RING, hipHostMallocDefault) == hipSuccess;
+    for (auto& e : c->view_ev) ok &= hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     ok &= hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) == hipSuccess;
     ok &= hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok &= hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
@@ -189,6 +199,8 @@ extern "C" void zr_destroy(zr_ctx* c)
         dev_free(sc.rects); dev_free(sc.bins); dev_free(sc.work);
     }
     dev_free(c->d_clear_px); dev_free(c->d_empty_rgba);
+    if (c->h_view_ring) (void)hipHostFree(c->h_view_ring);
+    for (auto& e : c->view_ev) if (e) (void)hipEventDestroy(e);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -644,6 +656,7 @@ extern "C" int zr_set_cubemap(zr_ctx* c, const uint8_t* const faces[6], uint32_t
     }
     c->cube_dim = dim; c->cube_levels = levels;
     c->view.LightsCount[3] = (int32_t)levels;       // CubemapMaxMips, ZE:4308
+    c->view_dirty = true;
     return ZR_OK;
 }
 
@@ -679,6 +692,7 @@ extern "C" int zr_update_uniforms(zr_ctx* c, const zr_camera* cam, const XkLight
     ARGCHK(c, cam && n_dir <= XK_MAX_DIRECTIONAL_LIGHTS_NUM && n_point <= XK_MAX_POINT_LIGHTS_NUM && n_spot <= XK_MAX_SPOT_LIGHTS_NUM);
     ARGCHK(c, (n_dir == 0 || dir) && (n_point == 0 || point) && (n_spot == 0 || spot));
     XkView* V = &c->view;
+    c->view_dirty = true;
     for (uint32_t i = 0; i < n_dir; ++i) V->DirectionalLights[i] = dir[i];
     for (uint32_t i = 0; i < n_point; ++i) V->PointLights[i] = point[i];
     for (uint32_t i = 0; i < n_spot; ++i) V->SpotLights[i] = spot[i];
@@ -724,7 +738,7 @@ extern "C" int zr_set_frame(zr_ctx* c, const XkUniformBufferMVP* cam, const XkUn
     ARGCHK(c, cam && sh && v);
     ARGCHK(c, v->LightsCount[0] >= 0 && v->LightsCount[0] <= XK_MAX_DIRECTIONAL_LIGHTS_NUM && v->LightsCount[1] >= 0 &&
               v->LightsCount[1] <= XK_MAX_POINT_LIGHTS_NUM);
-    c->cam = *cam; c->shadow = *sh; c->view = *v;
+    c->cam = *cam; c->shadow = *sh; c->view = *v; c->view_dirty = true;
     c->frame_valid = true;
     return ZR_OK;
 }
@@ -768,7 +782,7 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
     P->n_objects = c->n_objs; P->n_work = c->n_work; P->n_inst_total = c->n_inst_total; P->bin_capacity = c->bin_capacity;
     // the instance-level pre-pass pays for itself on big scenes; small ones go straight to one wave per meshlet-instance
     P->use_worklist = c->n_inst_total >= 65536u ? 1u : 0u;
-    { const char* dbg = getenv("ZR_DEBUG_SKIP"); P->debug_skip = dbg ? (uint32_t)atoi(dbg) : 0u; }
+    P->debug_skip = c->env_skip;
     if (!finite16(P->PVM)) return false;
     // frustum planes of proj*view in world space (sphere centres are taken to world space by M in the kernel)
     bool fr_ok = !(c->cfg.flags & ZR_FLAG_NO_FRUSTUM_CULL) && finite16(u.Model);
@@ -838,13 +852,20 @@ static int frame_begin(zr_ctx* c)
     HIPCHK(c, hipSetDevice(c->device));
     int rc = finalize_scene(c);
     if (rc) return rc;
-    c->view.LightsCount[3] = (int32_t)c->cube_levels;
+    if (c->view.LightsCount[3] != (int32_t)c->cube_levels) { c->view.LightsCount[3] = (int32_t)c->cube_levels; c->view_dirty = true; }
     hipStream_t s = c->stream;
     c->timing_now = c->timing_interval != 0 && c->frame_no % c->timing_interval == 0;     // pass events cost ~6 us of stream bubble each
     hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
     if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
     HIPCHK(c, hipMemsetAsync(c->d_stats, 0, sizeof(ZrDevStats), s));
-    HIPCHK(c, hipMemcpyAsync(c->d_view, &c->view, sizeof(XkView), hipMemcpyHostToDevice, s));
+    if (c->view_dirty) {        // pinned ring slot: reused only after its previous upload has executed
+        const uint32_t k = c->view_slot++ % zr_ctx::VIEW_RING;
+        HIPCHK(c, hipEventSynchronize(c->view_ev[k]));
+        memcpy(&c->h_view_ring[k], &c->view, sizeof(XkView));
+        HIPCHK(c, hipMemcpyAsync(c->d_view, &c->h_view_ring[k], sizeof(XkView), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipEventRecord(c->view_ev[k], s));
+        c->view_dirty = false;
+    }
     return ZR_OK;
 }
 
@@ -939,10 +960,9 @@ static void light_params(const zr_ctx* c, ZrLightParams* Lp)
     L.W = c->W; L.H = c->H; L.SD = c->SD; L.tiles_x = c->tiles_x; L.debug_view = c->debug_view;
     L.cube_dim = c->cube_dim; L.cube_levels = c->cube_levels; L.tile_world = c->cfg.tile_world;
     L.packed_out = c->cfg.tile_world > 1 ? 1u : 0u;
-    { const char* dbg = getenv("ZR_DEBUG_SKIP_LIGHT"); L.debug_skip = dbg ? (uint32_t)atoi(dbg) : 0u; }
+    L.debug_skip = c->env_skip_light;
     L.bg_enabled = (c->bg_set && c->bg_enabled) ? 1u : 0u;
-    { const char* e = getenv("ZR_LIGHT_LIST_MIN"); const int32_t lmin = e ? atoi(e) : 4;      // env: A/B only
-      const int32_t np = c->view.LightsCount[1]; L.light_list = (np >= lmin && np <= XK_MAX_POINT_LIGHTS_NUM) ? 1u : 0u; }
+    { const int32_t np = c->view.LightsCount[1]; L.light_list = (np >= c->env_light_list_min && np <= XK_MAX_POINT_LIGHTS_NUM) ? 1u : 0u; }
     L.bg.data = c->d_bg; L.bg.w = c->bg_w; L.bg.h = c->bg_h; L.bg.levels = c->bg_levels; L.bg._pad = 0;
 }
 
@@ -952,7 +972,7 @@ static void light_params(const zr_ctx* c, ZrLightParams* Lp)
 static int empty_pixel_pass(zr_ctx* c, hipStream_t s)
 {
     c->empty_ready = false;
-    if (c->debug_view == 6u || getenv("ZR_NO_EMPTY_PIXEL")) return ZR_OK;      // env: A/B only
+    if (c->debug_view == 6u || c->env_no_empty_px) return ZR_OK;
     ZrLightParams L; light_params(c, &L);
     L.W = 1; L.H = 1; L.tiles_x = 1; L.packed_out = 0; L.bg_enabled = 0;
     zr_launch_lighting(L, c->d_view, c->d_sowned, 1, c->Gclear, shadow_buf(c), c->cube, c->d_lut, c->d_unorm_lut, c->d_empty_rgba, s);
@@ -999,7 +1019,7 @@ extern "C" int zr_render(zr_ctx* c)
     if (!c) return ZR_ERR_ARG;
     int rc = frame_begin(c);
     if (rc != ZR_OK) return rc;
-    const bool overlap = !(c->cfg.flags & ZR_FLAG_SERIAL_PASSES) && c->aux != nullptr && !getenv("ZR_SERIAL_PASSES");    // env: A/B only
+    const bool overlap = !(c->cfg.flags & ZR_FLAG_SERIAL_PASSES) && c->aux != nullptr && !c->env_serial;
     if (overlap) {
         HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));

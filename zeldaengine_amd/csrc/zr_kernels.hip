@@ -1,15 +1,19 @@
 // zr_kernels.hip — CDNA4 (gfx950) kernels of the deferred render path.
 //
 //   k_instance_prep   XkInstanceData -> ZrInstance (rotation matrix), once per zr_object_add
-//   k_cull<MODE>      one 64-lane wavefront per meshlet-instance: frustum + cone test on the bounds,
-//                     lane-per-vertex transform, exact snapped screen bbox -> tile rect + tile counters
-//   k_scan            exclusive scan of the per-tile counters (one workgroup)
-//   k_bin_fill        scatter meshlet-instance ids into per-tile lists
-//   k_raster_chunks<MODE>  persistent workgroups pull chunks (<= ZR_CHUNK entries of one 32x32 tile's list): per wave,
-//                     stage a meshlet's transformed vertices in LDS, set up <=124 triangles (2 per lane), rasterise
-//                     into the tile's LDS depth/visibility keys with ds_min; merge touched keys into HBM (atomic min)
-//   k_resolve_gbuffer BaseScene.frag per pixel from the key buffer; SoA GBuffer planes, coalesced row stores
-//   k_lighting        BaseLighting.frag per pixel (PCF 5x5, all lights, ambient, cubemap IBL, gamma)
+//   k_cull_instances  big scenes only: whole-mesh sphere vs frustum per instance -> compacted work list
+//   k_cull<MODE>      a wave owns a few meshlet-instances: lane-per-meshlet bounds tests (frustum, normal cone), then
+//                     wave-per-survivor lane-per-vertex transform -> exact snapped screen box -> tile rect (+ Hi-Z inputs)
+//   k_bin_count / k_scan / k_bin_fill   per-tile lists of self-contained 32-byte meshlet records (LDS histograms)
+//   k_raster_chunks<MODE, HIZ>  persistent workgroups pull chunks (<= ZR_CHUNK entries of one 32x32 tile's list): per wave,
+//                     stage a meshlet's transformed vertices in LDS, test its <=128 triangles (2 per lane), compact the
+//                     survivors, rasterise them lane-per-triangle into the tile's LDS depth/visibility keys with ds_min;
+//                     merge touched keys into HBM (atomic min)
+//   k_hiz_build       max-depth pyramid of the key buffer after round 1 (two-pass occlusion culling of the camera pass)
+//   k_resolve_gbuffer BaseScene.frag per pixel from the key buffer; SoA GBuffer planes, coalesced row stores; marks the
+//                     meshlet-instances that own a pixel (next frame's round 1)
+//   k_lighting        BaseLighting.frag per pixel (PCF 5x5, per-tile light list, ambient, cubemap IBL, gamma, debug views)
+//   k_gbuffer_vis     debug view 9: the GBufferVis mosaic
 //   k_untile          multi-GPU composite: all-gathered packed tiles -> row-major frame
 //
 // Replaces: SH/Shadowmap*.vert, SH/Base*.vert, SH/BaseScene.frag, SH/Background.vert + SH/BaseLighting.frag,
