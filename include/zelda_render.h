@@ -152,6 +152,12 @@ int  zr_render(zr_ctx* ctx);
 int  zr_render_shadow(zr_ctx* ctx);
 int  zr_render_gbuffer(zr_ctx* ctx);
 int  zr_render_lighting(zr_ctx* ctx);
+/* Both geometry passes at once, side by side as zr_render runs them (shadow pass on the library's second stream, deferred-scene
+ * pass on the render stream), WITHOUT joining them: the host makes whatever consumes the shadow map wait for it with
+ * zr_stream_wait_shadow (e.g. its collective stream before the min all-reduce, then the render stream before
+ * zr_render_lighting).  Replaces the pair zr_render_shadow + zr_render_gbuffer. */
+int  zr_render_geometry(zr_ctx* ctx);
+int  zr_stream_wait_shadow(zr_ctx* ctx, void* hip_stream);   /* hip_stream waits for the last enqueued shadow pass */
 int  zr_finish(zr_ctx* ctx);                        /* stream sync + overflow check */
 int  zr_get_pass_times(zr_ctx* ctx, float ms[ZR_PASS_COUNT]);              /* last frame */
 int  zr_get_pass_times_avg(zr_ctx* ctx, uint32_t last_n, float ms[ZR_PASS_COUNT]);  /* mean of the last n <= 64 timed frames */

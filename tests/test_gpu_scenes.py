@@ -261,6 +261,36 @@ def test_staged_frame_and_shadow_instance_partition(oracle_lib, gpu_engine):
     assert (maps[0] != want_shadow).any()                # a single share really is partial
 
 
+def test_geometry_stage_runs_both_passes_side_by_side(oracle_lib, gpu_engine):
+    """zr_render_geometry (shadow pass on the library's second stream next to the deferred-scene pass) + zr_stream_wait_shadow
+    + zr_render_lighting, as a multi-GPU host drives it, over a few frames; and the single-stream flag gives the same frame."""
+    import torch
+    cfg = scenes.config3(500, 320, 200)
+    full = gpu_engine.Renderer(cfg["width"], cfg["height"], 512, flags=abi.FLAG_SERIAL_PASSES)
+    gpu_engine.load_scene(full, cfg)
+    full.render()
+    want_color, want_shadow = full.color(), full.shadowmap()
+    g = gpu_engine.Renderer(cfg["width"], cfg["height"], 512)
+    gpu_engine.load_scene(g, cfg)
+    side = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    done = torch.cuda.Event()
+    for _ in range(3):
+        g.render_geometry()
+        with pytest.raises(gpu_engine.ZeldaRenderError):
+            g.render_gbuffer()                                   # already part of the geometry stage
+        g.stream_wait_shadow(side.cuda_stream)                   # where a host would all-reduce the shadow map
+        done.record(side)
+        main.wait_event(done)
+        g.stream_wait_shadow(main.cuda_stream)
+        g.render_lighting()
+    g.finish()
+    assert np.array_equal(g.color(), want_color)
+    assert np.array_equal(g.shadowmap().view(np.uint32), want_shadow.view(np.uint32))
+    g.render(); g.finish()                                       # the fused call after staged frames
+    assert np.array_equal(g.color(), want_color)
+
+
 def test_instance_level_precull_path(oracle_lib, gpu_engine):
     """>= 65536 instances switch on the two-level cull (instance spheres, then meshlets of the survivors): same frame."""
     v, idx = scenes.uv_sphere(8, 4, 0.5)                      # 48 triangles: keeps the oracle quick

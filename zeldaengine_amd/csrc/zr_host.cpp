@@ -952,6 +952,32 @@ extern "C" int zr_render_gbuffer(zr_ctx* c)
     return rc;
 }
 
+extern "C" int zr_render_geometry(zr_ctx* c)
+{
+    if (!c) return ZR_ERR_ARG;
+    int rc = frame_begin(c);
+    if (rc != ZR_OK) return rc;
+    if (!c->aux || c->env_serial || (c->cfg.flags & ZR_FLAG_SERIAL_PASSES)) {
+        rc = shadow_pass(c, c->stream);
+        if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, c->stream));
+    } else {
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        rc = shadow_pass(c, c->aux);
+        if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
+    }
+    if (rc == ZR_OK) rc = gbuffer_pass(c, c->stream);
+    if (rc == ZR_OK) c->stage = 2;
+    return rc;
+}
+
+extern "C" int zr_stream_wait_shadow(zr_ctx* c, void* hip_stream)
+{
+    if (!c) return ZR_ERR_ARG;
+    HIPCHK(c, hipStreamWaitEvent((hipStream_t)hip_stream, c->ev_join, 0));
+    return ZR_OK;
+}
+
 static void light_params(const zr_ctx* c, ZrLightParams* Lp)
 {
     ZrLightParams& L = *Lp; memset(&L, 0, sizeof L);

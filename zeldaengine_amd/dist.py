@@ -105,13 +105,12 @@ class DistributedRenderer:
         self.r.set_tiles_buffer(self.tiles[b].data_ptr())
         with torch.cuda.stream(self.render_stream):
             if self.split_shadow:
-                self.r.render_shadow()                          # this rank's share of the shadow casters
-                self.shadow_done.record(self.render_stream)
-                with torch.cuda.stream(self.comm_stream):       # min-reduce the maps while the camera passes run
-                    self.comm_stream.wait_event(self.shadow_done)
+                # this rank's share of the shadow casters (library's second stream) next to the camera passes (render stream)
+                self.r.render_geometry()
+                with torch.cuda.stream(self.comm_stream):       # min-reduce the maps as soon as the share is drawn
+                    self.r.stream_wait_shadow(self.comm_stream.cuda_stream)
                     dist.all_reduce(self.shadow, op=dist.ReduceOp.MIN)
                     self.shadow_reduced.record(self.comm_stream)
-                self.r.render_gbuffer()
                 self.render_stream.wait_event(self.shadow_reduced)
                 self.r.render_lighting()
             else:

@@ -61,6 +61,7 @@ def lib():
         "zr_set_debug_view": [vp, u32],
         "zr_render": [vp],
         "zr_render_shadow": [vp], "zr_render_gbuffer": [vp], "zr_render_lighting": [vp],
+        "zr_render_geometry": [vp], "zr_stream_wait_shadow": [vp, vp],
         "zr_set_shadow_partition": [vp, u32, u32], "zr_set_shadow_buffer": [vp, vp],
         "zr_finish": [vp],
         "zr_get_pass_times": [vp, vp],
@@ -293,6 +294,14 @@ class Renderer:
 
     def render_lighting(self):
         self._chk(self.L.zr_render_lighting(self.h))
+
+    def render_geometry(self):
+        """Shadow pass and deferred-scene pass side by side (not joined: see stream_wait_shadow)."""
+        self._chk(self.L.zr_render_geometry(self.h))
+
+    def stream_wait_shadow(self, hip_stream):
+        """Make a HIP stream (its raw handle) wait for the shadow pass enqueued last."""
+        self._chk(self.L.zr_stream_wait_shadow(self.h, hip_stream))
 
     def set_shadow_partition(self, rank, world):
         self._chk(self.L.zr_set_shadow_partition(self.h, rank, world))
