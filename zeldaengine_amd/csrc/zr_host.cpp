@@ -902,6 +902,7 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
     // not depend on the history; without one (first frame of a scene) or with ZR_FLAG_NO_HIZ everything is drawn at once.
     const bool hiz_on = !(c->cfg.flags & ZR_FLAG_NO_HIZ) && P.n_work != 0;
     ZrHiz Z = c->hiz;
+    Z.tiles_x = c->tiles_x; Z.tile_rank = c->cfg.tile_rank; Z.tile_world = c->cfg.tile_world;
     Z.pxrect = hiz_on ? c->d_pxrect : nullptr; Z.zmin = hiz_on ? c->d_zmin : nullptr;
     Z.vis_prev = c->d_visflag[c->vis_cur ^ 1]; Z.vis_now = hiz_on ? c->d_visflag[c->vis_cur] : nullptr;
     Z.phase = 0;

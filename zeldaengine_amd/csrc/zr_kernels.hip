@@ -378,7 +378,12 @@ __global__ __launch_bounds__(256) void k_hiz_build(const unsigned long long* __r
     bool any = false;
     for (uint32_t i = 0; i < 16u; ++i) {
         const uint32_t px = rx * 64u + bx * 8u + (i & 7u), py = ry * 64u + by * 8u + q * 2u + (i >> 3);
-        if (px < W && py < H) { m = __builtin_fmaxf(m, zr_u2f((uint32_t)(vis64[(size_t)py * W + px] >> 32))); any = true; }
+        if (px < W && py < H) {
+            // a tile of another rank never receives a fragment here: it must not keep the meshlets that straddle it alive
+            const bool mine = Z.tile_world <= 1u || ((py / TILE) * Z.tiles_x + px / TILE) % Z.tile_world == Z.tile_rank;
+            if (mine) m = __builtin_fmaxf(m, zr_u2f((uint32_t)(vis64[(size_t)py * W + px] >> 32)));
+            any = true;
+        }
     }
     if (!any) m = 0.0f;
     // combine the 4 quarters (lanes tid, tid+64, tid+128, tid+192) through LDS

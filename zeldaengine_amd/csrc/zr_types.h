@@ -110,6 +110,7 @@ struct ZrHiz {
     const uint8_t* vis_prev;         // per meshlet-instance: owned a pixel of the previous frame
     uint8_t*  vis_now;               // marked by the resolve
     uint32_t  phase;                 // 0: no Hi-Z (one round); 1: round 1 = last frame's visible set; 2: round 2 = the rest, Hi-Z tested
+    uint32_t  tiles_x, tile_rank, tile_world;   // pyramid texels over another rank's tiles read 0 ("hidden"): nothing is drawn there
 };
 
 // Uniforms of the lighting pass that are not in XkView.
