@@ -17,7 +17,7 @@ for n in (50, 200):
     print("n=%d enqueue %.1f us/frame, total %.1f us/frame" % (n, (t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6))
 # the same with the uniforms updated every frame (pinned upload ring in use)
 cam, d, p, s = cfg["camera"], cfg["dir"], cfg["point"], cfg["spot"]
-for n in (50, 200):
+for n in (50, 50, 200):
     t0 = time.perf_counter()
     for i in range(n):
         dr.r.update_uniforms(cam, d, p, s, 0.001 * i, 0.0, 1.0)

@@ -76,17 +76,23 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     c->stream = c->own_stream;
     for (auto& fr : c->evr) for (auto& e : fr) ok &= hipEventCreate(&e) == hipSuccess;
     const size_t n = (size_t)c->W * c->H;
-    ok &= dev_alloc(&c->G.depth, n) == hipSuccess;
-    ok &= dev_alloc(&c->G.scene_color, n) == hipSuccess;
-    ok &= dev_alloc(&c->G.gA, n) == hipSuccess;
-    ok &= dev_alloc(&c->G.gB, n) == hipSuccess;
-    ok &= dev_alloc(&c->G.gC, n) == hipSuccess;
-    ok &= dev_alloc(&c->G.gD, n) == hipSuccess;
-    ok &= dev_alloc(&c->G.overlay, n) == hipSuccess;
-    if (ok) ok &= hipMemset(c->G.overlay, 0, n * 4) == hipSuccess;
+    for (int b = 0; b < 2; ++b) {       // two frames in flight: see zr_ctx.h
+        GBufferPtrs& G = c->Gb[b];
+        ok &= dev_alloc(&G.depth, n) == hipSuccess;
+        ok &= dev_alloc(&G.scene_color, n) == hipSuccess;
+        ok &= dev_alloc(&G.gA, n) == hipSuccess;
+        ok &= dev_alloc(&G.gB, n) == hipSuccess;
+        ok &= dev_alloc(&G.gC, n) == hipSuccess;
+        ok &= dev_alloc(&G.gD, n) == hipSuccess;
+        ok &= dev_alloc(&G.overlay, n) == hipSuccess;
+        if (ok) ok &= hipMemset(G.overlay, 0, n * 4) == hipSuccess;
+        ok &= dev_alloc(&c->d_shadow_b[b], (size_t)c->SD * c->SD) == hipSuccess;
+        ok &= dev_alloc(&c->d_view_b[b], 1) == hipSuccess;
+        ok &= dev_alloc(&c->d_empty_b[b], 1) == hipSuccess;
+        ok &= hipEventCreateWithFlags(&c->ev_lit[b], hipEventDisableTiming) == hipSuccess;
+    }
+    c->G = c->Gb[0]; c->d_shadow = c->d_shadow_b[0]; c->d_view = c->d_view_b[0]; c->d_empty_rgba = c->d_empty_b[0];
     ok &= dev_alloc(&c->d_color, n) == hipSuccess;
-    ok &= dev_alloc(&c->d_shadow, (size_t)c->SD * c->SD) == hipSuccess;
-    ok &= dev_alloc(&c->d_view, 1) == hipSuccess;
     ok &= dev_alloc(&c->d_stats, 1) == hipSuccess;
     ok &= dev_alloc(&c->d_lut, 256) == hipSuccess;
     if (ok) ok &= hipMemcpy(c->d_lut, c->lut, sizeof c->lut, hipMemcpyHostToDevice) == hipSuccess;
@@ -124,7 +130,6 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     }
     {   // the clear values of ZE:3427-3433, as resolve_pixel writes them for an empty pixel
         ok &= dev_alloc(&c->d_clear_px, 64) == hipSuccess;
-        ok &= dev_alloc(&c->d_empty_rgba, 1) == hipSuccess;
         uint32_t px[16] = { 0 };
         px[0] = 0x3F800000u;                    // depth 1.0
         px[1] = 0xFF000000u; px[2] = 0u; px[3] = 0xFF000000u; px[4] = 0xFF000000u;   // SceneColor, A, B, C
@@ -146,6 +151,14 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     ok &= hipHostMalloc((void**)&c->h_view_ring, sizeof(XkView) * zr_ctx::VIEW_RING, hipHostMallocDefault) == hipSuccess;
     for (auto& e : c->view_ev) ok &= hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     ok &= hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) == hipSuccess;
+    {   // The camera lane must not share a hardware queue with the host's stream (HIP multiplexes streams onto a few of them and
+        // two streams on one queue run strictly one after the other).  Streams of different priority come from different queue
+        // pools, so the camera lane - the frame's critical path anyway - is created with the highest priority.
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        ok &= hipStreamCreateWithPriority(&c->cam_s, hipStreamNonBlocking, greatest) == hipSuccess;
+    }
+    ok &= hipEventCreateWithFlags(&c->ev_cam, hipEventDisableTiming) == hipSuccess;
     ok &= hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok &= hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     ok &= dev_alloc(&c->d_vis, n) == hipSuccess;
@@ -191,17 +204,24 @@ extern "C" void zr_destroy(zr_ctx* c)
     free_scene(c);
     free_mesh_buffers(c->sky_mesh); dev_free(c->sky_obj.d_inst); for (auto& t : c->sky_obj.d_tex) dev_free(t); dev_free(c->d_bg);
     for (auto p : c->d_cube) if (p) (void)hipFree(p);
-    dev_free(c->G.depth); dev_free(c->G.scene_color); dev_free(c->G.gA); dev_free(c->G.gB); dev_free(c->G.gC); dev_free(c->G.gD); dev_free(c->G.overlay);
-    dev_free(c->d_color); dev_free(c->d_shadow); dev_free(c->d_view); dev_free(c->d_stats); dev_free(c->d_lut); dev_free(c->d_unorm_lut);
+    for (int b = 0; b < 2; ++b) {
+        GBufferPtrs& G = c->Gb[b];
+        dev_free(G.depth); dev_free(G.scene_color); dev_free(G.gA); dev_free(G.gB); dev_free(G.gC); dev_free(G.gD); dev_free(G.overlay);
+        dev_free(c->d_shadow_b[b]); dev_free(c->d_view_b[b]); dev_free(c->d_empty_b[b]);
+        if (c->ev_lit[b]) (void)hipEventDestroy(c->ev_lit[b]);
+    }
+    dev_free(c->d_color); dev_free(c->d_stats); dev_free(c->d_lut); dev_free(c->d_unorm_lut);
     dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles);
     for (auto& sc : c->sc) {
         dev_free(sc.tile_count); dev_free(sc.tile_offset); dev_free(sc.tile_cursor); dev_free(sc.chunk_offset);
         dev_free(sc.rects); dev_free(sc.bins); dev_free(sc.work);
     }
-    dev_free(c->d_clear_px); dev_free(c->d_empty_rgba);
+    dev_free(c->d_clear_px);
     if (c->h_view_ring) (void)hipHostFree(c->h_view_ring);
     for (auto& e : c->view_ev) if (e) (void)hipEventDestroy(e);
     if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->cam_s) (void)hipStreamDestroy(c->cam_s);
+    if (c->ev_cam) (void)hipEventDestroy(c->ev_cam);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     dev_free(c->d_vis);
@@ -843,7 +863,10 @@ static inline float* shadow_buf(zr_ctx* c) { return c->d_shadow_ext ? c->d_shado
 //   zr_render_gbuffer   deferred-scene pass (ZE:3417-3480): cull + bin + raster + resolve of the owned tiles
 //   zr_render_lighting  deferred-lighting pass (ZE:3531-3540) [+ skydome / background overlay]
 // zr_render = all three.
-static int frame_begin(zr_ctx* c)
+// Start of a frame on stream s: pick this frame's copies of the double-buffered resources, make s wait until the lighting pass
+// that last read them (two frames ago) and the previous frame's shadow pipeline (it shares d_stats) are done, reset the
+// statistics, upload the uniforms if this copy does not hold them yet.
+static int frame_begin(zr_ctx* c, hipStream_t s)
 {
     if (!c->frame_valid) return zr_fail(c, ZR_ERR_STATE, "no frame uniforms: call zr_update_uniforms or zr_set_frame first");
     if (c->stage != 0) return zr_fail(c, ZR_ERR_STATE, "zr_render_shadow out of order");
@@ -853,18 +876,24 @@ static int frame_begin(zr_ctx* c)
     int rc = finalize_scene(c);
     if (rc) return rc;
     if (c->view.LightsCount[3] != (int32_t)c->cube_levels) { c->view.LightsCount[3] = (int32_t)c->cube_levels; c->view_dirty = true; }
-    hipStream_t s = c->stream;
+    const int par = (int)(c->frame_no & 1u);
+    c->G = c->Gb[par]; c->d_shadow = c->d_shadow_b[par]; c->d_view = c->d_view_b[par]; c->d_empty_rgba = c->d_empty_b[par];
+    if (s != c->stream) {
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_lit[par], 0));
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0));
+    }
     c->timing_now = c->timing_interval != 0 && c->frame_no % c->timing_interval == 0;     // pass events cost ~6 us of stream bubble each
     hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
     if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
     HIPCHK(c, hipMemsetAsync(c->d_stats, 0, sizeof(ZrDevStats), s));
-    if (c->view_dirty) {        // pinned ring slot: reused only after its previous upload has executed
+    if (c->view_dirty) { c->view_version++; c->view_dirty = false; }
+    if (c->view_uploaded[par] != c->view_version) {        // pinned ring slot: reused only after its previous upload has executed
         const uint32_t k = c->view_slot++ % zr_ctx::VIEW_RING;
         HIPCHK(c, hipEventSynchronize(c->view_ev[k]));
         memcpy(&c->h_view_ring[k], &c->view, sizeof(XkView));
         HIPCHK(c, hipMemcpyAsync(c->d_view, &c->h_view_ring[k], sizeof(XkView), hipMemcpyHostToDevice, s));
         HIPCHK(c, hipEventRecord(c->view_ev[k], s));
-        c->view_dirty = false;
+        c->view_uploaded[par] = c->view_version;
     }
     return ZR_OK;
 }
@@ -937,7 +966,7 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
 extern "C" int zr_render_shadow(zr_ctx* c)
 {
     if (!c) return ZR_ERR_ARG;
-    int rc = frame_begin(c);
+    int rc = frame_begin(c, c->stream);
     if (rc == ZR_OK) rc = shadow_pass(c, c->stream);
     if (rc == ZR_OK) c->stage = 1;
     return rc;
@@ -956,7 +985,7 @@ extern "C" int zr_render_gbuffer(zr_ctx* c)
 extern "C" int zr_render_geometry(zr_ctx* c)
 {
     if (!c) return ZR_ERR_ARG;
-    int rc = frame_begin(c);
+    int rc = frame_begin(c, c->stream);
     if (rc != ZR_OK) return rc;
     if (!c->aux || c->env_serial || (c->cfg.flags & ZR_FLAG_SERIAL_PASSES)) {
         rc = shadow_pass(c, c->stream);
@@ -1019,6 +1048,7 @@ static int lighting_pass(zr_ctx* c)
     if (c->debug_view == 9u)        // GBufferVis mosaic over the lit frame (needs the whole GBuffer: single-rank contexts only)
         zr_launch_gbuffer_vis(L, c->d_view, c->G, shadow_buf(c), c->cube, c->d_lut, c->d_color, s);
     if (ev) HIPCHK(c, hipEventRecord(ev[8], s));
+    HIPCHK(c, hipEventRecord(c->ev_lit[c->frame_no & 1u], s));      // this frame's GBuffer / shadow map / uniforms copies are free again
     HIPCHK(c, hipGetLastError());
     if (c->timing_now) c->sample_no++;
     c->rendered = true; c->frame_no++; c->stage = 0;
@@ -1035,28 +1065,38 @@ extern "C" int zr_render_lighting(zr_ctx* c)
     return rc;
 }
 
-// RecordCommandBuffer (ZE:3160-3744) + vkQueueSubmit (ZE:2014): shadow -> deferred scene -> deferred lighting.
-// The shadow pass and the deferred-scene pass do not depend on each other (the reference serialises them with subpass
-// barriers it does not need): here the shadow pipeline runs on an internal second stream next to the camera pipeline, and the
-// lighting pass joins them.  Their kernels are bound by different things at different moments (VALU issue, memory latency,
-// the small launch-bound binning kernels), so together they fill the machine better than one after the other.
-// ZR_FLAG_SERIAL_PASSES keeps everything on the one stream (as the staged entry points always do).
+// RecordCommandBuffer (ZE:3160-3744) + vkQueueSubmit (ZE:2014): shadow -> deferred scene -> deferred lighting, with two
+// frames in flight as in the reference (MAX_FRAMES_IN_FLIGHT, ZE:77).
+// The shadow pass and the deferred-scene pass do not depend on each other, and the next frame's geometry does not depend on this
+// frame's lighting.  zr_render therefore runs two lanes: the camera pipeline on the library's high-priority stream cam_s, and
+// shadow pipeline -> lighting on the host's stream.  Whatever the host enqueues on its stream after zr_render is ordered after
+// the finished frame, as before.  ZR_FLAG_SERIAL_PASSES keeps everything on the one stream, as the staged entry points do.
 extern "C" int zr_render(zr_ctx* c)
 {
     if (!c) return ZR_ERR_ARG;
-    int rc = frame_begin(c);
-    if (rc != ZR_OK) return rc;
-    const bool overlap = !(c->cfg.flags & ZR_FLAG_SERIAL_PASSES) && c->aux != nullptr && !c->env_serial;
+    const bool overlap = !(c->cfg.flags & ZR_FLAG_SERIAL_PASSES) && c->aux != nullptr && c->cam_s != nullptr && !c->env_serial;
+    int rc;
     if (overlap) {
-        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-        rc = shadow_pass(c, c->aux);
-        if (rc == ZR_OK) rc = empty_pixel_pass(c, c->aux);
-        if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
-        if (rc == ZR_OK) rc = gbuffer_pass(c, c->stream);
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    } else {
+        // Two lanes: the camera pipeline on cam_s; shadow pipeline, then lighting, on the host's stream.  The next frame's camera
+        // pipeline starts as soon as this one's is through, next to this frame's lighting; its shadow pipeline follows the
+        // lighting.  Never more than two kernels side by side: a third only takes occupancy from the other two (measured).
+        rc = frame_begin(c, c->cam_s);
+        if (rc != ZR_OK) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->cam_s));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fork, 0));          // the uniforms and the zeroed statistics
         rc = shadow_pass(c, c->stream);
+        if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, c->stream));
+        if (rc == ZR_OK) rc = empty_pixel_pass(c, c->stream);
+        if (rc == ZR_OK) rc = gbuffer_pass(c, c->cam_s);
+        if (rc == ZR_OK) {
+            HIPCHK(c, hipEventRecord(c->ev_cam, c->cam_s));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_cam, 0));
+        }
+    } else {
+        rc = frame_begin(c, c->stream);
+        if (rc != ZR_OK) return rc;
+        rc = shadow_pass(c, c->stream);
+        if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, c->stream));
         if (rc == ZR_OK) rc = empty_pixel_pass(c, c->stream);
         if (rc == ZR_OK) rc = gbuffer_pass(c, c->stream);
     }
