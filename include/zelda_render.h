@@ -152,10 +152,11 @@ int  zr_render(zr_ctx* ctx);
 int  zr_render_shadow(zr_ctx* ctx);
 int  zr_render_gbuffer(zr_ctx* ctx);
 int  zr_render_lighting(zr_ctx* ctx);
-/* Both geometry passes at once, side by side as zr_render runs them (shadow pass on the library's second stream, deferred-scene
- * pass on the render stream), WITHOUT joining them: the host makes whatever consumes the shadow map wait for it with
- * zr_stream_wait_shadow (e.g. its collective stream before the min all-reduce, then the render stream before
- * zr_render_lighting).  Replaces the pair zr_render_shadow + zr_render_gbuffer. */
+/* Both geometry passes at once, side by side as zr_render runs them: the shadow pass on the render stream, the deferred-scene
+ * pass on the library's own high-priority stream (zr_render_lighting waits for it).  A host that post-processes the shadow map
+ * on another stream (the min all-reduce over ranks) makes that stream wait with zr_stream_wait_shadow, and the render stream
+ * wait for its result, before zr_render_lighting.  zr_render = zr_render_geometry + zr_render_lighting.  Replaces the pair
+ * zr_render_shadow + zr_render_gbuffer. */
 int  zr_render_geometry(zr_ctx* ctx);
 int  zr_stream_wait_shadow(zr_ctx* ctx, void* hip_stream);   /* hip_stream waits for the last enqueued shadow pass */
 int  zr_finish(zr_ctx* ctx);                        /* stream sync + overflow check */

@@ -92,12 +92,12 @@ struct zr_ctx {
     static constexpr int VIEW_RING = 4;
     XkView* h_view_ring = nullptr; hipEvent_t view_ev[VIEW_RING] = {}; uint32_t view_slot = 0; bool view_dirty = true;
     uint64_t view_version = 1, view_uploaded[2] = { 0, 0 };      // which version of the uniforms each device copy holds
-    // zr_render keeps two frames in flight (the reference does: MAX_FRAMES_IN_FLIGHT, ZE:77): the shadow pipeline runs on `aux`,
-    // the camera pipeline on `cam_s`, the lighting pass on the host's `stream`; frame N + 1's geometry overlaps frame N's lighting.
+    // Two frames in flight (the reference does: MAX_FRAMES_IN_FLIGHT, ZE:77): the camera pipeline runs on `cam_s`, the shadow
+    // pipeline and the lighting pass on the host's `stream`; frame N + 1's camera pipeline overlaps frame N's lighting.
     // What a lighting pass reads is therefore double-buffered (GBuffer, shadow map, XkView, the empty-pixel colour); G, d_shadow,
     // d_view, d_empty_rgba are aliases of the current frame's copies (set at frame begin, so the read-back entry points see the
     // frame rendered last).
-    hipStream_t aux = nullptr, cam_s = nullptr;
+    hipStream_t cam_s = nullptr; bool camera_on_lane = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cam = nullptr, ev_lit[2] = { nullptr, nullptr };
     GBufferPtrs Gb[2] = {}; float* d_shadow_b[2] = { nullptr, nullptr }; XkView* d_view_b[2] = { nullptr, nullptr };
     uint32_t* d_empty_b[2] = { nullptr, nullptr };

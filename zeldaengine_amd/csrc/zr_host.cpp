@@ -150,7 +150,6 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     }
     ok &= hipHostMalloc((void**)&c->h_view_ring, sizeof(XkView) * zr_ctx::VIEW_RING, hipHostMallocDefault) == hipSuccess;
     for (auto& e : c->view_ev) ok &= hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-    ok &= hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) == hipSuccess;
     {   // The camera lane must not share a hardware queue with the host's stream (HIP multiplexes streams onto a few of them and
         // two streams on one queue run strictly one after the other).  Streams of different priority come from different queue
         // pools, so the camera lane - the frame's critical path anyway - is created with the highest priority.
@@ -219,7 +218,6 @@ extern "C" void zr_destroy(zr_ctx* c)
     dev_free(c->d_clear_px);
     if (c->h_view_ring) (void)hipHostFree(c->h_view_ring);
     for (auto& e : c->view_ev) if (e) (void)hipEventDestroy(e);
-    if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->cam_s) (void)hipStreamDestroy(c->cam_s);
     if (c->ev_cam) (void)hipEventDestroy(c->ev_cam);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -966,8 +964,10 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
 extern "C" int zr_render_shadow(zr_ctx* c)
 {
     if (!c) return ZR_ERR_ARG;
+    c->camera_on_lane = false;
     int rc = frame_begin(c, c->stream);
     if (rc == ZR_OK) rc = shadow_pass(c, c->stream);
+    if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, c->stream));
     if (rc == ZR_OK) c->stage = 1;
     return rc;
 }
@@ -982,23 +982,39 @@ extern "C" int zr_render_gbuffer(zr_ctx* c)
     return rc;
 }
 
+// Both geometry passes of a frame.  Two lanes (unless ZR_FLAG_SERIAL_PASSES): the camera pipeline on cam_s; the shadow pipeline on
+// the host's stream, where the lighting pass will follow.  The next frame's camera pipeline starts as soon as this one's is
+// through, next to this frame's lighting; its shadow pipeline follows the lighting.  Never more than two kernels side by side:
+// a third only takes occupancy from the other two (measured).
+static int geometry_passes(zr_ctx* c)
+{
+    const bool lanes = !(c->cfg.flags & ZR_FLAG_SERIAL_PASSES) && c->cam_s != nullptr && !c->env_serial;
+    int rc;
+    c->camera_on_lane = false;
+    if (lanes) {
+        rc = frame_begin(c, c->cam_s);
+        if (rc != ZR_OK) return rc;
+        HIPCHK(c, hipEventRecord(c->ev_fork, c->cam_s));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fork, 0));          // the uniforms and the zeroed statistics
+        rc = shadow_pass(c, c->stream);
+        if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, c->stream));
+        if (rc == ZR_OK) rc = gbuffer_pass(c, c->cam_s);
+        if (rc == ZR_OK) { HIPCHK(c, hipEventRecord(c->ev_cam, c->cam_s)); c->camera_on_lane = true; }
+    } else {
+        rc = frame_begin(c, c->stream);
+        if (rc != ZR_OK) return rc;
+        rc = shadow_pass(c, c->stream);
+        if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, c->stream));
+        if (rc == ZR_OK) rc = gbuffer_pass(c, c->stream);
+    }
+    if (rc == ZR_OK) c->stage = 2;
+    return rc;
+}
+
 extern "C" int zr_render_geometry(zr_ctx* c)
 {
     if (!c) return ZR_ERR_ARG;
-    int rc = frame_begin(c, c->stream);
-    if (rc != ZR_OK) return rc;
-    if (!c->aux || c->env_serial || (c->cfg.flags & ZR_FLAG_SERIAL_PASSES)) {
-        rc = shadow_pass(c, c->stream);
-        if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, c->stream));
-    } else {
-        HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
-        HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-        rc = shadow_pass(c, c->aux);
-        if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
-    }
-    if (rc == ZR_OK) rc = gbuffer_pass(c, c->stream);
-    if (rc == ZR_OK) c->stage = 2;
-    return rc;
+    return geometry_passes(c);
 }
 
 extern "C" int zr_stream_wait_shadow(zr_ctx* c, void* hip_stream)
@@ -1060,7 +1076,8 @@ extern "C" int zr_render_lighting(zr_ctx* c)
     if (!c) return ZR_ERR_ARG;
     if (c->stage != 2) return zr_fail(c, ZR_ERR_STATE, "zr_render_lighting out of order");
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = empty_pixel_pass(c, c->stream);       // staged frame: the shadow map (possibly reduced over ranks) is final only now
+    int rc = empty_pixel_pass(c, c->stream);       // the shadow map (possibly reduced over ranks by the host) is final only now
+    if (rc == ZR_OK && c->camera_on_lane) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_cam, 0));
     if (rc == ZR_OK) rc = lighting_pass(c);
     return rc;
 }
@@ -1074,33 +1091,8 @@ extern "C" int zr_render_lighting(zr_ctx* c)
 extern "C" int zr_render(zr_ctx* c)
 {
     if (!c) return ZR_ERR_ARG;
-    const bool overlap = !(c->cfg.flags & ZR_FLAG_SERIAL_PASSES) && c->aux != nullptr && c->cam_s != nullptr && !c->env_serial;
-    int rc;
-    if (overlap) {
-        // Two lanes: the camera pipeline on cam_s; shadow pipeline, then lighting, on the host's stream.  The next frame's camera
-        // pipeline starts as soon as this one's is through, next to this frame's lighting; its shadow pipeline follows the
-        // lighting.  Never more than two kernels side by side: a third only takes occupancy from the other two (measured).
-        rc = frame_begin(c, c->cam_s);
-        if (rc != ZR_OK) return rc;
-        HIPCHK(c, hipEventRecord(c->ev_fork, c->cam_s));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fork, 0));          // the uniforms and the zeroed statistics
-        rc = shadow_pass(c, c->stream);
-        if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, c->stream));
-        if (rc == ZR_OK) rc = empty_pixel_pass(c, c->stream);
-        if (rc == ZR_OK) rc = gbuffer_pass(c, c->cam_s);
-        if (rc == ZR_OK) {
-            HIPCHK(c, hipEventRecord(c->ev_cam, c->cam_s));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_cam, 0));
-        }
-    } else {
-        rc = frame_begin(c, c->stream);
-        if (rc != ZR_OK) return rc;
-        rc = shadow_pass(c, c->stream);
-        if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, c->stream));
-        if (rc == ZR_OK) rc = empty_pixel_pass(c, c->stream);
-        if (rc == ZR_OK) rc = gbuffer_pass(c, c->stream);
-    }
-    if (rc == ZR_OK) { c->stage = 2; HIPCHK(c, hipSetDevice(c->device)); rc = lighting_pass(c); }
+    int rc = geometry_passes(c);
+    if (rc == ZR_OK) rc = zr_render_lighting(c);
     if (rc != ZR_OK) c->stage = 0;
     return rc;
 }
