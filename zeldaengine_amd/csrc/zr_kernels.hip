@@ -321,30 +321,36 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
                 J.s = lane_bcast(I.s, src[c]);
                 const bool inst = lane_bcast(instanced, src[c]) != 0u;
                 const uint32_t vc = lane_bcast(vcount, src[c]);
-                // per lane: clip flags, and for an unflagged vertex the first / last pixel centre its snapped position can bound
-                // ((X - 128 + 255) >> 8 and (X - 128) >> 8 are monotonic, so min / max commute with them); the four box sides travel
-                // as two packed int16 pairs and the OR / AND of the flags as one word: 3 wave reductions (+ 1 for the depth)
-                uint32_t fbits = 0u;           // f | (~f & 0xFF) << 8
+                // The clip tests of vertex_flags() as wave-wide votes: a comparison IS a 64-lane mask on this machine, so "every vertex
+                // outside plane k" / "some vertex needs the clipper" / "some vertex is not finite" cost one v_cmp each and no cross-lane
+                // reduction.  For a plain vertex the first / last pixel centre its snapped position can bound is formed per lane
+                // ((X - 128 + 255) >> 8 and (X - 128) >> 8 are monotonic, so min / max commute with them); the four box sides travel as
+                // two packed int16 pairs: 2 wave reductions (+ 1 for the depth).
+                const bool valid = lane < vc;
+                const zf4 cl = zr_mat4_point(P.PVM, vs_position(zr3(pp[c].x, pp[c].y, pp[c].z), J, inst));
+                const float FM = 3.402823466e38f;
+                const bool fin = __builtin_fabsf(cl.x) <= FM && __builtin_fabsf(cl.y) <= FM && __builtin_fabsf(cl.z) <= FM && __builtin_fabsf(cl.w) <= FM;
+                const float gb = ZR_GUARD * cl.w;
+                const bool clip = cl.z < 0.0f || !(cl.w > 0.0f) || __builtin_fabsf(cl.x) > gb || __builtin_fabsf(cl.y) > gb;
+                const unsigned long long vm = __ballot(valid);
+                const bool any_nonfinite = __ballot(valid && !fin) != 0ull;
+                const bool any_clip = __ballot(valid && clip) != 0ull;
+                const bool all_outside = __ballot(valid && cl.x < -cl.w) == vm || __ballot(valid && cl.x > cl.w) == vm ||
+                                         __ballot(valid && cl.y < -cl.w) == vm || __ballot(valid && cl.y > cl.w) == vm ||
+                                         __ballot(valid && cl.z < 0.0f) == vm || __ballot(valid && cl.z > cl.w) == vm;
                 int lo2 = 0x7FFF7FFF, hi2 = (int)0x80008000;
                 int zb = 0x7FFFFFFF;           // least NDC depth over the vertices, as ordered int bits (depths here are >= 0)
-                if (lane < vc) {
-                    const zf4 cl = zr_mat4_point(P.PVM, vs_position(zr3(pp[c].x, pp[c].y, pp[c].z), J, inst));
-                    const uint32_t f = vertex_flags(cl);
-                    fbits = f | ((~f & 0xFFu) << 8);
-                    if (!(f & 129u)) {
-                        const SV sv = project(cl, P.hw, P.hh);
-                        lo2 = (clamp16((sv.X - 128 + 255) >> 8) & 0xFFFF) | (clamp16((sv.Y - 128 + 255) >> 8) << 16);
-                        hi2 = (clamp16((sv.X - 128) >> 8) & 0xFFFF) | (clamp16((sv.Y - 128) >> 8) << 16);
-                        zb = (int)zr_f2u(sv.z + 0.0f);
-                    }
+                if (valid && fin && !clip) {
+                    const SV sv = project(cl, P.hw, P.hh);
+                    lo2 = (clamp16((sv.X - 128 + 255) >> 8) & 0xFFFF) | (clamp16((sv.Y - 128 + 255) >> 8) << 16);
+                    hi2 = (clamp16((sv.X - 128) >> 8) & 0xFFFF) | (clamp16((sv.Y - 128) >> 8) << 16);
+                    zb = (int)zr_f2u(sv.z + 0.0f);
                 }
-                fbits = wave_or(fbits);
-                const uint32_t f_or = fbits & 0xFFu, f_and = ~(fbits >> 8) & 0xFFu;
                 uint32_t r = ZR_RECT_CULLED; uint2 pr = make_uint2(0u, 0u); float zm = -1.0f;
-                if ((f_or & 1u) || !(f_and & 0x7Eu)) {
+                if (any_nonfinite || !all_outside) {
                     int px0 = 0, py0 = 0, px1 = (int)P.W - 1, py1 = (int)P.H - 1;
                     bool any = true;
-                    if (!(f_or & 129u)) {
+                    if (!any_nonfinite && !any_clip) {
                         const int lo = wave_pkmin16(lo2), hi = wave_pkmax16(hi2);
                         px0 = max(px0, (int)(short)(lo & 0xFFFF)); py0 = max(py0, lo >> 16);
                         px1 = min(px1, (int)(short)(hi & 0xFFFF)); py1 = min(py1, hi >> 16);
