@@ -170,7 +170,7 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel_ms": round(times[dom], 4), "algorithmic_bytes": int(alg[dom]),
                          "note": "two lanes (camera pipeline || shadow pipeline + previous frame's lighting): kernel_ms is the "
-                                 "kernel's duration while sharing the GPU (alone: ZR_SERIAL_PASSES=1, profiles/r01_e_kernel_stats.csv)"},
+                                 "kernel's duration while sharing the GPU (alone: ZR_SERIAL_PASSES=1, profiles/r01_j_serial_kernel_stats.csv)"},
             "passes_ms": {k: round(v, 4) for k, v in times.items()},
             "passes_timing": "hipEvents on the render stream, every %d-th timed frame" % interval,
             "passes_gbs": {k: round(alg[k] / (times[k] * 1e-3) / 1e9, 2) for k in alg if times[k] > 0},
