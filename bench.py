@@ -75,6 +75,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal only (one-GPU box): ZR_BENCH_REHEARSAL=1 runs every rank on cuda:0 over gloo, to exercise the N > 1 frame loop end to
+    # end (staged frame, shadow all-reduce, all-gather, composite) where RCCL cannot run; its numbers mean nothing.
+    rehearsal = os.environ.get("ZR_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
@@ -86,7 +91,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
     if args.config == 3:
         cfg = scenes.config3(args.instances)

@@ -1,0 +1,22 @@
+"""GPU: the multi-process frame loop with real torch.distributed collectives (two and three ranks sharing the one GPU, gloo)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_composite_the_single_gpu_frame(world):
+    """Every rank renders its tiles and its share of the shadow casters, min-all-reduces the shadow map, all-gathers the packed
+    tiles and composites: every rank must end up with the frame (and shadow map) one context renders alone."""
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29540 + world), os.path.join(HERE, "mp_dist_worker.py")]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    text = out.stdout.decode(errors="replace")
+    assert out.returncode == 0 and "MP_DIST_OK" in text, text[-3000:]
