@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_multiproc.py: one rank of a world-N DistributedRenderer, every rank on cuda:0, collectives over gloo
+"""Worker of tests/test_gpu_0_multiproc.py: one rank of a world-N DistributedRenderer, every rank on cuda:0, collectives over gloo
 (RCCL needs one GPU per rank; the frame loop, the buffers and the collective calls are the same)."""
 import os
 import sys
