@@ -1130,12 +1130,22 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
             const ZrInstance I = *ip;
 
             lds_fence();   // this wave's previous readers are done with its staging area
-            if (lane < vcount) {
+            // Almost every meshlet has no vertex outside the frustum at all: that is one wave-wide vote over ten comparisons (each a
+            // 64-lane mask by itself); only a flagged meshlet pays for the per-vertex flag words and the per-triangle classification.
+            bool flagged;
+            {
                 const zf4 c = zr_mat4_point(P.PVM, vs_position(zr3(pp.x, pp.y, pp.z), I, instanced));
-                const uint32_t f = vertex_flags(c);
-                SV s; s.X = 0; s.Y = 0; s.z = 0.0f; s.rw = 0.0f;
-                if (!(f & 129u)) s = project(c, P.hw, P.hh);
-                vstage[wv][lane] = make_int4(s.X, s.Y, (int)zr_f2u(s.z), (int)f);      // snapped x, y, depth, clip flags
+                const float FM = 3.402823466e38f, gb = ZR_GUARD * c.w;
+                const bool fin = __builtin_fabsf(c.x) <= FM && __builtin_fabsf(c.y) <= FM && __builtin_fabsf(c.z) <= FM && __builtin_fabsf(c.w) <= FM;
+                const bool odd = !fin || c.x < -c.w || c.x > c.w || c.y < -c.w || c.y > c.w || c.z < 0.0f || c.z > c.w ||
+                                 !(c.w > 0.0f) || __builtin_fabsf(c.x) > gb || __builtin_fabsf(c.y) > gb;
+                flagged = __ballot(lane < vcount && odd) != 0ull;
+                if (lane < vcount) {
+                    const uint32_t f = flagged ? vertex_flags(c) : 0u;
+                    SV s; s.X = 0; s.Y = 0; s.z = 0.0f; s.rw = 0.0f;
+                    if (!(f & 129u)) s = project(c, P.hw, P.hh);
+                    vstage[wv][lane] = make_int4(s.X, s.Y, (int)zr_f2u(s.z), (int)f);      // snapped x, y, depth, clip flags
+                }
             }
             lds_fence();
 
@@ -1152,7 +1162,7 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
                 if (t < tcount) {
                     const uint32_t i0 = tri_w[round].x & 255u, i1 = (tri_w[round].x >> 8) & 255u, i2 = (tri_w[round].x >> 16) & 255u;
                     r0 = vstage[wv][i0]; r1 = vstage[wv][i1]; r2 = vstage[wv][i2];
-                    const int cls = classify((uint32_t)r0.w, (uint32_t)r1.w, (uint32_t)r2.w);
+                    const int cls = flagged ? classify((uint32_t)r0.w, (uint32_t)r1.w, (uint32_t)r2.w) : 1;
                     if (cls == 1) {
                         const float tz = HIZ ? __builtin_fminf(__builtin_fminf(zr_u2f((uint32_t)r0.z), zr_u2f((uint32_t)r1.z)), zr_u2f((uint32_t)r2.z)) : 0.0f;
                         alive = tri_prefilter<MODE, HIZ>(r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, T, tz, hz);
