@@ -17,6 +17,14 @@
 
 int zr_fail(zr_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
 
+// Everything the library has enqueued: the host's stream (shadow pipeline, lighting) and its own camera lane.
+static hipError_t sync_all(zr_ctx* c)
+{
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && c->cam_s) e = hipStreamSynchronize(c->cam_s);
+    return e;
+}
+
 static const uint8_t kDefaultTexel[7][4] = {    // ZE:4951-4978: default_{grey,black,white,normal,white,black,white}.png
     {127,127,127,255}, {0,0,0,255}, {255,255,255,255}, {127,127,255,255}, {255,255,255,255}, {0,0,0,255}, {255,255,255,255}
 };
@@ -199,7 +207,7 @@ extern "C" void zr_destroy(zr_ctx* c)
     if (!c) return;
     zr_livelink_stop(c);
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);                      // including a geometry stage whose lighting pass never came
     free_scene(c);
     free_mesh_buffers(c->sky_mesh); dev_free(c->sky_obj.d_inst); for (auto& t : c->sky_obj.d_tex) dev_free(t); dev_free(c->d_bg);
     for (auto p : c->d_cube) if (p) (void)hipFree(p);
@@ -433,7 +441,7 @@ int zr_object_add_internal(zr_ctx* c, uint32_t mesh_id, const ZrMaterialHost& ma
         if (e != hipSuccess) { dev_free(d_raw); cleanup(); return zr_fail(c, ZR_ERR_DEVICE, hipGetErrorString(e)); }
     }
     zr_launch_instance_prep(d_raw, o.d_inst, o.n_inst, o.instanced ? 1u : 0u, c->stream);
-    hipError_t e = hipStreamSynchronize(c->stream);
+    hipError_t e = sync_all(c);
     dev_free(d_raw);
     if (e != hipSuccess) { cleanup(); return zr_fail(c, ZR_ERR_DEVICE, hipGetErrorString(e)); }
     c->objects.push_back(std::move(o));
@@ -455,7 +463,7 @@ extern "C" int zr_scene_clear(zr_ctx* c)
 {
     if (!c) return ZR_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     free_scene(c);
     return ZR_OK;
 }
@@ -513,7 +521,7 @@ static int upload_mesh(zr_ctx* c, ZrMesh& m)
 static int finalize_scene(zr_ctx* c)
 {
     if (!c->scene_dirty) return ZR_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     for (auto& o : c->objects) { int rc = upload_mesh(c, c->meshes[o.mesh]); if (rc) return rc; }
     const bool sky = c->sky_set && c->sky_enabled;
     if (sky) { int rc = upload_mesh(c, c->sky_mesh); if (rc) return rc; }
@@ -584,7 +592,7 @@ extern "C" int zr_set_skydome(zr_ctx* c, const XkVertex* v, uint32_t nv, const u
 {
     if (!c) return ZR_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     free_mesh_buffers(c->sky_mesh); c->sky_mesh = ZrMesh();
     dev_free(c->sky_obj.d_inst); for (auto& t : c->sky_obj.d_tex) dev_free(t);
     c->sky_obj = ZrSceneObject(); c->sky_set = false; c->scene_dirty = true;
@@ -600,7 +608,7 @@ extern "C" int zr_set_skydome(zr_ctx* c, const XkVertex* v, uint32_t nv, const u
     if (rc) return rc;
     HIPCHK(c, dev_alloc(&o.d_inst, 1));
     zr_launch_instance_prep(nullptr, o.d_inst, 1, 0u, c->stream);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     c->sky_set = true;
     return ZR_OK;
 }
@@ -609,7 +617,7 @@ extern "C" int zr_set_background(zr_ctx* c, const zr_image* tex)
 {
     if (!c) return ZR_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     dev_free(c->d_bg); c->bg_set = false;
     if (!tex || !tex->rgba8) return ZR_OK;
     int rc = upload_texture(c, tex, true, &c->d_bg, &c->bg_w, &c->bg_h, &c->bg_levels);
@@ -636,7 +644,7 @@ extern "C" int zr_set_cubemap(zr_ctx* c, const uint8_t* const faces[6], uint32_t
     ARGCHK(c, dim > 0 && dim <= 16384);
     if (faces) for (int f = 0; f < 6; ++f) ARGCHK(c, faces[f] != nullptr);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     for (auto p : c->d_cube) if (p) (void)hipFree(p);
     c->d_cube.clear();
     uint32_t levels = 1; for (uint32_t d = dim; d > 1; d >>= 1) levels++;      // floor(log2(dim)) + 1, ZE:6887
@@ -1119,7 +1127,7 @@ extern "C" int zr_finish(zr_ctx* c)
 {
     if (!c) return ZR_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_all(c));
     if (c->rendered) {
         HIPCHK(c, hipMemcpy(&c->h_stats, c->d_stats, sizeof(ZrDevStats), hipMemcpyDeviceToHost));
         c->h_stats.covered_shadow = 0;
