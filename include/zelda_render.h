@@ -145,7 +145,11 @@ int  zr_get_frame(zr_ctx* ctx, XkUniformBufferMVP* camera, XkUniformBufferMVP* s
 int  zr_set_debug_view(zr_ctx* ctx, uint32_t spec_constants);
 
 /* --- the frame (replaces RecordCommandBuffer ZE:3160-3744 + vkQueueSubmit ZE:2014) ---
- * cull -> shadow -> cull -> gbuffer -> lighting [-> composite].  Asynchronous on the render stream. */
+ * cull -> shadow -> cull -> gbuffer -> lighting [-> composite].  Asynchronous: the call only enqueues.  The shadow pipeline and
+ * the lighting pass go to the render stream (zr_set_stream), the camera pipeline to a stream of the library's own that the
+ * lighting pass waits for; so work the host enqueues on the render stream afterwards is ordered after the finished frame, and
+ * up to two frames are in flight (the next frame's camera pipeline runs next to this frame's lighting), as in the reference
+ * (MAX_FRAMES_IN_FLIGHT, ZE:77).  zr_finish and the read-back entry points wait for everything. */
 int  zr_render(zr_ctx* ctx);
 /* The same frame in three stages (zr_render = all three, in this order), so that a multi-GPU host can place its
  * collectives between them: shadow pass | deferred-scene pass (cull, raster, GBuffer write) | deferred-lighting pass. */
