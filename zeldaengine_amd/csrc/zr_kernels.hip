@@ -238,7 +238,7 @@ __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, uint32_t src) { retur
 template <int MODE, bool WORKLIST>
 __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
                                               uint32_t* __restrict__ rects, uint2* __restrict__ pxrect, float* __restrict__ zmin,
-                                              const ZrDevStats* __restrict__ stats, int slot)
+                                              uint8_t* __restrict__ vis_clear, const ZrDevStats* __restrict__ stats, int slot)
 {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t n = WORKLIST ? stats->n_vis_work[slot] : P.n_work;
@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
         I.t[0] = I.t[1] = I.t[2] = 0.0f; I.s = 1.0f;
         if (alive) {
             const uint32_t w = WORKLIST ? work[k] : k;
+            if (!WORKLIST && vis_clear) vis_clear[w] = 0;        // this frame's visibility marks start from zero (saves a fill launch)
             const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w);
             const uint32_t local = w - O->work_base, nm = O->n_meshlets;
             const uint32_t inst_i = local / nm, m = local - inst_i * nm;
@@ -1791,13 +1792,13 @@ void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint3
     if (P.mode == ZR_MODE_GBUFFER) {
         if (P.use_worklist) {
             hipLaunchKernelGGL(k_cull_instances<ZR_MODE_GBUFFER>, gi, b, 0, s, P, objs, work, stats, slot);
-            hipLaunchKernelGGL((k_cull<ZR_MODE_GBUFFER, true>), dim3(blocks), b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, stats, slot);
-        } else hipLaunchKernelGGL((k_cull<ZR_MODE_GBUFFER, false>), dim3(blocks), b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, stats, slot);
+            hipLaunchKernelGGL((k_cull<ZR_MODE_GBUFFER, true>), dim3(blocks), b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot);
+        } else hipLaunchKernelGGL((k_cull<ZR_MODE_GBUFFER, false>), dim3(blocks), b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot);
     } else {
         if (P.use_worklist) {
             hipLaunchKernelGGL(k_cull_instances<ZR_MODE_SHADOW>, gi, b, 0, s, P, objs, work, stats, slot);
-            hipLaunchKernelGGL((k_cull<ZR_MODE_SHADOW, true>), dim3(blocks), b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, stats, slot);
-        } else hipLaunchKernelGGL((k_cull<ZR_MODE_SHADOW, false>), dim3(blocks), b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, stats, slot);
+            hipLaunchKernelGGL((k_cull<ZR_MODE_SHADOW, true>), dim3(blocks), b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot);
+        } else hipLaunchKernelGGL((k_cull<ZR_MODE_SHADOW, false>), dim3(blocks), b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot);
     }
 }
 void zr_launch_bin_count(const ZrPass& P, const uint32_t* work, uint32_t* rects, uint32_t* tile_count, const ZrHiz& Z, ZrDevStats* stats,
