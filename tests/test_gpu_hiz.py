@@ -134,3 +134,25 @@ def test_tile_partitioned_ranks_keep_their_own_history(oracle_lib, gpu_engine):
             assert np.array_equal(g.read_tiles(), zdist.pack_tiles(want, k, 2)), "frame %d rank %d" % (i, k)
         if i:
             assert all(g.stats()["round1_survivors"] > 0 for g in ranks)
+
+
+def test_config4_scale_culling_paths_agree(gpu_engine):
+    """BASELINE config 4's size (1 M instances = 14 M meshlet-instances, 3840x2160; too big for the scalar oracle): the frame with
+    every conservative cull on (instance pre-pass + work list, frustum, cone, two-pass Hi-Z, second frame = history in use) must
+    equal the frame with all of them off, in every target."""
+    from zeldaengine_amd import engine as eng
+    cfg = scenes.config4(1000000, 16)
+    frames = []
+    for flags in (0, abi.FLAG_NO_FRUSTUM_CULL | abi.FLAG_NO_CONE_CULL | abi.FLAG_NO_HIZ):
+        g = gpu_engine.Renderer(cfg["width"], cfg["height"], 1024, flags=flags)
+        eng.load_scene(g, cfg)
+        g.render(); g.render(); g.finish()
+        frames.append((g.color(), [g.gbuffer(t) for t in range(6)], g.shadowmap(), g.stats()))
+        g.close()
+    a, b = frames
+    assert np.array_equal(a[0], b[0])
+    for t in range(6):
+        assert np.array_equal(a[1][t].view(np.uint8), b[1][t].view(np.uint8)), "GBuffer target %d" % t
+    assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+    assert a[3]["covered_pixels"] == b[3]["covered_pixels"] and a[3]["overflow"] == 0 and b[3]["overflow"] == 0
+    assert a[3]["hiz_culled"] > 100000 and a[3]["survivors"][1] < b[3]["survivors"][1] // 4
