@@ -51,6 +51,7 @@ def lib():
         L.zo_gbuffer.argtypes = [C.c_void_p, C.c_int]
         L.zo_covered_pixels.restype = C.c_uint64
         L.zo_covered_pixels.argtypes = [C.c_void_p]
+        L.zo_set_threads.argtypes = [C.c_void_p, C.c_int]
         L.zo_meshlet_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         for n, args, res in [
             ("zo_kat_D_GGX", 2, C.c_float), ("zo_kat_V_SmithGGXCorrelated", 3, C.c_float),
@@ -178,6 +179,10 @@ class Oracle:
 
     def visibility(self):
         return self._view(self.L.zo_visibility(self.h), np.uint32, (self.H, self.W))
+
+    def set_threads(self, n):
+        """OpenMP team for the per-pixel stages (resolve, lighting): the all-cores CPU baseline.  Results do not change."""
+        self.L.zo_set_threads(self.h, int(n))
 
     def covered_pixels(self):
         return int(self.L.zo_covered_pixels(self.h))

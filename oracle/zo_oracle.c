@@ -46,6 +46,7 @@ struct zo_ctx {
     float* depth; uint32_t* scene_color; uint32_t* gA; uint32_t* gB; uint32_t* gC; uint64_t* gD;
     uint32_t* vis; float* shadowmap; uint8_t* color;
     uint64_t covered;
+    int threads;                /* OpenMP team of the per-pixel stages (resolve, lighting); 1 unless zo_set_threads */
     /* skydome + background passes (ZE:2657-2744, 3681-3699) */
     zo_mesh sky_mesh; zo_tex sky_tex; int sky_set, sky_enabled; zo_tex bg_tex; int bg_set, bg_enabled;
     uint32_t* overlay; float* main_depth; uint32_t* sky_vis;
@@ -100,6 +101,7 @@ zo_ctx* zo_create(uint32_t W, uint32_t H, uint32_t SD)
     c->shadowmap = (float*)malloc((size_t)c->SD * c->SD * 4);
     c->overlay = (uint32_t*)calloc(n, 4); c->main_depth = (float*)malloc(n * 4); c->sky_vis = (uint32_t*)malloc(n * 4);
     c->sky_enabled = c->bg_enabled = 1;
+    c->threads = 1;
     for (int i = 0; i < 256; ++i) c->srgb_lut[i] = zo_srgb_decode((uint32_t)i);
     zo_default_lights(&c->view);
     zo_set_cubemap(c, NULL, 0);
@@ -826,12 +828,14 @@ static const zo_object* zo_find_object(const zo_ctx* c, uint32_t prim, uint32_t*
 static void zo_resolve_gbuffer(zo_ctx* c, const float* PVM)
 {
     float hw = 0.5f * (float)c->W, hh = 0.5f * (float)c->H;
-    c->covered = 0;
+    uint64_t covered = 0;
+    /* rows are independent: optional OpenMP team for the all-cores CPU baseline (zo_set_threads; default 1 thread) */
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : covered) num_threads(c->threads)
     for (uint32_t py = 0; py < c->H; ++py) for (uint32_t px = 0; px < c->W; ++px) {
         size_t p = (size_t)py * c->W + px;
         uint32_t prim = c->vis[p];
         if (prim == ZO_EMPTY) continue;
-        c->covered++;
+        covered++;
         uint32_t inst, tri;
         const zo_object* o = zo_find_object(c, prim, &inst, &tri);
         const zo_mesh* m = &c->meshes[o->mesh];
@@ -885,6 +889,7 @@ static void zo_resolve_gbuffer(zo_ctx* c, const float* PVM)
         c->gD[p] = (uint64_t)zo_f32_to_f16(f0.P.x) | (uint64_t)zo_f32_to_f16(f0.P.y) << 16 |
                    (uint64_t)zo_f32_to_f16(f0.P.z) << 32 | (uint64_t)0x3C00u << 48;
     }
+    c->covered = covered;
 }
 
 /* ------------------------------------------------------------------ deferred lighting (SH/BaseLighting.frag:147-254) */
@@ -1058,6 +1063,7 @@ static void zo_lighting(zo_ctx* c, uint32_t debug_view)
     uint32_t nDir = (uint32_t)V->LightsCount[0], nPoint = (uint32_t)V->LightsCount[1];
     float maxmips = (float)(uint32_t)V->LightsCount[3];
     float dxy = 1.5f * 1.0f / (float)c->SD;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(c->threads)
     for (uint32_t py = 0; py < c->H; ++py) for (uint32_t px = 0; px < c->W; ++px) {
         size_t p = (size_t)py * c->W + px;
         uint32_t sc = c->scene_color[p], A = c->gA[p], B = c->gB[p], C = c->gC[p]; uint64_t D = c->gD[p];
@@ -1282,6 +1288,7 @@ const uint8_t* zo_color(zo_ctx* c) { return c->color; }
 const float* zo_shadowmap(zo_ctx* c) { return c->shadowmap; }
 const uint32_t* zo_visibility(zo_ctx* c) { return c->vis; }
 uint64_t zo_covered_pixels(zo_ctx* c) { return c->covered; }
+void zo_set_threads(zo_ctx* c, int n) { c->threads = n < 1 ? 1 : n; }
 const void* zo_gbuffer(zo_ctx* c, int t)
 {
     switch (t) { case 0: return c->depth; case 1: return c->scene_color; case 2: return c->gA; case 3: return c->gB;

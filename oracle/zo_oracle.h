@@ -44,6 +44,7 @@ const void*     zo_gbuffer(zo_ctx*, int target);/* 0 depth f32, 1..4 u32, 5 4xf1
 const float*    zo_shadowmap(zo_ctx*);
 const uint32_t* zo_visibility(zo_ctx*);         /* W*H winning primitive id, 0xFFFFFFFF = none */
 uint64_t        zo_covered_pixels(zo_ctx*);
+void            zo_set_threads(zo_ctx*, int n); /* OpenMP threads of the per-pixel stages (all-cores CPU baseline); default 1 */
 
 /* meshlet builder + bounds (the library's clusteriser is checked against these invariants, not for equality) */
 int  zo_meshlet_bounds(const XkVertex* v, const uint32_t* mv, const uint8_t* mt, uint32_t ntri, XkMeshlet* out);
