@@ -185,3 +185,16 @@ def test_debug_view_9_is_a_mosaic_of_the_other_views(oracle_lib):
     assert np.array_equal(m[ch:2 * ch, cw:2 * cw], views[0][ch:2 * ch, cw:2 * cw])    # centre: FinalColor
     assert (m[2 * ch:, :cw, :3] == 0).all()
     assert np.array_equal(m[2 * ch:, 2 * cw:], sub(views[8])[:ch, :cw])               # shadow factor
+
+
+@pytest.mark.parametrize("name", ["textured_aniso", "debug_view_9", "clipping_256_lights"])
+def test_oracle_regression_pins(oracle_lib, name):
+    """Golden hashes of three more small oracle frames (all targets): textures + anisotropic filtering + normal mapping, the view-9
+    mosaic with editor bars, clipping with 256 lights.  Regenerate deliberately with tests/golden/make_golden_oracle.py."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import oracle_cases
+    h, _keep = oracle_cases.CASES[name](oracle_lib, abi, scenes)
+    path = os.path.join(HERE, "golden", "oracle_%s.sha256" % name)
+    assert os.path.exists(path), "golden hash missing; run tests/golden/make_golden_oracle.py: %s" % h
+    assert open(path).read().strip() == h
