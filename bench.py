@@ -132,6 +132,7 @@ def main():
 
     # per-kernel means over the timed frames, from hipEvents recorded on the render stream
     times = r.pass_times(max(1, min(args.steps // interval, 64)))
+    lat = sorted(r.frame_latencies(max(1, min(args.steps // interval, 64))))
     stats = r.stats()
     # Informative only (never `value`): the rate when the host reads every frame back over PCIe (zr_read_color), N = 1
     pcie_rate = None
@@ -184,6 +185,9 @@ def main():
             "passes_gbs": {k: round(alg[k] / (times[k] * 1e-3) / 1e9, 2) for k in alg if times[k] > 0},
             "stats": stats,
             "pcie_inclusive_mpixels_s": None if pcie_rate is None else round(pcie_rate, 1),
+            # GPU begin-to-end time of the sampled frames (two frames are in flight, so this exceeds ms_per_step)
+            "frame_latency_ms": {"p10": round(lat[int(0.1 * (len(lat) - 1))], 4), "p50": round(lat[len(lat) // 2], 4),
+                                 "p90": round(lat[int(0.9 * (len(lat) - 1) + 0.5)], 4), "samples": len(lat)} if lat else None,
         }
         if world == 1 and not args.no_cpu_baseline and args.config == 3:     # defined on the metric's workload only
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_instances)

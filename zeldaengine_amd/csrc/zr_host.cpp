@@ -1167,6 +1167,24 @@ extern "C" int zr_get_pass_times_avg(zr_ctx* c, uint32_t last_n, float ms[ZR_PAS
 }
 extern "C" int zr_get_pass_times(zr_ctx* c, float ms[ZR_PASS_COUNT]) { return zr_get_pass_times_avg(c, 1, ms); }
 
+// Begin-to-end GPU time (first kernel of the camera lane to the end of the lighting pass) of each of the last `n` timed frames,
+// newest first; returns how many were written.  With two frames in flight this latency is longer than the frame period.
+extern "C" int zr_get_frame_latencies(zr_ctx* c, uint32_t n, float* ms)
+{
+    if (!c || !ms) return ZR_ERR_ARG;
+    if (!c->rendered) return zr_fail(c, ZR_ERR_STATE, "nothing rendered yet");
+    int rc = zr_finish(c);
+    if (rc && rc != ZR_ERR_OVERFLOW) return rc;
+    if (n > (uint32_t)zr_ctx::EV_RING) n = zr_ctx::EV_RING;
+    if ((uint64_t)n > c->sample_no) n = (uint32_t)c->sample_no;
+    for (uint32_t k = 0; k < n; ++k) {
+        hipEvent_t* ev = c->evr[(c->sample_no - 1 - k) % zr_ctx::EV_RING];
+        ms[k] = 0.0f;
+        (void)hipEventElapsedTime(&ms[k], ev[0], ev[8]);
+    }
+    return (int)n;
+}
+
 // Per-pass hipEvents are recorded on every interval-th frame (default 1 = every frame, 0 = never).  Each record is a small
 // bubble on the render stream (~6 us on MI355X, six per frame), so a host that only wants throughput samples sparsely.
 extern "C" int zr_set_timing_interval(zr_ctx* c, uint32_t interval)

@@ -67,6 +67,7 @@ def lib():
         "zr_get_pass_times": [vp, vp],
         "zr_get_pass_times_avg": [vp, u32, vp],
         "zr_set_timing_interval": [vp, u32],
+        "zr_get_frame_latencies": [vp, u32, vp],
         "zr_get_stats": [vp, C.POINTER(abi.Stats)],
         "zr_read_color": [vp, vp, sz],
         "zr_read_gbuffer": [vp, C.c_int, vp, sz],
@@ -321,6 +322,14 @@ class Renderer:
         ms = (C.c_float * len(abi.PASS_NAMES))()
         self._chk(self.L.zr_get_pass_times_avg(self.h, last_n, ms))
         return dict(zip(abi.PASS_NAMES, [float(x) for x in ms]))
+
+    def frame_latencies(self, n=64):
+        """Begin-to-end GPU milliseconds of the last n (<= 64) timed frames, newest first."""
+        ms = (C.c_float * n)()
+        got = self.L.zr_get_frame_latencies(self.h, n, ms)
+        if got < 0:
+            self._chk(got)
+        return [float(ms[i]) for i in range(got)]
 
     def stats(self):
         s = abi.Stats()
