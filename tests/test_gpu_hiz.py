@@ -156,3 +156,26 @@ def test_config4_scale_culling_paths_agree(gpu_engine):
     assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
     assert a[3]["covered_pixels"] == b[3]["covered_pixels"] and a[3]["overflow"] == 0 and b[3]["overflow"] == 0
     assert a[3]["hiz_culled"] > 100000 and a[3]["survivors"][1] < b[3]["survivors"][1] // 4
+
+
+def test_soak_two_frames_in_flight(oracle_lib, gpu_engine):
+    """600 frames enqueued back to back (no host synchronisation in between) with the camera, the stage and the lights moving every
+    frame: the double-buffered uniforms / GBuffer / shadow map of the two-frames-in-flight schedule and the pinned upload ring must
+    never mix frames.  Every 75th frame is read back and compared with the oracle in all targets."""
+    W, H, SD = 256, 144, 128
+    o = oracle_lib.Oracle(W, H, SD)
+    g = gpu_engine.Renderer(W, H, SD)
+    for r in (o, g):
+        _crowd(r, 250, 8)
+    d, p, s = _lights()
+    import math
+    for i in range(600):
+        a = 0.01 * i
+        cam = abi.make_camera((7.0 * math.cos(a), 7.0 * math.sin(a), 1.0 + 0.6 * math.sin(3.0 * a)), (0.0, 0.0, 0.8), fov=50.0)
+        g.update_uniforms(cam, d, p, s, 0.002 * i, 0.001 * i, 0.1 * i)
+        g.render()
+        if i % 75 == 74 or i == 599:
+            o.update_uniforms(cam, d, p, s, 0.002 * i, 0.001 * i, 0.1 * i)
+            o.render(0)
+            g.finish()
+            _identical(o, g, "frame %d" % i)
