@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=[3, 4, 5],
                     help="3: the metric's workload (default); 4: 1M instances at 3840x2160; 5: config 4 with 256 point lights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replicated-shadow", action="store_true",
+                    help="N > 1: every rank renders the whole shadow map (no shadow all-reduce; the all-gather of the composite is then the "
+                         "only collective) instead of 1/N of the casters each + one MIN all-reduce of the 4 MB map")
     ap.add_argument("--timing-interval", type=int, default=0,
                     help="per-kernel hipEvents are recorded on every n-th timed frame (each record is a ~6 us stream bubble); "
                          "0 = steps // 6 clamped to 1..16, i.e. at least six timed frames")
@@ -101,7 +104,7 @@ def main():
     else:
         cfg = scenes.config4(args.instances if args.instances != 10000 else 1000000, 256 if args.config == 5 else 16)
     W, H = cfg["width"], cfg["height"]
-    dr = zdist.DistributedRenderer(W, H, 1024, device_index=local_rank, rank=rank, world=world)
+    dr = zdist.DistributedRenderer(W, H, 1024, device_index=local_rank, rank=rank, world=world, split_shadow=not args.replicated_shadow)
     r = dr.r
     engine.load_scene(r, cfg)
     step = dr.frame        # render [+ ONE RCCL all-gather of the packed RGBA8 tiles + untile when world > 1]
@@ -174,7 +177,8 @@ def main():
             "config": {"workload": "config%d: %d instanced 960-tri spheres (%d meshlet-instances), %dx%d, 1 directional + %d point "
                                    "lights, 1024^2 shadow map + 5x5 PCF, cubemap IBL" % (args.config, len(cfg["objects"][0]["instances"]),
                                                                                           stats["work_items"][1], W, H, len(cfg["point"])),
-                       "resolution": [W, H], "parallelism": "screen-tiles t%%%d" % world if world > 1 else "single GPU"},
+                       "resolution": [W, H], "parallelism": ("screen-tiles t%%%d, %s" % (world, "shadow map replicated" if args.replicated_shadow else
+                                                                    "shadow casters i%%%d + MIN all-reduce" % world)) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": KERNEL_OF_PASS[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel_ms": round(times[dom], 4), "algorithmic_bytes": int(alg[dom]),
