@@ -5,12 +5,14 @@ against its own tiles only, and lights its tiles into a packed, tile-major RGBA8
 collectives over xGMI:
 
 * shadow map: rank r rasterises instances i % world == r into its own 1024^2 map and the maps are all-reduced with MIN
-  (4 MB; the depth test LESS_OR_EQUAL is a min, so the split is exact).  It runs on the collective stream while the render
-  stream does the camera cull + raster + GBuffer write, which do not need the shadow map;
+  (4 MB; the depth test LESS_OR_EQUAL is a min, so the split is exact).  It runs on the collective stream while the library's
+  own stream does the camera cull + raster + GBuffer write, which do not need the shadow map (zr_render_geometry /
+  zr_stream_wait_shadow); `split_shadow=False` renders the whole map on every rank instead (no shadow collective);
 * composite: an all-gather of the packed tiles (4 B/pixel in total) followed by an untile kernel gives every rank the frame.
 
-Two HIP streams: the render stream produces frame k+1 while the collective stream gathers and composites frame k (packed
-and gathered buffers are double-buffered, ordering is by events), so the xGMI latency is hidden behind rendering.
+Streams: the render stream (shadow share, lighting) and the library's camera lane produce frame k+1 while the collective
+stream gathers and composites frame k (packed and gathered buffers are double-buffered, ordering is by events), so the xGMI
+latency is hidden behind rendering.
 
 `pack_tiles` / `untile` are the numpy statement of the packed layout (what k_lighting writes and k_untile reads); the
 gloo tests use them, the GPU path uses the kernels.
