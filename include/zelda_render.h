@@ -205,6 +205,9 @@ int  zr_world_get_camera(zr_ctx* ctx, zr_camera* out);
 int  zr_world_save_json(zr_ctx* ctx, char* dst, size_t cap, size_t* len);
 /* Context-free Load -> Save (pure host code, no GPU): validates a payload; on error dst receives the message. */
 int  zr_world_json_normalize(const char* utf8, size_t len_in, char* dst, size_t cap, size_t* len);
+/* Listens on loopback by default (the payload is unauthenticated); any != 0 selects the engine's wildcard bind (AI_PASSIVE,
+ * ZE:1630-1636).  Call before zr_livelink_serve.  A client that connects and stays silent is dropped after 2 s. */
+int  zr_livelink_bind_any(zr_ctx* ctx, int any);
 int  zr_livelink_serve(zr_ctx* ctx, uint16_t port);   /* port 0 = ephemeral (tests); the engine's port is 8080 */
 int  zr_livelink_port(zr_ctx* ctx, uint16_t* port);
 int  zr_livelink_poll(zr_ctx* ctx, int* reloaded);  /* DrawFrame's bReloadScene pickup, ZE:1943-1951 */

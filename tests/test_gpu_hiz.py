@@ -179,3 +179,54 @@ def test_soak_two_frames_in_flight(oracle_lib, gpu_engine):
             o.render(0)
             g.finish()
             _identical(o, g, "frame %d" % i)
+
+
+def test_config5_full_size_culling_paths_agree(gpu_engine):
+    """BASELINE config 5 at its full size (1 M instances = 14 M meshlet-instances, 3840x2160, two-pass Hi-Z, 256 point lights with
+    per-tile light lists; too big for the scalar oracle): two frames so that the visibility history and the pyramid are in use;
+    every conservative cull on must equal every cull off, in every target."""
+    from zeldaengine_amd import engine as eng
+    cfg = scenes.config4(1000000, 256)
+    assert len(cfg["point"]) == 256 and (cfg["width"], cfg["height"]) == (3840, 2160)
+    frames = []
+    for flags in (0, abi.FLAG_NO_FRUSTUM_CULL | abi.FLAG_NO_CONE_CULL | abi.FLAG_NO_HIZ):
+        g = gpu_engine.Renderer(cfg["width"], cfg["height"], 1024, flags=flags)
+        eng.load_scene(g, cfg)
+        g.render(); g.render(); g.finish()
+        frames.append((g.color(), [g.gbuffer(t) for t in range(6)], g.shadowmap(), g.stats()))
+        g.close()
+    a, b = frames
+    assert np.array_equal(a[0], b[0])
+    for t in range(6):
+        assert np.array_equal(a[1][t].view(np.uint8), b[1][t].view(np.uint8)), "GBuffer target %d" % t
+    assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
+    assert a[3]["covered_pixels"] == b[3]["covered_pixels"] and a[3]["overflow"] == 0 and b[3]["overflow"] == 0
+    assert a[3]["round1_survivors"] > 0 and a[3]["hiz_culled"] > 100000 and a[3]["survivors"][1] < b[3]["survivors"][1] // 4
+    assert len(np.unique(a[0].reshape(-1, 4), axis=0)) > 1000       # a lit frame, not a constant
+
+
+def test_config5_reduced_against_the_oracle_with_a_moving_camera(oracle_lib, gpu_engine):
+    """Config 5's ingredients together at a size the oracle finishes in seconds: 3 000 instanced spheres, 256 point lights (tile
+    light lists), 640x360, Hi-Z history in use, the camera orbiting and the lights riding their spiral between frames."""
+    import math
+    from zeldaengine_amd import engine as eng
+    cfg = scenes.config3(3000, 640, 360, 20.0, 256)
+    o = oracle_lib.Oracle(cfg["width"], cfg["height"], 512)
+    g = gpu_engine.Renderer(cfg["width"], cfg["height"], 512)
+    oracle_lib.load_scene(o, cfg)
+    eng.load_scene(g, cfg)
+    culled = 0
+    for i in range(3):
+        a = 0.6 + 0.12 * i
+        cam = abi.make_camera((8.0 * math.cos(a), 8.0 * math.sin(a), 4.0 + 0.3 * i), (0.0, 0.0, 0.3), fov=45.0)
+        for r in (o, g):
+            r.update_uniforms(cam, cfg["dir"], cfg["point"], cfg["spot"], 0.0, 0.01 * i, 0.5 * i)
+        o.render(0)
+        g.render(); g.finish()
+        _identical(o, g, "reduced config 5, frame %d" % i)
+        st = g.stats()
+        assert st["covered_pixels"] == o.covered_pixels() and st["overflow"] == 0
+        if i:
+            assert st["round1_survivors"] > 0
+            culled += st["hiz_culled"]
+    assert culled > 0

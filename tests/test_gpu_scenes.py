@@ -115,6 +115,41 @@ def test_caller_supplied_meshlets_follow_the_indirect_draw_order(oracle_lib, gpu
     _identical(o, g, "caller meshlets")
 
 
+def test_meshlet_file_from_the_tool_renders_like_the_engine_would(oracle_lib, gpu_engine, tmp_path):
+    """Row a4 end to end: OBJ -> ZeldaMeshlet tool (assets.meshlet_tool, ZM:235-294) -> `.meshlet` file on disk -> LoadMeshletAsset
+    (assets.read_meshlet, ZE:7046-7169) -> zr_mesh_set_meshlets -> GPU frame.  The oracle draws the flattened index buffer of
+    CreateMeshVertexBuffers<XkMeshIndirect> (ZE:4733-4756) built independently here from the file's sections."""
+    from zeldaengine_amd import assets
+    v, idx = scenes.uv_sphere(24, 12, 0.8)
+    obj = str(tmp_path / "ball.obj")
+    assets.write_obj(obj, v, idx)
+    path = str(tmp_path / "ball.meshlet")
+    n = assets.meshlet_tool(obj, path)
+    f = assets.read_meshlet(path)
+    assert n == len(f["meshlets"]) > 1
+    flat = []
+    for ml in f["meshlets"]:
+        for t in range(int(ml["TriangleCount"])):
+            for k in range(3):
+                flat.append(f["mverts"][int(ml["VertexOffset"]) + int(f["mtris"][int(ml["TriangleOffset"]) + 3 * t + k])])
+    flat = np.asarray(flat, dtype=np.uint32)
+    assert len(flat) == len(f["indices"])
+    inst = scenes.generate_instances(40, 1.0, 4.0, 0.4, 0.9, seed=11)
+    o = oracle_lib.Oracle(320, 180, 128)
+    o.object_add(o.mesh_create(f["vertices"], flat), None, inst)
+    o.object_add(o.mesh_create(f["vertices"], flat))
+    g = gpu_engine.Renderer(320, 180, 128)
+    m = g.mesh_create(f["vertices"], f["indices"])
+    g.mesh_set_meshlets(m, f["meshlets"], f["mverts"], f["mtris"])
+    g.object_add(m, None, inst)
+    g.object_add(m)
+    for r in (o, g):
+        r.set_cubemap(scenes.synthetic_cubemap(16))
+        _std_frame()(r)
+    o.render(); g.render(); g.render(); g.finish()
+    _identical(o, g, ".meshlet file")
+
+
 @pytest.mark.parametrize("view", [1, 2, 3, 4, 5, 7, 8])
 def test_debug_views(oracle_lib, gpu_engine, view):
     o, g = _both(oracle_lib, gpu_engine, 192, 128, 128, _mixed_scene, _std_frame(), debug_view=view)

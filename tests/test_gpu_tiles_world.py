@@ -212,6 +212,33 @@ def test_livelink_end_to_end(gpu_engine):
     g.livelink_stop()
 
 
+def test_livelink_silent_client_and_oversized_scene_do_not_hurt(gpu_engine):
+    """A client that connects and sends nothing must not park the listener (zr_livelink_stop / zr_destroy join it), and a payload
+    asking for billions of instances is a schema error, not an allocation."""
+    import socket
+    g = gpu_engine.Renderer(64, 64, 64)
+    _register_sample_profabs(g)
+    port = g.livelink_serve(0)
+    quiet = socket.create_connection(("127.0.0.1", port))
+    time.sleep(0.3)                          # the listener is now inside the connection, waiting for the first segment
+    t0 = time.time()
+    g.livelink_stop()
+    assert time.time() - t0 < 1.0
+    quiet.close()
+    port = g.livelink_serve(0)               # serving again works, and a later client is not blocked by an earlier silent one
+    quiet = socket.create_connection(("127.0.0.1", port))
+    huge = scenes.sample_world()
+    huge["Objects"][3]["InstanceCount"] = 4000000000
+    livelink.send_world(huge, port=port, host="127.0.0.1")      # queued behind the silent client: served once that one is dropped
+    time.sleep(0.3)                          # (send_world returned after the half-close, i.e. after the payload was parsed)
+    assert not g.livelink_poll()             # rejected at parse time
+    with pytest.raises(gpu_engine.ZeldaRenderError) as e:
+        g.world_load_json(json.dumps(huge))
+    assert e.value.code == abi.ERR_PARSE and "InstanceCount" in str(e.value)
+    quiet.close()
+    g.close()                                # zr_destroy stops the listener
+
+
 def test_full_size_config3_against_the_oracle(oracle_lib, gpu_engine):
     """BASELINE's own size: 10 000 instances / 140 000 meshlet-instances at 1920x1080, every target bit-exact."""
     cfg = scenes.config3()

@@ -66,6 +66,8 @@ FLAG_SKIP_COMPOSITE = 4
 FLAG_NO_HIZ = 8
 FLAG_SERIAL_PASSES = 16
 
+OK, ERR_ARG, ERR_DEVICE, ERR_OOM, ERR_PARSE, ERR_IO, ERR_STATE, ERR_OVERFLOW, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8
+
 
 def make_light(position=(0, 0, 0), type_=0, color=(1, 1, 1), intensity=1.0, direction=(0, 0, 1), radius=0.0,
                extra=(0, 0, 0, 0)):

@@ -101,6 +101,7 @@ struct zr_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cam = nullptr, ev_lit[2] = { nullptr, nullptr };
     GBufferPtrs Gb[2] = {}; float* d_shadow_b[2] = { nullptr, nullptr }; XkView* d_view_b[2] = { nullptr, nullptr };
     uint32_t* d_empty_b[2] = { nullptr, nullptr };
+    bool shadow_cleared[2] = { false, false };      // d_shadow_b[i] already holds depth 1.0 (cleared by the previous lighting pass)
     unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048;
     uint32_t work_capacity = 0, bin_capacity = 0; bool any_images = false;
     // two-pass Hi-Z occlusion culling of the camera pass: per work item pixel bbox + least depth (written by the cull),
@@ -126,10 +127,11 @@ struct zr_ctx {
     ZrWorld world;
     std::map<std::string, std::vector<ZrProfab>> profabs;
     std::mutex ll_mutex; std::thread ll_thread; std::atomic<bool> ll_run{ false };
-    int ll_listen_fd = -1; bool ll_pending = false; ZrWorld ll_world; uint16_t ll_port = 0;
+    int ll_listen_fd = -1; bool ll_pending = false, ll_bind_any = false; ZrWorld ll_world; uint16_t ll_port = 0;
 };
 
 int zr_fail(zr_ctx* c, int code, const std::string& msg);
+hipError_t zr_sync_all(zr_ctx* c);     // every stream the library enqueues on
 // helpers implemented in zr_host.cpp and used by zr_world.cpp
 float zr_srgb_decode8(uint32_t c);
 int zr_material_prepare(zr_ctx* c, const zr_material* mat, ZrMaterialHost* out);

@@ -1,13 +1,15 @@
 // zr_host.cpp — context, scene upload, per-frame uniforms and the frame graph behind the C-ABI (zelda_render.h).
 //
 // Host counterpart of XkZeldaEngineApp's CreateEngineScene / UpdateUniformBuffer / RecordCommandBuffer / DrawFrame
-// (ZE:4140, 4585, 3160, 1940).  All GPU work is enqueued on ONE HIP stream in pass order; nothing here computes a
-// pixel on the CPU and there is no fallback: without a usable HIP device zr_create fails.
+// (ZE:4140, 4585, 3160, 1940).  GPU work is enqueued on two HIP streams (the host's render stream and the library's camera
+// lane, see geometry_passes); nothing here computes a pixel on the CPU and there is no fallback: without a usable HIP device
+// zr_create fails.
 #include "zr_ctx.h"
 #include "zr_math.h"
 
 #include <cmath>
 #include <cstdio>
+#include <cstddef>
 #include <cstring>
 #include <cstdlib>
 
@@ -18,7 +20,7 @@
 int zr_fail(zr_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
 
 // Everything the library has enqueued: the host's stream (shadow pipeline, lighting) and its own camera lane.
-static hipError_t sync_all(zr_ctx* c)
+hipError_t zr_sync_all(zr_ctx* c)
 {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess && c->cam_s) e = hipStreamSynchronize(c->cam_s);
@@ -102,6 +104,7 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     c->G = c->Gb[0]; c->d_shadow = c->d_shadow_b[0]; c->d_view = c->d_view_b[0]; c->d_empty_rgba = c->d_empty_b[0];
     ok &= dev_alloc(&c->d_color, n) == hipSuccess;
     ok &= dev_alloc(&c->d_stats, 1) == hipSuccess;
+    if (ok) ok &= hipMemset(c->d_stats, 0, sizeof(ZrDevStats)) == hipSuccess;
     ok &= dev_alloc(&c->d_lut, 256) == hipSuccess;
     if (ok) ok &= hipMemcpy(c->d_lut, c->lut, sizeof c->lut, hipMemcpyHostToDevice) == hipSuccess;
     {
@@ -116,7 +119,7 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     // screen tiles: camera target partitioned t % world == rank; the shadow map is rendered whole on every rank
     c->tiles_x = (c->W + ZR_TILE - 1) / ZR_TILE; c->tiles_y = (c->H + ZR_TILE - 1) / ZR_TILE; c->n_tiles = c->tiles_x * c->tiles_y;
     c->stiles_x = (c->SD + ZR_TILE - 1) / ZR_TILE; c->stiles_y = c->stiles_x; c->sn_tiles = c->stiles_x * c->stiles_y;
-    if (c->n_tiles > 16384u || c->sn_tiles > 16384u) { zr_destroy(c); return ZR_ERR_ARG; }   // binning histograms live in 64 KB of LDS
+    if (c->n_tiles > 16000u || c->sn_tiles > 16000u) { zr_destroy(c); return ZR_ERR_ARG; }   // binning histograms (4 B per tile, dynamic) + a few static words must fit the default 64 KB of LDS per workgroup
     c->slots_per_rank = (c->n_tiles + c->cfg.tile_world - 1) / c->cfg.tile_world;
     std::vector<uint32_t> owned, sowned(c->sn_tiles);
     for (uint32_t t = c->cfg.tile_rank; t < c->n_tiles; t += c->cfg.tile_world) owned.push_back(t);
@@ -148,13 +151,15 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         c->Gclear.depth = (float*)w; c->Gclear.scene_color = w + 1; c->Gclear.gA = w + 2; c->Gclear.gB = w + 3; c->Gclear.gC = w + 4;
         c->Gclear.gD = (uint2*)(w + 6); c->Gclear.overlay = w + 8;
     }
-    {   // environment switches for diagnostics and A/B timing, read once
+    {   // environment switches, read once
+#ifdef ZR_DIAG       // work-skipping / A-B switches: diagnostic builds only (zeldaengine_amd.build.build(extra_flags=["-DZR_DIAG"]))
         const char* e;
         if ((e = getenv("ZR_DEBUG_SKIP"))) c->env_skip = (uint32_t)atoi(e);                 // 1: no pixel walk, 2: no triangle phase
         if ((e = getenv("ZR_DEBUG_SKIP_LIGHT"))) c->env_skip_light = (uint32_t)atoi(e);     // bits: 1 PCF, 2 lights, 4 reflection
         if ((e = getenv("ZR_LIGHT_LIST_MIN"))) c->env_light_list_min = atoi(e);
         c->env_no_empty_px = getenv("ZR_NO_EMPTY_PIXEL") != nullptr;
-        c->env_serial = getenv("ZR_SERIAL_PASSES") != nullptr;
+#endif
+        c->env_serial = getenv("ZR_SERIAL_PASSES") != nullptr;      // same frame, one stream (= ZR_FLAG_SERIAL_PASSES): profiling only
     }
     ok &= hipHostMalloc((void**)&c->h_view_ring, sizeof(XkView) * zr_ctx::VIEW_RING, hipHostMallocDefault) == hipSuccess;
     for (auto& e : c->view_ev) ok &= hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
@@ -207,7 +212,7 @@ extern "C" void zr_destroy(zr_ctx* c)
     if (!c) return;
     zr_livelink_stop(c);
     (void)hipSetDevice(c->device);
-    (void)sync_all(c);                      // including a geometry stage whose lighting pass never came
+    (void)zr_sync_all(c);                      // including a geometry stage whose lighting pass never came
     free_scene(c);
     free_mesh_buffers(c->sky_mesh); dev_free(c->sky_obj.d_inst); for (auto& t : c->sky_obj.d_tex) dev_free(t); dev_free(c->d_bg);
     for (auto p : c->d_cube) if (p) (void)hipFree(p);
@@ -441,7 +446,7 @@ int zr_object_add_internal(zr_ctx* c, uint32_t mesh_id, const ZrMaterialHost& ma
         if (e != hipSuccess) { dev_free(d_raw); cleanup(); return zr_fail(c, ZR_ERR_DEVICE, hipGetErrorString(e)); }
     }
     zr_launch_instance_prep(d_raw, o.d_inst, o.n_inst, o.instanced ? 1u : 0u, c->stream);
-    hipError_t e = sync_all(c);
+    hipError_t e = zr_sync_all(c);
     dev_free(d_raw);
     if (e != hipSuccess) { cleanup(); return zr_fail(c, ZR_ERR_DEVICE, hipGetErrorString(e)); }
     c->objects.push_back(std::move(o));
@@ -463,7 +468,7 @@ extern "C" int zr_scene_clear(zr_ctx* c)
 {
     if (!c) return ZR_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, sync_all(c));
+    HIPCHK(c, zr_sync_all(c));
     free_scene(c);
     return ZR_OK;
 }
@@ -521,7 +526,7 @@ static int upload_mesh(zr_ctx* c, ZrMesh& m)
 static int finalize_scene(zr_ctx* c)
 {
     if (!c->scene_dirty) return ZR_OK;
-    HIPCHK(c, sync_all(c));
+    HIPCHK(c, zr_sync_all(c));
     for (auto& o : c->objects) { int rc = upload_mesh(c, c->meshes[o.mesh]); if (rc) return rc; }
     const bool sky = c->sky_set && c->sky_enabled;
     if (sky) { int rc = upload_mesh(c, c->sky_mesh); if (rc) return rc; }
@@ -592,7 +597,7 @@ extern "C" int zr_set_skydome(zr_ctx* c, const XkVertex* v, uint32_t nv, const u
 {
     if (!c) return ZR_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, sync_all(c));
+    HIPCHK(c, zr_sync_all(c));
     free_mesh_buffers(c->sky_mesh); c->sky_mesh = ZrMesh();
     dev_free(c->sky_obj.d_inst); for (auto& t : c->sky_obj.d_tex) dev_free(t);
     c->sky_obj = ZrSceneObject(); c->sky_set = false; c->scene_dirty = true;
@@ -608,7 +613,7 @@ extern "C" int zr_set_skydome(zr_ctx* c, const XkVertex* v, uint32_t nv, const u
     if (rc) return rc;
     HIPCHK(c, dev_alloc(&o.d_inst, 1));
     zr_launch_instance_prep(nullptr, o.d_inst, 1, 0u, c->stream);
-    HIPCHK(c, sync_all(c));
+    HIPCHK(c, zr_sync_all(c));
     c->sky_set = true;
     return ZR_OK;
 }
@@ -617,7 +622,7 @@ extern "C" int zr_set_background(zr_ctx* c, const zr_image* tex)
 {
     if (!c) return ZR_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, sync_all(c));
+    HIPCHK(c, zr_sync_all(c));
     dev_free(c->d_bg); c->bg_set = false;
     if (!tex || !tex->rgba8) return ZR_OK;
     int rc = upload_texture(c, tex, true, &c->d_bg, &c->bg_w, &c->bg_h, &c->bg_levels);
@@ -644,7 +649,7 @@ extern "C" int zr_set_cubemap(zr_ctx* c, const uint8_t* const faces[6], uint32_t
     ARGCHK(c, dim > 0 && dim <= 16384);
     if (faces) for (int f = 0; f < 6; ++f) ARGCHK(c, faces[f] != nullptr);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, sync_all(c));
+    HIPCHK(c, zr_sync_all(c));
     for (auto p : c->d_cube) if (p) (void)hipFree(p);
     c->d_cube.clear();
     uint32_t levels = 1; for (uint32_t d = dim; d > 1; d >>= 1) levels++;      // floor(log2(dim)) + 1, ZE:6887
@@ -891,7 +896,7 @@ static int frame_begin(zr_ctx* c, hipStream_t s)
     c->timing_now = c->timing_interval != 0 && c->frame_no % c->timing_interval == 0;     // pass events cost ~6 us of stream bubble each
     hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
     if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
-    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, sizeof(ZrDevStats), s));
+    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, offsetof(ZrDevStats, overflow_sticky), s));      // the sticky overflow latch survives
     if (c->view_dirty) { c->view_version++; c->view_dirty = false; }
     if (c->view_uploaded[par] != c->view_version) {        // pinned ring slot: reused only after its previous upload has executed
         const uint32_t k = c->view_slot++ % zr_ctx::VIEW_RING;
@@ -912,7 +917,10 @@ static int shadow_pass(zr_ctx* c, hipStream_t s)
     const bool live = build_pass(c, c->shadow, ZR_MODE_SHADOW, &P);
     if (!live) P.n_work = 0;      // no finite vertex: the pass is its clear
     c->last_work[0] = P.n_work;
-    zr_launch_fill32((uint32_t*)shadow_buf(c), 0x3F800000u, (size_t)c->SD * c->SD, s);      // clear depth 1.0, ZE:3248
+    // clear depth 1.0 (ZE:3248): the previous frame's lighting pass already did it for the internal double-buffered map
+    const int spar = (int)(c->frame_no & 1u);
+    if (c->d_shadow_ext || !c->shadow_cleared[spar]) zr_launch_fill32((uint32_t*)shadow_buf(c), 0x3F800000u, (size_t)c->SD * c->SD, s);
+    c->shadow_cleared[spar] = false;
     ZrHiz Z; memset(&Z, 0, sizeof Z);
     zr_launch_cull(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, c->raster_blocks * 4u, s);
     bin_and_raster(c, P, Z, 0, c->sn_tiles, s);
@@ -1067,6 +1075,10 @@ static int lighting_pass(zr_ctx* c)
     hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
     ZrLightParams L; light_params(c, &L);
     L.empty_rgba = c->empty_ready ? c->d_empty_rgba : nullptr;
+    // The next frame's shadow pass follows on this stream and rasterises into the OTHER copy of the map, which nothing reads or
+    // writes while this pass runs: clear it here.
+    const int npar = (int)((c->frame_no + 1u) & 1u);
+    if (c->n_owned) { L.clear_next = (uint32_t*)c->d_shadow_b[npar]; L.clear_n = c->SD * c->SD; c->shadow_cleared[npar] = true; }
     zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, shadow_buf(c), c->cube, c->d_lut, c->d_unorm_lut,
                        L.packed_out ? (c->d_tiles_ext ? c->d_tiles_ext : c->d_tiles) : c->d_color, s);
     if (c->debug_view == 9u)        // GBufferVis mosaic over the lit frame (needs the whole GBuffer: single-rank contexts only)
@@ -1127,11 +1139,15 @@ extern "C" int zr_finish(zr_ctx* c)
 {
     if (!c) return ZR_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, sync_all(c));
+    HIPCHK(c, zr_sync_all(c));
     if (c->rendered) {
         HIPCHK(c, hipMemcpy(&c->h_stats, c->d_stats, sizeof(ZrDevStats), hipMemcpyDeviceToHost));
         c->h_stats.covered_shadow = 0;
-        if (c->h_stats.overflow) return zr_fail(c, ZR_ERR_OVERFLOW, "tile bin list overflow: frame is incomplete");
+        if (c->h_stats.overflow_sticky) {     // latched by ANY frame since the last zr_finish, not only the newest one
+            HIPCHK(c, hipMemset(&c->d_stats->overflow_sticky, 0, sizeof(uint32_t)));
+            c->h_stats.overflow = 1u;
+            return zr_fail(c, ZR_ERR_OVERFLOW, "tile bin list overflow: a frame since the last zr_finish is incomplete");
+        }
     }
     return ZR_OK;
 }

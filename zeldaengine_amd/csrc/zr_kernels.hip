@@ -30,6 +30,12 @@
 #define QCAP 128u
 #define RW (ZR_TILE >= 64 ? 8 : 4)          // waves per rasteriser workgroup: one 64x64 tile's keys (32 KB) are shared by 8 waves
 #define RTHREADS (RW * WAVE)
+// Diagnostic work-skipping switches (attribution of kernel time) exist only in -DZR_DIAG builds: the product library has none.
+#ifdef ZR_DIAG
+#define ZR_DIAG_SKIP(x) (x)
+#else
+#define ZR_DIAG_SKIP(x) 0u
+#endif
 
 // ------------------------------------------------------------------------------------------------ helpers
 
@@ -539,7 +545,7 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
         stats->bin_entries[slot] = part[1023];
         stats->n_chunks[slot] = cpart[1023];
         stats->chunk_counter[slot] = 0;
-        if (part[1023] > capacity) stats->overflow = 1u;
+        if (part[1023] > capacity) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
     }
 }
 
@@ -898,8 +904,6 @@ __device__ __forceinline__ zf4 tex_bilinear(const ZrTex& T, int level, float u, 
     { const float top = __builtin_fmaf(a, t10.w - t00.w, t00.w), bot = __builtin_fmaf(a, t11.w - t01.w, t01.w); r.w = __builtin_fmaf(b, bot - top, top); }
     return r;
 }
-// Isotropic LOD from the quad derivatives, trilinear.  Anisotropic filtering (maxAnisotropy = device max, ZE:6540) is
-// implementation-defined and not reproduced.  A constant slot returns its texel.
 // trilinear between the two mip levels around lambda (already clamped to the chain)
 __device__ __forceinline__ zf4 tex_trilinear(const ZrTex& T, float lambda, float u, float v, bool srgb, const float* __restrict__ lut)
 {
@@ -1155,7 +1159,7 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
 #pragma unroll
             for (int round = 0; round < 2; ++round) {
                 const uint32_t t0 = (uint32_t)round * WAVE;
-                if (t0 >= tcount || P.debug_skip >= 2u) break;
+                if (t0 >= tcount || ZR_DIAG_SKIP(P.debug_skip) >= 2u) break;
                 const uint32_t t = t0 + lane;
                 bool alive = false;
                 int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0;
@@ -1187,7 +1191,7 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
                     q[9 * QCAP] = (int)prim;
                 }
                 qn += (uint32_t)__popcll(mask);
-                if (P.debug_skip >= 1u) { qhead = (qhead + qn) & (QCAP - 1u); qn = 0; }
+                if (ZR_DIAG_SKIP(P.debug_skip) >= 1u) { qhead = (qhead + qn) & (QCAP - 1u); qn = 0; }
                 if (qn >= WAVE) {
                     lds_fence();
                     const int* q = &queue[wv][0][(qhead + lane) & (QCAP - 1u)];
@@ -1371,6 +1375,10 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
     for (uint32_t i = threadIdx.x; i < 256u; i += 256u) u8[i] = unorm_lut[i];
     for (uint32_t i = threadIdx.x; i < 1024u; i += 256u) u10[i] = unorm_lut[256u + i];
     __syncthreads();
+    if (L.clear_next) {      // the clear of the next frame's shadow pass (depth 1.0, ZE:3248), a slice per workgroup: saves a launch
+        const uint32_t per = (L.clear_n + gridDim.x - 1u) / gridDim.x, b = blockIdx.x * per;
+        for (uint32_t i = threadIdx.x; i < per && b + i < L.clear_n; i += 256u) L.clear_next[b + i] = 0x3F800000u;
+    }
     const uint32_t tile = owned_tiles[blockIdx.x];
     const int tx0 = (int)(tile % L.tiles_x) * TILE, ty0 = (int)(tile / L.tiles_x) * TILE;
     const zf3 cam = zr3(view->CameraInfo[0], view->CameraInfo[1], view->CameraInfo[2]);
@@ -1479,7 +1487,7 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
         // weight depend only on its x / y offset, so they are formed once per axis (5 + 5) instead of once per tap (25 + 25);
         // every tap still evaluates fma(sx + ox, dim, -0.5) etc. with the same operands, i.e. the same bits.
         float sum = 0.0f;
-        if (sz > -1.0f && sz < 1.0f && !(L.debug_skip & 1u)) {
+        if (sz > -1.0f && sz < 1.0f && !(ZR_DIAG_SKIP(L.debug_skip) & 1u)) {
             const int SDi = (int)L.SD;
             const float dim = (float)SDi;
             int cx0[5], cx1[5], ry0[5], ry1[5]; float wa[5], wb[5];
@@ -1541,7 +1549,7 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
         const zf3 Nn = zr_normalize(N);                      // Apply*Light and refract() re-normalise N
         const zf3 DiffuseColor = BaseColor * (1.0f - Metallic);
         // lights in the shader's order: directional, then point (with a tile list: only its set bits, ascending)
-        const uint32_t n_lights = (L.debug_skip & 2u) ? 0u : nDir + nPoint;
+        const uint32_t n_lights = (ZR_DIAG_SKIP(L.debug_skip) & 2u) ? 0u : nDir + nPoint;
         uint32_t mword = 0u, mnext = 0u;       // remaining bits of the current mask word, index of the next word
         for (uint32_t li = 0; li < n_lights; ++li) {
             if (use_mask && li >= nDir) {
@@ -1622,7 +1630,7 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
         }
         // ComputeReflectionMipFromRoughness, SH/Common.glsl:191-198
         const float MIPS = (maxmips - 1.0f) - __builtin_fmaf(-1.2f, zr_log2(__builtin_fmaxf(Roughness, 0.001f)), 1.0f);
-        const zf3 RL = (L.debug_skip & 4u) ? zr3(0.0f, 0.0f, 0.0f) : cube_sample(C, srgb_lut, L.cube_dim, (int)L.cube_levels, R, MIPS) * 10.0f;
+        const zf3 RL = (ZR_DIAG_SKIP(L.debug_skip) & 4u) ? zr3(0.0f, 0.0f, 0.0f) : cube_sample(C, srgb_lut, L.cube_dim, (int)L.cube_levels, R, MIPS) * 10.0f;
         const float RV = zr_saturate((zr_pow(NdotV + AO, Roughness * Roughness) - 1.0f) + AO);   // GetSpecularOcclusion :226
         const zf3 RefC = zr3((RL.x * RV) * RBRDF.x, (RL.y * RV) * RBRDF.y, (RL.z * RV) * RBRDF.z);
 

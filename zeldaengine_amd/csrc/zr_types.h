@@ -98,6 +98,7 @@ struct ZrDevStats {
     uint32_t chunk_counter[3];
     uint32_t n_vis_work[2];          // meshlet-instances of the instances that passed the instance-level frustum test
     uint32_t hiz_culled;             // meshlet-instances rejected by the Hi-Z test
+    uint32_t overflow_sticky;        // LAST member: not cleared at frame begin; set with `overflow`, cleared by zr_finish when it reports it
 };
 
 // Two-pass Hi-Z occlusion culling of the camera pass (config 5; conservative).
@@ -126,6 +127,8 @@ struct ZrLightParams {
     uint32_t bg_enabled;             // background quad (Background.vert/.frag) on
     uint32_t light_list;             // 1: per-tile point-light lists
     const uint32_t* empty_rgba;      // the lit colour of a pixel holding the GBuffer's clear values (same for all of them), or null
+    uint32_t* clear_next;            // the NEXT frame's shadow map (idle while this pass runs): cleared to depth 1.0 here, or null
+    uint32_t clear_n, _pad0;
     ZrTex    bg;                     // its sRGB texture
 };
 

@@ -19,6 +19,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <new>
+
+#define XK_WORLD_MAX_INSTANCES_PER_OBJECT 4194304u     // 2^22 per ObjectDesc (the sample scene uses 10 000); bigger scenes use zr_object_add
 
 // ------------------------------------------------------------------------------------------------ minimal JSON
 
@@ -221,6 +224,9 @@ bool world_parse(const char* utf8, size_t len, ZrWorld& w, std::string& err)
             d.MaxRotYaw = R.f(o, "MaxRotYaw"); d.MinRotRoll = R.f(o, "MinRotRoll"); d.MaxRotRoll = R.f(o, "MaxRotRoll");
             d.MinRotPitch = R.f(o, "MinRotPitch"); d.MaxRotPitch = R.f(o, "MaxRotPitch"); d.MinPScale = R.f(o, "MinPScale");
             d.MaxPScale = R.f(o, "MaxPScale");
+            // the payload is unauthenticated: one 64 KiB packet must not be able to ask for gigabytes of instances
+            if (d.InstanceCount > XK_WORLD_MAX_INSTANCES_PER_OBJECT && R.err.empty())
+                R.err = "InstanceCount of '" + d.ProfabName + "' exceeds " + std::to_string(XK_WORLD_MAX_INSTANCES_PER_OBJECT);
             w.ObjectDescs.push_back(d);
         }
     if (!R.err.empty()) { err = "[WORLD] JSON schema error: " + R.err; return false; }
@@ -304,6 +310,14 @@ int apply_world(zr_ctx* c, const ZrWorld& w)
                               L[2].data(), (uint32_t)L[2].size(), 0.0f, 0.0f, 0.0f);
 }
 
+// No C++ exception crosses the ABI: an allocation failure while instantiating a world becomes an error code.
+int apply_world_guarded(zr_ctx* c, const ZrWorld& w)
+{
+    try { return apply_world(c, w); }
+    catch (const std::bad_alloc&) { return zr_fail(c, ZR_ERR_OOM, "[WORLD] out of host memory while building the scene"); }
+    catch (const std::exception& e) { return zr_fail(c, ZR_ERR_STATE, std::string("[WORLD] ") + e.what()); }
+}
+
 void jnum(std::string& o, float v)
 {
     char buf[64];
@@ -345,7 +359,9 @@ extern "C" int zr_world_load_json(zr_ctx* c, const char* utf8, size_t len)
     if (!c || !utf8) return ZR_ERR_ARG;
     ZrWorld w; std::string err;
     if (!world_parse(utf8, len, w, err)) return zr_fail(c, ZR_ERR_PARSE, err);
-    return apply_world(c, w);
+    (void)hipSetDevice(c->device);
+    if (zr_sync_all(c) != hipSuccess) return zr_fail(c, ZR_ERR_DEVICE, "world load: device synchronisation failed");
+    return apply_world_guarded(c, w);
 }
 
 // XkWorld::Save (ZE:1149-1263), PrettyWriter layout (4-space indent).  The engine writes OverrideCubemap from
@@ -452,6 +468,9 @@ extern "C" int zr_object_get_instances(zr_ctx* c, uint32_t index, uint32_t* mesh
 
 // ------------------------------------------------------------------------------------------------ C-ABI: livelink
 
+// One connection: wait (in 100 ms slices, so that zr_livelink_stop is never held up by a silent client) for the first
+// segment, then ONE recv (ZE:1683).  A client that sends nothing within XK_LIVELINK_IDLE_MS is dropped.
+#define XK_LIVELINK_IDLE_MS 2000
 static void livelink_thread(zr_ctx* c)
 {
     std::vector<char> buf(XK_LIVELINK_RECV_MAX);
@@ -461,7 +480,13 @@ static void livelink_thread(zr_ctx* c)
         if (pr <= 0 || !(pfd.revents & POLLIN)) continue;
         const int cs = accept(c->ll_listen_fd, nullptr, nullptr);
         if (cs < 0) { fprintf(stderr, "[Socket] accept failed\n"); continue; }      // keep listening, ZE:1676-1679
-        const ssize_t n = recv(cs, buf.data(), buf.size(), 0);                       // ONE recv per connection, ZE:1683
+        ssize_t n = -2;                                                                // -2: timed out / stopping
+        for (int waited = 0; waited < XK_LIVELINK_IDLE_MS && c->ll_run.load(); waited += 100) {
+            struct pollfd cfd = { cs, POLLIN, 0 };
+            const int cr = poll(&cfd, 1, 100);
+            if (cr < 0) { n = -1; break; }
+            if (cr > 0) { n = recv(cs, buf.data(), buf.size(), 0); break; }            // ONE recv per connection, ZE:1683
+        }
         if (n > 0) {
             ZrWorld w; std::string err;
             if (world_parse(buf.data(), (size_t)n, w, err)) {
@@ -472,10 +497,20 @@ static void livelink_thread(zr_ctx* c)
                 fprintf(stderr, "%s\n", err.c_str());
             }
         } else if (n == 0) fprintf(stdout, "[Socket] Connection closing...\n");
+        else if (n == -2) fprintf(stderr, "[Socket] client sent nothing: dropped\n");
         else fprintf(stderr, "[Socket] recv failed\n");
         shutdown(cs, SHUT_WR);                                                        // no payload is ever sent back, ZE:1699
         close(cs);
     }
+}
+
+// The engine binds the wildcard address (AI_PASSIVE, ZE:1630-1636); the payload is unauthenticated, so the library listens on
+// loopback unless the host asks for the engine's behaviour with zr_livelink_bind_any(ctx, 1) before zr_livelink_serve.
+extern "C" int zr_livelink_bind_any(zr_ctx* c, int any)
+{
+    if (!c) return ZR_ERR_ARG;
+    c->ll_bind_any = any != 0;
+    return ZR_OK;
 }
 
 extern "C" int zr_livelink_serve(zr_ctx* c, uint16_t port)
@@ -486,7 +521,7 @@ extern "C" int zr_livelink_serve(zr_ctx* c, uint16_t port)
     if (fd < 0) return zr_fail(c, ZR_ERR_IO, "[Socket] socket failed");
     int one = 1; setsockopt(fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof one);
     struct sockaddr_in a; memset(&a, 0, sizeof a);
-    a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(INADDR_ANY); a.sin_port = htons(port);      // AI_PASSIVE wildcard, ZE:1630-1636
+    a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(c->ll_bind_any ? INADDR_ANY : INADDR_LOOPBACK); a.sin_port = htons(port);
     if (bind(fd, (struct sockaddr*)&a, sizeof a) < 0) { close(fd); return zr_fail(c, ZR_ERR_IO, "[Socket] bind failed"); }
     if (listen(fd, SOMAXCONN) < 0) { close(fd); return zr_fail(c, ZR_ERR_IO, "[Socket] listen failed"); }
     socklen_t al = sizeof a;
@@ -506,8 +541,8 @@ extern "C" int zr_livelink_poll(zr_ctx* c, int* reloaded)
     { std::lock_guard<std::mutex> g(c->ll_mutex); if (c->ll_pending) { w = std::move(c->ll_world); c->ll_pending = false; have = true; } }
     if (!have) return ZR_OK;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);     // "wait all fences" before CreateEngineScene, ZE:1943-1951
-    int rc = apply_world(c, w);
+    if (zr_sync_all(c) != hipSuccess) return zr_fail(c, ZR_ERR_DEVICE, "livelink: device synchronisation failed");   // "wait all fences" on both lanes before CreateEngineScene, ZE:1943-1951
+    int rc = apply_world_guarded(c, w);
     if (rc == ZR_OK && reloaded) *reloaded = 1;
     return rc;
 }

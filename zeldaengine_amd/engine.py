@@ -83,6 +83,7 @@ def lib():
         "zr_world_save_json": [vp, vp, sz, C.POINTER(sz)],
         "zr_world_get_camera": [vp, vp],
         "zr_world_json_normalize": [C.c_char_p, sz, vp, sz, C.POINTER(sz)],
+        "zr_livelink_bind_any": [vp, C.c_int],
         "zr_livelink_serve": [vp, C.c_uint16],
         "zr_livelink_port": [vp, C.POINTER(C.c_uint16)],
         "zr_livelink_poll": [vp, C.POINTER(C.c_int)],
@@ -398,7 +399,8 @@ class Renderer:
         self._chk(self.L.zr_world_get_camera(self.h, C.cast(C.pointer(cam), C.c_void_p)))
         return cam
 
-    def livelink_serve(self, port=8080):
+    def livelink_serve(self, port=8080, bind_any=False):
+        self._chk(self.L.zr_livelink_bind_any(self.h, int(bind_any)))
         self._chk(self.L.zr_livelink_serve(self.h, port))
         p = C.c_uint16()
         self._chk(self.L.zr_livelink_port(self.h, C.byref(p)))
