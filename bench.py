@@ -3,19 +3,24 @@
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A step is one full frame of the hot path on synthetic, HBM-resident input:
+A step is one full frame of the hot path on synthetic, HBM-resident input, INCLUDING the engine's per-frame uniform work
+(UpdateUniformBuffer, ZE:4585-4664: the point lights ride their spiral, XkView is rebuilt and uploaded every frame):
     meshlet cull+bin (shadow) -> shadow raster -> meshlet cull+bin (camera) -> tile raster of last frame's visible set
     -> Hi-Z pyramid -> bin + tile raster of the rest (occlusion-tested) -> GBuffer write (resolve)
     -> deferred PBR + PCF lighting [-> RCCL all-gather of the packed RGBA8 tiles + untile, N > 1].
-N > 1 partitions the SAME frame by screen tiles (tile t is rendered by rank t % N), so scaling is "strong".
-value = W*H*steps / max-over-ranks(wall time of the K steps).
+N > 1 partitions the SAME frame by screen tiles, so scaling is "strong".  value = W*H*steps / max-over-ranks(wall time).
 
-roofline: for the dominant kernel (largest mean hipEvent duration over the timed frames), algorithmic bytes
- / mean kernel time against the 8 TB/s HBM peak.  cpu_baseline: the scalar CPU oracle timed on rank 0 on a
-bounded sample of the same workload (N = 1 only).
+roofline: quoted for the pass the north star names, the GBuffer-write pass = k_raster<GBUFFER> + k_raster<GBUFFER,HiZ> +
+k_resolve_gbuffer, against the 8 TB/s HBM peak.  `achieved` = SURVEY 8(d)'s algorithmic bytes of that pass / the summed mean
+duration of its three kernels, measured live with HIP events on the stream they are launched on (the library's camera lane).
+`traffic` = the same kernels' FETCH_SIZE / WRITE_SIZE counter bytes from the committed rocprofv3 summary named in
+`traffic_source`, only when that summary was collected on this very workload (else null).  `kernels` lists every kernel the same
+way; `valu_roofline` states what actually bounds the frame (vector-ALU issue); `frame_hbm` is the whole frame's counter traffic
+over the frame time.  cpu_baseline: the scalar CPU oracle timed on rank 0 on the same workload (N = 1 only).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -26,66 +31,96 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+VALU_PEAK_PER_S = 256 * 4 * 2.4e9 / 4.0     # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
+PROFILE_INDEX = os.path.join(ROOT, "profiles", "current.json")     # written by tools/make_profile_summary.py
+
+# passes that are ONE kernel launch per frame (the cull / hiz passes are groups of launch-bound kernels)
+KERNEL_OF_PASS = {"shadow": "k_raster<SHADOW>", "gbuffer": "k_raster<GBUFFER>", "gbuffer2": "k_raster<GBUFFER,HiZ>",
+                  "resolve": "k_resolve_gbuffer", "lighting": "k_lighting"}
+GBUFFER_WRITE_PASS = ("gbuffer", "gbuffer2", "resolve")
 
 
-def algorithmic_bytes(stats, cfg, n_tiles_owned_px):
-    """SURVEY 8d per-frame algorithmic HBM bytes, split over the kernels that carry each term.
+def workload_name(config, n_inst, n_work, W, H, n_point, cube_dim):
+    return ("config%d: %d instanced 960-tri spheres (%d meshlet-instances), %dx%d, 1 directional + %d point lights riding the engine's "
+            "spiral (uniforms rebuilt every frame), 1024^2 shadow map + 5x5 PCF, %d^2 cubemap IBL" % (config, n_inst, n_work, W, H, n_point, cube_dim))
 
-    GBuffer-write pass = 28 B x W*H (clear) + 28 B x covered px + geometry once per surviving meshlet-instance: the geometry
-    term belongs to the rasteriser kernel (plus its 8 B visibility key per covered pixel), the 28 B terms to the resolve
-    kernel, which is the one that writes the GBuffer.
+
+def algorithmic_bytes(stats, mesh, n_inst, owned_px):
+    """SURVEY 8(d) per-frame algorithmic HBM bytes, literally, per pass.
+
+    Cull       64 B x meshlets tested + 32 B x instances + 4 B x survivors written
+    Shadow     44 B x unique verts + 4 B x indices + 32 B x instances + 4 B x 1024^2 clear + 4 B x covered shadow texels
+    GBuffer-w  28 B x W*H (clear) + 28 B x covered px + geometry once per surviving meshlet-instance
+               (vertexCount*44 + triangleCount*3 + 64 + 32, mean over the mesh's meshlets); split over the kernels that carry
+               each term: geometry -> the two rasteriser launches, the 28 B terms -> k_resolve_gbuffer
+    Lighting   28 B x W*H + 35 068 B UBO + 4 MB shadow map
     """
-    geo = cfg["_geo_bytes_per_meshlet_instance"]
     SD = 1024
+    geo = mesh["geo"]
+    r1 = stats["round1_survivors"] if stats["round1_survivors"] else stats["survivors"][1]
+    r2 = stats["survivors"][1] - r1
     return {
-        "cull_shadow": 64 * stats["work_items"][0] + 4 * stats["survivors"][0],
-        "shadow": geo * stats["survivors"][0] + 4 * SD * SD + 4 * stats["covered_shadow_texels"],
-        "cull_camera": 64 * stats["work_items"][1] + 4 * stats["survivors"][1],
-        "gbuffer": geo * stats["round1_survivors"] + 8 * stats["covered_pixels"] if stats["round1_survivors"] else
-                   geo * stats["survivors"][1] + 8 * stats["covered_pixels"],
-        "gbuffer2": geo * (stats["survivors"][1] - stats["round1_survivors"]) if stats["round1_survivors"] else 0,
-        "resolve": 28 * n_tiles_owned_px + 28 * stats["covered_pixels"],
-        "lighting": 28 * n_tiles_owned_px + 35068 + 4 * SD * SD,
+        "cull_shadow": 64 * stats["work_items"][0] + 32 * n_inst + 4 * stats["survivors"][0],
+        "shadow": 44 * mesh["n_verts"] + 4 * mesh["n_idx"] + 32 * n_inst + 4 * SD * SD + 4 * stats["covered_shadow_texels"],
+        "cull_camera": 64 * stats["work_items"][1] + 32 * n_inst + 4 * stats["survivors"][1],
+        "gbuffer": geo * r1,
+        "gbuffer2": geo * r2,
+        "resolve": 28 * owned_px + 28 * stats["covered_pixels"],
+        "lighting": 28 * owned_px + 35068 + 4 * SD * SD,
     }
 
 
-# passes that are ONE kernel launch (the roofline object is quoted on the longest of these); the cull / hiz passes are groups
-KERNEL_OF_PASS = {"shadow": "k_raster<SHADOW>", "gbuffer": "k_raster<GBUFFER>", "gbuffer2": "k_raster<GBUFFER,HiZ>",
-                  "resolve": "k_resolve_gbuffer", "lighting": "k_lighting"}
+def load_profile(workload):
+    """The committed rocprofv3 summary (kernel stats + separate FETCH_SIZE / WRITE_SIZE / SQ passes), if it is for this workload."""
+    try:
+        idx = json.load(open(PROFILE_INDEX))
+        prof = json.load(open(os.path.join(ROOT, "profiles", idx["pmc"])))
+    except Exception:      # noqa: BLE001
+        return None
+    if prof.get("workload") != workload:
+        return None
+    prof["_file"] = "profiles/" + idx["pmc"]
+    return prof
+
+
+def pct(xs, q):
+    xs = sorted(xs)
+    return xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))] if xs else None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--instances", type=int, default=10000, help="config 3 instance count (default: the metric's 10k)")
     ap.add_argument("--config", type=int, default=3, choices=[3, 4, 5],
                     help="3: the metric's workload (default); 4: 1M instances at 3840x2160; 5: config 4 with 256 point lights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--replicated-shadow", action="store_true",
-                    help="N > 1: every rank renders the whole shadow map (no shadow all-reduce; the all-gather of the composite is then the "
-                         "only collective) instead of 1/N of the casters each + one MIN all-reduce of the 4 MB map")
+    ap.add_argument("--no-extras", action="store_true", help="skip the moving-camera / textured / one-stream extra loops")
+    ap.add_argument("--split-shadow", action="store_true",
+                    help="N > 1: every rank rasterises 1/N of the shadow casters and the maps are MIN all-reduced (a second collective); "
+                         "default: every rank renders the whole 1024^2 map and the all-gather of the composite is the only collective")
+    ap.add_argument("--python-dist", action="store_true", help="N > 1: torch.distributed frame loop (dist.py) instead of the library's native RCCL host")
     ap.add_argument("--timing-interval", type=int, default=0,
                     help="per-kernel hipEvents are recorded on every n-th timed frame (each record is a ~6 us stream bubble); "
-                         "0 = steps // 6 clamped to 1..16, i.e. at least six timed frames")
-    ap.add_argument("--cpu-sample-instances", type=int, default=10000)
+                         "0 = steps // 12 clamped to 1..8")
+    ap.add_argument("--cube-dim", type=int, default=1024, help="cubemap face edge (the engine's is 1024: 11 mips)")
     args = ap.parse_args()
 
     import torch
-    from zeldaengine_amd import dist as zdist, engine, scenes
+    from zeldaengine_amd import abi, dist as zdist, engine, scenes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # Rehearsal only (one-GPU box): ZR_BENCH_REHEARSAL=1 runs every rank on cuda:0 over gloo, to exercise the N > 1 frame loop end to
-    # end (staged frame, shadow all-reduce, all-gather, composite) where RCCL cannot run; its numbers mean nothing.
+    # end where RCCL cannot run; its numbers mean nothing.
     rehearsal = os.environ.get("ZR_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -99,115 +134,200 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
 
+    n_point = 256 if args.config == 5 else 16
     if args.config == 3:
-        cfg = scenes.config3(args.instances)
+        cfg = scenes.config3(args.instances, cube_dim=args.cube_dim)
     else:
-        cfg = scenes.config4(args.instances if args.instances != 10000 else 1000000, 256 if args.config == 5 else 16)
+        cfg = scenes.config4(args.instances if args.instances != 10000 else 1000000, n_point, cube_dim=args.cube_dim)
     W, H = cfg["width"], cfg["height"]
-    dr = zdist.DistributedRenderer(W, H, 1024, device_index=local_rank, rank=rank, world=world, split_shadow=not args.replicated_shadow)
+    n_inst = len(cfg["objects"][0]["instances"])
+
+    def make_renderer(cfg_, flags=0):
+        native = world > 1 and not args.python_dist and not rehearsal
+        dr_ = zdist.make_distributed(W, H, 1024, device_index=local_rank, rank=rank, world=world, flags=flags,
+                                     split_shadow=args.split_shadow, native=native)
+        engine.load_scene(dr_.r, cfg_)
+        return dr_
+
+    dr = make_renderer(cfg)
     r = dr.r
-    engine.load_scene(r, cfg)
-    step = dr.frame        # render [+ ONE RCCL all-gather of the packed RGBA8 tiles + untile when world > 1]
-    interval = args.timing_interval if args.timing_interval > 0 else max(1, min(16, args.steps // 6))
+    interval = args.timing_interval if args.timing_interval > 0 else max(1, min(8, args.steps // 12))
     interval = max(1, min(interval, args.steps))
     r.set_timing_interval(interval)
 
-    for _ in range(args.warmup):
-        step()
-    dr.synchronize()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    dr.synchronize()                # the render stream (render -> all-gather -> composite)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    cam0 = cfg["camera"]
 
-    # per-kernel means over the timed frames, from hipEvents recorded on the render stream
-    times = r.pass_times(max(1, min(args.steps // interval, 64)))
-    lat = sorted(r.frame_latencies(max(1, min(args.steps // interval, 64))))
+    def uniforms_static(dr_, i):
+        # UpdateUniformBuffer (ZE:4585-4664) every frame: RollLight advances, the point lights move along their spiral, XkView is
+        # rebuilt on the host and uploaded; the camera stays (SURVEY 8d "camera static")
+        dr_.r.update_uniforms(cam0, cfg["dir"], cfg["point"], cfg["spot"], 0.0, 0.002 * i, 0.016 * i)
+
+    def uniforms_orbit(dr_, i):
+        a = math.radians(45.0 + 2.0 * i)                 # 2 degrees per frame around the scene at the default camera's radius / height
+        cam = abi.make_camera((math.sqrt(50.0) * math.cos(a), math.sqrt(50.0) * math.sin(a), 5.0), (0.0, 0.0, 0.0))
+        dr_.r.update_uniforms(cam, cfg["dir"], cfg["point"], cfg["spot"], 0.0, 0.002 * i, 0.016 * i)
+
+    def timed_loop(dr_, steps, warmup, per_frame):
+        for i in range(warmup):
+            per_frame(dr_, i)
+            dr_.frame()
+        dr_.synchronize()
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            per_frame(dr_, warmup + i)
+            dr_.frame()
+        dr_.synchronize()                # render stream + camera lane + collective stream
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    elapsed = timed_loop(dr, args.steps, args.warmup, uniforms_static)
+
+    # per-kernel means over the sampled frames (hipEvents on the stream each kernel runs on), per-frame GPU periods of ALL timed frames
+    n_s = max(1, min(args.steps // interval, 64))
+    times = r.pass_times(n_s)
+    lat = r.frame_latencies(n_s)
+    periods = r.frame_periods(min(args.steps - 1, 511)) if args.steps > 1 else []
     stats = r.stats()
-    # Informative only (never `value`): the rate when the host reads every frame back over PCIe (zr_read_color), N = 1
-    pcie_rate = None
-    if world == 1:
-        n_rb = max(5, min(20, args.steps))
-        t1 = time.perf_counter()
-        for _ in range(n_rb):
-            step()
-            r.color()
-        pcie_rate = W * H * n_rb / (time.perf_counter() - t1) / 1e6
+    mlt, _, _ = r.mesh_get_meshlets(0)
+    mesh = {"geo": float(np.mean(mlt["VertexCount"] * 44.0 + mlt["TriangleCount"] * 3.0 + 96.0)),
+            "n_verts": len(cfg["objects"][0]["mesh"][0]), "n_idx": len(cfg["objects"][0]["mesh"][1])}
+
+    extras = {}
+    if not args.no_extras:
+        k = max(10, min(args.steps, 60))
+        el = timed_loop(dr, k, 5, uniforms_orbit)
+        extras["value_moving_camera"] = round(W * H * k / el / 1e6, 3)
+        extras["moving_camera_note"] = "same workload, camera orbiting 2 deg/frame (stale Hi-Z history every frame), %d frames" % k
+        if world == 1:
+            n_rb = max(5, min(20, args.steps))        # informative only (never `value`): every frame read back over PCIe
+            t1 = time.perf_counter()
+            for i in range(n_rb):
+                uniforms_static(dr, i)
+                dr.frame()
+                r.color()
+            extras["pcie_inclusive_mpixels_s"] = round(W * H * n_rb / (time.perf_counter() - t1) / 1e6, 1)
+    r.close()
+    serial = None
+    if not args.no_extras and world == 1:
+        # every kernel alone on the GPU (one stream): what the rocprofv3 summaries under profiles/*_serial_* show
+        ds = make_renderer(cfg, flags=abi.FLAG_SERIAL_PASSES)
+        ds.r.set_timing_interval(1)
+        k = max(10, min(args.steps, 40))
+        el = timed_loop(ds, k, 5, uniforms_static)
+        serial = {"ms_per_step": round(el / k * 1e3, 4), "passes_ms": {a: round(b, 4) for a, b in ds.r.pass_times(min(k, 64)).items()}}
+        ds.r.close()
+        if args.config == 3:
+            cfg_t = scenes.config3(args.instances, cube_dim=args.cube_dim, textured=True)
+            dt = make_renderer(cfg_t)
+            dt.r.set_timing_interval(0)
+            k = max(10, min(args.steps, 60))
+            el = timed_loop(dt, k, 5, uniforms_static)
+            extras["value_textured"] = round(W * H * k / el / 1e6, 3)
+            extras["textured_note"] = "same scene with seven non-constant 512^2 material textures (trilinear + anisotropic sampling in the resolve), %d frames" % k
+            dt.r.close()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = W * H * args.steps / elapsed / 1e6
-        # geometry bytes per surviving meshlet-instance: mean over the mesh's meshlets of v*44 + t*3 + 64 + 32
-        # (recomputed here from a fresh single-GPU-independent query of the mesh)
-        mlt, _, _ = r.mesh_get_meshlets(0)
-        cfg["_geo_bytes_per_meshlet_instance"] = float(np.mean(mlt["VertexCount"] * 44.0 + mlt["TriangleCount"] * 3.0 + 96.0))
         owned_px = 0
+        tiles = zdist.owned_tiles(rank, world, ((W + 31) // 32) * ((H + 31) // 32)) if world > 1 else range(((W + 31) // 32) * ((H + 31) // 32))
         tx = (W + 31) // 32
-        ty = (H + 31) // 32
-        for t in range(rank, tx * ty, world):
+        for t in tiles:
             x0, y0 = (t % tx) * 32, (t // tx) * 32
             owned_px += (min(W, x0 + 32) - x0) * (min(H, y0 + 32) - y0)
-        alg = algorithmic_bytes(stats, cfg, owned_px)
-        dom = max(KERNEL_OF_PASS, key=lambda k: times[k])
-        achieved = alg[dom] / (times[dom] * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(KERNEL_OF_PASS[dom])
-            except Exception:      # noqa: BLE001
-                traffic = None
+        alg = algorithmic_bytes(stats, mesh, n_inst, owned_px)
+        workload = workload_name(args.config, n_inst, stats["work_items"][1], W, H, len(cfg["point"]), args.cube_dim)
+        prof = load_profile(workload) if world == 1 else None
+        ptraffic = (prof or {}).get("kernels", {})
+
+        def kernel_row(p, ms):
+            t = ptraffic.get(KERNEL_OF_PASS[p], {}).get("hbm_bytes_per_launch")
+            return {"kernel": KERNEL_OF_PASS[p], "ms": round(ms[p], 4), "algorithmic_bytes": int(alg[p]),
+                    "achieved_gbs": round(alg[p] / (ms[p] * 1e-3) / 1e9, 2) if ms[p] > 0 else None, "traffic": t}
+
+        def gb_pass(ms):
+            t = sum(ms[p] for p in GBUFFER_WRITE_PASS)
+            b = sum(alg[p] for p in GBUFFER_WRITE_PASS)
+            return t, b, (b / (t * 1e-3) / 1e9 if t > 0 else 0.0)
+
+        t_gb, b_gb, gbs_gb = gb_pass(times)
+        tr = [ptraffic.get(KERNEL_OF_PASS[p], {}).get("hbm_bytes_per_launch") for p in GBUFFER_WRITE_PASS]
+        roofline = {
+            "bound": "hbm",
+            "kernel": "GBuffer-write pass (k_raster<GBUFFER> + k_raster<GBUFFER,HiZ> + k_resolve_gbuffer)",
+            "achieved": round(gbs_gb, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_gb / HBM_PEAK_GBS, 6),
+            "traffic": int(sum(tr)) if prof and all(t is not None for t in tr) else None,
+            "traffic_source": prof["_file"] if prof else None,
+            "kernel_ms": round(t_gb, 4), "algorithmic_bytes": int(b_gb),
+            "algorithmic_bytes_formula": "28*W*H + 28*covered_px + mean(v*44 + t*3 + 96) * camera survivors (SURVEY 8d)",
+            "timing": "HIP events on the library's camera lane, mean over %d sampled frames; the lane shares the GPU with the shadow pipeline and "
+                      "the previous frame's lighting" % n_s,
+        }
+        if serial:
+            t1, b1, g1 = gb_pass(serial["passes_ms"])
+            roofline["one_stream"] = {"kernel_ms": round(t1, 4), "achieved": round(g1, 3), "frac": round(g1 / HBM_PEAK_GBS, 6),
+                                      "note": "the same three kernels alone on the GPU (ZR_FLAG_SERIAL_PASSES run below)"}
+        valu = None
+        if prof and prof.get("valu_insts_per_frame"):
+            mn = prof["valu_insts_per_frame"] / VALU_PEAK_PER_S * 1e3
+            valu = {"valu_wave_insts_per_frame": int(prof["valu_insts_per_frame"]), "peak_per_s": VALU_PEAK_PER_S, "min_ms": round(mn, 4),
+                    "frame_ms": round(ms_per_step, 4), "frac": round(mn / ms_per_step, 4), "source": prof["_file"],
+                    "note": "sum of SQ_INSTS_VALU over the frame's kernels x 4 cycles / (1024 SIMDs x 2.4 GHz): what bounds the frame"}
+        frame_hbm = None
+        if prof and prof.get("hbm_bytes_per_frame"):
+            g = prof["hbm_bytes_per_frame"] / (ms_per_step * 1e-3) / 1e9
+            frame_hbm = {"traffic": int(prof["hbm_bytes_per_frame"]), "gbs": round(g, 1), "frac": round(g / HBM_PEAK_GBS, 4),
+                         "algorithmic_bytes": int(sum(alg.values())), "source": prof["_file"]}
         line = {
             "metric": "Mpixels/s shaded (deferred PBR, 1080p, 100k meshlets) + achieved HBM GB/s",
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "config%d: %d instanced 960-tri spheres (%d meshlet-instances), %dx%d, 1 directional + %d point "
-                                   "lights, 1024^2 shadow map + 5x5 PCF, cubemap IBL" % (args.config, len(cfg["objects"][0]["instances"]),
-                                                                                          stats["work_items"][1], W, H, len(cfg["point"])),
-                       "resolution": [W, H], "parallelism": ("screen-tiles t%%%d, %s" % (world, "shadow map replicated" if args.replicated_shadow else
-                                                                    "shadow casters i%%%d + MIN all-reduce" % world)) if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": KERNEL_OF_PASS[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel_ms": round(times[dom], 4), "algorithmic_bytes": int(alg[dom]),
-                         "note": "two lanes (camera pipeline || shadow pipeline + previous frame's lighting): kernel_ms is the "
-                                 "kernel's duration while sharing the GPU (alone: ZR_SERIAL_PASSES=1, profiles/r01_j_serial_kernel_stats.csv)"},
+            "config": {"workload": workload, "resolution": [W, H],
+                       "parallelism": ("screen super-tiles over %d ranks, %s, %s" % (world, "shadow casters i%%%d + MIN all-reduce" % world if args.split_shadow
+                                       else "shadow map replicated (all-gather of the composite is the only collective)",
+                                       "torch.distributed loop" if (args.python_dist or rehearsal) else "native RCCL host (zr_dist_*)")) if world > 1 else "single GPU"},
+            "roofline": roofline,
+            "kernels": [kernel_row(p, times) for p in KERNEL_OF_PASS],
+            "valu_roofline": valu,
+            "frame_hbm": frame_hbm,
             "passes_ms": {k: round(v, 4) for k, v in times.items()},
-            "passes_timing": "hipEvents on the render stream, every %d-th timed frame" % interval,
-            "passes_gbs": {k: round(alg[k] / (times[k] * 1e-3) / 1e9, 2) for k in alg if times[k] > 0},
+            "passes_timing": "hipEvents on the stream each kernel runs on, every %d-th timed frame (%d samples)" % (interval, n_s),
+            "frame_gpu_ms": {"median": round(pct(periods, 0.5), 4), "p10": round(pct(periods, 0.1), 4), "p90": round(pct(periods, 0.9), 4),
+                             "samples": len(periods), "what": "GPU time between the ends of consecutive frames, every timed frame"} if periods else None,
+            "frame_latency_ms": {"p10": round(pct(lat, 0.1), 4), "p50": round(pct(lat, 0.5), 4), "p90": round(pct(lat, 0.9), 4),
+                                 "samples": len(lat), "what": "first kernel to end of lighting (two frames are in flight)"} if lat else None,
+            "one_stream": serial,
             "stats": stats,
-            "pcie_inclusive_mpixels_s": None if pcie_rate is None else round(pcie_rate, 1),
-            # GPU begin-to-end time of the sampled frames (two frames are in flight, so this exceeds ms_per_step)
-            "frame_latency_ms": {"p10": round(lat[int(0.1 * (len(lat) - 1))], 4), "p50": round(lat[len(lat) // 2], 4),
-                                 "p90": round(lat[int(0.9 * (len(lat) - 1) + 0.5)], 4), "samples": len(lat)} if lat else None,
         }
+        line.update(extras)
         if world == 1 and not args.no_cpu_baseline and args.config == 3:     # defined on the metric's workload only
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample_instances)
+            line["cpu_baseline"] = cpu_baseline(args.instances, args.cube_dim)
         print(json.dumps(line), flush=True)
-    r.close()
+    dr.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(n_inst):
-    """The scalar CPU oracle on a bounded sample of the same workload (1 frame, 1 core)."""
+def cpu_baseline(n_inst, cube_dim):
+    """The scalar CPU oracle on the same workload (1 frame, 1 core; then the per-pixel stages on all cores)."""
     from oracle import pyoracle
     from zeldaengine_amd import scenes
     pyoracle.build()
-    cfg = scenes.config3(n_inst)
+    cfg = scenes.config3(n_inst, cube_dim=cube_dim)
     o = pyoracle.Oracle(cfg["width"], cfg["height"], 1024)
     pyoracle.load_scene(o, cfg)
     t0 = time.perf_counter()

@@ -167,6 +167,7 @@ int  zr_finish(zr_ctx* ctx);                        /* stream sync + overflow ch
 int  zr_get_pass_times(zr_ctx* ctx, float ms[ZR_PASS_COUNT]);              /* last frame */
 int  zr_get_pass_times_avg(zr_ctx* ctx, uint32_t last_n, float ms[ZR_PASS_COUNT]);  /* mean of the last n <= 64 timed frames */
 int  zr_get_frame_latencies(zr_ctx* ctx, uint32_t n, float* ms);   /* begin-to-end GPU ms of the last n timed frames, newest first; returns the count */
+int  zr_get_frame_periods(zr_ctx* ctx, uint32_t n, float* ms);     /* GPU ms between the ends of consecutive frames, last n <= 511 frames, newest first; returns the count */
 int  zr_set_timing_interval(zr_ctx* ctx, uint32_t interval);  /* pass events on every interval-th frame (default 1, 0 = never) */
 int  zr_get_stats(zr_ctx* ctx, zr_stats* out);
 

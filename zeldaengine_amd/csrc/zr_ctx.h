@@ -98,7 +98,11 @@ struct zr_ctx {
     // d_view, d_empty_rgba are aliases of the current frame's copies (set at frame begin, so the read-back entry points see the
     // frame rendered last).
     hipStream_t cam_s = nullptr; bool camera_on_lane = false;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cam = nullptr, ev_lit[2] = { nullptr, nullptr };
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cam = nullptr;
+    // End of every frame's lighting pass, one (timing-enabled) event per frame in a ring: the next-but-one frame waits for it before
+    // it reuses the double-buffered copies, and consecutive ones give the per-frame GPU period (zr_get_frame_periods) for free.
+    static constexpr int END_RING = 512;
+    hipEvent_t ev_end[END_RING] = {};
     GBufferPtrs Gb[2] = {}; float* d_shadow_b[2] = { nullptr, nullptr }; XkView* d_view_b[2] = { nullptr, nullptr };
     uint32_t* d_empty_b[2] = { nullptr, nullptr };
     bool shadow_cleared[2] = { false, false };      // d_shadow_b[i] already holds depth 1.0 (cleared by the previous lighting pass)

@@ -85,6 +85,7 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     ok &= hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess;
     c->stream = c->own_stream;
     for (auto& fr : c->evr) for (auto& e : fr) ok &= hipEventCreate(&e) == hipSuccess;
+    for (auto& e : c->ev_end) ok &= hipEventCreate(&e) == hipSuccess;
     const size_t n = (size_t)c->W * c->H;
     for (int b = 0; b < 2; ++b) {       // two frames in flight: see zr_ctx.h
         GBufferPtrs& G = c->Gb[b];
@@ -99,7 +100,6 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         ok &= dev_alloc(&c->d_shadow_b[b], (size_t)c->SD * c->SD) == hipSuccess;
         ok &= dev_alloc(&c->d_view_b[b], 1) == hipSuccess;
         ok &= dev_alloc(&c->d_empty_b[b], 1) == hipSuccess;
-        ok &= hipEventCreateWithFlags(&c->ev_lit[b], hipEventDisableTiming) == hipSuccess;
     }
     c->G = c->Gb[0]; c->d_shadow = c->d_shadow_b[0]; c->d_view = c->d_view_b[0]; c->d_empty_rgba = c->d_empty_b[0];
     ok &= dev_alloc(&c->d_color, n) == hipSuccess;
@@ -220,7 +220,6 @@ extern "C" void zr_destroy(zr_ctx* c)
         GBufferPtrs& G = c->Gb[b];
         dev_free(G.depth); dev_free(G.scene_color); dev_free(G.gA); dev_free(G.gB); dev_free(G.gC); dev_free(G.gD); dev_free(G.overlay);
         dev_free(c->d_shadow_b[b]); dev_free(c->d_view_b[b]); dev_free(c->d_empty_b[b]);
-        if (c->ev_lit[b]) (void)hipEventDestroy(c->ev_lit[b]);
     }
     dev_free(c->d_color); dev_free(c->d_stats); dev_free(c->d_lut); dev_free(c->d_unorm_lut);
     dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles);
@@ -238,6 +237,7 @@ extern "C" void zr_destroy(zr_ctx* c)
     dev_free(c->d_vis);
     dev_free(c->d_pxrect); dev_free(c->d_zmin); dev_free(c->d_visflag[0]); dev_free(c->d_visflag[1]); dev_free(c->d_hiz);
     for (auto& fr : c->evr) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ev_end) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -890,7 +890,7 @@ static int frame_begin(zr_ctx* c, hipStream_t s)
     const int par = (int)(c->frame_no & 1u);
     c->G = c->Gb[par]; c->d_shadow = c->d_shadow_b[par]; c->d_view = c->d_view_b[par]; c->d_empty_rgba = c->d_empty_b[par];
     if (s != c->stream) {
-        HIPCHK(c, hipStreamWaitEvent(s, c->ev_lit[par], 0));
+        if (c->frame_no >= 2) HIPCHK(c, hipStreamWaitEvent(s, c->ev_end[(c->frame_no - 2) % zr_ctx::END_RING], 0));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0));
     }
     c->timing_now = c->timing_interval != 0 && c->frame_no % c->timing_interval == 0;     // pass events cost ~6 us of stream bubble each
@@ -1084,7 +1084,7 @@ static int lighting_pass(zr_ctx* c)
     if (c->debug_view == 9u)        // GBufferVis mosaic over the lit frame (needs the whole GBuffer: single-rank contexts only)
         zr_launch_gbuffer_vis(L, c->d_view, c->G, shadow_buf(c), c->cube, c->d_lut, c->d_color, s);
     if (ev) HIPCHK(c, hipEventRecord(ev[8], s));
-    HIPCHK(c, hipEventRecord(c->ev_lit[c->frame_no & 1u], s));      // this frame's GBuffer / shadow map / uniforms copies are free again
+    HIPCHK(c, hipEventRecord(c->ev_end[c->frame_no % zr_ctx::END_RING], s));      // this frame's GBuffer / shadow map / uniforms copies are free again
     HIPCHK(c, hipGetLastError());
     if (c->timing_now) c->sample_no++;
     c->rendered = true; c->frame_no++; c->stage = 0;
@@ -1197,6 +1197,25 @@ extern "C" int zr_get_frame_latencies(zr_ctx* c, uint32_t n, float* ms)
         hipEvent_t* ev = c->evr[(c->sample_no - 1 - k) % zr_ctx::EV_RING];
         ms[k] = 0.0f;
         (void)hipEventElapsedTime(&ms[k], ev[0], ev[8]);
+    }
+    return (int)n;
+}
+
+// GPU time between the ends of consecutive frames (the frame period the GPU sustained) for the last `n` frames, newest first;
+// returns how many were written (<= END_RING - 1).  Costs nothing extra: the end-of-frame event exists for the double buffering.
+extern "C" int zr_get_frame_periods(zr_ctx* c, uint32_t n, float* ms)
+{
+    if (!c || !ms) return ZR_ERR_ARG;
+    if (!c->rendered) return zr_fail(c, ZR_ERR_STATE, "nothing rendered yet");
+    int rc = zr_finish(c);
+    if (rc && rc != ZR_ERR_OVERFLOW) return rc;
+    const uint64_t have = c->frame_no > 0 ? c->frame_no - 1 : 0;
+    if (n > (uint32_t)zr_ctx::END_RING - 1u) n = zr_ctx::END_RING - 1;
+    if ((uint64_t)n > have) n = (uint32_t)have;
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint64_t f = c->frame_no - 1 - k;
+        ms[k] = 0.0f;
+        (void)hipEventElapsedTime(&ms[k], c->ev_end[(f - 1) % zr_ctx::END_RING], c->ev_end[f % zr_ctx::END_RING]);
     }
     return (int)n;
 }

@@ -68,6 +68,7 @@ def lib():
         "zr_get_pass_times_avg": [vp, u32, vp],
         "zr_set_timing_interval": [vp, u32],
         "zr_get_frame_latencies": [vp, u32, vp],
+        "zr_get_frame_periods": [vp, u32, vp],
         "zr_get_stats": [vp, C.POINTER(abi.Stats)],
         "zr_read_color": [vp, vp, sz],
         "zr_read_gbuffer": [vp, C.c_int, vp, sz],
@@ -328,6 +329,14 @@ class Renderer:
         """Begin-to-end GPU milliseconds of the last n (<= 64) timed frames, newest first."""
         ms = (C.c_float * n)()
         got = self.L.zr_get_frame_latencies(self.h, n, ms)
+        if got < 0:
+            self._chk(got)
+        return [float(ms[i]) for i in range(got)]
+
+    def frame_periods(self, n=511):
+        """GPU milliseconds between the ends of consecutive frames for the last n (<= 511) frames, newest first."""
+        ms = (C.c_float * n)()
+        got = self.L.zr_get_frame_periods(self.h, n, ms)
         if got < 0:
             self._chk(got)
         return [float(ms[i]) for i in range(got)]

@@ -291,19 +291,51 @@ def config2():
             "cubemap": synthetic_cubemap(64)}
 
 
-def config3(n_instances=10000, width=1920, height=1080, max_radius=8.0, n_point=16, seed=1234):
-    """n instanced 960-tri spheres (~10 meshlets each), 1 directional + 16 point lights, 1024^2 PCF shadow."""
+def synthetic_material(dim=512):
+    """Seven NON-constant RGBA8 images (bc, m, r, n, ao, ev, ms) for the sampled-material path (trilinear, anisotropic, sRGB slot 0):
+    deterministic bands / checkers / ripples, so every slot really goes through the filter."""
+    t = (np.arange(dim, dtype=np.float32) + 0.5) / dim
+    u, v = np.meshgrid(t, t)
+    chk = ((np.floor(u * 16) + np.floor(v * 16)) % 2).astype(np.float32)
+    rip = 0.5 + 0.5 * np.sin(40.0 * u) * np.cos(36.0 * v)
+
+    def img(r, g, b, a=None):
+        out = np.zeros((dim, dim, 4), dtype=np.uint8)
+        for k, ch in enumerate((r, g, b, a if a is not None else np.ones_like(u))):
+            out[..., k] = np.clip(np.asarray(ch, dtype=np.float32) * 255.0 + 0.5, 0, 255).astype(np.uint8)
+        return out
+    one = np.ones_like(u)
+    return [img(0.25 + 0.6 * chk, 0.3 + 0.5 * u, 0.2 + 0.6 * v),                       # base colour (sRGB)
+            img(0.1 + 0.8 * rip, 0 * one, 0 * one),                                      # metallic
+            img(0.25 + 0.6 * (1.0 - chk) * v, 0 * one, 0 * one),                         # roughness
+            img(0.5 + 0.08 * np.sin(60.0 * u), 0.5 + 0.08 * np.cos(50.0 * v), one),      # normal map
+            img(0.6 + 0.4 * rip, one, one),                                              # ambient occlusion
+            img(0.05 * chk, 0.02 * one, 0.1 * (1.0 - chk)),                              # emissive
+            img(one, 0.5 + 0.5 * chk, v)]                                                # mask: r = 1 (lit everywhere), g / b vary so that
+    #                                                                                      the slot is an image, not a constant
+
+
+def config3(n_instances=10000, width=1920, height=1080, max_radius=8.0, n_point=16, seed=1234, cube_dim=64, textured=False):
+    """n instanced 960-tri spheres (~10 meshlets each), 1 directional + 16 point lights, 1024^2 PCF shadow.
+
+    cube_dim: edge of the synthetic cubemap; the engine always holds 6 x 1024^2 faces / 11 mips (ZE:5908-6150, ZE:4308), which is
+    what bench.py passes; the parity tests keep 64 (7 mips) so that the oracle's mip chain builds in a moment."""
     v, idx = uv_sphere()
     world = sample_world()
     d, _, s = lights_from_world(world)
     world["PointLights"] = sample_point_lights(n_point)
     _, p, _ = lights_from_world(world)
     inst = generate_instances(n_instances, 2.0, max_radius, 0.1, 0.5, seed)
-    return {"width": width, "height": height, "camera": abi.make_camera(),
-            "objects": [{"mesh": (v, idx), "instances": inst}],
-            "dir": d, "point": p, "spot": s, "cubemap": synthetic_cubemap(64)}
+    obj = {"mesh": (v, idx), "instances": inst}
+    cfg = {"width": width, "height": height, "camera": abi.make_camera(), "objects": [obj],
+           "dir": d, "point": p, "spot": s, "cubemap": synthetic_cubemap(cube_dim)}
+    if textured:
+        mat, keep = abi.make_material(synthetic_material(512))
+        obj["material"] = mat
+        cfg["_keepalive"] = keep
+    return cfg
 
 
-def config4(n_instances=1000000, n_point=16):
+def config4(n_instances=1000000, n_point=16, cube_dim=64):
     """1M instances / ~5M meshlet-instances at 3840x2160 (8-GPU configuration); config 5 uses n_point = 256."""
-    return config3(n_instances, 3840, 2160, 60.0, n_point)
+    return config3(n_instances, 3840, 2160, 60.0, n_point, cube_dim=cube_dim)
