@@ -253,7 +253,7 @@ def main():
         ptraffic = (prof or {}).get("kernels", {})
 
         def kernel_row(p, ms):
-            t = ptraffic.get(KERNEL_OF_PASS[p], {}).get("hbm_bytes_per_launch")
+            t = ptraffic.get(KERNEL_OF_PASS[p], {}).get("hbm_bytes_per_frame")
             return {"kernel": KERNEL_OF_PASS[p], "ms": round(ms[p], 4), "algorithmic_bytes": int(alg[p]),
                     "achieved_gbs": round(alg[p] / (ms[p] * 1e-3) / 1e9, 2) if ms[p] > 0 else None, "traffic": t}
 
@@ -263,7 +263,7 @@ def main():
             return t, b, (b / (t * 1e-3) / 1e9 if t > 0 else 0.0)
 
         t_gb, b_gb, gbs_gb = gb_pass(times)
-        tr = [ptraffic.get(KERNEL_OF_PASS[p], {}).get("hbm_bytes_per_launch") for p in GBUFFER_WRITE_PASS]
+        tr = [ptraffic.get(KERNEL_OF_PASS[p], {}).get("hbm_bytes_per_frame") for p in GBUFFER_WRITE_PASS]
         roofline = {
             "bound": "hbm",
             "kernel": "GBuffer-write pass (k_raster<GBUFFER> + k_raster<GBUFFER,HiZ> + k_resolve_gbuffer)",

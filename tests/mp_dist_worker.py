@@ -17,7 +17,8 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     cfg = scenes.config3(300, 416, 250)
-    dr = zdist.DistributedRenderer(cfg["width"], cfg["height"], 256, device_index=0, rank=rank, world=world)
+    split = os.environ.get("ZR_TEST_SPLIT_SHADOW") == "1"     # default: all-gather of the composite is the only collective
+    dr = zdist.DistributedRenderer(cfg["width"], cfg["height"], 256, device_index=0, rank=rank, world=world, split_shadow=split)
     engine.load_scene(dr.r, cfg)
     for _ in range(5):                  # both halves of the double buffers, occlusion history in use
         dr.frame()

@@ -9,12 +9,13 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_ranks_composite_the_single_gpu_frame(world):
-    """Every rank renders its tiles and its share of the shadow casters, min-all-reduces the shadow map, all-gathers the packed
+@pytest.mark.parametrize("world,split", [(2, 0), (3, 1)])
+def test_ranks_composite_the_single_gpu_frame(world, split):
+    """Every rank renders its tiles (split = 1: and its share of the shadow casters, min-all-reduced), all-gathers the packed
     tiles and composites: every rank must end up with the frame (and shadow map) one context renders alone."""
     env = dict(os.environ)
     env["MASTER_ADDR"] = "127.0.0.1"
+    env["ZR_TEST_SPLIT_SHADOW"] = str(split)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(29540 + world), os.path.join(HERE, "mp_dist_worker.py")]
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)

@@ -70,7 +70,7 @@ def test_pipelined_distributed_renderer_with_a_stand_in_collective(gpu_engine, m
         calls.append(-1)
     monkeypatch.setattr(tdist, "all_gather_into_tensor", fake_all_gather)
     monkeypatch.setattr(tdist, "all_reduce", fake_all_reduce)
-    dr = zdist.DistributedRenderer(cfg["width"], cfg["height"], 256, device_index=0, rank=0, world=2)
+    dr = zdist.DistributedRenderer(cfg["width"], cfg["height"], 256, device_index=0, rank=0, world=2, split_shadow=True)
     gpu_engine.load_scene(dr.r, cfg)
     for _ in range(5):                  # exercises both halves of the double buffers
         dr.frame()

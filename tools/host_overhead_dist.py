@@ -18,7 +18,7 @@ def fake_all_reduce(t, op=None, group=None, async_op=False):
 tdist.all_gather_into_tensor = fake_all_gather
 tdist.all_reduce = fake_all_reduce
 cfg = scenes.config3()
-dr = zdist.DistributedRenderer(cfg["width"], cfg["height"], 1024, device_index=0, rank=0, world=2)
+dr = zdist.DistributedRenderer(cfg["width"], cfg["height"], 1024, device_index=0, rank=0, world=2, split_shadow=True)
 engine.load_scene(dr.r, cfg)
 dr.r.set_timing_interval(0)
 for _ in range(20):

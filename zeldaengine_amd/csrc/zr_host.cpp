@@ -183,6 +183,14 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         float* p = c->d_hiz;
         for (int l = 0; l < 4; ++l) { c->hiz.lvl[l] = p; p += (size_t)c->hiz.hw[l] * c->hiz.hh[l]; }
     }
+    if (ok) {
+        // The runtime backs an event with a signal on its FIRST record and grows that pool in batches, which blocks the host for
+        // milliseconds at unpredictable frames of a short run: record every event once now.
+        for (auto& fr : c->evr) for (auto& e : fr) ok &= hipEventRecord(e, c->stream) == hipSuccess;
+        for (auto& e : c->ev_end) ok &= hipEventRecord(e, c->stream) == hipSuccess;
+        for (auto& e : c->view_ev) ok &= hipEventRecord(e, c->stream) == hipSuccess;
+        ok &= hipStreamSynchronize(c->stream) == hipSuccess;
+    }
     if (!ok) { zr_destroy(c); return ZR_ERR_DEVICE; }
     if (zr_set_cubemap(c, nullptr, 0) != ZR_OK) { zr_destroy(c); return ZR_ERR_DEVICE; }
     *out = c;
@@ -896,16 +904,17 @@ static int frame_begin(zr_ctx* c, hipStream_t s)
     c->timing_now = c->timing_interval != 0 && c->frame_no % c->timing_interval == 0;     // pass events cost ~6 us of stream bubble each
     hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
     if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
-    HIPCHK(c, hipMemsetAsync(c->d_stats, 0, offsetof(ZrDevStats, overflow_sticky), s));      // the sticky overflow latch survives
     if (c->view_dirty) { c->view_version++; c->view_dirty = false; }
-    if (c->view_uploaded[par] != c->view_version) {        // pinned ring slot: reused only after its previous upload has executed
-        const uint32_t k = c->view_slot++ % zr_ctx::VIEW_RING;
+    const XkView* src = nullptr;
+    uint32_t k = 0;
+    if (c->view_uploaded[par] != c->view_version) {        // pinned ring slot: reused only after the kernel that read it last has run
+        k = c->view_slot++ % zr_ctx::VIEW_RING;
         HIPCHK(c, hipEventSynchronize(c->view_ev[k]));
         memcpy(&c->h_view_ring[k], &c->view, sizeof(XkView));
-        HIPCHK(c, hipMemcpyAsync(c->d_view, &c->h_view_ring[k], sizeof(XkView), hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipEventRecord(c->view_ev[k], s));
-        c->view_uploaded[par] = c->view_version;
+        src = &c->h_view_ring[k];
     }
+    zr_launch_frame_begin(c->d_stats, src, c->d_view, s);      // zeroes the statistics (the sticky overflow latch survives), uploads XkView
+    if (src) { HIPCHK(c, hipEventRecord(c->view_ev[k], s)); c->view_uploaded[par] = c->view_version; }
     return ZR_OK;
 }
 

@@ -23,6 +23,7 @@
 #include "zr_types.h"
 
 #include <algorithm>
+#include <cstddef>
 
 #define WAVE 64
 #define TILE ZR_TILE
@@ -1051,6 +1052,17 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
 
 // ------------------------------------------------------------------------------------------------ tile raster kernels
 
+// First launch of a frame: zero the frame statistics (all but the sticky overflow latch) and, when the uniforms changed, copy
+// XkView from the pinned host ring slot into this frame's device copy.  (The runtime's own hipMemcpyAsync / hipMemsetAsync
+// paths cost two extra launches per frame, and the copy path stalls the host for milliseconds the first times it is used.)
+__global__ __launch_bounds__(1024) void k_frame_begin(uint32_t* __restrict__ stats, uint32_t n_stats, const uint32_t* __restrict__ view_src,
+                                                      uint32_t* __restrict__ view_dst, uint32_t n_view)
+{
+    const uint32_t i0 = blockIdx.x * 1024u + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < n_stats) stats[threadIdx.x] = 0u;
+    if (view_src) for (uint32_t i = i0; i < n_view; i += gridDim.x * 1024u) view_dst[i] = view_src[i];
+}
+
 __global__ void k_fill32(uint32_t* __restrict__ p, uint32_t v, size_t n)
 {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
@@ -1832,6 +1844,12 @@ void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* w
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
     hipLaunchKernelGGL(k_bin_fill, dim3((P.n_work + 1023) / 1024), dim3(1024), n_tiles * sizeof(uint32_t), s, P, objs, work, rects,
                        tile_offset, tile_cursor, bins, Z, stats, slot);
+}
+void zr_launch_frame_begin(ZrDevStats* stats, const XkView* view_src_pinned, XkView* view_dst, hipStream_t s)
+{
+    static_assert(sizeof(XkView) % 4 == 0 && offsetof(ZrDevStats, overflow_sticky) % 4 == 0, "dword copies");
+    hipLaunchKernelGGL(k_frame_begin, dim3(view_src_pinned ? 4 : 1), dim3(1024), 0, s, (uint32_t*)stats, (uint32_t)(offsetof(ZrDevStats, overflow_sticky) / 4),
+                       (const uint32_t*)view_src_pinned, (uint32_t*)view_dst, (uint32_t)(sizeof(XkView) / 4));
 }
 void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s)
 {

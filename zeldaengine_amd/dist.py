@@ -66,7 +66,7 @@ class DistributedRenderer:
     """
 
     def __init__(self, width, height, shadow_dim=1024, device_index=0, rank=0, world=1, flags=0, pipeline=True,
-                 split_shadow=True):
+                 split_shadow=False):
         import torch
         from . import engine
         self.torch = torch
@@ -134,3 +134,10 @@ class DistributedRenderer:
     def close(self):
         self.synchronize()
         self.r.close()
+
+
+def make_distributed(width, height, shadow_dim=1024, device_index=0, rank=0, world=1, flags=0, split_shadow=False, native=False):
+    """One rank of the partition.  native=True: the library's own RCCL host (zr_dist_*, no Python or torch in the frame loop)."""
+    if native and world > 1:
+        return NativeDistributedRenderer(width, height, shadow_dim, device_index, rank, world, flags, split_shadow)
+    return DistributedRenderer(width, height, shadow_dim, device_index, rank, world, flags, split_shadow=split_shadow)
