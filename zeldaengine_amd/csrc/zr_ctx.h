@@ -17,7 +17,7 @@ struct ZrMesh {
     ZrMeshletSet ms;
     bool has_meshlets = false, uploaded = false;
     float center[3] = { 0, 0, 0 }; float radius = 0;
-    XkVertex* d_v = nullptr; uint32_t* d_idx = nullptr; XkMeshlet* d_meshlets = nullptr;
+    XkVertex* d_v = nullptr; ZrRVertex* d_rv = nullptr; uint32_t* d_idx = nullptr; XkMeshlet* d_meshlets = nullptr;
     float4* d_mpos = nullptr; uint2* d_mtri = nullptr; uint32_t* d_tri_meshlet = nullptr;
 };
 
@@ -105,6 +105,7 @@ struct zr_ctx {
     hipEvent_t ev_end[END_RING] = {};
     GBufferPtrs Gb[2] = {}; float* d_shadow_b[2] = { nullptr, nullptr }; XkView* d_view_b[2] = { nullptr, nullptr };
     uint32_t* d_empty_b[2] = { nullptr, nullptr };
+    bool overlay_dirty[2] = { false, false };       // Gb[i].overlay may hold skydome pixels of an earlier frame
     bool shadow_cleared[2] = { false, false };      // d_shadow_b[i] already holds depth 1.0 (cleared by the previous lighting pass)
     unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048;
     uint32_t work_capacity = 0, bin_capacity = 0; bool any_images = false;

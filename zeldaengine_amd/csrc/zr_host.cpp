@@ -199,7 +199,7 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
 
 static void free_mesh_buffers(ZrMesh& m)
 {
-    dev_free(m.d_v); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mtri); dev_free(m.d_tri_meshlet);
+    dev_free(m.d_v); dev_free(m.d_rv); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mtri); dev_free(m.d_tri_meshlet);
     m.uploaded = false;
 }
 
@@ -208,7 +208,7 @@ static void free_scene(zr_ctx* c)
     for (auto& o : c->objects) { dev_free(o.d_inst); for (auto& t : o.d_tex) dev_free(t); }
     c->objects.clear();
     for (auto& m : c->meshes) {
-        dev_free(m.d_v); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mtri); dev_free(m.d_tri_meshlet);
+        dev_free(m.d_v); dev_free(m.d_rv); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mtri); dev_free(m.d_tri_meshlet);
     }
     c->meshes.clear();
     c->profabs.clear();
@@ -303,6 +303,22 @@ extern "C" int zr_mesh_set_meshlets(zr_ctx* c, uint32_t mesh_id, const XkMeshlet
     // CreateMeshVertexBuffers<XkMeshIndirect> (ZE:4733-4756): the draw becomes "meshlet by meshlet"; rebuild the
     // draw-order index buffer accordingly so primitive ids follow meshlet order.
     m.ms.meshlets.assign(ml, ml + nm); m.ms.mverts.assign(mv, mv + nmv); m.ms.mtris.assign(mt, mt + nmt);
+    // Every cull trusts the bounding sphere to enclose the meshlet's vertices (and the cone to describe its triangles): a record
+    // whose sphere does not is recomputed (ZM:149-166 fills them from meshopt_computeMeshletBounds, so a sound file never is).
+    for (uint32_t i = 0; i < nm; ++i) {
+        XkMeshlet& d = m.ms.meshlets[i];
+        bool ok = std::isfinite(d.BoundsRadius) && d.BoundsRadius >= 0.0f;
+        for (uint32_t k = 0; ok && k < d.VertexCount; ++k) {
+            const float* q = m.v[mv[d.VertexOffset + k]].Position;
+            const double dx = (double)q[0] - d.BoundsCenter[0], dy = (double)q[1] - d.BoundsCenter[1], dz = (double)q[2] - d.BoundsCenter[2];
+            if (!(std::sqrt(dx * dx + dy * dy + dz * dz) <= (double)d.BoundsRadius * (1.0 + 1e-5) + 1e-30)) ok = false;
+        }
+        if (!ok) {
+            XkMeshlet b = d;
+            zr_meshlet_bounds(m.v.data(), mv + d.VertexOffset, d.VertexCount, mt + d.TriangleOffset, d.TriangleCount, &b);
+            d = b;
+        }
+    }
     m.ms.tri_order.clear(); m.idx.clear();
     uint32_t base = 0;
     for (uint32_t i = 0; i < nm; ++i) {
@@ -515,7 +531,13 @@ static int upload_mesh(zr_ctx* c, ZrMesh& m)
             mtri[ml.BindlessContext + t] = make_uint2((uint32_t)tp[0] | (uint32_t)tp[1] << 8 | (uint32_t)tp[2] << 16,
                                                       m.ms.tri_order[ml.BindlessContext + t]);
         }
-    HIPCHK(c, upload(&m.d_v, m.v)); HIPCHK(c, upload(&m.d_idx, m.idx)); HIPCHK(c, upload(&m.d_meshlets, m.ms.meshlets));
+    std::vector<ZrRVertex> rv(m.v.size());             // the resolve's vertex record: position + uv + the normalised normal
+    for (size_t i = 0; i < rv.size(); ++i) {
+        const XkVertex& x = m.v[i];
+        const zf3 n = zr_normalize(zr3(x.Normal[0], x.Normal[1], x.Normal[2]));
+        rv[i] = ZrRVertex{ x.Position[0], x.Position[1], x.Position[2], x.TexCoord[0], n.x, n.y, n.z, x.TexCoord[1] };
+    }
+    HIPCHK(c, upload(&m.d_v, m.v)); HIPCHK(c, upload(&m.d_rv, rv)); HIPCHK(c, upload(&m.d_idx, m.idx)); HIPCHK(c, upload(&m.d_meshlets, m.ms.meshlets));
     // draw-order triangle -> meshlet (the resolve marks the meshlet-instances that own a pixel)
     std::vector<uint32_t> tri_meshlet(std::max<size_t>(1, m.idx.size() / 3), 0u);
     for (size_t mi = 0; mi < m.ms.meshlets.size(); ++mi) {
@@ -542,7 +564,7 @@ static int finalize_scene(zr_ctx* c)
     uint64_t work = 0, prim = 0, inst_total = 0;
     auto emit = [&](const ZrSceneObject& o, const ZrMesh& m, uint32_t flags) {
         ZrObject d; memset(&d, 0, sizeof d);
-        d.verts = m.d_v; d.indices = m.d_idx; d.meshlets = m.d_meshlets; d.mpos = m.d_mpos; d.mtri = m.d_mtri; d.tri_meshlet = m.d_tri_meshlet;
+        d.verts = m.d_v; d.rverts = m.d_rv; d.indices = m.d_idx; d.meshlets = m.d_meshlets; d.mpos = m.d_mpos; d.mtri = m.d_mtri; d.tri_meshlet = m.d_tri_meshlet;
         d.inst = o.d_inst;
         d.n_meshlets = (uint32_t)m.ms.meshlets.size(); d.n_tris = (uint32_t)(m.idx.size() / 3);
         d.n_inst = o.n_inst; d.instanced = o.instanced; d.flags = flags;
@@ -556,6 +578,13 @@ static int finalize_scene(zr_ctx* c)
             }
         for (int t = 0; t < 7; ++t) { d.tex[t].data = o.d_tex[t]; d.tex[t].w = o.tex_w[t]; d.tex[t].h = o.tex_h[t]; d.tex[t].levels = o.tex_levels[t]; d.tex[t]._pad = 0; }
         memcpy(d.mesh_center, m.center, sizeof d.mesh_center); d.mesh_radius = m.radius;
+        // BaseScene.frag on constant slots, once per draw instead of once per pixel (the kernels' own arithmetic: zr_math.h)
+        for (int t = 0; t < 7; ++t) if (!o.d_tex[t]) d.const_slots |= 1u << t;
+        const zf3 ts = zr_tangent_space_normal(zr3(d.texc[3][0], d.texc[3][1], d.texc[3][2]));
+        d.ts_const[0] = ts.x; d.ts_const[1] = ts.y; d.ts_const[2] = ts.z;
+        d.c_scene_color = zr_unorm(d.texc[5][0], 255.0f) | zr_unorm(d.texc[5][1], 255.0f) << 8 | zr_unorm(d.texc[5][2], 255.0f) << 16 | zr_unorm(d.texc[6][0], 255.0f) << 24;
+        d.c_gB = zr_unorm(d.texc[1][0], 255.0f) | zr_unorm(1.0f, 255.0f) << 8 | zr_unorm(fmaxf(0.01f, d.texc[2][0]), 255.0f) << 16 | 255u << 24;
+        d.c_gC = zr_unorm(d.texc[0][0], 255.0f) | zr_unorm(d.texc[0][1], 255.0f) << 8 | zr_unorm(d.texc[0][2], 255.0f) << 16 | zr_unorm(d.texc[4][0], 255.0f) << 24;
         work += (uint64_t)d.n_meshlets * d.n_inst; prim += (uint64_t)d.n_tris * d.n_inst;
         tab.push_back(d);
     };
@@ -822,6 +851,10 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
     // the instance-level pre-pass pays for itself on big scenes; small ones go straight to one wave per meshlet-instance
     P->use_worklist = c->n_inst_total >= 65536u ? 1u : 0u;
     P->debug_skip = c->env_skip;
+    {
+        static const float ident[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
+        P->m_identity = memcmp(u.Model, ident, 64) == 0 ? 1u : 0u;      // bitwise: a -0 entry would not do
+    }
     if (!finite16(P->PVM)) return false;
     // frustum planes of proj*view in world space (sphere centres are taken to world space by M in the kernel)
     bool fr_ok = !(c->cfg.flags & ZR_FLAG_NO_FRUSTUM_CULL) && finite16(u.Model);
@@ -978,6 +1011,12 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
         raster(c, P, Z, 1, s);
         if (ev) { HIPCHK(c, hipEventRecord(ev[4], s)); HIPCHK(c, hipEventRecord(ev[5], s)); }
     }
+    {   // the overlay plane (skydome pixels) is written only when a skydome is drawn, or once more to wipe one that was
+        const int par = (int)(c->frame_no & 1u);
+        const bool sky = c->sky_set && c->sky_enabled;
+        P.write_overlay = (sky || c->overlay_dirty[par]) ? 1u : 0u;
+        c->overlay_dirty[par] = sky;
+    }
     if (ev) HIPCHK(c, hipEventRecord(ev[6], s));
     zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_lut, Z.vis_now, c->d_stats, s);
     if (ev) HIPCHK(c, hipEventRecord(ev[7], s));
@@ -1059,6 +1098,7 @@ static void light_params(const zr_ctx* c, ZrLightParams* Lp)
     L.packed_out = c->cfg.tile_world > 1 ? 1u : 0u;
     L.debug_skip = c->env_skip_light;
     L.bg_enabled = (c->bg_set && c->bg_enabled) ? 1u : 0u;
+    L.has_overlay = c->overlay_dirty[c->frame_no & 1u] ? 1u : 0u;      // set by this frame's gbuffer pass
     { const int32_t np = c->view.LightsCount[1]; L.light_list = (np >= c->env_light_list_min && np <= XK_MAX_POINT_LIGHTS_NUM) ? 1u : 0u; }
     L.bg.data = c->d_bg; L.bg.w = c->bg_w; L.bg.h = c->bg_h; L.bg.levels = c->bg_levels; L.bg._pad = 0;
 }

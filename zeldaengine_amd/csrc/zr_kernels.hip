@@ -855,8 +855,8 @@ __device__ __forceinline__ zf3 interp3(Bary b, zf3 a0, zf3 a1, zf3 a2)
     return zr3(interp1(b, a0.x, a1.x, a2.x), interp1(b, a0.y, a1.y, a2.y), interp1(b, a0.z, a1.z, a2.z));
 }
 
-// ComputeNormal(fragPosition, fragTexCoord, fragNormal, texNormal), SH/Common.glsl:113-127
-__device__ __forceinline__ zf3 compute_normal(zf3 pos_dx, zf3 pos_dy, float s1, float t1, float s2, float t2, zf3 fragN, zf3 texN)
+// ComputeNormal(fragPosition, fragTexCoord, fragNormal, texNormal), SH/Common.glsl:113-127; ts = zr_tangent_space_normal(texNormal)
+__device__ __forceinline__ zf3 compute_normal(zf3 pos_dx, zf3 pos_dy, float s1, float t1, float s2, float t2, zf3 fragN, zf3 ts)
 {
     const float det = __builtin_fmaf(s1, t2, -(s2 * t1));
     zf3 T = zr3(__builtin_fmaf(t2, pos_dx.x, -(t1 * pos_dy.x)) / det,
@@ -865,8 +865,6 @@ __device__ __forceinline__ zf3 compute_normal(zf3 pos_dx, zf3 pos_dy, float s1, 
     const zf3 N = zr_normalize(fragN);
     T = zr_normalize(T - N * zr_dot(N, T));
     const zf3 B = zr_normalize(zr_cross(N, T));
-    const zf3 n = zr_normalize(texN);
-    const zf3 ts = zr_normalize(zr3(__builtin_fmaf(2.0f, n.x, -1.0f), __builtin_fmaf(2.0f, n.y, -1.0f), __builtin_fmaf(2.0f, n.z, -1.0f)));
     const zf3 w = zr3(__builtin_fmaf(N.x, ts.z, __builtin_fmaf(B.x, ts.y, T.x * ts.x)),
                       __builtin_fmaf(N.y, ts.z, __builtin_fmaf(B.y, ts.y, T.y * ts.x)),
                       __builtin_fmaf(N.z, ts.z, __builtin_fmaf(B.z, ts.y, T.z * ts.x)));
@@ -958,6 +956,23 @@ __device__ __forceinline__ zf4 tex_sample(const ZrTex& T, const float* __restric
     return tex_sample_image(T, srgb, lut, u, v, dudx, dvdx, dudy, dvdy);
 }
 
+// fp32 -> fp16 with the conversion unit (round to nearest even, denormals kept, overflow to inf: what zr_f32_to_f16 spells out
+// in integer arithmetic for the host); NaN is canonicalised as there.
+__device__ __forceinline__ uint32_t f32_to_f16_hw(float f)
+{
+    const _Float16 h = (_Float16)f;
+    uint16_t b; __builtin_memcpy(&b, &h, 2);
+    return (f != f) ? (((zr_f2u(f) >> 16) & 0x8000u) | 0x7E00u) : (uint32_t)b;
+}
+// M * vec4(p, 1) when M may be the identity: for finite p every product with a zero entry is +-0, the sum is p (or a zero of either
+// sign) and the final "+ M[12]" with M[12] = +0 turns -0 into +0 - which is exactly what p + 0.0f does.
+__device__ __forceinline__ zf3 model_point(const ZrPass& P, zf3 p)
+{
+    if (P.m_identity) return zr3(p.x + 0.0f, p.y + 0.0f, p.z + 0.0f);
+    const zf4 w = zr_mat4_point(P.M, p);
+    return zr3(w.x, w.y, w.z);
+}
+
 // BaseScene.frag:26-48 for the pixel (px, py) whose winning primitive is `prim`
 // returns true when the pixel holds scene geometry (not empty, not sky)
 template <bool IMAGES>
@@ -969,7 +984,7 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
     if (prim == ZR_EMPTY_PRIM) {   // clears, ZE:3427-3433
         G.depth[p] = 1.0f; G.scene_color[p] = 0xFF000000u; G.gA[p] = 0u; G.gB[p] = 0xFF000000u; G.gC[p] = 0xFF000000u;
         G.gD[p] = make_uint2(0u, 0x3C000000u);
-        G.overlay[p] = 0u;
+        if (P.write_overlay) G.overlay[p] = 0u;
         return false;
     }
     const ZrObject* __restrict__ O = objs + find_object_prim(objs, (int)P.n_objects, prim);
@@ -981,13 +996,15 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
     if (vis_now) vis_now[O->work_base + inst_i * O->n_meshlets + O->tri_meshlet[tri]] = 1;
     zf4 clip[3]; zf3 WP[3], WN[3]; float U[3], V[3]; uint32_t fl[3];
     for (int k = 0; k < 3; ++k) {
-        const XkVertex* __restrict__ vtx = O->verts + O->indices[3u * tri + (uint32_t)k];
-        const zf3 pos = vs_position(zr3(vtx->Position[0], vtx->Position[1], vtx->Position[2]), I, instanced);
+        const float4* __restrict__ rv = (const float4*)(O->rverts + O->indices[3u * tri + (uint32_t)k]);
+        const float4 q0 = rv[0], q1 = rv[1];       // position.xyz u | normalize(normal).xyz v
+        const zf3 pos = vs_position(zr3(q0.x, q0.y, q0.z), I, instanced);
         clip[k] = zr_mat4_point(P.PVM, pos);
-        const zf4 wp = zr_mat4_point(P.M, pos);
-        WP[k] = zr3(wp.x, wp.y, wp.z);
-        WN[k] = vs_normal(zr3(vtx->Normal[0], vtx->Normal[1], vtx->Normal[2]), I, instanced, P.M);
-        U[k] = vtx->TexCoord[0]; V[k] = vtx->TexCoord[1];
+        WP[k] = model_point(P, pos);
+        // outNormal = (M * vec4(normalize(n), 1)).xyz [* mat3(rotMat)], Base.vert:29 / BaseInstanced.vert:73
+        const zf3 mn = model_point(P, zr3(q1.x, q1.y, q1.z));
+        WN[k] = instanced ? zr_rowvec_mat3(mn, I.R) : mn;
+        U[k] = q0.w; V[k] = q1.w;
         fl[k] = vertex_flags(clip[k]);
     }
     const int cls = classify(fl[0], fl[1], fl[2]);
@@ -1022,31 +1039,37 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
                        zr_unorm(zr_pow(sk.z, 0.4545f), 255.0f) << 16 | 255u << 24;
         return false;
     }
-    G.overlay[p] = 0u;
-    // texture(samplerN, fragTexCoord), BaseScene.frag:30-36; slot 0 (base colour) is R8G8B8A8_SRGB (ZE:5878)
-    const zf4 tb = tex_sample<IMAGES>(O->tex[0], O->texc[0], true, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tme = tex_sample<IMAGES>(O->tex[1], O->texc[1], false, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tro = tex_sample<IMAGES>(O->tex[2], O->texc[2], false, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tno = tex_sample<IMAGES>(O->tex[3], O->texc[3], false, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tao = tex_sample<IMAGES>(O->tex[4], O->texc[4], false, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tem = tex_sample<IMAGES>(O->tex[5], O->texc[5], false, lut, u0, v0, s1, t1, s2, t2);
-    const zf4 tms = tex_sample<IMAGES>(O->tex[6], O->texc[6], false, lut, u0, v0, s1, t1, s2, t2);
-    const float Metallic = tme.x;
-    const float Rough = __builtin_fmaxf(0.01f, tro.x);
-    const zf3 texN = zr3(tno.x, tno.y, tno.z);
-    const float AO = tao.x;
-    const zf3 Em = zr3(tem.x, tem.y, tem.z);
-    const float Mask = tms.x;
-
-    const zf3 Nw = compute_normal(pos_dx, pos_dy, s1, t1, s2, t2, N0, texN);
+    if (P.write_overlay) G.overlay[p] = 0u;
+    // texture(samplerN, fragTexCoord), BaseScene.frag:30-36; slot 0 (base colour) is R8G8B8A8_SRGB (ZE:5878).  Targets whose slots are
+    // all constant were packed on the host (same zr_unorm), and so was the tangent-space normal of a constant normal map.
+    uint32_t w_sc, w_gB, w_gC;
+    zf3 ts;
+    if (!IMAGES) {
+        w_sc = O->c_scene_color; w_gB = O->c_gB; w_gC = O->c_gC;
+        ts = zr3(O->ts_const[0], O->ts_const[1], O->ts_const[2]);
+    } else {
+        const zf4 tb = tex_sample<IMAGES>(O->tex[0], O->texc[0], true, lut, u0, v0, s1, t1, s2, t2);
+        const zf4 tme = tex_sample<IMAGES>(O->tex[1], O->texc[1], false, lut, u0, v0, s1, t1, s2, t2);
+        const zf4 tro = tex_sample<IMAGES>(O->tex[2], O->texc[2], false, lut, u0, v0, s1, t1, s2, t2);
+        const zf4 tno = tex_sample<IMAGES>(O->tex[3], O->texc[3], false, lut, u0, v0, s1, t1, s2, t2);
+        const zf4 tao = tex_sample<IMAGES>(O->tex[4], O->texc[4], false, lut, u0, v0, s1, t1, s2, t2);
+        const zf4 tem = tex_sample<IMAGES>(O->tex[5], O->texc[5], false, lut, u0, v0, s1, t1, s2, t2);
+        const zf4 tms = tex_sample<IMAGES>(O->tex[6], O->texc[6], false, lut, u0, v0, s1, t1, s2, t2);
+        const float Rough = __builtin_fmaxf(0.01f, tro.x);
+        w_sc = zr_unorm(tem.x, 255.0f) | zr_unorm(tem.y, 255.0f) << 8 | zr_unorm(tem.z, 255.0f) << 16 | zr_unorm(tms.x, 255.0f) << 24;
+        w_gB = zr_unorm(tme.x, 255.0f) | zr_unorm(1.0f, 255.0f) << 8 | zr_unorm(Rough, 255.0f) << 16 | 255u << 24;
+        w_gC = zr_unorm(tb.x, 255.0f) | zr_unorm(tb.y, 255.0f) << 8 | zr_unorm(tb.z, 255.0f) << 16 | zr_unorm(tao.x, 255.0f) << 24;
+        ts = (O->const_slots & 8u) ? zr3(O->ts_const[0], O->ts_const[1], O->ts_const[2]) : zr_tangent_space_normal(zr3(tno.x, tno.y, tno.z));
+    }
+    const zf3 Nw = compute_normal(pos_dx, pos_dy, s1, t1, s2, t2, N0, ts);
     const zf3 Nn = zr_normalize(Nw);
     const zf3 NP = zr3((Nn.x + 1.0f) / 2.0f, (Nn.y + 1.0f) / 2.0f, (Nn.z + 1.0f) / 2.0f);
     G.depth[p] = depth;
-    G.scene_color[p] = zr_unorm(Em.x, 255.0f) | zr_unorm(Em.y, 255.0f) << 8 | zr_unorm(Em.z, 255.0f) << 16 | zr_unorm(Mask, 255.0f) << 24;
+    G.scene_color[p] = w_sc;
     G.gA[p] = zr_unorm(NP.z, 1023.0f) | zr_unorm(NP.y, 1023.0f) << 10 | zr_unorm(NP.x, 1023.0f) << 20 | 3u << 30;
-    G.gB[p] = zr_unorm(Metallic, 255.0f) | zr_unorm(1.0f, 255.0f) << 8 | zr_unorm(Rough, 255.0f) << 16 | 255u << 24;
-    G.gC[p] = zr_unorm(tb.x, 255.0f) | zr_unorm(tb.y, 255.0f) << 8 | zr_unorm(tb.z, 255.0f) << 16 | zr_unorm(AO, 255.0f) << 24;
-    G.gD[p] = make_uint2(zr_f32_to_f16(P0.x) | zr_f32_to_f16(P0.y) << 16, zr_f32_to_f16(P0.z) | 0x3C000000u);
+    G.gB[p] = w_gB;
+    G.gC[p] = w_gC;
+    G.gD[p] = make_uint2(f32_to_f16_hw(P0.x) | f32_to_f16_hw(P0.y) << 16, f32_to_f16_hw(P0.z) | 0x3C000000u);
     return true;
 }
 
@@ -1461,7 +1484,7 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
         // what every path ends with: the skydome / background drawn over the lit quad in view 0 (ZE:3681-3699), then the store
         auto emit = [&](uint32_t rgba) {
             if (L.debug_view == 0u) {
-                const uint32_t ov = G.overlay[p];
+                const uint32_t ov = L.has_overlay ? G.overlay[p] : 0u;
                 if (ov) rgba = ov;
                 else if (BACKGROUND && L.bg_enabled && 1.0f <= G.depth[p]) {
                     const float u = ((float)px + 0.5f) / (float)L.W, v = ((float)py + 0.5f) / (float)L.H;

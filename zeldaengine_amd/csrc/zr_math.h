@@ -34,6 +34,12 @@ ZR_HD zf3 zr_cross(zf3 a, zf3 b)
 ZR_HD float zr_length(zf3 a) { return __builtin_sqrtf(zr_dot(a, a)); }
 // normalize(v) = v * inversesqrt(dot(v, v)); a zero vector gives NaN, as on the GPUs the engine targets
 ZR_HD zf3 zr_normalize(zf3 a) { return a * (1.0f / __builtin_sqrtf(zr_dot(a, a))); }
+// normalize(2.0 * normalize(texNormal) - 1.0), SH/Common.glsl:125-126: a per-object constant when the normal map is one texel
+ZR_HD zf3 zr_tangent_space_normal(zf3 texN)
+{
+    const zf3 n = zr_normalize(texN);
+    return zr_normalize(zr3(__builtin_fmaf(2.0f, n.x, -1.0f), __builtin_fmaf(2.0f, n.y, -1.0f), __builtin_fmaf(2.0f, n.z, -1.0f)));
+}
 ZR_HD float zr_saturate(float t) { return __builtin_fminf(__builtin_fmaxf(t, 0.0f), 1.0f); }   // SH/Common.glsl:23
 ZR_HD float zr_clamp(float t, float a, float b) { return __builtin_fminf(__builtin_fmaxf(t, a), b); }
 

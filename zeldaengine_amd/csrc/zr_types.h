@@ -26,12 +26,19 @@ struct ZrInstance {
 };
 static_assert(sizeof(ZrInstance) == 64, "ZrInstance");
 
+// Vertex record of the GBuffer resolve: two aligned 16-byte loads per corner instead of the eleven dwords of an XkVertex.
+// nx..nz hold normalize(XkVertex::Normal), formed once on the host with the kernels' own zr_normalize (Base.vert:29 normalises the
+// attribute before anything else, so the value is a per-vertex constant).
+struct ZrRVertex { float px, py, pz, u; float nx, ny, nz, v; };
+static_assert(sizeof(ZrRVertex) == 32, "ZrRVertex");
+
 // One material texture: RGBA8 mip chain, level l = max(1, w >> l) x max(1, h >> l) texels, levels concatenated.
 struct ZrTex { const uint8_t* data; uint32_t w, h, levels, _pad; };
 
 // One draw (object) of the scene, in the reference's draw order (non-instanced draws first, ZE:3445-3476).
 struct ZrObject {
     const XkVertex*   verts;
+    const ZrRVertex*  rverts;        // the same vertices repacked for the resolve (see ZrRVertex)
     const uint32_t*   indices;       // draw-order index buffer (3 per triangle)
     const XkMeshlet*  meshlets;      // device copy; BindlessContext = tri_base (triangles in earlier meshlets)
     const float4*     mpos;          // flattened meshlet vertices: mpos[VertexOffset + k] = position of meshlet vertex k
@@ -51,7 +58,10 @@ struct ZrObject {
     float    mesh_center[3];         // object-space bounding sphere of the whole mesh
     float    mesh_radius;
     uint32_t flags;                  // ZR_OBJ_*
-    uint32_t _pad;
+    uint32_t const_slots;            // bit t: material slot t is a constant texel (no image)
+    // What BaseScene.frag makes of constant slots, formed once on the host with the kernels' own arithmetic:
+    float    ts_const[3];            // normalize(2 * normalize(texNormal) - 1) when slot 3 is constant (ComputeNormal, SH/Common.glsl:125-126)
+    uint32_t c_scene_color, c_gB, c_gC;   // the packed SceneColor / GBufferB / GBufferC words when their slots (5,6 / 1,2 / 0,4) are constant
 };
 
 // One (tile, meshlet-instance) entry of a bin list, self-contained: the rasteriser starts every load of a meshlet from
@@ -85,6 +95,8 @@ struct ZrPass {
     uint32_t bin_capacity;
     uint32_t images;                 // some material slot (or the skydome) holds an image: the resolve needs the texture filter
     uint32_t debug_skip;             // diagnostics only (env ZR_DEBUG_SKIP): 1 skip pixel walk, 2 skip triangle phase too
+    uint32_t m_identity;             // M is bit for bit the identity: M * vec4(p, 1) == p + 0.0f for finite p
+    uint32_t write_overlay;          // the resolve must write the overlay plane (a skydome is drawn, or stale sky pixels must go)
 };
 
 // Frame statistics block in device memory (one per pass slot: [shadow, camera]).
@@ -126,6 +138,7 @@ struct ZrLightParams {
     uint32_t debug_skip;             // diagnostics only (env ZR_DEBUG_SKIP_LIGHT bits: 1 PCF, 2 lights, 4 reflection)
     uint32_t bg_enabled;             // background quad (Background.vert/.frag) on
     uint32_t light_list;             // 1: per-tile point-light lists
+    uint32_t has_overlay;            // the overlay plane may hold skydome pixels (else it is all zero and is not read)
     const uint32_t* empty_rgba;      // the lit colour of a pixel holding the GBuffer's clear values (same for all of them), or null
     uint32_t* clear_next;            // the NEXT frame's shadow map (idle while this pass runs): cleared to depth 1.0 here, or null
     uint32_t clear_n, _pad0;
