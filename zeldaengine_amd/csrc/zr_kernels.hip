@@ -964,6 +964,12 @@ __device__ __forceinline__ uint32_t f32_to_f16_hw(float f)
     uint16_t b; __builtin_memcpy(&b, &h, 2);
     return (f != f) ? (((zr_f2u(f) >> 16) & 0x8000u) | 0x7E00u) : (uint32_t)b;
 }
+__device__ __forceinline__ float f16_to_f32_hw(uint32_t h)      // exact (every fp16 value is an fp32 value); quiet NaNs map as in zr_f16_to_f32
+{
+    const uint16_t b = (uint16_t)h;
+    _Float16 v; __builtin_memcpy(&v, &b, 2);
+    return (float)v;
+}
 // M * vec4(p, 1) when M may be the identity: for finite p every product with a zero entry is +-0, the sum is p (or a zero of either
 // sign) and the final "+ M[12]" with M[12] = +0 turns -0 into +0 - which is exactly what p + 0.0f does.
 __device__ __forceinline__ zf3 model_point(const ZrPass& P, zf3 p)
@@ -1407,7 +1413,8 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
     // UNORM loads are IEEE quotients c / 255 and c / 1023: 14 per pixel, served from an LDS copy of the host-built table
     __shared__ float u8[256];
     __shared__ float u10[1024];
-    for (uint32_t i = threadIdx.x; i < 256u; i += 256u) u8[i] = unorm_lut[i];
+    __shared__ float slut[256];          // sRGB decode table of the cubemap fetches (24 per pixel)
+    for (uint32_t i = threadIdx.x; i < 256u; i += 256u) { u8[i] = unorm_lut[i]; slut[i] = srgb_lut[i]; }
     for (uint32_t i = threadIdx.x; i < 1024u; i += 256u) u10[i] = unorm_lut[256u + i];
     __syncthreads();
     if (L.clear_next) {      // the clear of the next frame's shadow pass (depth 1.0, ZE:3248), a slice per workgroup: saves a launch
@@ -1437,7 +1444,7 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
             const size_t p = (size_t)py * L.W + (size_t)px;
             if ((G.scene_color[p] >> 24) == 0u) continue;
             const uint2 D = G.gD[p];
-            const float q[3] = { zr_f16_to_f32(D.x & 0xFFFFu), zr_f16_to_f32(D.x >> 16), zr_f16_to_f32(D.y & 0xFFFFu) };
+            const float q[3] = { f16_to_f32_hw(D.x & 0xFFFFu), f16_to_f32_hw(D.x >> 16), f16_to_f32_hw(D.y & 0xFFFFu) };
             for (int a = 0; a < 3; ++a) {
                 if (!(__builtin_fabsf(q[a]) <= 3.402823466e38f)) odd = true;
                 lo[a] = __builtin_fminf(lo[a], q[a]); hi[a] = __builtin_fmaxf(hi[a], q[a]);
@@ -1512,7 +1519,7 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
         const float Mask = u8[sc >> 24];
         Roughness = __builtin_fmaxf(0.01f, Roughness);
         const zf3 N = zr_normalize(Normal);
-        const zf3 Pw = zr3(zr_f16_to_f32(D.x & 0xFFFFu), zr_f16_to_f32(D.x >> 16), zr_f16_to_f32(D.y & 0xFFFFu));
+        const zf3 Pw = zr3(f16_to_f32_hw(D.x & 0xFFFFu), f16_to_f32_hw(D.x >> 16), f16_to_f32_hw(D.y & 0xFFFFu));
         const zf3 Vv = zr_normalize(cam - Pw);
         const float NdotV = zr_saturate(zr_dot(N, Vv));
 
@@ -1665,7 +1672,7 @@ __global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView*
         }
         // ComputeReflectionMipFromRoughness, SH/Common.glsl:191-198
         const float MIPS = (maxmips - 1.0f) - __builtin_fmaf(-1.2f, zr_log2(__builtin_fmaxf(Roughness, 0.001f)), 1.0f);
-        const zf3 RL = (ZR_DIAG_SKIP(L.debug_skip) & 4u) ? zr3(0.0f, 0.0f, 0.0f) : cube_sample(C, srgb_lut, L.cube_dim, (int)L.cube_levels, R, MIPS) * 10.0f;
+        const zf3 RL = (ZR_DIAG_SKIP(L.debug_skip) & 4u) ? zr3(0.0f, 0.0f, 0.0f) : cube_sample(C, slut, L.cube_dim, (int)L.cube_levels, R, MIPS) * 10.0f;
         const float RV = zr_saturate((zr_pow(NdotV + AO, Roughness * Roughness) - 1.0f) + AO);   // GetSpecularOcclusion :226
         const zf3 RefC = zr3((RL.x * RV) * RBRDF.x, (RL.y * RV) * RBRDF.y, (RL.z * RV) * RBRDF.z);
 
