@@ -195,10 +195,28 @@ int  zr_composite(zr_ctx* ctx, const void* gathered_dev);
 int  zr_color_device_ptr(zr_ctx* ctx, void** dev_ptr);
 
 /* --- world JSON + livelink (replaces XkWorld::Load ZE:1051-1147, socket thread ZE:1617-1710) --- */
-/* A Profab is the engine's asset bundle `Profabs/<name>/{models, textures}` (ZE:4922-5000).  The library has no
- * file-system asset search yet: the caller registers each model of a Profab (mesh + 7-texture material) under its name;
- * zr_world_load_json instantiates ObjectDescs from the registry.  Unknown names draw nothing, like a missing directory. */
+/* A Profab is the engine's asset bundle `Profabs/<name>/{models, textures}` (ZE:4922-5000).  Either the caller registers each
+ * model of a Profab (mesh + 7-texture material) under its name, or - after zr_set_asset_root - zr_world_load_json finds
+ * `Profabs/<name>` on disk itself.  Unknown names draw nothing, like a missing directory. */
 int  zr_profab_register(zr_ctx* ctx, const char* name, uint32_t mesh_id, const zr_material* mat);
+
+/* --- the content tree (replaces ASSETS()/AssetPathSearch ZE:7173-7263, LoadMeshAsset ZE:6899-6948, LoadTextureAsset ZE:6882-6896,
+ *     LoadMeshletAsset ZE:7046-7169, the Profab walk ZE:4922-5000 and the world's sky / cubemap / background overrides ZE:4147-4183) --- */
+/* dir = the engine's working directory (holds Profabs/ and Content/); NULL switches file-system lookups off again.  With a root
+ * set, zr_world_load_json also applies OverrideCubemap / OverrideSkydome (mesh: Content/Models/skydome.obj) / OverrideBackground. */
+int  zr_set_asset_root(zr_ctx* ctx, const char* dir);
+/* literal path -> Profabs/<set>/{models,textures} -> Content/<set>/...; returns the input (rooted) when nothing is found */
+int  zr_asset_path_search(zr_ctx* ctx, const char* name, char* dst, size_t cap, size_t* len);
+/* context-free loaders (host code only).  NULL outputs = size query (*nv / *ni, or *w / *h, are set). */
+int  zr_load_obj(const char* path, XkVertex* v, uint32_t* nv, uint32_t* idx, uint32_t* ni);
+int  zr_load_png_rgba8(const char* path, uint8_t* dst, size_t cap, uint32_t* w, uint32_t* h);
+/* `.meshlet` file (ZM:52-75) -> mesh with the file's meshlets attached (zr_mesh_create + zr_mesh_set_meshlets) */
+int  zr_load_meshlet_file(zr_ctx* ctx, const char* path, uint32_t* mesh_id);
+/* XkWorld::Load() / Save() on a file (NULL = "Content/World.json", ZE:1027), relative to the asset root */
+int  zr_world_load_file(zr_ctx* ctx, const char* path);
+int  zr_world_save_file(zr_ctx* ctx, const char* path);
+/* per-frame UpdateWorld + UpdateUniformBuffer from the loaded world's camera and lights (ZE:4294-4308, 4585-4664) */
+int  zr_world_update_uniforms(zr_ctx* ctx, float roll_stage, float roll_light, float time);
 /* XkWorld::Load + CreateEngineScene + the first UpdateUniformBuffer: replaces the scene's objects (InstanceCount > 1 ->
  * GenerateInstance, seeded PCG32(1234 + object index)) and sets camera + lights. */
 int  zr_world_load_json(zr_ctx* ctx, const char* utf8, size_t len);

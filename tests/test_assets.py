@@ -93,3 +93,81 @@ def test_profab_directory_search(tmp_path):
     assert tex_b == [None] * 7                                  # every slot falls back to the engine default
     img = assets.load_image_rgba8(tex_a[0])
     assert img.shape == (4, 4, 4) and (img[..., 3] == 255).all() and (img[..., :3] == 200).all()
+
+
+# ---------------------------------------------------------------- the library's own (C++) loaders against the Python ones / PIL
+
+def _obj_with_quirks(path):
+    """Faces as quads and fans, negative indices, v//vn and v/vt forms mixed in, more normals than positions."""
+    with open(path, "w") as f:
+        f.write("# test\no thing\n")
+        for p in [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0.5, 0.5, 1)]:
+            f.write("v %g %g %g\n" % p)
+        for t in [(0, 0), (1, 0), (1, 1), (0, 1), (0.5, 0.5)]:
+            f.write("vt %g %g\n" % t)
+        for n in [(0, 0, 1), (0, 0, -1), (1, 0, 0), (0, 1, 0), (0.6, 0, 0.8), (0, 0.6, 0.8)]:
+            f.write("vn %g %g %g\n" % n)
+        f.write("s off\nusemtl none\n")
+        f.write("f 1/1/1 2/2/1 3/3/1 4/4/1\n")          # a quad: fan of two triangles
+        f.write("f -5/1/2 -4/2/2 -1/5/6\n")             # negative (relative) indices
+        f.write("f 2/2/3 3/3/3 5/5/5\nf 3/3 4/4 5/5\nf 4/4/4 1/1/4 5/5/5\n")
+
+
+def test_native_obj_loader_matches_the_python_ingest(tmp_path):
+    p = str(tmp_path / "quirks.obj")
+    _obj_with_quirks(p)
+    v0, i0 = assets.load_obj(p)
+    v1, i1 = engine.load_obj(p)
+    assert np.array_equal(i0, i1) and v0.tobytes() == v1.tobytes()
+    # and on a mesh written by write_obj (the path Profab trees in the GPU tests take)
+    v, idx = scenes.uv_sphere(12, 6, 0.7)
+    q = str(tmp_path / "ball.obj")
+    assets.write_obj(q, v, idx)
+    v0, i0 = assets.load_obj(q)
+    v1, i1 = engine.load_obj(q)
+    assert np.array_equal(i0, i1) and v0.tobytes() == v1.tobytes()
+    with pytest.raises(engine.ZeldaRenderError):
+        engine.load_obj(str(tmp_path / "missing.obj"))
+
+
+@pytest.mark.parametrize("mode,kw", [("RGBA", {}), ("RGB", {}), ("L", {}), ("LA", {}), ("P", {}), ("1", {}), ("RGB", {"interlace": True}),
+                                     ("RGBA", {"compress_level": 0}), ("P", {"transparency": 3, "bits": 4})])
+def test_native_png_loader_matches_pil(tmp_path, mode, kw):
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    w, h = 37, 23                                           # odd sizes: partial bytes at low bit depths, ragged Adam7 passes
+    base = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    im = Image.fromarray(base, "RGBA")
+    if mode == "P":
+        im = im.convert("RGB").quantize(16 if kw.get("bits") == 4 else 200)
+    else:
+        im = im.convert(mode)
+    path = str(tmp_path / ("t_%s.png" % mode))
+    save_kw = {k: v for k, v in kw.items() if k != "interlace"}
+    if kw.get("interlace"):
+        # PIL cannot write Adam7; assemble one from its non-interlaced IDAT by hand
+        path = _write_adam7_rgb(path, np.asarray(im.convert("RGB")))
+    else:
+        im.save(path, **save_kw)
+    want = np.asarray(Image.open(path).convert("RGBA"))
+    got = engine.load_png_rgba8(path)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def _write_adam7_rgb(path, rgb):
+    import struct
+    import zlib
+    h, w, _ = rgb.shape
+    raw = b""
+    for x0, y0, dx, dy in [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]:
+        sub = rgb[y0::dy, x0::dx]
+        if sub.size == 0:
+            continue
+        for row in sub:
+            raw += b"\x00" + row.tobytes()
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    return path

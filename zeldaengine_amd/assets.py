@@ -61,7 +61,7 @@ def load_obj(path):
     for tri in faces:
         for vi, ti, _ni in tri:
             n = nrm[vi] if vi < len(nrm) else nrm[-1]          # quirk: normals[3 * vertex_index + k]
-            rec = (pos[vi], n, (1.0, 1.0, 1.0), (uvs[ti][0], 1.0 - uvs[ti][1]))
+            rec = (pos[vi], n, (1.0, 1.0, 1.0), (uvs[ti][0], float(np.float32(1.0) - np.float32(uvs[ti][1]))))      # float arithmetic, as tinyobj's real_t
             key = tuple(np.float32(x).tobytes() for grp in rec for x in grp)
             if key not in lookup:
                 lookup[key] = len(verts)
@@ -79,7 +79,7 @@ def load_obj_for_meshlet_tool(path):
     verts, index, lookup = [], [], {}
     for tri in faces:
         for vi, ti, ni in tri:
-            rec = (pos[vi], nrm[ni], (uvs[ti][0], 1.0 - uvs[ti][1]))
+            rec = (pos[vi], nrm[ni], (uvs[ti][0], float(np.float32(1.0) - np.float32(uvs[ti][1]))))
             key = tuple(np.float32(x).tobytes() for grp in rec for x in grp)
             if key not in lookup:
                 lookup[key] = len(verts)

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libzelda_render.so")
-SOURCES = ["zr_kernels.hip", "zr_host.cpp", "zr_world.cpp", "zr_meshlet.cpp"]
+SOURCES = ["zr_kernels.hip", "zr_host.cpp", "zr_world.cpp", "zr_meshlet.cpp", "zr_assets.cpp"]
 HEADERS = ["zr_math.h", "zr_types.h", "zr_ctx.h", "zr_meshlet.h", "../../include/zelda_abi.h", "../../include/zelda_render.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__"]
@@ -61,10 +61,26 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
     except Exception:      # noqa: BLE001
         pass
     cmd = ["g++", "-shared", "-fPIC", "-o", out_path] + objs + ["-L" + hip_dir, "-l:libamdhip64.so", "-Wl,-rpath,/opt/rocm/lib",
-                                                                 "-Wl,--no-as-needed", "-lpthread"]
+                                                                 "-Wl,--no-as-needed", "-lpthread", "-lz", "-lstdc++fs"]
     subprocess.check_call(cmd)
     return out_path
 
 
+HEADLESS_SRC = os.path.join(os.path.dirname(HERE), "tools", "zelda_headless.cpp")
+HEADLESS_OUT = os.path.join(os.path.dirname(HERE), "tools", "zelda_headless")
+
+
+def build_headless(force=False):
+    """tools/zelda_headless: a C++ program that uses nothing but include/zelda_render.h and links -lzelda_render (the engine's main
+    loop without a window).  Plain g++; the library is found through an $ORIGIN-relative RUNPATH."""
+    lib = build()
+    if not force and os.path.exists(HEADLESS_OUT) and os.path.getmtime(HEADLESS_OUT) >= max(os.path.getmtime(HEADLESS_SRC), os.path.getmtime(lib)):
+        return HEADLESS_OUT
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", HEADLESS_OUT, HEADLESS_SRC, "-L" + HERE, "-l:libzelda_render.so",
+                           "-Wl,-rpath,$ORIGIN/../zeldaengine_amd", "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-lpthread"])
+    return HEADLESS_OUT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_headless(force="--force" in sys.argv))

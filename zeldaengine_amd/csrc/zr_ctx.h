@@ -128,7 +128,8 @@ struct zr_ctx {
     hipEvent_t evr[EV_RING][10] = {}; uint64_t frame_no = 0; bool rendered = false;
     uint32_t timing_interval = 1; bool timing_now = true; uint64_t sample_no = 0;    // pass events every interval-th frame
 
-    // world + livelink
+    // world + livelink + the content tree (zr_assets.cpp)
+    std::string asset_root; bool assets_on = false;     // directory holding Profabs/ and Content/ (the engine's working directory)
     ZrWorld world;
     std::map<std::string, std::vector<ZrProfab>> profabs;
     std::mutex ll_mutex; std::thread ll_thread; std::atomic<bool> ll_run{ false };
@@ -141,3 +142,7 @@ hipError_t zr_sync_all(zr_ctx* c);     // every stream the library enqueues on
 float zr_srgb_decode8(uint32_t c);
 int zr_material_prepare(zr_ctx* c, const zr_material* mat, ZrMaterialHost* out);
 int zr_object_add_internal(zr_ctx* c, uint32_t mesh_id, const ZrMaterialHost& mat, const XkInstanceData* inst, uint32_t n_inst);
+// zr_assets.cpp
+std::string zr_asset_search(const zr_ctx* c, const std::string& name);
+int zr_profab_from_disk(zr_ctx* c, const std::string& name, int* found);
+int zr_world_apply_overrides(zr_ctx* c, const ZrWorld& w);

@@ -268,6 +268,8 @@ void generate_instances(const ZrObjectDesc& d, uint64_t seed, std::vector<XkInst
     }
 }
 
+int world_uniforms(zr_ctx* c, const ZrWorld& w, float roll_stage, float roll_light, float time);
+
 int apply_world(zr_ctx* c, const ZrWorld& w)
 {
     // CreateEngineScene (ZE:4250-4267): drop the render objects, keep meshes and registered Profabs
@@ -283,9 +285,16 @@ int apply_world(zr_ctx* c, const ZrWorld& w)
     }
     c->world = w;
     zr_set_sky_flags(c, w.EnableSkydome ? 1 : 0, w.EnableBackground ? 1 : 0);       // gates of ZE:3682 / ZE:3693
+    rc = zr_world_apply_overrides(c, w);            // CreateEngineScene (1): cubemap / skydome / background named by the world, via ASSETS()
     for (size_t oi = 0; oi < w.ObjectDescs.size() && rc == ZR_OK; ++oi) {
         const ZrObjectDesc& d = w.ObjectDescs[oi];
         auto it = c->profabs.find(d.ProfabName);
+        if (it == c->profabs.end() && c->assets_on) {          // not registered by the host: look for Profabs/<name> on disk (ZE:4922-5000)
+            int found = 0;
+            rc = zr_profab_from_disk(c, d.ProfabName, &found);
+            if (rc) break;
+            it = c->profabs.find(d.ProfabName);
+        }
         if (it == c->profabs.end()) continue;      // no such Profab directory: the engine finds no models and draws nothing
         std::vector<XkInstanceData> inst;
         if (d.InstanceCount > 1) generate_instances(d, 1234u + oi, inst);
@@ -295,6 +304,11 @@ int apply_world(zr_ctx* c, const ZrWorld& w)
         }
     }
     if (rc) return rc;
+    return world_uniforms(c, w, 0.0f, 0.0f, 0.0f);
+}
+
+int world_uniforms(zr_ctx* c, const ZrWorld& w, float roll_stage, float roll_light, float time)
+{
     std::vector<XkLight> L[3];
     const std::vector<ZrLightDesc>* src[3] = { &w.DirectionalLights, &w.PointLights, &w.SpotLights };
     for (int k = 0; k < 3; ++k)
@@ -307,7 +321,7 @@ int apply_world(zr_ctx* c, const ZrWorld& w)
             L[k].push_back(x);
         }
     return zr_update_uniforms(c, &w.MainCamera, L[0].data(), (uint32_t)L[0].size(), L[1].data(), (uint32_t)L[1].size(),
-                              L[2].data(), (uint32_t)L[2].size(), 0.0f, 0.0f, 0.0f);
+                              L[2].data(), (uint32_t)L[2].size(), roll_stage, roll_light, time);
 }
 
 // No C++ exception crosses the ABI: an allocation failure while instantiating a world becomes an error code.
@@ -444,6 +458,15 @@ extern "C" int zr_world_json_normalize(const char* utf8, size_t len_in, char* ds
         memcpy(dst, o.data(), o.size());
     }
     return ok ? ZR_OK : ZR_ERR_PARSE;
+}
+
+// UpdateWorld + UpdateUniformBuffer (ZE:4294-4308, 4585-4664) from the loaded world's camera and lights: what the engine does every
+// frame with its RollStage / RollLight / Time state.
+extern "C" int zr_world_update_uniforms(zr_ctx* c, float roll_stage, float roll_light, float time)
+{
+    if (!c) return ZR_ERR_ARG;
+    if (!c->world.loaded) return zr_fail(c, ZR_ERR_STATE, "no world loaded");
+    return world_uniforms(c, c->world, roll_stage, roll_light, time);
 }
 
 extern "C" int zr_world_get_camera(zr_ctx* c, zr_camera* out)

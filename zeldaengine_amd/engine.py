@@ -81,6 +81,14 @@ def lib():
         "zr_color_device_ptr": [vp, C.POINTER(vp)],
         "zr_profab_register": [vp, C.c_char_p, u32, vp],
         "zr_world_load_json": [vp, C.c_char_p, sz],
+        "zr_set_asset_root": [vp, C.c_char_p],
+        "zr_asset_path_search": [vp, C.c_char_p, vp, sz, C.POINTER(sz)],
+        "zr_load_obj": [C.c_char_p, vp, C.POINTER(u32), vp, C.POINTER(u32)],
+        "zr_load_png_rgba8": [C.c_char_p, vp, sz, C.POINTER(u32), C.POINTER(u32)],
+        "zr_load_meshlet_file": [vp, C.c_char_p, C.POINTER(u32)],
+        "zr_world_load_file": [vp, C.c_char_p],
+        "zr_world_save_file": [vp, C.c_char_p],
+        "zr_world_update_uniforms": [vp, C.c_float, C.c_float, C.c_float],
         "zr_world_save_json": [vp, vp, sz, C.POINTER(sz)],
         "zr_world_get_camera": [vp, vp],
         "zr_world_json_normalize": [C.c_char_p, sz, vp, sz, C.POINTER(sz)],
@@ -125,6 +133,35 @@ def build_meshlets(verts, idx, max_vertices=64, max_triangles=124, cone_weight=0
     if rc:
         raise ZeldaRenderError(rc, "zr_meshlets_build")
     return ml, mv, mt, order
+
+
+def load_obj(path):
+    """LoadMeshAsset through the library's own OBJ reader (host code only) -> (XkVertex[], uint32 indices)."""
+    L = lib()
+    nv, ni = C.c_uint32(), C.c_uint32()
+    rc = L.zr_load_obj(os.fsencode(path), None, C.byref(nv), None, C.byref(ni))
+    if rc:
+        raise ZeldaRenderError(rc, "zr_load_obj(%s)" % path)
+    v = np.zeros(nv.value, dtype=abi.XkVertex)
+    idx = np.zeros(ni.value, dtype=np.uint32)
+    rc = L.zr_load_obj(os.fsencode(path), _ptr(v), C.byref(nv), _ptr(idx), C.byref(ni))
+    if rc:
+        raise ZeldaRenderError(rc, "zr_load_obj(%s)" % path)
+    return v, idx
+
+
+def load_png_rgba8(path):
+    """LoadTextureAsset through the library's own PNG reader (host code only) -> (H, W, 4) uint8."""
+    L = lib()
+    w, h = C.c_uint32(), C.c_uint32()
+    rc = L.zr_load_png_rgba8(os.fsencode(path), None, 0, C.byref(w), C.byref(h))
+    if rc:
+        raise ZeldaRenderError(rc, "zr_load_png_rgba8(%s)" % path)
+    out = np.zeros((h.value, w.value, 4), dtype=np.uint8)
+    rc = L.zr_load_png_rgba8(os.fsencode(path), _ptr(out), out.nbytes, C.byref(w), C.byref(h))
+    if rc:
+        raise ZeldaRenderError(rc, "zr_load_png_rgba8(%s)" % path)
+    return out
 
 
 def world_json_normalize(text):
@@ -395,6 +432,31 @@ class Renderer:
     def world_load_json(self, text):
         b = text.encode() if isinstance(text, str) else bytes(text)
         self._chk(self.L.zr_world_load_json(self.h, b, len(b)))
+
+    def set_asset_root(self, path):
+        """The engine's working directory (Profabs/, Content/): world loads then resolve Profabs and sky / cubemap / background files."""
+        self._chk(self.L.zr_set_asset_root(self.h, os.fsencode(path) if path is not None else None))
+
+    def asset_path_search(self, name):
+        n = C.c_size_t()
+        self._chk(self.L.zr_asset_path_search(self.h, name.encode(), None, 0, C.byref(n)))
+        buf = C.create_string_buffer(max(1, n.value))
+        self._chk(self.L.zr_asset_path_search(self.h, name.encode(), buf, n.value, C.byref(n)))
+        return buf.raw[:n.value].decode()
+
+    def load_meshlet_file(self, path):
+        m = C.c_uint32()
+        self._chk(self.L.zr_load_meshlet_file(self.h, os.fsencode(path), C.byref(m)))
+        return m.value
+
+    def world_load_file(self, path=None):
+        self._chk(self.L.zr_world_load_file(self.h, os.fsencode(path) if path is not None else None))
+
+    def world_save_file(self, path=None):
+        self._chk(self.L.zr_world_save_file(self.h, os.fsencode(path) if path is not None else None))
+
+    def world_update_uniforms(self, roll_stage=0.0, roll_light=0.0, time=0.0):
+        self._chk(self.L.zr_world_update_uniforms(self.h, roll_stage, roll_light, time))
 
     def world_save_json(self):
         n = C.c_size_t()
