@@ -242,8 +242,8 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = W * H * args.steps / elapsed / 1e6
         owned_px = 0
-        tiles = zdist.owned_tiles(rank, world, ((W + 31) // 32) * ((H + 31) // 32)) if world > 1 else range(((W + 31) // 32) * ((H + 31) // 32))
         tx = (W + 31) // 32
+        tiles = zdist.owned_tiles(rank, world, tx, (H + 31) // 32)
         for t in tiles:
             x0, y0 = (t % tx) * 32, (t // tx) * 32
             owned_px += (min(W, x0 + 32) - x0) * (min(H, y0 + 32) - y0)

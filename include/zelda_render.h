@@ -39,6 +39,12 @@ extern "C" {
 #define ZR_TILE 32            /* screen tile edge in pixels (raster + multi-GPU partition unit); 32 or 64 */
 #endif
 
+/* Multi-GPU screen partition: tiles are owned in super-tiles of (1 << ZR_SUPERTILE_SHIFT)^2 tiles (128 x 128 pixels), dealt to the
+ * ranks round-robin along x with a skew per super-tile row, so that a meshlet (tens of pixels) nearly always falls to ONE rank and
+ * that rank alone transforms it, while neighbouring super-tiles still go to different ranks. */
+#define ZR_SUPERTILE_SHIFT 2
+#define ZR_SUPERTILE_SKEW  3
+
 typedef struct zr_ctx zr_ctx;
 
 /* Flags for zr_config.flags */
@@ -47,6 +53,8 @@ typedef struct zr_ctx zr_ctx;
 #define ZR_FLAG_SKIP_COMPOSITE  4u  /* tile_world>1: caller gathers packed tiles itself */
 #define ZR_FLAG_NO_HIZ          8u  /* disable two-pass Hi-Z occlusion culling of the camera pass (parity A/B) */
 #define ZR_FLAG_SERIAL_PASSES   16u /* zr_render: shadow and camera pipelines on the one stream instead of side by side */
+#define ZR_FLAG_PACKED_TILES    32u /* tile_world == 1: still light into the packed tile buffer (the multi-GPU data path on one GPU) */
+#define ZR_FLAG_NO_RECT_CULL    64u /* tile_world > 1: do not reject meshlets by the rank's owned screen region before stage B (parity A/B) */
 
 typedef struct zr_config {
     uint32_t width, height;   /* swapchain extent, ZE:78-79 (default 1920x1080) */
@@ -179,6 +187,12 @@ int  zr_read_gbuffer(zr_ctx* ctx, int target, void* dst, size_t bytes);
 int  zr_read_shadowmap(zr_ctx* ctx, float* dst, size_t bytes);        /* dim*dim*4 */
 
 /* --- multi-GPU screen-tile partition --- */
+/* Owner of tile (tx, ty) in a world of `world` ranks, and the list of tiles a rank owns in increasing tile index (= its slot order
+ * in the packed buffer); slots_per_rank = the largest count over all ranks (every rank contributes that many slots to the all-gather).
+ * Context-free; owned may be NULL. */
+uint32_t zr_tile_owner(uint32_t tx, uint32_t ty, uint32_t world);
+int  zr_tile_partition(uint32_t width, uint32_t height, uint32_t world, uint32_t rank, uint32_t* owned, uint32_t* n_owned,
+                       uint32_t* slots_per_rank);
 /* Shadow pass split: this context draws instances i % world == rank into its shadow map; the caller min-reduces the maps
  * (depth test LESS_OR_EQUAL = min) between zr_render_shadow and zr_render_lighting.  Default 0 / 1 = everything. */
 int  zr_set_shadow_partition(zr_ctx* ctx, uint32_t rank, uint32_t world);
@@ -193,6 +207,20 @@ int  zr_read_tiles(zr_ctx* ctx, uint8_t* dst, size_t bytes);             /* host
 /* Scatter the all-gathered buffer (tile_world * bytes_per_rank, rank-major, device pointer) into the frame. */
 int  zr_composite(zr_ctx* ctx, const void* gathered_dev);
 int  zr_color_device_ptr(zr_ctx* ctx, void** dev_ptr);
+
+/* --- native multi-GPU host: one process per GPU, RCCL over xGMI called by the library itself (no Python, no torch in the frame) ---
+ * rank 0 makes the id (zr_dist_unique_id: 128 bytes, ncclGetUniqueId) and hands it to the other ranks by any means; every rank then
+ * calls zr_dist_init on a context created with the matching tile_rank / tile_world.  zr_dist_frame enqueues one frame:
+ *   render stream + camera lane: the frame of this rank's tiles into packed buffer k & 1
+ *   collective stream: ncclAllGather of the packed RGBA8 tiles (4 B per pixel of the frame in total) -> untile into the frame,
+ *   overlapped with the rendering of frame k + 1 (buffers are double-buffered, ordering is by events).
+ * The all-gather of the composite is the ONLY collective, unless ZR_DIST_SPLIT_SHADOW is given: then each rank rasterises the shadow
+ * casters i % world == rank and the 1024^2 maps are reduced with ncclAllReduce(min) next to the camera passes.
+ * zr_finish / the read-back entry points wait for the collective stream too.  librccl is loaded on first use (dlopen). */
+#define ZR_DIST_SPLIT_SHADOW 1u
+int  zr_dist_unique_id(void* id, size_t bytes);                       /* bytes must be 128 */
+int  zr_dist_init(zr_ctx* ctx, const void* id, size_t bytes, uint32_t rank, uint32_t world, uint32_t dist_flags);
+int  zr_dist_frame(zr_ctx* ctx);
 
 /* --- world JSON + livelink (replaces XkWorld::Load ZE:1051-1147, socket thread ZE:1617-1710) --- */
 /* A Profab is the engine's asset bundle `Profabs/<name>/{models, textures}` (ZE:4922-5000).  Either the caller registers each

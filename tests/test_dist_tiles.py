@@ -14,15 +14,36 @@ from zeldaengine_amd import dist as zdist
 
 
 def test_layout_arithmetic():
-    lay = zdist.tile_layout(1920, 1080, 8)
-    assert lay == {"tiles_x": 60, "tiles_y": 34, "n_tiles": 2040, "slots_per_rank": 255}
-    lay = zdist.tile_layout(3840, 2160, 8)
-    assert lay["n_tiles"] == 8160 and lay["slots_per_rank"] == 1020
-    for world in (1, 2, 3, 4, 8):
-        owned = [zdist.owned_tiles(r, world, 2040) for r in range(world)]
-        assert sorted(sum(owned, [])) == list(range(2040))
-        assert max(map(len, owned)) - min(map(len, owned)) <= 1
-        assert all(len(o) <= zdist.tile_layout(1920, 1080, world)["slots_per_rank"] for o in owned)
+    lay = zdist.tile_layout(1920, 1080, 1)
+    assert lay == {"tiles_x": 60, "tiles_y": 34, "n_tiles": 2040, "slots_per_rank": 2040}
+    assert zdist.tile_layout(3840, 2160, 8)["n_tiles"] == 8160
+    for W, H in ((1920, 1080), (3840, 2160), (416, 250)):
+        tx, ty = (W + 31) // 32, (H + 31) // 32
+        for world in (1, 2, 3, 4, 8):
+            owned = [zdist.owned_tiles(r, world, tx, ty) for r in range(world)]
+            assert sorted(sum(owned, [])) == list(range(tx * ty))                     # a partition
+            lay = zdist.tile_layout(W, H, world)
+            assert max(map(len, owned)) == lay["slots_per_rank"]
+            if W >= 1920:     # super-tiles of 128 px: shares within 25 % of each other at the benchmark sizes
+                assert max(map(len, owned)) <= 1.25 * min(map(len, owned)), (W, H, world, list(map(len, owned)))
+            # neighbouring super-tiles go to different ranks (the skew keeps columns from lining up)
+            if world > 1:
+                assert zdist.tile_owner(0, 0, world) != zdist.tile_owner(4, 0, world)
+                assert world == 3 or zdist.tile_owner(0, 0, world) != zdist.tile_owner(0, 4, world)
+
+
+def test_python_partition_is_the_librarys():
+    """dist.py's numpy statement of the ownership and the C library's zr_tile_partition / zr_tile_owner must be one function."""
+    from zeldaengine_amd import engine
+    L = engine.lib()
+    for W, H in ((1920, 1080), (3840, 2160), (352, 208), (33, 31)):
+        tx, ty = (W + 31) // 32, (H + 31) // 32
+        for world in (1, 2, 3, 5, 8):
+            for r in range(world):
+                owned, spr = engine.tile_partition(W, H, world, r)
+                assert list(owned) == zdist.owned_tiles(r, world, tx, ty)
+                assert spr == zdist.tile_layout(W, H, world)["slots_per_rank"]
+            assert all(L.zr_tile_owner(x, y, world) == zdist.tile_owner(x, y, world) for x in range(0, tx, 3) for y in range(0, ty, 2))
 
 
 @pytest.mark.parametrize("shape", [(64, 64), (100, 70), (33, 31)])

@@ -262,3 +262,59 @@ def test_full_size_config3_against_the_oracle(oracle_lib, gpu_engine):
     h.render()
     assert np.array_equal(first[0], h.color()) and np.array_equal(first[2].view(np.uint32), h.shadowmap().view(np.uint32))
     assert h.stats()["survivors"][1] > st["survivors"][1]
+
+
+def test_owned_region_reject_keeps_the_frame_and_cuts_per_rank_work(gpu_engine):
+    """Super-tile ownership + the bounding-sphere reject of stage A: a rank transforms (stage B), bins and rasterises only what can
+    reach its own screen region.  The packed tiles must not change (reject on / off), and the per-rank survivor count must fall to
+    about 1 / world of the single-GPU count instead of staying at it."""
+    cfg = scenes.config3(3000, 1280, 720, 9.0)
+    single = gpu_engine.Renderer(cfg["width"], cfg["height"], 256, flags=abi.FLAG_NO_HIZ)
+    gpu_engine.load_scene(single, cfg)
+    single.render()
+    want = single.color()
+    total = single.stats()["survivors"][1]
+    world = 4
+    per_rank, per_rank_off = [], []
+    for r in range(world):
+        g = gpu_engine.Renderer(cfg["width"], cfg["height"], 256, tile_rank=r, tile_world=world, flags=abi.FLAG_NO_HIZ)
+        h = gpu_engine.Renderer(cfg["width"], cfg["height"], 256, tile_rank=r, tile_world=world, flags=abi.FLAG_NO_HIZ | abi.FLAG_NO_RECT_CULL)
+        for x in (g, h):
+            gpu_engine.load_scene(x, cfg)
+            x.render()
+        assert np.array_equal(g.read_tiles(), zdist.pack_tiles(want, r, world))
+        assert np.array_equal(g.read_tiles(), h.read_tiles())
+        per_rank.append(g.stats()["survivors"][1]); per_rank_off.append(h.stats()["survivors"][1])
+        g.close(); h.close()
+    # without the reject every rank carries every frustum / cone survivor through the vertex stage and the binning kernels ...
+    assert per_rank_off == [total] * world
+    # ... with it a meshlet stays on the one rank (rarely two: the bounding sphere is a loose fit) that owns its super-tile
+    assert total <= sum(per_rank) <= 1.45 * total, (total, per_rank)
+    assert max(per_rank) < 0.45 * total, (total, per_rank)
+
+
+def test_native_rccl_host_world_of_one(gpu_engine):
+    """zr_dist_* with a communicator of one rank: the library loads librccl itself, ncclCommInitRank / ncclAllGather run on the
+    hardware, and five pipelined frames (both halves of the double buffers) composite to the frame a plain context renders."""
+    cfg = scenes.config3(300, 416, 250)
+    single = gpu_engine.Renderer(cfg["width"], cfg["height"], 256)
+    gpu_engine.load_scene(single, cfg)
+    single.render()
+    want = single.color()
+    dr = zdist.NativeDistributedRenderer(cfg["width"], cfg["height"], 256, device_index=0, rank=0, world=1)
+    gpu_engine.load_scene(dr.r, cfg)
+    for _ in range(5):
+        dr.frame()
+    dr.synchronize()
+    assert np.array_equal(dr.r.color(), want)
+    assert np.array_equal(dr.r.read_tiles(), zdist.pack_tiles(want, 0, 1))
+    with pytest.raises(gpu_engine.ZeldaRenderError):
+        dr.r.dist_init(bytes(128), 0, 1)                  # already initialised
+    dr.close()
+    # a context without the packed path, or with the wrong rank, is refused before RCCL is touched
+    g = gpu_engine.Renderer(64, 64, 64)
+    with pytest.raises(gpu_engine.ZeldaRenderError):
+        g.dist_init(bytes(128), 0, 1)
+    with pytest.raises(gpu_engine.ZeldaRenderError):
+        g.dist_init(bytes(128), 1, 2)
+    g.close()

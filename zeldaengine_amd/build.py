@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libzelda_render.so")
-SOURCES = ["zr_kernels.hip", "zr_host.cpp", "zr_world.cpp", "zr_meshlet.cpp", "zr_assets.cpp"]
+SOURCES = ["zr_kernels.hip", "zr_host.cpp", "zr_world.cpp", "zr_meshlet.cpp", "zr_assets.cpp", "zr_dist.cpp"]
 HEADERS = ["zr_math.h", "zr_types.h", "zr_ctx.h", "zr_meshlet.h", "../../include/zelda_abi.h", "../../include/zelda_render.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__"]
@@ -61,7 +61,7 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
     except Exception:      # noqa: BLE001
         pass
     cmd = ["g++", "-shared", "-fPIC", "-o", out_path] + objs + ["-L" + hip_dir, "-l:libamdhip64.so", "-Wl,-rpath,/opt/rocm/lib",
-                                                                 "-Wl,--no-as-needed", "-lpthread", "-lz", "-lstdc++fs"]
+                                                                 "-Wl,--no-as-needed", "-lpthread", "-lz", "-lstdc++fs", "-ldl"]
     subprocess.check_call(cmd)
     return out_path
 

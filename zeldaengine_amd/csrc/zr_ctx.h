@@ -73,6 +73,8 @@ struct zr_ctx {
     uint32_t tiles_x = 0, tiles_y = 0, n_tiles = 0, n_owned = 0, slots_per_rank = 0;
     uint32_t stiles_x = 0, stiles_y = 0, sn_tiles = 0;
     uint32_t *d_owned = nullptr, *d_sowned = nullptr;
+    uint32_t* d_tile_map = nullptr;      // tile -> owner * slots_per_rank + slot (k_untile)
+    struct ZrDist* dist = nullptr;       // native multi-GPU host (zr_dist.cpp), or null
     GBufferPtrs G = {};
     float* d_shadow = nullptr; uint32_t* d_color = nullptr; uint32_t* d_tiles = nullptr;
     float* d_shadow_ext = nullptr;       // caller-owned shadow map (zr_set_shadow_buffer), or null
@@ -142,6 +144,9 @@ hipError_t zr_sync_all(zr_ctx* c);     // every stream the library enqueues on
 float zr_srgb_decode8(uint32_t c);
 int zr_material_prepare(zr_ctx* c, const zr_material* mat, ZrMaterialHost* out);
 int zr_object_add_internal(zr_ctx* c, uint32_t mesh_id, const ZrMaterialHost& mat, const XkInstanceData* inst, uint32_t n_inst);
+// zr_dist.cpp
+void zr_dist_destroy(zr_ctx* c);
+hipError_t zr_dist_sync(zr_ctx* c);
 // zr_assets.cpp
 std::string zr_asset_search(const zr_ctx* c, const std::string& name);
 int zr_profab_from_disk(zr_ctx* c, const std::string& name, int* found);

@@ -24,6 +24,7 @@ hipError_t zr_sync_all(zr_ctx* c)
 {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess && c->cam_s) e = hipStreamSynchronize(c->cam_s);
+    if (e == hipSuccess) e = zr_dist_sync(c);           // the native multi-GPU host's collective stream, if any
     return e;
 }
 
@@ -120,9 +121,19 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     c->tiles_x = (c->W + ZR_TILE - 1) / ZR_TILE; c->tiles_y = (c->H + ZR_TILE - 1) / ZR_TILE; c->n_tiles = c->tiles_x * c->tiles_y;
     c->stiles_x = (c->SD + ZR_TILE - 1) / ZR_TILE; c->stiles_y = c->stiles_x; c->sn_tiles = c->stiles_x * c->stiles_y;
     if (c->n_tiles > 16000u || c->sn_tiles > 16000u) { zr_destroy(c); return ZR_ERR_ARG; }   // binning histograms (4 B per tile, dynamic) + a few static words must fit the default 64 KB of LDS per workgroup
-    c->slots_per_rank = (c->n_tiles + c->cfg.tile_world - 1) / c->cfg.tile_world;
-    std::vector<uint32_t> owned, sowned(c->sn_tiles);
-    for (uint32_t t = c->cfg.tile_rank; t < c->n_tiles; t += c->cfg.tile_world) owned.push_back(t);
+    // tile ownership (zr_tile_owner): per rank the owned tiles in increasing index = its slots in the packed buffer
+    std::vector<uint32_t> owned, sowned(c->sn_tiles), tile_map(c->n_tiles), counts(c->cfg.tile_world, 0u);
+    for (uint32_t t = 0; t < c->n_tiles; ++t) {
+        const uint32_t o = zr_tile_owner(t % c->tiles_x, t / c->tiles_x, c->cfg.tile_world);
+        tile_map[t] = counts[o]++;                       // slot within its owner, for now
+        if (o == c->cfg.tile_rank) owned.push_back(t);
+    }
+    c->slots_per_rank = 0;
+    for (uint32_t n : counts) c->slots_per_rank = std::max(c->slots_per_rank, n);
+    for (uint32_t t = 0; t < c->n_tiles; ++t)
+        tile_map[t] += zr_tile_owner(t % c->tiles_x, t / c->tiles_x, c->cfg.tile_world) * c->slots_per_rank;
+    ok &= dev_alloc(&c->d_tile_map, tile_map.size()) == hipSuccess;
+    if (ok) ok &= hipMemcpy(c->d_tile_map, tile_map.data(), tile_map.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     for (uint32_t t = 0; t < c->sn_tiles; ++t) sowned[t] = t;
     c->n_owned = (uint32_t)owned.size();
     ok &= dev_alloc(&c->d_owned, owned.size()) == hipSuccess;
@@ -221,6 +232,7 @@ extern "C" void zr_destroy(zr_ctx* c)
     zr_livelink_stop(c);
     (void)hipSetDevice(c->device);
     (void)zr_sync_all(c);                      // including a geometry stage whose lighting pass never came
+    zr_dist_destroy(c);
     free_scene(c);
     free_mesh_buffers(c->sky_mesh); dev_free(c->sky_obj.d_inst); for (auto& t : c->sky_obj.d_tex) dev_free(t); dev_free(c->d_bg);
     for (auto p : c->d_cube) if (p) (void)hipFree(p);
@@ -230,7 +242,7 @@ extern "C" void zr_destroy(zr_ctx* c)
         dev_free(c->d_shadow_b[b]); dev_free(c->d_view_b[b]); dev_free(c->d_empty_b[b]);
     }
     dev_free(c->d_color); dev_free(c->d_stats); dev_free(c->d_lut); dev_free(c->d_unorm_lut);
-    dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles);
+    dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles); dev_free(c->d_tile_map);
     for (auto& sc : c->sc) {
         dev_free(sc.tile_count); dev_free(sc.tile_offset); dev_free(sc.tile_cursor); dev_free(sc.chunk_offset);
         dev_free(sc.rects); dev_free(sc.bins); dev_free(sc.work);
@@ -253,6 +265,28 @@ extern "C" void zr_destroy(zr_ctx* c)
 extern "C" const char* zr_last_error(const zr_ctx* c) { return c ? c->err.c_str() : "no context (no usable HIP device?)"; }
 
 extern "C" int zr_tile_size(void) { return ZR_TILE; }
+
+extern "C" uint32_t zr_tile_owner(uint32_t tx, uint32_t ty, uint32_t world)
+{
+    return world <= 1 ? 0u : ((tx >> ZR_SUPERTILE_SHIFT) + (ty >> ZR_SUPERTILE_SHIFT) * ZR_SUPERTILE_SKEW) % world;
+}
+
+extern "C" int zr_tile_partition(uint32_t width, uint32_t height, uint32_t world, uint32_t rank, uint32_t* owned, uint32_t* n_owned,
+                                 uint32_t* slots_per_rank)
+{
+    if (!width || !height || !world || rank >= world || !n_owned || !slots_per_rank) return ZR_ERR_ARG;
+    const uint32_t tx = (width + ZR_TILE - 1) / ZR_TILE, ty = (height + ZR_TILE - 1) / ZR_TILE;
+    std::vector<uint32_t> counts(world, 0u);
+    uint32_t n = 0;
+    for (uint32_t t = 0; t < tx * ty; ++t) {
+        const uint32_t o = zr_tile_owner(t % tx, t / tx, world);
+        counts[o]++;
+        if (o == rank) { if (owned) owned[n] = t; ++n; }
+    }
+    *n_owned = n; *slots_per_rank = 0;
+    for (uint32_t k : counts) *slots_per_rank = std::max(*slots_per_rank, k);
+    return ZR_OK;
+}
 
 extern "C" int zr_set_stream(zr_ctx* c, void* s)
 {
@@ -851,6 +885,16 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
     // the instance-level pre-pass pays for itself on big scenes; small ones go straight to one wave per meshlet-instance
     P->use_worklist = c->n_inst_total >= 65536u ? 1u : 0u;
     P->debug_skip = c->env_skip;
+    if (mode == ZR_MODE_GBUFFER && c->cfg.tile_world > 1 && !(c->cfg.flags & ZR_FLAG_NO_RECT_CULL) && ZR_TILE == 32) {
+        // the owned-region reject needs clip.x = p00 * x_view, clip.y = p11 * y_view, clip.w = -z_view and view-space radii = object radii
+        const float* pr = u.Proj;
+        const bool centred = pr[1] == 0 && pr[2] == 0 && pr[3] == 0 && pr[4] == 0 && pr[6] == 0 && pr[7] == 0 && pr[8] == 0 && pr[9] == 0 &&
+                             pr[11] == -1.0f && pr[12] == 0 && pr[13] == 0 && pr[15] == 0 && std::isfinite(pr[0]) && std::isfinite(pr[5]) &&
+                             pr[0] != 0 && pr[5] != 0;
+        zr_mat4_mul(u.View, u.Model, P->VM);
+        P->p00 = pr[0]; P->p11 = pr[5];
+        P->rect_cull = (centred && rigid3(u.Model) && rigid3(u.View) && finite16(P->VM)) ? 1u : 0u;
+    }
     {
         static const float ident[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
         P->m_identity = memcmp(u.Model, ident, 64) == 0 ? 1u : 0u;      // bitwise: a -0 entry would not do
@@ -1095,7 +1139,7 @@ static void light_params(const zr_ctx* c, ZrLightParams* Lp)
     zr_mat4_mul(Bias, c->view.ShadowmapSpace, L.SB);
     L.W = c->W; L.H = c->H; L.SD = c->SD; L.tiles_x = c->tiles_x; L.debug_view = c->debug_view;
     L.cube_dim = c->cube_dim; L.cube_levels = c->cube_levels; L.tile_world = c->cfg.tile_world;
-    L.packed_out = c->cfg.tile_world > 1 ? 1u : 0u;
+    L.packed_out = (c->cfg.tile_world > 1 || (c->cfg.flags & ZR_FLAG_PACKED_TILES)) ? 1u : 0u;
     L.debug_skip = c->env_skip_light;
     L.bg_enabled = (c->bg_set && c->bg_enabled) ? 1u : 0u;
     L.has_overlay = c->overlay_dirty[c->frame_no & 1u] ? 1u : 0u;      // set by this frame's gbuffer pass
@@ -1363,7 +1407,7 @@ extern "C" int zr_composite(zr_ctx* c, const void* gathered)
     if (!c) return ZR_ERR_ARG;
     ARGCHK(c, gathered != nullptr);
     HIPCHK(c, hipSetDevice(c->device));
-    zr_launch_untile((const uint32_t*)gathered, c->d_color, c->W, c->H, c->tiles_x, c->n_tiles, c->cfg.tile_world, c->slots_per_rank, c->stream);
+    zr_launch_untile((const uint32_t*)gathered, c->d_tile_map, c->d_color, c->W, c->H, c->tiles_x, c->n_tiles, c->stream);
     HIPCHK(c, hipGetLastError());
     return ZR_OK;
 }

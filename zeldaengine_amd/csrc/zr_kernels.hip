@@ -111,6 +111,12 @@ __device__ __forceinline__ SV project(zf4 c, float hw, float hh)
     return s;
 }
 
+// Multi-GPU ownership of a tile (zelda_render.h: zr_tile_owner)
+__device__ __forceinline__ uint32_t tile_owner(uint32_t tx, uint32_t ty, uint32_t world)
+{
+    return ((tx >> ZR_SUPERTILE_SHIFT) + (ty >> ZR_SUPERTILE_SHIFT) * ZR_SUPERTILE_SKEW) % world;
+}
+
 __device__ __forceinline__ int imin3(int a, int b, int c) { return min(a, min(b, c)); }
 __device__ __forceinline__ int imax3(int a, int b, int c) { return max(a, max(b, c)); }
 
@@ -181,6 +187,39 @@ __device__ __forceinline__ int find_object_inst(const ZrObject* __restrict__ obj
     return lo;
 }
 
+// Multi-GPU: can a bounding sphere (centre `co` after the instance transform, radius ri there) reach a tile this rank owns?
+// View space: centre (x, y, -d), radius r, d > r (the eye is outside, the whole sphere in front of it).  In the x-d plane the lines
+// through the eye tangent to the circle have slopes (x d +- r sqrt(x^2 + d^2 - r^2)) / (d^2 - r^2): every point of the sphere
+// projects between them; ndc = Proj[0][0] * slope (Proj[1][1] for y).  Conservative: the radius is rounded up, a slack covers the
+// arithmetic here and in the rasteriser's own transform, the pixel range gets a margin of one.  "true" whenever in doubt.
+__device__ __forceinline__ bool sphere_reaches_owned_tile(const ZrPass& P, zf3 co, float ri)
+{
+    const zf4 cv = zr_mat4_point(P.VM, co);
+    const float d = -cv.z;
+    const float r = __builtin_fmaf(ri, 1.003f, 1e-6f * (__builtin_fabsf(cv.x) + __builtin_fabsf(cv.y) + __builtin_fabsf(d)) + 1e-30f);
+    const float den = __builtin_fmaf(d, d, -(r * r));
+    if (!(d > r && den > 0.0f && d < 3.0e18f)) return true;
+    const float tx = r * __builtin_sqrtf(__builtin_fmaxf(__builtin_fmaf(cv.x, cv.x, den), 0.0f));
+    const float ty = r * __builtin_sqrtf(__builtin_fmaxf(__builtin_fmaf(cv.y, cv.y, den), 0.0f));
+    const float ax = ((cv.x * d - tx) / den) * P.p00, bx = ((cv.x * d + tx) / den) * P.p00;
+    const float ay = ((cv.y * d - ty) / den) * P.p11, by = ((cv.y * d + ty) / den) * P.p11;
+    float nx0 = __builtin_fminf(ax, bx), nx1 = __builtin_fmaxf(ax, bx), ny0 = __builtin_fminf(ay, by), ny1 = __builtin_fmaxf(ay, by);
+    const float sl = 1e-5f;
+    nx0 -= sl * (1.0f + __builtin_fabsf(nx0)); nx1 += sl * (1.0f + __builtin_fabsf(nx1));
+    ny0 -= sl * (1.0f + __builtin_fabsf(ny0)); ny1 += sl * (1.0f + __builtin_fabsf(ny1));
+    const float sx0 = __builtin_fmaf(nx0, P.hw, P.hw), sx1 = __builtin_fmaf(nx1, P.hw, P.hw);
+    const float sy0 = __builtin_fmaf(ny0, P.hh, P.hh), sy1 = __builtin_fmaf(ny1, P.hh, P.hh);
+    if (!(sx0 >= -1.0e9f && sx1 <= 1.0e9f && sy0 >= -1.0e9f && sy1 <= 1.0e9f)) return true;      // NaN or huge
+    const int px0 = max(0, (int)__builtin_floorf(sx0) - 1), px1 = min((int)P.W - 1, (int)__builtin_floorf(sx1) + 1);
+    const int py0 = max(0, (int)__builtin_floorf(sy0) - 1), py1 = min((int)P.H - 1, (int)__builtin_floorf(sy1) + 1);
+    if (px0 > px1 || py0 > py1) return false;                                                    // off the target altogether
+    const uint32_t sh = 5u + ZR_SUPERTILE_SHIFT;      // TILE == 32 pixels: pixel -> super-tile (checked where rect_cull is set)
+    for (uint32_t sy = (uint32_t)py0 >> sh; sy <= (uint32_t)py1 >> sh; ++sy)
+        for (uint32_t sx = (uint32_t)px0 >> sh; sx <= (uint32_t)px1 >> sh; ++sx)
+            if ((sx + sy * ZR_SUPERTILE_SKEW) % P.tile_world == P.tile_rank) return true;
+    return false;
+}
+
 // Level 1 of the cull hierarchy: one lane per instance, whole-mesh bounding sphere against the frustum (same inflated
 // bounds as the meshlet test, so it is conservative).  The meshlet-instances of the surviving instances are appended to
 // work[]; one atomic per wave reserves the range.  Also applies the shadow-pass filters (skydome, instance partition).
@@ -197,18 +236,20 @@ __global__ __launch_bounds__(256) void k_cull_instances(ZrPass P, const ZrObject
         // the skydome is not a shadow caster (ZE:4709-4720); with N GPUs each draws every N-th instance into its own copy of
         // the shadow map and the copies are min-reduced (depth test LESS_OR_EQUAL is a min, so the split is exact)
         if (MODE == ZR_MODE_SHADOW && ((O->flags & ZR_OBJ_SKY) || inst_i % P.inst_world != P.inst_rank)) vis = false;
-        if (vis && P.frustum_ok) {
+        if (vis && (P.frustum_ok | P.rect_cull)) {
             const ZrInstance I = O->inst[inst_i];
             const bool instanced = O->instanced != 0;
             const zf3 co = vs_position(zr3(O->mesh_center[0], O->mesh_center[1], O->mesh_center[2]), I, instanced);
             const zf4 cw4 = zr_mat4_point(P.M, co);
             float rw = O->mesh_radius * (instanced ? __builtin_fabsf(I.s) : 1.0f) * P.m_scale;
             rw = __builtin_fmaf(rw, 1.001f, 1e-5f * (__builtin_fabsf(cw4.x) + __builtin_fabsf(cw4.y) + __builtin_fabsf(cw4.z) + 1.0f));
-            for (int k = 0; k < 6; ++k) {
+            for (int k = 0; k < 6 && P.frustum_ok; ++k) {
                 const float d = __builtin_fmaf(P.planes[k][0], cw4.x, __builtin_fmaf(P.planes[k][1], cw4.y,
                                 __builtin_fmaf(P.planes[k][2], cw4.z, P.planes[k][3])));
                 if (d < -rw) vis = false;
             }
+            if (vis && MODE == ZR_MODE_GBUFFER && P.rect_cull &&
+                !sphere_reaches_owned_tile(P, co, O->mesh_radius * (instanced ? __builtin_fabsf(I.s) : 1.0f))) vis = false;
         }
         if (vis) { nm = O->n_meshlets; wbase = O->work_base + inst_i * nm; }
     }
@@ -276,7 +317,7 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
             instanced = O->instanced != 0 ? 1u : 0u;
             // the skydome is not a shadow caster (ZE:4709-4720); with N GPUs each draws every N-th instance (see k_cull_instances)
             if (MODE == ZR_MODE_SHADOW && ((O->flags & ZR_OBJ_SKY) || inst_i % P.inst_world != P.inst_rank)) alive = false;
-            if (alive && (P.frustum_ok | P.cone_ok)) {
+            if (alive && (P.frustum_ok | P.cone_ok | P.rect_cull)) {
                 const zf3 co = vs_position(zr3(bs.x, bs.y, bs.z), I, instanced != 0);
                 const zf4 cw4 = zr_mat4_point(P.M, co);
                 const zf3 cw = zr3(cw4.x, cw4.y, cw4.z);
@@ -301,6 +342,9 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
                     const float L = zr_length(d);
                     if (zr_dot(d, aw) >= __builtin_fmaf(cn.w + 0.02f, L, rw)) alive = false;
                 }
+                // multi-GPU: nothing of this meshlet can land on a tile this rank owns -> no vertex of it is transformed here
+                if (alive && MODE == ZR_MODE_GBUFFER && P.rect_cull &&
+                    !sphere_reaches_owned_tile(P, co, bs.w * (instanced ? __builtin_fabsf(I.s) : 1.0f))) alive = false;
             }
         }
         uint32_t out_rect = ZR_RECT_CULLED; uint2 out_px = make_uint2(0u, 0u); float out_z = -1.0f;
@@ -394,7 +438,7 @@ __global__ __launch_bounds__(256) void k_hiz_build(const unsigned long long* __r
         const uint32_t px = rx * 64u + bx * 8u + (i & 7u), py = ry * 64u + by * 8u + q * 2u + (i >> 3);
         if (px < W && py < H) {
             // a tile of another rank never receives a fragment here: it must not keep the meshlets that straddle it alive
-            const bool mine = Z.tile_world <= 1u || ((py / TILE) * Z.tiles_x + px / TILE) % Z.tile_world == Z.tile_rank;
+            const bool mine = Z.tile_world <= 1u || tile_owner(px / TILE, py / TILE, Z.tile_world) == Z.tile_rank;
             if (mine) m = __builtin_fmaxf(m, zr_u2f((uint32_t)(vis64[(size_t)py * W + px] >> 32)));
             any = true;
         }
@@ -496,7 +540,7 @@ __global__ __launch_bounds__(1024) void k_bin_count(ZrPass P, const uint32_t* __
             for (uint32_t ty = ty0; ty <= ty1; ++ty)
                 for (uint32_t tx = tx0; tx <= tx1; ++tx) {
                     const uint32_t t = ty * P.tiles_x + tx;
-                    if (t % P.tile_world == P.tile_rank && !tile_hides(Z, zt, t)) atomicAdd(&hist[t], 1u);
+                    if (tile_owner(tx, ty, P.tile_world) == P.tile_rank && !tile_hides(Z, zt, t)) atomicAdd(&hist[t], 1u);
                 }
         }
     }
@@ -581,7 +625,7 @@ __global__ __launch_bounds__(1024) void k_bin_fill(ZrPass P, const ZrObject* __r
         for (uint32_t ty = ty0; ty <= ty1; ++ty)
             for (uint32_t tx = tx0; tx <= tx1; ++tx) {
                 const uint32_t t = ty * P.tiles_x + tx;
-                if (t % P.tile_world == P.tile_rank && !tile_hides(Z, zt, t)) atomicAdd(&hist[t], 1u);
+                if (tile_owner(tx, ty, P.tile_world) == P.tile_rank && !tile_hides(Z, zt, t)) atomicAdd(&hist[t], 1u);
             }
     }
     __syncthreads();
@@ -604,7 +648,7 @@ __global__ __launch_bounds__(1024) void k_bin_fill(ZrPass P, const ZrObject* __r
         for (uint32_t ty = ty0; ty <= ty1; ++ty)
             for (uint32_t tx = tx0; tx <= tx1; ++tx) {
                 const uint32_t t = ty * P.tiles_x + tx;
-                if (t % P.tile_world != P.tile_rank || tile_hides(Z, zt, t)) continue;
+                if (tile_owner(tx, ty, P.tile_world) != P.tile_rank || tile_hides(Z, zt, t)) continue;
                 const uint32_t pos = atomicAdd(&hist[t], 1u);
                 if (pos < P.bin_capacity) bins[pos] = be;
             }
@@ -1809,15 +1853,13 @@ __global__ __launch_bounds__(256) void k_gbuffer_vis(ZrLightParams L, const XkVi
     out[(size_t)py * L.W + px] = zr_unorm(o.x, 255.0f) | zr_unorm(o.y, 255.0f) << 8 | zr_unorm(o.z, 255.0f) << 16 | 255u << 24;
 }
 
-// Multi-GPU composite: gathered[rank][slot][TILE_PIX] (slot = tile / world for tiles with tile % world == rank) -> frame
-__global__ __launch_bounds__(256) void k_untile(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ frame,
-                                                uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
-                                                uint32_t world, uint32_t slots_per_rank)
+// Multi-GPU composite: gathered[rank][slot][TILE_PIX] -> frame; tile_map[t] = owner * slots_per_rank + slot of tile t
+__global__ __launch_bounds__(256) void k_untile(const uint32_t* __restrict__ gathered, const uint32_t* __restrict__ tile_map,
+                                                uint32_t* __restrict__ frame, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles)
 {
     const uint32_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
-    const uint32_t rank = tile % world, slot = tile / world;
-    const uint32_t* src = gathered + ((size_t)rank * slots_per_rank + slot) * TILE_PIX;
+    const uint32_t* src = gathered + (size_t)tile_map[tile] * TILE_PIX;
     const uint32_t tx0 = (tile % tiles_x) * TILE, ty0 = (tile / tiles_x) * TILE;
     for (uint32_t i = threadIdx.x; i < TILE_PIX; i += 256u) {
         const uint32_t px = tx0 + (i & (TILE - 1)), py = ty0 + i / TILE;
@@ -1929,8 +1971,8 @@ void zr_launch_gbuffer_vis(const ZrLightParams& L, const XkView* view, const GBu
 {
     hipLaunchKernelGGL(k_gbuffer_vis, dim3((L.W + 15) / 16, (L.H + 15) / 16), dim3(256), 0, s, L, view, G, shadowmap, C, lut, out);
 }
-void zr_launch_untile(const uint32_t* gathered, uint32_t* frame, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
-                      uint32_t world, uint32_t slots_per_rank, hipStream_t s)
+void zr_launch_untile(const uint32_t* gathered, const uint32_t* tile_map, uint32_t* frame, uint32_t W, uint32_t H, uint32_t tiles_x,
+                      uint32_t n_tiles, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_untile, dim3(n_tiles), dim3(256), 0, s, gathered, frame, W, H, tiles_x, n_tiles, world, slots_per_rank);
+    hipLaunchKernelGGL(k_untile, dim3(n_tiles), dim3(256), 0, s, gathered, tile_map, frame, W, H, tiles_x, n_tiles);
 }

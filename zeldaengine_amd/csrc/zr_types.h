@@ -85,7 +85,12 @@ struct ZrPass {
     float hw, hh;                    // half extent of the target in pixels
     uint32_t W, H;                   // target extent
     uint32_t tiles_x, tiles_y;
-    uint32_t tile_rank, tile_world;  // this device owns tiles with t % tile_world == tile_rank
+    uint32_t tile_rank, tile_world;  // this device owns the tiles whose zr_tile_owner(tx, ty, tile_world) == tile_rank (super-tiles of
+                                     // (1 << ZR_SUPERTILE_SHIFT)^2 tiles, skewed round-robin: see zelda_render.h)
+    uint32_t rect_cull;              // camera pass, tile_world > 1: reject meshlets (instances) whose bounding sphere cannot reach an owned
+                                     // tile, before any vertex is transformed (needs the engine's centred perspective and rigid view * model)
+    float    VM[16];                 // view * model (rect_cull)
+    float    p00, p11;               // Proj[0][0], Proj[1][1] (rect_cull)
     uint32_t inst_rank, inst_world;  // shadow pass only: this device draws instances with i % inst_world == inst_rank
     uint32_t n_objects, n_work;
     uint32_t n_inst_total;           // instances over all draws
@@ -179,5 +184,5 @@ void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32
                         uint32_t* out, hipStream_t s);
 void zr_launch_gbuffer_vis(const ZrLightParams& L, const XkView* view, const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C,
                            const float* lut, uint32_t* out, hipStream_t s);
-void zr_launch_untile(const uint32_t* gathered, uint32_t* frame, uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t n_tiles,
-                      uint32_t world, uint32_t slots_per_rank, hipStream_t s);
+void zr_launch_untile(const uint32_t* gathered, const uint32_t* tile_map, uint32_t* frame, uint32_t W, uint32_t H, uint32_t tiles_x,
+                      uint32_t n_tiles, hipStream_t s);

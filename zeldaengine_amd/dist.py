@@ -1,14 +1,17 @@
 """Screen-tile data parallelism across the GPUs of one node.
 
-The frame is cut into 32x32 tiles; tile t belongs to rank t % world.  Every rank holds the whole scene, culls and bins
-against its own tiles only, and lights its tiles into a packed, tile-major RGBA8 buffer.  Per frame there are two RCCL
-collectives over xGMI:
+The frame is cut into 32x32 tiles, owned in super-tiles of 4 x 4 tiles (128 x 128 pixels) dealt round-robin with a skew
+(`tile_owner` = zr_tile_owner): a meshlet nearly always falls to ONE rank, and only that rank transforms it.  Every rank holds the
+whole scene, rejects what cannot reach its region before any vertex work, bins against its own tiles only, and lights its tiles
+into a packed, tile-major RGBA8 buffer.  Collectives over xGMI per frame:
 
-* shadow map: rank r rasterises instances i % world == r into its own 1024^2 map and the maps are all-reduced with MIN
-  (4 MB; the depth test LESS_OR_EQUAL is a min, so the split is exact).  It runs on the collective stream while the library's
-  own stream does the camera cull + raster + GBuffer write, which do not need the shadow map (zr_render_geometry /
-  zr_stream_wait_shadow); `split_shadow=False` renders the whole map on every rank instead (no shadow collective);
-* composite: an all-gather of the packed tiles (4 B/pixel in total) followed by an untile kernel gives every rank the frame.
+* composite: an all-gather of the packed tiles (4 B/pixel in total) followed by an untile kernel gives every rank the frame.  By
+  default this is the ONLY collective (every rank renders the whole 1024^2 shadow map);
+* `split_shadow=True` adds one: rank r rasterises instances i % world == r into its own map and the maps are all-reduced with MIN
+  (4 MB; the depth test LESS_OR_EQUAL is a min, so the split is exact), on the collective stream next to the camera passes.
+
+`NativeDistributedRenderer` runs that loop inside the library (zr_dist_frame: RCCL called from C++, nothing of Python or torch in the
+frame); `DistributedRenderer` is the same loop spelled with torch.distributed (any backend: the gloo tests use it).
 
 Streams: the render stream (shadow share, lighting) and the library's camera lane produce frame k+1 while the collective
 stream gathers and composites frame k (packed and gathered buffers are double-buffered, ordering is by events), so the xGMI
@@ -20,24 +23,33 @@ gloo tests use them, the GPU path uses the kernels.
 import numpy as np
 
 TILE = 32
+SUPERTILE_SHIFT = 2      # ZR_SUPERTILE_SHIFT: ownership unit = 4 x 4 tiles = 128 x 128 pixels
+SUPERTILE_SKEW = 3       # ZR_SUPERTILE_SKEW
+
+
+def tile_owner(tx, ty, world):
+    """zr_tile_owner: super-tiles dealt round-robin along x, skewed per super-tile row."""
+    return ((tx >> SUPERTILE_SHIFT) + (ty >> SUPERTILE_SHIFT) * SUPERTILE_SKEW) % world if world > 1 else 0
+
+
+def owned_tiles(rank, world, tiles_x, tiles_y):
+    """Tile indices a rank owns, increasing (= its slot order in the packed buffer)."""
+    return [t for t in range(tiles_x * tiles_y) if tile_owner(t % tiles_x, t // tiles_x, world) == rank]
 
 
 def tile_layout(width, height, world):
     tx, ty = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
     n = tx * ty
-    return {"tiles_x": tx, "tiles_y": ty, "n_tiles": n, "slots_per_rank": (n + world - 1) // world}
-
-
-def owned_tiles(rank, world, n_tiles):
-    return list(range(rank, n_tiles, world))
+    return {"tiles_x": tx, "tiles_y": ty, "n_tiles": n,
+            "slots_per_rank": max(len(owned_tiles(r, world, tx, ty)) for r in range(world))}
 
 
 def pack_tiles(frame, rank, world):
-    """frame (H, W, 4) uint8 -> (slots_per_rank, 32, 32, 4): slot k holds tile rank + k * world, zero padded."""
+    """frame (H, W, 4) uint8 -> (slots_per_rank, 32, 32, 4): slot k holds the rank's k-th owned tile, zero padded."""
     H, W = frame.shape[:2]
     lay = tile_layout(W, H, world)
     out = np.zeros((lay["slots_per_rank"], TILE, TILE, 4), dtype=np.uint8)
-    for k, t in enumerate(owned_tiles(rank, world, lay["n_tiles"])):
+    for k, t in enumerate(owned_tiles(rank, world, lay["tiles_x"], lay["tiles_y"])):
         x0, y0 = (t % lay["tiles_x"]) * TILE, (t // lay["tiles_x"]) * TILE
         blk = frame[y0:y0 + TILE, x0:x0 + TILE]
         out[k, :blk.shape[0], :blk.shape[1]] = blk
@@ -49,11 +61,11 @@ def untile(gathered, width, height):
     world = gathered.shape[0]
     lay = tile_layout(width, height, world)
     frame = np.zeros((height, width, 4), dtype=np.uint8)
-    for t in range(lay["n_tiles"]):
-        x0, y0 = (t % lay["tiles_x"]) * TILE, (t // lay["tiles_x"]) * TILE
-        blk = gathered[t % world, t // world]
-        h, w = min(TILE, height - y0), min(TILE, width - x0)
-        frame[y0:y0 + h, x0:x0 + w] = blk[:h, :w]
+    for r in range(world):
+        for k, t in enumerate(owned_tiles(r, world, lay["tiles_x"], lay["tiles_y"])):
+            x0, y0 = (t % lay["tiles_x"]) * TILE, (t // lay["tiles_x"]) * TILE
+            h, w = min(TILE, height - y0), min(TILE, width - x0)
+            frame[y0:y0 + h, x0:x0 + w] = gathered[r, k][:h, :w]
     return frame
 
 
@@ -141,3 +153,33 @@ def make_distributed(width, height, shadow_dim=1024, device_index=0, rank=0, wor
     if native and world > 1:
         return NativeDistributedRenderer(width, height, shadow_dim, device_index, rank, world, flags, split_shadow)
     return DistributedRenderer(width, height, shadow_dim, device_index, rank, world, flags, split_shadow=split_shadow)
+
+
+class NativeDistributedRenderer:
+    """One rank of the partition with the library's own RCCL host (zr_dist_*).  torch.distributed (already initialised when
+    world > 1) is used ONCE, to hand rank 0's ncclUniqueId to the other ranks; frames are enqueued by one C call each."""
+
+    def __init__(self, width, height, shadow_dim=1024, device_index=0, rank=0, world=1, flags=0, split_shadow=False):
+        import torch
+        from . import abi, engine
+        self.torch = torch
+        self.rank, self.world = rank, world
+        if world == 1:
+            flags |= abi.FLAG_PACKED_TILES
+        self.r = engine.Renderer(width, height, shadow_dim, device=device_index, tile_rank=rank, tile_world=world, flags=flags)
+        uid = engine.dist_unique_id() if rank == 0 else bytes(128)
+        if world > 1:
+            import torch.distributed as dist
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+        self.r.dist_init(uid, rank, world, split_shadow)
+
+    def frame(self):
+        self.r.dist_frame()
+
+    def synchronize(self):
+        self.r.finish()
+
+    def close(self):
+        self.r.close()

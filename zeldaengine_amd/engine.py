@@ -79,6 +79,10 @@ def lib():
         "zr_set_tiles_buffer": [vp, vp],
         "zr_tile_size": [],
         "zr_color_device_ptr": [vp, C.POINTER(vp)],
+        "zr_tile_partition": [u32, u32, u32, u32, vp, C.POINTER(u32), C.POINTER(u32)],
+        "zr_dist_unique_id": [vp, sz],
+        "zr_dist_init": [vp, vp, sz, u32, u32, u32],
+        "zr_dist_frame": [vp],
         "zr_profab_register": [vp, C.c_char_p, u32, vp],
         "zr_world_load_json": [vp, C.c_char_p, sz],
         "zr_set_asset_root": [vp, C.c_char_p],
@@ -102,6 +106,8 @@ def lib():
         f = getattr(L, name)
         f.argtypes = args
         f.restype = C.c_int
+    L.zr_tile_owner.argtypes = [u32, u32, u32]
+    L.zr_tile_owner.restype = u32
     L.zr_destroy.argtypes = [vp]
     L.zr_destroy.restype = None
     L.zr_last_error.argtypes = [vp]
@@ -162,6 +168,27 @@ def load_png_rgba8(path):
     if rc:
         raise ZeldaRenderError(rc, "zr_load_png_rgba8(%s)" % path)
     return out
+
+
+def tile_partition(width, height, world, rank):
+    """The library's own statement of the multi-GPU tile ownership (host code only) -> (owned tile indices, slots_per_rank)."""
+    L = lib()
+    n, spr = C.c_uint32(), C.c_uint32()
+    rc = L.zr_tile_partition(width, height, world, rank, None, C.byref(n), C.byref(spr))
+    if rc:
+        raise ZeldaRenderError(rc, "zr_tile_partition")
+    owned = np.zeros(n.value, dtype=np.uint32)
+    L.zr_tile_partition(width, height, world, rank, _ptr(owned), C.byref(n), C.byref(spr))
+    return owned, spr.value
+
+
+def dist_unique_id():
+    """ncclGetUniqueId through the library (128 bytes); rank 0 makes it, every rank passes it to Renderer.dist_init."""
+    buf = C.create_string_buffer(128)
+    rc = lib().zr_dist_unique_id(buf, 128)
+    if rc:
+        raise ZeldaRenderError(rc, "zr_dist_unique_id (librccl not loadable?)")
+    return buf.raw
 
 
 def world_json_normalize(text):
@@ -423,6 +450,14 @@ class Renderer:
         p = C.c_void_p()
         self._chk(self.L.zr_color_device_ptr(self.h, C.byref(p)))
         return p.value
+
+    def dist_init(self, unique_id, rank, world, split_shadow=False):
+        """Native multi-GPU host: the library calls RCCL itself (zr_dist_frame = render + all-gather + composite)."""
+        self._dist_id = bytes(unique_id)
+        self._chk(self.L.zr_dist_init(self.h, self._dist_id, len(self._dist_id), rank, world, 1 if split_shadow else 0))
+
+    def dist_frame(self):
+        self._chk(self.L.zr_dist_frame(self.h))
 
     # ---- world / livelink
     def profab_register(self, name, mesh, material=None):
