@@ -245,7 +245,7 @@ extern "C" void zr_destroy(zr_ctx* c)
     dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles); dev_free(c->d_tile_map);
     for (auto& sc : c->sc) {
         dev_free(sc.tile_count); dev_free(sc.tile_offset); dev_free(sc.tile_cursor); dev_free(sc.chunk_offset);
-        dev_free(sc.rects); dev_free(sc.bins); dev_free(sc.work);
+        dev_free(sc.rects); dev_free(sc.bins); dev_free(sc.work); dev_free(sc.chunk_tab);
     }
     dev_free(c->d_clear_px);
     if (c->h_view_ring) (void)hipHostFree(c->h_view_ring);
@@ -631,15 +631,17 @@ static int finalize_scene(zr_ctx* c)
     HIPCHK(c, upload(&c->d_objs, tab));
     c->n_objs = (uint32_t)tab.size(); c->n_work = (uint32_t)work; c->n_inst_total = (uint32_t)inst_total;
     if (c->n_work > c->work_capacity) {
-        for (auto& sc : c->sc) { dev_free(sc.rects); dev_free(sc.bins); dev_free(sc.work); }
+        for (auto& sc : c->sc) { dev_free(sc.rects); dev_free(sc.bins); dev_free(sc.work); dev_free(sc.chunk_tab); }
         dev_free(c->d_pxrect); dev_free(c->d_zmin); dev_free(c->d_visflag[0]); dev_free(c->d_visflag[1]);
         c->work_capacity = c->n_work;
         const uint64_t cap = std::max<uint64_t>(1u << 20, 8ull * c->n_work);
         c->bin_capacity = (uint32_t)std::min<uint64_t>(cap, 0x3FFFFFFFull);
+        c->chunk_capacity = c->bin_capacity / ZR_CHUNK + std::max(c->n_tiles, c->sn_tiles) + 1u;
         for (auto& sc : c->sc) {
             HIPCHK(c, dev_alloc(&sc.rects, c->work_capacity));
             HIPCHK(c, dev_alloc(&sc.work, c->work_capacity));
             HIPCHK(c, dev_alloc(&sc.bins, c->bin_capacity));
+            HIPCHK(c, dev_alloc(&sc.chunk_tab, c->chunk_capacity));
         }
         HIPCHK(c, dev_alloc(&c->d_pxrect, c->work_capacity)); HIPCHK(c, dev_alloc(&c->d_zmin, c->work_capacity));
         HIPCHK(c, dev_alloc(&c->d_visflag[0], c->work_capacity)); HIPCHK(c, dev_alloc(&c->d_visflag[1], c->work_capacity));
@@ -942,13 +944,13 @@ static void bin_and_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot,
 {
     const zr_ctx::Scratch& sc = c->sc[slot ? 1 : 0];
     zr_launch_bin_count(P, sc.work, sc.rects, sc.tile_count, Z, c->d_stats, slot, s);
-    zr_launch_scan(sc.tile_count, sc.tile_offset, sc.tile_cursor, sc.chunk_offset, n_tiles, c->bin_capacity, c->d_stats, slot, s);
+    zr_launch_scan(sc.tile_count, sc.tile_offset, sc.tile_cursor, sc.chunk_offset, sc.chunk_tab, c->chunk_capacity, n_tiles, c->bin_capacity, c->d_stats, slot, s);
     zr_launch_bin_fill(P, c->d_objs, sc.work, sc.rects, sc.tile_offset, sc.tile_cursor, sc.bins, Z, c->d_stats, slot, s);
 }
 static void raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s)
 {
     const zr_ctx::Scratch& sc = c->sc[slot ? 1 : 0];
-    zr_launch_raster_chunks(P, c->d_objs, sc.tile_offset, sc.chunk_offset, sc.bins, c->d_stats, slot, c->d_vis,
+    zr_launch_raster_chunks(P, c->d_objs, sc.chunk_tab, sc.bins, c->d_stats, slot, c->d_vis,
                             (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), c->raster_blocks, Z, s);
 }
 

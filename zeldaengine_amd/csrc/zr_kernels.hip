@@ -31,6 +31,9 @@
 #define QCAP 128u
 #define RW (ZR_TILE >= 64 ? 8 : 4)          // waves per rasteriser workgroup: one 64x64 tile's keys (32 KB) are shared by 8 waves
 #define RTHREADS (RW * WAVE)
+#ifndef ZR_RASTER_WAVES
+#define ZR_RASTER_WAVES 5                    // waves per SIMD the tile rasteriser is compiled for (it waits on dependent loads: see k_raster_chunks)
+#endif
 // Diagnostic work-skipping switches (attribution of kernel time) exist only in -DZR_DIAG builds: the product library has none.
 #ifdef ZR_DIAG
 #define ZR_DIAG_SKIP(x) (x)
@@ -560,6 +563,7 @@ __global__ __launch_bounds__(1024) void k_bin_count(ZrPass P, const uint32_t* __
 // into chunk_offset[0..n]; zeroes tile_count and tile_cursor for the fill and resets the chunk work counter.
 __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
                                                uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ chunk_offset,
+                                               uint4* __restrict__ chunk_tab, uint32_t chunk_cap,
                                                uint32_t n, uint32_t capacity, ZrDevStats* __restrict__ stats, int slot)
 {
     __shared__ uint32_t part[1024];
@@ -580,15 +584,19 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
     uint32_t run = part[tid] - s, crun = cpart[tid] - cs;
     for (uint32_t i = b; i < e; ++i) {
         const uint32_t c = tile_count[i];
-        tile_offset[i] = run; run += c;
-        chunk_offset[i] = crun; crun += (c + ZR_CHUNK - 1u) / ZR_CHUNK;
+        tile_offset[i] = run;
+        chunk_offset[i] = crun;
+        // one record per raster work unit: (tile, first entry, end): the rasteriser finds its chunk with one load, not a search
+        for (uint32_t k = 0; k * ZR_CHUNK < c; ++k)
+            if (crun + k < chunk_cap) chunk_tab[crun + k] = make_uint4(i, run + k * ZR_CHUNK, run + min(c, (k + 1u) * ZR_CHUNK), 0u);
+        run += c; crun += (c + ZR_CHUNK - 1u) / ZR_CHUNK;
         tile_count[i] = 0; tile_cursor[i] = 0;
     }
     if (tid == 1023) {
         tile_offset[n] = part[1023];
         chunk_offset[n] = cpart[1023];
         stats->bin_entries[slot] = part[1023];
-        stats->n_chunks[slot] = cpart[1023];
+        stats->n_chunks[slot] = min(cpart[1023], chunk_cap);
         stats->chunk_counter[slot] = 0;
         if (part[1023] > capacity) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
     }
@@ -717,16 +725,20 @@ __device__ __forceinline__ void shade_key(int x, int y, float fy, const SV& v0, 
 //   SHADOW : key = biased depth bits,        ds_min_u32  == depth test LESS_OR_EQUAL, depth write only
 // Coverage is exact integer arithmetic (edge functions of the snapped vertices, top-left rule as a -1 bias); the
 // 32-bit loop is taken when every edge value met while walking the clipped bounding box fits, and is bit-identical.
-template <int MODE>
+// SMALL: every lane's triangle is small (every edge component below 2^14 sub-pixel units = 64 px) and given in TILE-RELATIVE
+// coordinates.  The whole setup then stays in 32 bits: the clipped box lies in the tile, so |P - v| < 2^14 + 2^13 for every corner P of
+// the walk and vertex v, an edge value is a difference of two products below 1.5 * 2^28 (|E| < 2^29.6 at the box origin), and the walk
+// adds at most 31 steps of 256 |e| < 2^22 per axis (< 2^28): everything stays below 2^31; the area is a difference of two products
+// below 2^28.  The tile kernels instantiate ONLY this form in their hot loop - bigger triangles take the clipper's route
+// (raster_clipped, a call), which holds the general form - so the loop's register budget carries no 64-bit edge state.  Both forms
+// produce the same integers.
+#define ZR_SMALL_EDGE (1 << 14)
+template <int MODE, bool SMALL>
 __device__ __forceinline__ void raster_sub(const SV& v0, const SV& v1, const SV& v2, uint32_t prim, const TileCtx& T,
                                            unsigned long long* __restrict__ keys64, uint32_t* __restrict__ keys32)
 {
     const int dX1 = v1.X - v0.X, dY1 = v1.Y - v0.Y, dX2 = v2.X - v0.X, dY2 = v2.Y - v0.Y;
-    // Small triangles (every edge component below 2^12 sub-pixel units = 16 px) keep the whole setup in 32 bits: products stay
-    // below 2^27 and every edge value met in the walk below 2^28.  The test is made wave-uniform so that the 64-bit code is
-    // skipped altogether; both routes produce the same integers.
-    const int ext = max(max(abs(dX1), abs(dY1)), max(abs(dX2), abs(dY2)));
-    const bool all_small = __ballot(ext >= (1 << 12)) == 0ull;
+    constexpr bool all_small = SMALL;
     long long A;
     if (all_small) A = (long long)(dX1 * dY2 - dX2 * dY1);
     else A = (long long)dX1 * dY2 - (long long)dX2 * dY1;
@@ -829,8 +841,9 @@ __device__ __forceinline__ zf4 lerp4(zf4 in, zf4 out, float t)
     r.z = __builtin_fmaf(t, out.z - in.z, in.z); r.w = __builtin_fmaf(t, out.w - in.w, in.w);
     return r;
 }
+// T and the keys are tile-relative (see k_raster_chunks): (ox, oy) = the tile's origin in sub-pixel units is taken off after projecting.
 template <int MODE>
-__device__ __noinline__ void raster_clipped(zf4 c0, zf4 c1, zf4 c2, uint32_t prim, TileCtx T, float hw, float hh,
+__device__ __noinline__ void raster_clipped(zf4 c0, zf4 c1, zf4 c2, uint32_t prim, TileCtx T, float hw, float hh, int ox, int oy,
                                             unsigned long long* keys64, uint32_t* keys32)
 {
     zf4 a[10], b[10];
@@ -850,11 +863,11 @@ __device__ __noinline__ void raster_clipped(zf4 c0, zf4 c1, zf4 c2, uint32_t pri
         for (int i = 0; i < na; ++i) a[i] = b[i];
     }
     for (int i = 0; i < na; ++i) if (!(a[i].w > 0.0f)) return;
-    const SV s0 = project(a[0], hw, hh);
-    SV sp = project(a[1], hw, hh);
+    SV s0 = project(a[0], hw, hh); s0.X -= ox; s0.Y -= oy;
+    SV sp = project(a[1], hw, hh); sp.X -= ox; sp.Y -= oy;
     for (int i = 2; i < na; ++i) {
-        const SV sn = project(a[i], hw, hh);
-        raster_sub<MODE>(s0, sp, sn, prim, T, keys64, keys32);
+        SV sn = project(a[i], hw, hh); sn.X -= ox; sn.Y -= oy;
+        raster_sub<MODE, false>(s0, sp, sn, prim, T, keys64, keys32);
         sp = sn;
     }
 }
@@ -1153,9 +1166,8 @@ __global__ void k_fill64(unsigned long long* __restrict__ p, unsigned long long 
 //   GBUFFER: vis64[W*H] (depth bits << 32 | prim), resolved later by k_resolve_gbuffer
 //   SHADOW : the shadow map itself (float bits as uint): the merge IS the LESS_OR_EQUAL depth write
 template <int MODE, bool HIZ>
-__global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs,
-                                                       const uint32_t* __restrict__ tile_offset,
-                                                       const uint32_t* __restrict__ chunk_offset,
+__global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(ZR_RASTER_WAVES))) void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs,
+                                                       const uint4* __restrict__ chunk_tab,
                                                        const ZrBinEntry* __restrict__ bins, ZrDevStats* __restrict__ stats, int slot,
                                                        unsigned long long* __restrict__ vis64, uint32_t* __restrict__ shadow_bits,
                                                        const float* __restrict__ hiz0, uint32_t hiz0_w, uint32_t hiz0_h)
@@ -1164,11 +1176,15 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
     __shared__ unsigned long long keys64[MODE == ZR_MODE_GBUFFER ? TILE_PIX : 1];
     __shared__ uint32_t keys32[MODE == ZR_MODE_SHADOW ? TILE_PIX : 1];
     __shared__ int4 vstage[RW][WAVE];
-    __shared__ int queue[RW][10][QCAP];      // per-wave ring of surviving triangles: 3 x (X, Y, z) + prim, SoA
+    // per-wave ring of surviving triangles, SoA: 3 x (tile-relative X | Y << 16, z) + prim.  Only small triangles (edges under 64 px)
+    // that reach the tile are queued, so a relative coordinate lies within [-16384, 24576] sub-pixel units and fits 16 bits.
+    __shared__ int queue[RW][7][QCAP];
     __shared__ uint32_t cur_chunk;
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const uint32_t n_tiles = P.tiles_x * P.tiles_y;
+    // the wave index is made KNOWN-uniform: entry indices, bin records, the instance record and every pointer derived from them
+    // then live in SGPRs and are fetched with scalar loads - some 30 VGPRs less in the hot loop (one more wave per SIMD, and this
+    // kernel waits on dependent loads most of the time)
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = wave_uniform(tid >> 6);
     const uint32_t n_chunks = stats->n_chunks[slot];
 
     // the first chunk of a workgroup is its own index (no atomic: an empty pass costs nothing), later ones come from the counter
@@ -1180,17 +1196,18 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
             else keys32[i] = 0x3F800000u;
         }
         __syncthreads();
-        // tile = last t with chunk_offset[t] <= chunk (tiles without entries have zero-width ranges and are skipped)
-        uint32_t lo = 0, hi = n_tiles;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (chunk_offset[mid] <= chunk) lo = mid; else hi = mid; }
-        const uint32_t tile = lo;
-        const uint32_t beg = tile_offset[tile] + (chunk - chunk_offset[tile]) * ZR_CHUNK;
-        const uint32_t end = min(min(beg + ZR_CHUNK, tile_offset[tile + 1]), P.bin_capacity);
+        // this work unit: (tile, first entry, end) as k_scan laid it out: one load, not a search over the tiles' chunk offsets
+        const uint4 ct = chunk_tab[chunk];
+        const uint32_t tile = ct.x, beg = ct.y, end = min(ct.z, P.bin_capacity);
+        // Everything below works in TILE-RELATIVE coordinates (origin = the tile's first pixel): edge functions, depth planes and
+        // bounding boxes are built from coordinate differences, so the integers and floats are the ones absolute coordinates give.
+        const int tpx0 = (int)(tile % P.tiles_x) * TILE, tpy0 = (int)(tile / P.tiles_x) * TILE;
+        const int ox = tpx0 * 256, oy = tpy0 * 256;
         TileCtx T;
-        T.px0 = (int)(tile % P.tiles_x) * TILE; T.py0 = (int)(tile / P.tiles_x) * TILE; T.W = (int)P.W; T.H = (int)P.H;
+        T.px0 = 0; T.py0 = 0; T.W = (int)P.W - tpx0; T.H = (int)P.H - tpy0;
         if (HIZ) {      // this tile's finest pyramid texels (blocks past the target's edge hold no pixel: 0 = "hides everything")
             if (tid < (TILE / 8) * (TILE / 8)) {
-                const uint32_t bx = (uint32_t)T.px0 / 8u + tid % (TILE / 8), by = (uint32_t)T.py0 / 8u + tid / (TILE / 8);
+                const uint32_t bx = (uint32_t)tpx0 / 8u + tid % (TILE / 8), by = (uint32_t)tpy0 / 8u + tid / (TILE / 8);
                 hz[tid] = (bx < hiz0_w && by < hiz0_h) ? hiz0[(size_t)by * hiz0_w + bx] : 0.0f;
             }
             __syncthreads();
@@ -1234,7 +1251,7 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
                     const uint32_t f = flagged ? vertex_flags(c) : 0u;
                     SV s; s.X = 0; s.Y = 0; s.z = 0.0f; s.rw = 0.0f;
                     if (!(f & 129u)) s = project(c, P.hw, P.hh);
-                    vstage[wv][lane] = make_int4(s.X, s.Y, (int)zr_f2u(s.z), (int)f);      // snapped x, y, depth, clip flags
+                    vstage[wv][lane] = make_int4(s.X - ox, s.Y - oy, (int)zr_f2u(s.z), (int)f);      // snapped x, y (tile-relative), depth, clip flags
                 }
             }
             lds_fence();
@@ -1252,7 +1269,10 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
                 if (t < tcount) {
                     const uint32_t i0 = tri_w[round].x & 255u, i1 = (tri_w[round].x >> 8) & 255u, i2 = (tri_w[round].x >> 16) & 255u;
                     r0 = vstage[wv][i0]; r1 = vstage[wv][i1]; r2 = vstage[wv][i2];
-                    const int cls = flagged ? classify((uint32_t)r0.w, (uint32_t)r1.w, (uint32_t)r2.w) : 1;
+                    int cls = flagged ? classify((uint32_t)r0.w, (uint32_t)r1.w, (uint32_t)r2.w) : 1;
+                    // a triangle with an edge of 64 pixels or more goes the clipper's way too: that route holds the 64-bit walk
+                    // (it leaves a triangle that needs no clipping as it is, so the pixels are the same)
+                    if (cls == 1 && max(max(abs(r1.x - r0.x), abs(r1.y - r0.y)), max(abs(r2.x - r0.x), abs(r2.y - r0.y))) >= ZR_SMALL_EDGE) cls = 2;
                     if (cls == 1) {
                         const float tz = HIZ ? __builtin_fminf(__builtin_fminf(zr_u2f((uint32_t)r0.z), zr_u2f((uint32_t)r1.z)), zr_u2f((uint32_t)r2.z)) : 0.0f;
                         alive = tri_prefilter<MODE, HIZ>(r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, T, tz, hz);
@@ -1263,17 +1283,17 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
                             const float4 pk = mp[li[k]];
                             cc[k] = zr_mat4_point(P.PVM, vs_position(zr3(pk.x, pk.y, pk.z), I, instanced));
                         }
-                        raster_clipped<MODE>(cc[0], cc[1], cc[2], prim, T, P.hw, P.hh, keys64, keys32);
+                        raster_clipped<MODE>(cc[0], cc[1], cc[2], prim, T, P.hw, P.hh, ox, oy, keys64, keys32);
                     }
                 }
                 const unsigned long long mask = __ballot(alive);
                 if (alive) {
                     const uint32_t slot = (qhead + qn + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))) & (QCAP - 1u);
                     int* q = &queue[wv][0][slot];
-                    q[0 * QCAP] = r0.x; q[1 * QCAP] = r0.y; q[2 * QCAP] = r0.z;
-                    q[3 * QCAP] = r1.x; q[4 * QCAP] = r1.y; q[5 * QCAP] = r1.z;
-                    q[6 * QCAP] = r2.x; q[7 * QCAP] = r2.y; q[8 * QCAP] = r2.z;
-                    q[9 * QCAP] = (int)prim;
+                    q[0 * QCAP] = (r0.x & 0xFFFF) | (r0.y << 16); q[1 * QCAP] = r0.z;
+                    q[2 * QCAP] = (r1.x & 0xFFFF) | (r1.y << 16); q[3 * QCAP] = r1.z;
+                    q[4 * QCAP] = (r2.x & 0xFFFF) | (r2.y << 16); q[5 * QCAP] = r2.z;
+                    q[6 * QCAP] = (int)prim;
                 }
                 qn += (uint32_t)__popcll(mask);
                 if (ZR_DIAG_SKIP(P.debug_skip) >= 1u) { qhead = (qhead + qn) & (QCAP - 1u); qn = 0; }
@@ -1281,10 +1301,10 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
                     lds_fence();
                     const int* q = &queue[wv][0][(qhead + lane) & (QCAP - 1u)];
                     SV a, b, c;
-                    a.X = q[0 * QCAP]; a.Y = q[1 * QCAP]; a.z = zr_u2f((uint32_t)q[2 * QCAP]); a.rw = 0.0f;
-                    b.X = q[3 * QCAP]; b.Y = q[4 * QCAP]; b.z = zr_u2f((uint32_t)q[5 * QCAP]); b.rw = 0.0f;
-                    c.X = q[6 * QCAP]; c.Y = q[7 * QCAP]; c.z = zr_u2f((uint32_t)q[8 * QCAP]); c.rw = 0.0f;
-                    raster_sub<MODE>(a, b, c, (uint32_t)q[9 * QCAP], T, keys64, keys32);
+                    a.X = (short)q[0 * QCAP]; a.Y = q[0 * QCAP] >> 16; a.z = zr_u2f((uint32_t)q[1 * QCAP]); a.rw = 0.0f;
+                    b.X = (short)q[2 * QCAP]; b.Y = q[2 * QCAP] >> 16; b.z = zr_u2f((uint32_t)q[3 * QCAP]); b.rw = 0.0f;
+                    c.X = (short)q[4 * QCAP]; c.Y = q[4 * QCAP] >> 16; c.z = zr_u2f((uint32_t)q[5 * QCAP]); c.rw = 0.0f;
+                    raster_sub<MODE, true>(a, b, c, (uint32_t)q[6 * QCAP], T, keys64, keys32);
                     qhead = (qhead + WAVE) & (QCAP - 1u); qn -= WAVE;
                 }
             }
@@ -1294,10 +1314,10 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
             if (lane < qn) {
                 const int* q = &queue[wv][0][(qhead + lane) & (QCAP - 1u)];
                 SV a, b, c;
-                a.X = q[0 * QCAP]; a.Y = q[1 * QCAP]; a.z = zr_u2f((uint32_t)q[2 * QCAP]); a.rw = 0.0f;
-                b.X = q[3 * QCAP]; b.Y = q[4 * QCAP]; b.z = zr_u2f((uint32_t)q[5 * QCAP]); b.rw = 0.0f;
-                c.X = q[6 * QCAP]; c.Y = q[7 * QCAP]; c.z = zr_u2f((uint32_t)q[8 * QCAP]); c.rw = 0.0f;
-                raster_sub<MODE>(a, b, c, (uint32_t)q[9 * QCAP], T, keys64, keys32);
+                a.X = (short)q[0 * QCAP]; a.Y = q[0 * QCAP] >> 16; a.z = zr_u2f((uint32_t)q[1 * QCAP]); a.rw = 0.0f;
+                b.X = (short)q[2 * QCAP]; b.Y = q[2 * QCAP] >> 16; b.z = zr_u2f((uint32_t)q[3 * QCAP]); b.rw = 0.0f;
+                c.X = (short)q[4 * QCAP]; c.Y = q[4 * QCAP] >> 16; c.z = zr_u2f((uint32_t)q[5 * QCAP]); c.rw = 0.0f;
+                raster_sub<MODE, true>(a, b, c, (uint32_t)q[6 * QCAP], T, keys64, keys32);
             }
             qhead = (qhead + qn) & (QCAP - 1u); qn = 0;
         }
@@ -1305,8 +1325,8 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
 
         // merge the touched keys into HBM
         for (uint32_t i = tid; i < TILE_PIX; i += RTHREADS) {
-            const int px = T.px0 + (int)(i & (TILE - 1)), py = T.py0 + (int)(i / TILE);
-            if (px >= T.W || py >= T.H) continue;
+            const int px = tpx0 + (int)(i & (TILE - 1)), py = tpy0 + (int)(i / TILE);
+            if (px >= (int)P.W || py >= (int)P.H) continue;
             const size_t p = (size_t)py * P.W + (size_t)px;
             if (MODE == ZR_MODE_GBUFFER) {
                 const unsigned long long k = keys64[i];
@@ -1316,6 +1336,7 @@ __global__ __launch_bounds__(RTHREADS) void k_raster_chunks(ZrPass P, const ZrOb
                 if (k < shadow_bits[p]) atomicMin(&shadow_bits[p], k);
             }
         }
+        // (the next unit is claimed only when this one is done: claiming early costs more in tail balance than the atomic's latency)
         if (tid == 0) cur_chunk = gridDim.x + atomicAdd(&stats->chunk_counter[slot], 1u);
         __syncthreads();   // keys are re-cleared at the top of the loop
         chunk = cur_chunk;
@@ -1904,10 +1925,10 @@ void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H
 {
     hipLaunchKernelGGL(k_hiz_build, dim3((W + 63) / 64, (H + 63) / 64), dim3(256), 0, s, vis64, W, H, Z);
 }
-void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint32_t n,
-                    uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s)
+void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint4* chunk_tab,
+                    uint32_t chunk_cap, uint32_t n, uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, chunk_offset, n, capacity, stats, slot);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, chunk_offset, chunk_tab, chunk_cap, n, capacity, stats, slot);
 }
 void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
                         uint32_t* tile_cursor, ZrBinEntry* bins, const ZrHiz& Z, ZrDevStats* stats, int slot, hipStream_t s)
@@ -1931,17 +1952,17 @@ void zr_launch_fill64(unsigned long long* p, unsigned long long v, size_t n, hip
 {
     hipLaunchKernelGGL(k_fill64, dim3(1024), dim3(256), 0, s, p, v, n);
 }
-void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint32_t* tile_offset, const uint32_t* chunk_offset,
+void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4* chunk_tab,
                              const ZrBinEntry* bins, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t* shadow_bits,
                              uint32_t n_blocks, const ZrHiz& Z, hipStream_t s)
 {
     const float* none = nullptr;
     if (P.mode == ZR_MODE_GBUFFER && Z.phase == 2u)
-        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_GBUFFER, true>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, tile_offset, chunk_offset, bins, stats, slot, vis64, shadow_bits, (const float*)Z.lvl[0], Z.hw[0], Z.hh[0]);
+        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_GBUFFER, true>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, (const float*)Z.lvl[0], Z.hw[0], Z.hh[0]);
     else if (P.mode == ZR_MODE_GBUFFER)
-        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_GBUFFER, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, tile_offset, chunk_offset, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u);
+        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_GBUFFER, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u);
     else
-        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, tile_offset, chunk_offset, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u);
+        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u);
 }
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, uint8_t* vis_now,
