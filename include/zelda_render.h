@@ -54,6 +54,8 @@ typedef struct zr_ctx zr_ctx;
 #define ZR_FLAG_NO_HIZ          8u  /* disable two-pass Hi-Z occlusion culling of the camera pass (parity A/B) */
 #define ZR_FLAG_SERIAL_PASSES   16u /* zr_render: shadow and camera pipelines on the one stream instead of side by side */
 #define ZR_FLAG_PACKED_TILES    32u /* tile_world == 1: still light into the packed tile buffer (the multi-GPU data path on one GPU) */
+#define ZR_FLAG_MESHLET_BINS   128u /* camera pass: the meshlet-binned rasteriser of round 1 (every (meshlet, tile) entry re-transforms and
+                                     * re-tests the meshlet) instead of the triangle-binned one (A/B; the shadow pass always uses it) */
 #define ZR_FLAG_NO_RECT_CULL    64u /* tile_world > 1: do not reject meshlets by the rank's owned screen region before stage B (parity A/B) */
 
 typedef struct zr_config {

@@ -256,6 +256,7 @@ extern "C" void zr_destroy(zr_ctx* c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     dev_free(c->d_vis);
     dev_free(c->d_pxrect); dev_free(c->d_zmin); dev_free(c->d_visflag[0]); dev_free(c->d_visflag[1]); dev_free(c->d_hiz);
+    dev_free(c->tb.sel); dev_free(c->tb.recs); dev_free(c->tb.idx); dev_free(c->tb.slow); dev_free(c->tb.wave_fill);
     for (auto& fr : c->evr) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_end) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -643,6 +644,19 @@ static int finalize_scene(zr_ctx* c)
             HIPCHK(c, dev_alloc(&sc.bins, c->bin_capacity));
             HIPCHK(c, dev_alloc(&sc.chunk_tab, c->chunk_capacity));
         }
+        // triangle-binned camera pass: every wave of k_geom's fixed grid owns a region of record slots (no allocator).  A launch
+        // takes `batch` meshlet-instances, ~64 per wave and ~50 records each; a region of 8192 leaves a wide margin (a region that
+        // does fill up is reported like a bin overflow).  1.5 GB of 288: HBM is not scarce.
+        dev_free(c->tb.sel); dev_free(c->tb.recs); dev_free(c->tb.idx); dev_free(c->tb.slow); dev_free(c->tb.wave_fill); dev_free(c->tb.wave_fill);
+        c->tb.n_waves = 8192; c->tb.region = 4096; c->tb.batch = 262144; c->tb.slow_cap = 1u << 18;
+        const uint32_t rec_cap = c->tb.n_waves * c->tb.region;
+        HIPCHK(c, dev_alloc(&c->tb.sel, c->work_capacity));
+        HIPCHK(c, dev_alloc(&c->tb.recs, 3ull * rec_cap));
+        HIPCHK(c, dev_alloc(&c->tb.idx, rec_cap));
+        HIPCHK(c, dev_alloc(&c->tb.wave_fill, c->tb.n_waves));
+        HIPCHK(c, dev_alloc(&c->tb.slow, 4ull * c->tb.slow_cap));
+        c->chunk_capacity = std::max<uint32_t>(c->chunk_capacity, rec_cap / ZR_TCHUNK + 2u * std::max(c->n_tiles, c->sn_tiles) + 1u);
+        for (auto& sc : c->sc) { dev_free(sc.chunk_tab); HIPCHK(c, dev_alloc(&sc.chunk_tab, c->chunk_capacity)); }
         HIPCHK(c, dev_alloc(&c->d_pxrect, c->work_capacity)); HIPCHK(c, dev_alloc(&c->d_zmin, c->work_capacity));
         HIPCHK(c, dev_alloc(&c->d_visflag[0], c->work_capacity)); HIPCHK(c, dev_alloc(&c->d_visflag[1], c->work_capacity));
     }
@@ -947,6 +961,26 @@ static void bin_and_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot,
     zr_launch_scan(sc.tile_count, sc.tile_offset, sc.tile_cursor, sc.chunk_offset, sc.chunk_tab, c->chunk_capacity, n_tiles, c->bin_capacity, c->d_stats, slot, s);
     zr_launch_bin_fill(P, c->d_objs, sc.work, sc.rects, sc.tile_offset, sc.tile_cursor, sc.bins, Z, c->d_stats, slot, s);
 }
+// One round of the triangle-binned camera pass: which meshlet-instances (k_select: timed with the cull), then their triangles as
+// records (k_geom), the records' places per tile (k_scan, k_index) and the tile kernel: those four are what the meshlet-binned
+// path's one raster launch does, and are timed as the raster.
+static void tri_select(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s)
+{
+    zr_launch_select(P, c->sc[1].work, c->sc[1].rects, Z, c->tb, c->d_stats, slot, s);
+}
+static void tri_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s)
+{
+    const zr_ctx::Scratch& sc = c->sc[1];
+    // the selection's size is only known on the device: big scenes launch every batch the work items could need (an empty one costs
+    // four near-empty launches); config 3 fits one
+    for (uint32_t first = 0; first < P.n_work; first += c->tb.batch) {
+        zr_launch_geom(P, c->d_objs, Z, c->tb, first, sc.tile_count, c->d_stats, slot, s);
+        zr_launch_scan(sc.tile_count, sc.tile_offset, sc.tile_cursor, sc.chunk_offset, sc.chunk_tab, c->chunk_capacity, c->n_tiles,
+                       c->tb.n_waves * c->tb.region, c->d_stats, slot, s, ZR_TCHUNK, c->tiles_x, c->cfg.tile_rank, c->cfg.tile_world);
+        zr_launch_index(c->tb, sc.tile_offset, sc.tile_cursor, s);
+        zr_launch_tile(P, sc.chunk_tab, c->tb, c->d_owned, c->n_owned, c->d_stats, slot, c->d_vis, c->raster_blocks, s);
+    }
+}
 static void raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s)
 {
     const zr_ctx::Scratch& sc = c->sc[slot ? 1 : 0];
@@ -1040,21 +1074,24 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
     zr_launch_cull(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, c->raster_blocks * 4u, s);
     if (hiz_on && P.use_worklist) HIPCHK(c, hipMemsetAsync(c->d_visflag[c->vis_cur], 0, c->n_work, s));     // else k_cull clears them
     c->last_two_round = hiz_on && c->vis_history;
+    const bool tri_bins = !(c->cfg.flags & ZR_FLAG_MESHLET_BINS) && ZR_TILE == 32;
+    auto bin = [&](int slot) { if (tri_bins) tri_select(c, P, Z, slot, s); else bin_and_raster(c, P, Z, slot, c->n_tiles, s); };
+    auto rast = [&](int slot) { if (tri_bins) tri_raster(c, P, Z, slot, s); else raster(c, P, Z, slot, s); };
     if (c->last_two_round) {
         Z.phase = 1;
-        bin_and_raster(c, P, Z, 1, c->n_tiles, s);
+        bin(1);
         if (ev) HIPCHK(c, hipEventRecord(ev[3], s));
-        raster(c, P, Z, 1, s);
+        rast(1);
         if (ev) HIPCHK(c, hipEventRecord(ev[4], s));
         zr_launch_hiz_build(c->d_vis, c->W, c->H, Z, s);
         Z.phase = 2;
-        bin_and_raster(c, P, Z, 2, c->n_tiles, s);
+        bin(2);
         if (ev) HIPCHK(c, hipEventRecord(ev[5], s));
-        raster(c, P, Z, 2, s);
+        rast(2);
     } else {
-        bin_and_raster(c, P, Z, 1, c->n_tiles, s);
+        bin(1);
         if (ev) HIPCHK(c, hipEventRecord(ev[3], s));
-        raster(c, P, Z, 1, s);
+        rast(1);
         if (ev) { HIPCHK(c, hipEventRecord(ev[4], s)); HIPCHK(c, hipEventRecord(ev[5], s)); }
     }
     {   // the overlay plane (skydome pixels) is written only when a skydome is drawn, or once more to wipe one that was

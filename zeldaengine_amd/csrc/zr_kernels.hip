@@ -559,20 +559,26 @@ __global__ __launch_bounds__(1024) void k_bin_count(ZrPass P, const uint32_t* __
     if (threadIdx.x == 0 && tally) atomicAdd(&stats->hiz_culled, tally);
 }
 
-// Exclusive scan of tile_count[0..n) into tile_offset[0..n] and of the per-tile chunk counts ceil(count / ZR_CHUNK)
-// into chunk_offset[0..n]; zeroes tile_count and tile_cursor for the fill and resets the chunk work counter.
+// Exclusive scan of tile_count[0..n) into tile_offset[0..n] and of the per-tile work-unit counts ceil(count / chunk)
+// into chunk_offset[0..n]; lays out the rasteriser's work units (tile, first entry, end, kind); zeroes tile_count and tile_cursor
+// for the fill and resets the work counter.  Triangle-binned pass (tiles_x != 0): also notes which slow triangles this batch added.
 __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
                                                uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ chunk_offset,
                                                uint4* __restrict__ chunk_tab, uint32_t chunk_cap,
-                                               uint32_t n, uint32_t capacity, ZrDevStats* __restrict__ stats, int slot)
+                                               uint32_t n, uint32_t capacity, ZrDevStats* __restrict__ stats, int slot,
+                                               uint32_t chunk, uint32_t tiles_x, uint32_t tile_rank, uint32_t tile_world)
 {
     __shared__ uint32_t part[1024];
     __shared__ uint32_t cpart[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t b = tid * per, e = min(n, b + per);
+    // slow triangles this batch added: [what earlier batches of the round already tried, the running total)
+    const uint32_t slow_lo = tiles_x != 0u ? stats->slow_hi[slot] : 0u, slow_hi = tiles_x != 0u ? stats->n_slow[slot] : 0u;
+    (void)tile_rank; (void)tile_world;
+    auto units_of = [&](uint32_t, uint32_t c) -> uint32_t { return (c + chunk - 1u) / chunk; };
     uint32_t s = 0, cs = 0;
-    for (uint32_t i = b; i < e; ++i) { const uint32_t c = tile_count[i]; s += c; cs += (c + ZR_CHUNK - 1u) / ZR_CHUNK; }
+    for (uint32_t i = b; i < e; ++i) { const uint32_t c = tile_count[i]; s += c; cs += units_of(i, c); }
     part[tid] = s; cpart[tid] = cs;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {
@@ -586,18 +592,22 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
         const uint32_t c = tile_count[i];
         tile_offset[i] = run;
         chunk_offset[i] = crun;
-        // one record per raster work unit: (tile, first entry, end): the rasteriser finds its chunk with one load, not a search
-        for (uint32_t k = 0; k * ZR_CHUNK < c; ++k)
-            if (crun + k < chunk_cap) chunk_tab[crun + k] = make_uint4(i, run + k * ZR_CHUNK, run + min(c, (k + 1u) * ZR_CHUNK), 0u);
-        run += c; crun += (c + ZR_CHUNK - 1u) / ZR_CHUNK;
+        // one record per raster work unit: (tile, first entry, end, kind): the rasteriser finds its unit with one load, not a search
+        const uint32_t nu = units_of(i, c), nreg = (c + chunk - 1u) / chunk;
+        for (uint32_t k = 0; k < nu; ++k)
+            if (crun + k < chunk_cap)
+                chunk_tab[crun + k] = k < nreg ? make_uint4(i, run + k * chunk, run + min(c, (k + 1u) * chunk), 0u) : make_uint4(i, 0u, 0u, 1u);
+        run += c; crun += nu;
         tile_count[i] = 0; tile_cursor[i] = 0;
     }
     if (tid == 1023) {
         tile_offset[n] = part[1023];
         chunk_offset[n] = cpart[1023];
-        stats->bin_entries[slot] = part[1023];
+        if (tiles_x != 0u) stats->bin_entries[slot] += part[1023];       // triangle records: summed over the round's batches
+        else stats->bin_entries[slot] = part[1023];
         stats->n_chunks[slot] = min(cpart[1023], chunk_cap);
         stats->chunk_counter[slot] = 0;
+        if (tiles_x != 0u) { stats->slow_lo[slot] = slow_lo; stats->slow_hi[slot] = slow_hi; }
         if (part[1023] > capacity) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
     }
 }
@@ -1343,6 +1353,305 @@ __global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(ZR_RAS
     }
 }
 
+// ------------------------------------------------------------------------------------------------ triangle-binned camera pass
+//
+// The meshlet-binned rasteriser above re-transforms a meshlet's vertices and re-tests all of its triangles in every tile the
+// meshlet touches (2.5 on average in the camera pass) and walks the survivors in whatever mix of sizes the queue hands a wave.
+// Here a meshlet is processed ONCE: k_geom transforms its vertices, applies the exact per-triangle tests (facing, degenerate, no
+// pixel centre, Hi-Z in round 2) and emits one 48-byte record per (triangle, owned tile); k_scan lays the records' ranks out per
+// tile, k_index turns (tile, rank) into a gather list, and k_tile's lanes do nothing but edge setup + walk on live triangles.
+// Same arithmetic, same keys: the frame is bit for bit the one the meshlet-binned path produces.
+
+// Which meshlet-instances does this round draw?  (The split of the two-pass occlusion culling, as k_bin_count makes it.)
+// Compacted per workgroup: one global atomic per 1024 work items (atomics on one address run at ~10 ns apiece on this part).
+__global__ __launch_bounds__(1024) void k_select(ZrPass P, const uint32_t* __restrict__ work, const uint32_t* __restrict__ rects, ZrHiz Z,
+                                                 uint32_t* __restrict__ sel, ZrDevStats* __restrict__ stats, int slot)
+{
+    __shared__ uint32_t wcount[16], wbase[16], nocc;
+    const uint32_t n_vis = P.use_worklist ? stats->n_vis_work[1] : P.n_work;
+    if (blockIdx.x * 1024u >= n_vis) return;
+    const uint32_t k = blockIdx.x * 1024u + threadIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) nocc = 0;
+    bool take = false, occluded = false;
+    uint32_t w = 0;
+    if (k < n_vis) {
+        w = P.use_worklist ? work[k] : k;
+        take = rects[k] != ZR_RECT_CULLED;
+        if (take && Z.phase) {
+            const bool was_visible = Z.vis_prev[w] != 0;
+            if (Z.phase == 1u) take = was_visible;
+            else if (was_visible) take = false;
+            else if (hiz_occluded(Z, Z.pxrect[k], Z.zmin[k])) { take = false; occluded = true; }
+        }
+    }
+    const unsigned long long m = __ballot(take);
+    if (lane == 0) wcount[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    const unsigned long long mo = __ballot(occluded);
+    if (lane == 0 && mo) atomicAdd(&nocc, (uint32_t)__popcll(mo));
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int i = 0; i < 16; ++i) { wbase[i] = tot; tot += wcount[i]; }
+        const uint32_t base = tot ? atomicAdd(&stats->n_sel[slot], tot) : 0u;
+        for (int i = 0; i < 16; ++i) wbase[i] += base;
+        if (tot) atomicAdd(&stats->survivors[slot], tot);
+    }
+    __syncthreads();
+    if (take) sel[wbase[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = w;
+    if (threadIdx.x == 0 && nocc) atomicAdd(&stats->hiz_culled, nocc);
+}
+
+// One wave per selected meshlet-instance: vertices -> LDS, triangles -> records.
+// Records need no allocator: wave k of the grid owns record slots [k * region, (k + 1) * region) and reports its fill.
+template <bool HIZ>
+__global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ sel, uint32_t first,
+                                              uint32_t batch, ZrHiz Z, uint4* __restrict__ recs, uint32_t region,
+                                              uint32_t* __restrict__ wave_fill, uint4* __restrict__ slow, uint32_t slow_cap,
+                                              uint32_t* __restrict__ tile_count, ZrDevStats* __restrict__ stats, int slot)
+{
+    __shared__ int4 vstage[4][WAVE];
+    const uint32_t lane = threadIdx.x & 63u, wv = wave_uniform(threadIdx.x >> 6);
+    const uint32_t n_sel = stats->n_sel[slot];
+    const uint32_t n = min(n_sel, first + batch);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t wave_id = blockIdx.x * 4u + wv;
+    const uint32_t rec0 = wave_id * region;
+    uint32_t fill = 0;                          // wave-uniform
+    for (uint32_t i = first + wave_id; i < n; i += gridDim.x * 4u) {
+        const uint32_t w = wave_uniform(sel[i]);
+        const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w);
+        const uint32_t local = w - O->work_base, nm = O->n_meshlets;
+        const uint32_t inst_i = local / nm, m = local - inst_i * nm;
+        const XkMeshlet* __restrict__ ml = O->meshlets + m;
+        const uint32_t vcount = ml->VertexCount, tcount = ml->TriangleCount;
+        const float4* __restrict__ mp = O->mpos + ml->VertexOffset;
+        const uint2* __restrict__ tw = O->mtri + ml->BindlessContext;
+        const bool instanced = O->instanced != 0;
+        const uint32_t pbase = O->prim_base + inst_i * O->n_tris;
+        uint2 tri_w[2];
+        tri_w[0] = lane < tcount ? tw[lane] : make_uint2(0u, 0u);
+        tri_w[1] = lane + WAVE < tcount ? tw[lane + WAVE] : make_uint2(0u, 0u);
+        const float4 pp = lane < vcount ? mp[lane] : make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        const ZrInstance I = O->inst[inst_i];
+
+        lds_fence();   // this wave's previous readers are done with its staging area
+        bool flagged;
+        {
+            const zf4 c = zr_mat4_point(P.PVM, vs_position(zr3(pp.x, pp.y, pp.z), I, instanced));
+            const float FM = 3.402823466e38f, gb = ZR_GUARD * c.w;
+            const bool fin = __builtin_fabsf(c.x) <= FM && __builtin_fabsf(c.y) <= FM && __builtin_fabsf(c.z) <= FM && __builtin_fabsf(c.w) <= FM;
+            const bool odd = !fin || c.x < -c.w || c.x > c.w || c.y < -c.w || c.y > c.w || c.z < 0.0f || c.z > c.w ||
+                             !(c.w > 0.0f) || __builtin_fabsf(c.x) > gb || __builtin_fabsf(c.y) > gb;
+            flagged = __ballot(lane < vcount && odd) != 0ull;
+            if (lane < vcount) {
+                const uint32_t f = flagged ? vertex_flags(c) : 0u;
+                SV sv; sv.X = 0; sv.Y = 0; sv.z = 0.0f; sv.rw = 0.0f;
+                if (!(f & 129u)) sv = project(c, P.hw, P.hh);
+                vstage[wv][lane] = make_int4(sv.X, sv.Y, (int)zr_f2u(sv.z), (int)f);      // snapped x, y (absolute), depth, clip flags
+            }
+        }
+        lds_fence();
+
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            const uint32_t t0 = (uint32_t)round * WAVE;
+            if (t0 >= tcount) break;
+            const uint32_t t = t0 + lane;
+            int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0;
+            const uint32_t prim = pbase + tri_w[round].y;
+            bool alive = false, is_slow = false;
+            int tx0 = 0, ty0 = 0, tx1 = -1, ty1 = -1;
+            uint32_t i0 = 0, i1 = 0, i2 = 0;
+            if (t < tcount) {
+                i0 = tri_w[round].x & 255u; i1 = (tri_w[round].x >> 8) & 255u; i2 = (tri_w[round].x >> 16) & 255u;
+                r0 = vstage[wv][i0]; r1 = vstage[wv][i1]; r2 = vstage[wv][i2];
+                int cls = flagged ? classify((uint32_t)r0.w, (uint32_t)r1.w, (uint32_t)r2.w) : 1;
+                if (cls == 1 && max(max(abs(r1.x - r0.x), abs(r1.y - r0.y)), max(abs(r2.x - r0.x), abs(r2.y - r0.y))) >= ZR_SMALL_EDGE) cls = 2;
+                if (cls == 2) is_slow = true;
+                else if (cls == 1) {
+                    // the tests of tri_prefilter / raster_sub that do not depend on the tile: facing + degenerate (edges below 2^14:
+                    // the area fits 32 bits), pixel centres of the TARGET inside the snapped box, and in round 2 the Hi-Z test
+                    const int A = (r1.x - r0.x) * (r2.y - r0.y) - (r2.x - r0.x) * (r1.y - r0.y);
+                    const int x0 = max((imin3(r0.x, r1.x, r2.x) - 128 + 255) >> 8, 0), x1 = min((imax3(r0.x, r1.x, r2.x) - 128) >> 8, (int)P.W - 1);
+                    const int y0 = max((imin3(r0.y, r1.y, r2.y) - 128 + 255) >> 8, 0), y1 = min((imax3(r0.y, r1.y, r2.y) - 128) >> 8, (int)P.H - 1);
+                    alive = A < 0 && x0 <= x1 && y0 <= y1;
+                    if (HIZ && alive) {
+                        // max depth already in the key buffer over the 8 x 8 pixel blocks the box touches (blocks of other ranks' tiles
+                        // hold 0): a triangle whose least vertex depth lies behind it cannot win a pixel
+                        const float tz = __builtin_fminf(__builtin_fminf(zr_u2f((uint32_t)r0.z), zr_u2f((uint32_t)r1.z)), zr_u2f((uint32_t)r2.z));
+                        float h = 0.0f;
+                        for (int by = y0 >> 3; by <= (y1 >> 3); ++by)
+                            for (int bx = x0 >> 3; bx <= (x1 >> 3); ++bx) h = __builtin_fmaxf(h, Z.lvl[0][(size_t)by * Z.hw[0] + (size_t)bx]);
+                        if (tz > h) alive = false;
+                    }
+                    if (alive) { tx0 = x0 / TILE; tx1 = x1 / TILE; ty0 = y0 / TILE; ty1 = y1 / TILE; }
+                }
+            }
+            // ---- slow triangles: the three clip-space vertices go to the list every owned tile tries
+            const unsigned long long ms = __ballot(is_slow);
+            if (ms) {
+                uint32_t base = 0;
+                if (lane == (uint32_t)__builtin_ctzll(ms)) base = atomicAdd(&stats->n_slow[slot], (uint32_t)__popcll(ms));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(ms));
+                if (is_slow) {
+                    const uint32_t pos = base + (uint32_t)__popcll(ms & lt);
+                    if (pos < slow_cap) {
+                        const uint32_t li[3] = { i0, i1, i2 };
+                        for (int k = 0; k < 3; ++k) {
+                            const float4 pk = mp[li[k]];
+                            const zf4 cc = zr_mat4_point(P.PVM, vs_position(zr3(pk.x, pk.y, pk.z), I, instanced));
+                            slow[4u * pos + (uint32_t)k] = make_uint4(zr_f2u(cc.x), zr_f2u(cc.y), zr_f2u(cc.z), zr_f2u(cc.w));
+                        }
+                        slow[4u * pos + 3u] = make_uint4(prim, 0u, 0u, 0u);
+                    } else { stats->overflow = 1u; stats->overflow_sticky = 1u; }
+                }
+            }
+            // ---- one record per (triangle, owned tile); ranks within a tile come from one atomic per (wave, tile)
+            const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1, ntile = alive ? nx * ny : 0;
+            for (int step = 0; __ballot(step < ntile) != 0ull; ++step) {
+                bool emit = step < ntile;
+                uint32_t tile = 0;
+                if (emit) {
+                    const uint32_t tx = (uint32_t)(tx0 + step % nx), ty = (uint32_t)(ty0 + step / nx);
+                    tile = ty * P.tiles_x + tx;
+                    if (P.tile_world > 1u && tile_owner(tx, ty, P.tile_world) != P.tile_rank) emit = false;
+                }
+                unsigned long long me = __ballot(emit);
+                if (!me) continue;
+                if (fill + (uint32_t)__popcll(me) > region) {          // this wave's record region is full: the frame is incomplete
+                    if (lane == 0) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
+                    continue;
+                }
+                // count per tile: one atomic per (wave, tile), and nobody waits for it (ranks are handed out by k_index)
+                unsigned long long pend = me;
+                while (pend) {
+                    const int leader = __builtin_ctzll(pend);
+                    const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
+                    const unsigned long long same = __ballot(emit && tile == tl) & pend;
+                    if ((int)lane == leader) atomicAdd(&tile_count[tl], (uint32_t)__popcll(same));
+                    pend &= ~same;
+                }
+                if (emit) {
+                    const uint32_t pos = rec0 + fill + (uint32_t)__popcll(me & lt);
+                    recs[3u * pos] = make_uint4((uint32_t)r0.x, (uint32_t)r0.y, (uint32_t)r0.z, prim);
+                    recs[3u * pos + 1u] = make_uint4((uint32_t)r1.x, (uint32_t)r1.y, (uint32_t)r1.z, tile);
+                    recs[3u * pos + 2u] = make_uint4((uint32_t)r2.x, (uint32_t)r2.y, (uint32_t)r2.z, 0u);
+                }
+                fill += (uint32_t)__popcll(me);
+            }
+        }
+    }
+    if (lane == 0) wave_fill[wave_id] = fill;
+}
+
+// Every record -> a place in its tile's stretch of the gather list: a cursor per tile, advanced once per (wave, distinct tile) - the
+// records of a region come meshlet by meshlet, so the 64 of a wave name a handful of tiles - because atomics on one address run at
+// about 10 ns apiece on this part and there are half a million records.  One workgroup per k_geom wave's record region.
+__global__ __launch_bounds__(256) void k_index(const uint4* __restrict__ recs, uint32_t region, const uint32_t* __restrict__ wave_fill,
+                                               const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
+                                               uint32_t* __restrict__ idx)
+{
+    const uint32_t n = wave_fill[blockIdx.x], r0 = blockIdx.x * region, lane = threadIdx.x & 63u;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (uint32_t j0 = (threadIdx.x >> 6) * 64u; j0 < n; j0 += 256u) {
+        const uint32_t j = j0 + lane, i = r0 + j;
+        const bool have = j < n;
+        const uint32_t tile = have ? recs[3u * i + 1u].w : 0u;
+        uint32_t rank = 0;
+        unsigned long long pend = __ballot(have);
+        while (pend) {
+            const int leader = __builtin_ctzll(pend);
+            const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
+            const unsigned long long same = __ballot(have && tile == tl) & pend;
+            uint32_t b = 0;
+            if ((int)lane == leader) b = atomicAdd(&tile_cursor[tl], (uint32_t)__popcll(same));
+            b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
+            if (same >> lane & 1ull) rank = b + (uint32_t)__popcll(same & lt);
+            pend &= ~same;
+        }
+        if (have) idx[tile_offset[tile] + rank] = i;
+    }
+}
+
+// Persistent workgroups pull work units: <= ZR_TCHUNK records of one tile; lane per triangle: edge setup + walk into the tile's LDS
+// keys; touched keys are merged into the frame key buffer.  Nothing else: no vertices, no tests, no call in the loop.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_tile(ZrPass P, const uint4* __restrict__ chunk_tab, const uint4* __restrict__ recs,
+                                              const uint32_t* __restrict__ idx, ZrDevStats* __restrict__ stats, int slot,
+                                              unsigned long long* __restrict__ vis64)
+{
+    __shared__ unsigned long long keys64[TILE_PIX];
+    __shared__ uint32_t cur_unit;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_units = stats->n_chunks[slot];
+    uint32_t unit = blockIdx.x;
+    for (;;) {
+        if (unit >= n_units) break;
+        for (uint32_t i = tid; i < TILE_PIX; i += 256u) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
+        __syncthreads();
+        const uint4 ct = chunk_tab[unit];
+        const uint32_t tile = ct.x;
+        const int tpx0 = (int)(tile % P.tiles_x) * TILE, tpy0 = (int)(tile / P.tiles_x) * TILE;
+        const int ox = tpx0 * 256, oy = tpy0 * 256;
+        TileCtx T;
+        T.px0 = 0; T.py0 = 0; T.W = (int)P.W - tpx0; T.H = (int)P.H - tpy0;
+        for (uint32_t j = ct.y + tid; j < ct.z; j += 256u) {
+            const uint32_t i = idx[j];
+            const uint4 q0 = recs[3u * i], q1 = recs[3u * i + 1u], q2 = recs[3u * i + 2u];
+            SV a, b, c;
+            a.X = (int)q0.x - ox; a.Y = (int)q0.y - oy; a.z = zr_u2f(q0.z); a.rw = 0.0f;
+            b.X = (int)q1.x - ox; b.Y = (int)q1.y - oy; b.z = zr_u2f(q1.z); b.rw = 0.0f;
+            c.X = (int)q2.x - ox; c.Y = (int)q2.y - oy; c.z = zr_u2f(q2.z); c.rw = 0.0f;
+            raster_sub<MODE, true>(a, b, c, q0.w, T, keys64, nullptr);
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
+            const int px = tpx0 + (int)(i & (TILE - 1)), py = tpy0 + (int)(i / TILE);
+            if (px >= (int)P.W || py >= (int)P.H) continue;
+            const size_t p = (size_t)py * P.W + (size_t)px;
+            const unsigned long long k = keys64[i];
+            if ((uint32_t)k != ZR_EMPTY_PRIM && k < vis64[p]) atomicMin(&vis64[p], k);
+        }
+        if (tid == 0) cur_unit = gridDim.x + atomicAdd(&stats->chunk_counter[slot], 1u);
+        __syncthreads();
+        unit = cur_unit;
+    }
+}
+
+// The slow triangles of the batch (they need the clipper, or have an edge of 64 px or more): every owned tile tries every one of
+// them through raster_clipped.  One workgroup per owned tile; returns at once when the batch has none (the usual case).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __restrict__ owned_tiles, const uint4* __restrict__ slow,
+                                                   uint32_t slow_cap, const ZrDevStats* __restrict__ stats, int slot,
+                                                   unsigned long long* __restrict__ vis64)
+{
+    __shared__ unsigned long long keys64[TILE_PIX];
+    const uint32_t slow_lo = stats->slow_lo[slot], slow_hi = min(stats->slow_hi[slot], slow_cap);
+    if (slow_lo >= slow_hi) return;
+    const uint32_t tid = threadIdx.x, tile = owned_tiles[blockIdx.x];
+    for (uint32_t i = tid; i < TILE_PIX; i += 256u) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
+    __syncthreads();
+    const int tpx0 = (int)(tile % P.tiles_x) * TILE, tpy0 = (int)(tile / P.tiles_x) * TILE;
+    TileCtx T;
+    T.px0 = 0; T.py0 = 0; T.W = (int)P.W - tpx0; T.H = (int)P.H - tpy0;
+    for (uint32_t j = slow_lo + tid; j < slow_hi; j += 256u) {
+        const uint4 q0 = slow[4u * j], q1 = slow[4u * j + 1u], q2 = slow[4u * j + 2u];
+        zf4 c0, c1, c2;
+        c0.x = zr_u2f(q0.x); c0.y = zr_u2f(q0.y); c0.z = zr_u2f(q0.z); c0.w = zr_u2f(q0.w);
+        c1.x = zr_u2f(q1.x); c1.y = zr_u2f(q1.y); c1.z = zr_u2f(q1.z); c1.w = zr_u2f(q1.w);
+        c2.x = zr_u2f(q2.x); c2.y = zr_u2f(q2.y); c2.z = zr_u2f(q2.z); c2.w = zr_u2f(q2.w);
+        raster_clipped<MODE>(c0, c1, c2, slow[4u * j + 3u].x, T, P.hw, P.hh, tpx0 * 256, tpy0 * 256, keys64, nullptr);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
+        const int px = tpx0 + (int)(i & (TILE - 1)), py = tpy0 + (int)(i / TILE);
+        if (px >= (int)P.W || py >= (int)P.H) continue;
+        const size_t p = (size_t)py * P.W + (size_t)px;
+        const unsigned long long k = keys64[i];
+        if ((uint32_t)k != ZR_EMPTY_PRIM && k < vis64[p]) atomicMin(&vis64[p], k);
+    }
+}
+
 // BaseScene.frag for every pixel of the owned tiles, from the frame's key buffer; resets the keys for the next frame.
 template <bool IMAGES>
 __global__ __launch_bounds__(256) void k_resolve_gbuffer(ZrPass P, const ZrObject* __restrict__ objs,
@@ -1926,9 +2235,11 @@ void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H
     hipLaunchKernelGGL(k_hiz_build, dim3((W + 63) / 64, (H + 63) / 64), dim3(256), 0, s, vis64, W, H, Z);
 }
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint4* chunk_tab,
-                    uint32_t chunk_cap, uint32_t n, uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s)
+                    uint32_t chunk_cap, uint32_t n, uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s,
+                    uint32_t chunk, uint32_t tiles_x, uint32_t tile_rank, uint32_t tile_world)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, chunk_offset, chunk_tab, chunk_cap, n, capacity, stats, slot);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, chunk_offset, chunk_tab, chunk_cap, n, capacity, stats, slot,
+                       chunk, tiles_x, tile_rank, tile_world);
 }
 void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
                         uint32_t* tile_cursor, ZrBinEntry* bins, const ZrHiz& Z, ZrDevStats* stats, int slot, hipStream_t s)
@@ -1963,6 +2274,29 @@ void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4*
         hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_GBUFFER, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u);
     else
         hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u);
+}
+void zr_launch_select(const ZrPass& P, const uint32_t* work, const uint32_t* rects, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats,
+                      int slot, hipStream_t s)
+{
+    if (P.n_work == 0) return;
+    hipLaunchKernelGGL(k_select, dim3((P.n_work + 1023) / 1024), dim3(1024), 0, s, P, work, rects, Z, B.sel, stats, slot);
+}
+void zr_launch_geom(const ZrPass& P, const ZrObject* objs, const ZrHiz& Z, const ZrTriBins& B, uint32_t first, uint32_t* tile_count,
+                    ZrDevStats* stats, int slot, hipStream_t s)
+{
+    const dim3 g(B.n_waves / 4u), b(256);
+    if (Z.phase == 2u) hipLaunchKernelGGL(k_geom<true>, g, b, 0, s, P, objs, B.sel, first, B.batch, Z, B.recs, B.region, B.wave_fill, B.slow, B.slow_cap, tile_count, stats, slot);
+    else hipLaunchKernelGGL(k_geom<false>, g, b, 0, s, P, objs, B.sel, first, B.batch, Z, B.recs, B.region, B.wave_fill, B.slow, B.slow_cap, tile_count, stats, slot);
+}
+void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* tile_cursor, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_index, dim3(B.n_waves), dim3(256), 0, s, B.recs, B.region, B.wave_fill, tile_offset, tile_cursor, B.idx);
+}
+void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned,
+                    ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_tile<ZR_MODE_GBUFFER>, dim3(n_blocks), dim3(256), 0, s, P, chunk_tab, B.recs, B.idx, stats, slot, vis64);
+    if (n_owned) hipLaunchKernelGGL(k_tile_slow<ZR_MODE_GBUFFER>, dim3(n_owned), dim3(256), 0, s, P, owned_tiles, B.slow, B.slow_cap, stats, slot, vis64);
 }
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, uint8_t* vis_now,

@@ -115,6 +115,9 @@ struct ZrDevStats {
     uint32_t chunk_counter[3];
     uint32_t n_vis_work[2];          // meshlet-instances of the instances that passed the instance-level frustum test
     uint32_t hiz_culled;             // meshlet-instances rejected by the Hi-Z test
+    uint32_t n_sel[3];               // triangle-binned camera pass: meshlet-instances selected for a round (slots as above)
+    uint32_t n_slow[3];              //   triangles that need the clipper / the 64-bit walk, running total of the round
+    uint32_t slow_lo[3], slow_hi[3]; //   the part of them the current batch's tile kernel has to try (set by k_scan)
     uint32_t overflow_sticky;        // LAST member: not cleared at frame begin; set with `overflow`, cleared by zr_finish when it reports it
 };
 
@@ -166,7 +169,27 @@ void zr_launch_bin_count(const ZrPass& P, const uint32_t* work, uint32_t* rects,
                          int slot, hipStream_t s);
 void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H, const ZrHiz& Z, hipStream_t s);
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint4* chunk_tab,
-                    uint32_t chunk_cap, uint32_t n, uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s);
+                    uint32_t chunk_cap, uint32_t n, uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s,
+                    uint32_t chunk = ZR_CHUNK, uint32_t tiles_x = 0, uint32_t tile_rank = 0, uint32_t tile_world = 0);
+// triangle-binned camera pass (k_select -> k_geom -> k_scan -> k_index -> k_tile)
+struct ZrTriBins {
+    uint32_t* sel;                   // meshlet-instances of this round
+    uint4*    recs;                  // 3 x uint4 per record: (X0, Y0, z0, prim) (X1, Y1, z1, tile) (X2, Y2, z2, 0).  Every wave of k_geom
+    uint32_t  region;                //   owns `region` consecutive record slots (no allocator, no atomics) and reports how many it
+    uint32_t* wave_fill;             //   filled in wave_fill[wave]
+    uint32_t  n_waves;               // waves of the k_geom grid (= regions)
+    uint32_t* idx;                   // record indices grouped by tile
+    uint4*    slow; uint32_t slow_cap;      // 4 x uint4 per slow triangle: three clip-space vertices, (prim, 0, 0, 0)
+    uint32_t  batch;                 // meshlet-instances per k_geom launch (big scenes take several)
+};
+#define ZR_TCHUNK 512u               // triangle records per work unit of the tile kernel
+void zr_launch_select(const ZrPass& P, const uint32_t* work, const uint32_t* rects, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats,
+                      int slot, hipStream_t s);
+void zr_launch_geom(const ZrPass& P, const ZrObject* objs, const ZrHiz& Z, const ZrTriBins& B, uint32_t first, uint32_t* tile_count,
+                    ZrDevStats* stats, int slot, hipStream_t s);
+void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* tile_cursor, hipStream_t s);
+void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned,
+                    ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s);
 void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
                         uint32_t* tile_cursor, ZrBinEntry* bins, const ZrHiz& Z, ZrDevStats* stats, int slot, hipStream_t s);
 void zr_launch_frame_begin(ZrDevStats* stats, const XkView* view_src_pinned, XkView* view_dst, hipStream_t s);
