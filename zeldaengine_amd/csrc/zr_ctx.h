@@ -18,7 +18,7 @@ struct ZrMesh {
     bool has_meshlets = false, uploaded = false;
     float center[3] = { 0, 0, 0 }; float radius = 0;
     XkVertex* d_v = nullptr; ZrRVertex* d_rv = nullptr; uint32_t* d_idx = nullptr; XkMeshlet* d_meshlets = nullptr;
-    float4* d_mpos = nullptr; uint2* d_mtri = nullptr; uint32_t* d_tri_meshlet = nullptr;
+    float4* d_mpos = nullptr; float4* d_mbox = nullptr; uint2* d_mtri = nullptr; uint32_t* d_tri_meshlet = nullptr;
 };
 
 // Host form of one material: per slot either a constant texel or an RGBA8 image (mips are built at zr_object_add).

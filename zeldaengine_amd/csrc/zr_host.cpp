@@ -142,7 +142,7 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     if (ok && !owned.empty()) ok &= hipMemcpy(c->d_owned, owned.data(), owned.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     if (ok) ok &= hipMemcpy(c->d_sowned, sowned.data(), sowned.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     if (ok) ok &= hipMemset(c->d_tiles, 0, (size_t)c->slots_per_rank * ZR_TILE * ZR_TILE * 4) == hipSuccess;
-    const uint32_t mt = (c->n_tiles > c->sn_tiles ? c->n_tiles : c->sn_tiles) + 1;
+    const uint32_t mt = (c->n_tiles > c->sn_tiles ? c->n_tiles : c->sn_tiles) * ZR_TCLASSES + 4;    // (the triangle-binned pass bins by tile x class)
     for (auto& sc : c->sc) {
         ok &= dev_alloc(&sc.tile_count, mt) == hipSuccess;
         ok &= dev_alloc(&sc.tile_offset, mt) == hipSuccess;
@@ -210,7 +210,7 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
 
 static void free_mesh_buffers(ZrMesh& m)
 {
-    dev_free(m.d_v); dev_free(m.d_rv); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mtri); dev_free(m.d_tri_meshlet);
+    dev_free(m.d_v); dev_free(m.d_rv); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mbox); dev_free(m.d_mtri); dev_free(m.d_tri_meshlet);
     m.uploaded = false;
 }
 
@@ -219,7 +219,7 @@ static void free_scene(zr_ctx* c)
     for (auto& o : c->objects) { dev_free(o.d_inst); for (auto& t : o.d_tex) dev_free(t); }
     c->objects.clear();
     for (auto& m : c->meshes) {
-        dev_free(m.d_v); dev_free(m.d_rv); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mtri); dev_free(m.d_tri_meshlet);
+        dev_free(m.d_v); dev_free(m.d_rv); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mbox); dev_free(m.d_mtri); dev_free(m.d_tri_meshlet);
     }
     c->meshes.clear();
     c->profabs.clear();
@@ -256,7 +256,7 @@ extern "C" void zr_destroy(zr_ctx* c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     dev_free(c->d_vis);
     dev_free(c->d_pxrect); dev_free(c->d_zmin); dev_free(c->d_visflag[0]); dev_free(c->d_visflag[1]); dev_free(c->d_hiz);
-    dev_free(c->tb.sel); dev_free(c->tb.recs); dev_free(c->tb.idx); dev_free(c->tb.slow); dev_free(c->tb.wave_fill);
+    dev_free(c->tb.sel); dev_free(c->tb.recs); dev_free(c->tb.idx); dev_free(c->tb.slow); dev_free(c->tb.chunk_fill); dev_free(c->tb.wave_culled);
     for (auto& fr : c->evr) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_end) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -582,7 +582,18 @@ static int upload_mesh(zr_ctx* c, ZrMesh& m)
             if (tri < tri_meshlet.size()) tri_meshlet[tri] = (uint32_t)mi;
         }
     }
-    HIPCHK(c, upload(&m.d_mpos, mpos)); HIPCHK(c, upload(&m.d_mtri, mtri)); HIPCHK(c, upload(&m.d_tri_meshlet, tri_meshlet));
+    std::vector<float4> mbox(2 * std::max<size_t>(1, m.ms.meshlets.size()), make_float4(0.0f, 0.0f, 0.0f, 0.0f));   // object-space box per meshlet
+    for (size_t mi = 0; mi < m.ms.meshlets.size(); ++mi) {
+        const XkMeshlet& ml = m.ms.meshlets[mi];
+        float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+        for (uint32_t v = 0; v < ml.VertexCount; ++v) {
+            const float4& q = mpos[ml.VertexOffset + v];
+            const float e[3] = { q.x, q.y, q.z };
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], e[a]); hi[a] = std::max(hi[a], e[a]); }      // (a NaN coordinate drops out: k_geom sees it)
+        }
+        mbox[2 * mi] = make_float4(lo[0], lo[1], lo[2], 0.0f); mbox[2 * mi + 1] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    }
+    HIPCHK(c, upload(&m.d_mpos, mpos)); HIPCHK(c, upload(&m.d_mbox, mbox)); HIPCHK(c, upload(&m.d_mtri, mtri)); HIPCHK(c, upload(&m.d_tri_meshlet, tri_meshlet));
     m.uploaded = true;
     return ZR_OK;
 }
@@ -599,7 +610,7 @@ static int finalize_scene(zr_ctx* c)
     uint64_t work = 0, prim = 0, inst_total = 0;
     auto emit = [&](const ZrSceneObject& o, const ZrMesh& m, uint32_t flags) {
         ZrObject d; memset(&d, 0, sizeof d);
-        d.verts = m.d_v; d.rverts = m.d_rv; d.indices = m.d_idx; d.meshlets = m.d_meshlets; d.mpos = m.d_mpos; d.mtri = m.d_mtri; d.tri_meshlet = m.d_tri_meshlet;
+        d.verts = m.d_v; d.rverts = m.d_rv; d.indices = m.d_idx; d.meshlets = m.d_meshlets; d.mpos = m.d_mpos; d.mbox = m.d_mbox; d.mtri = m.d_mtri; d.tri_meshlet = m.d_tri_meshlet;
         d.inst = o.d_inst;
         d.n_meshlets = (uint32_t)m.ms.meshlets.size(); d.n_tris = (uint32_t)(m.idx.size() / 3);
         d.n_inst = o.n_inst; d.instanced = o.instanced; d.flags = flags;
@@ -644,18 +655,20 @@ static int finalize_scene(zr_ctx* c)
             HIPCHK(c, dev_alloc(&sc.bins, c->bin_capacity));
             HIPCHK(c, dev_alloc(&sc.chunk_tab, c->chunk_capacity));
         }
-        // triangle-binned camera pass: every wave of k_geom's fixed grid owns a region of record slots (no allocator).  A launch
-        // takes `batch` meshlet-instances, ~64 per wave and ~50 records each; a region of 8192 leaves a wide margin (a region that
-        // does fill up is reported like a bin overflow).  1.5 GB of 288: HBM is not scarce.
-        dev_free(c->tb.sel); dev_free(c->tb.recs); dev_free(c->tb.idx); dev_free(c->tb.slow); dev_free(c->tb.wave_fill); dev_free(c->tb.wave_fill);
-        c->tb.n_waves = 8192; c->tb.region = 4096; c->tb.batch = 262144; c->tb.slow_cap = 1u << 18;
-        const uint32_t rec_cap = c->tb.n_waves * c->tb.region;
+        // triangle-binned camera pass: triangle records live in chunks of ZR_TPOOL_CHUNK; every wave of k_geom's fixed grid starts in
+        // its own chunk and takes further ones from the pool (a pool that runs dry is reported like a bin overflow).  1.5 GB of
+        // 288: HBM is not scarce.
+        dev_free(c->tb.sel); dev_free(c->tb.recs); dev_free(c->tb.idx); dev_free(c->tb.slow); dev_free(c->tb.chunk_fill); dev_free(c->tb.wave_culled);
+        // capacity as for the meshlet bins: 8 records per meshlet-instance of the scene, at least 32 Mi (1.5 GiB)
+        c->tb.n_waves = 8192; c->tb.slow_cap = 1u << 18;
+        c->tb.n_chunks = (uint32_t)(std::min<uint64_t>(std::max<uint64_t>(32ull << 20, 8ull * c->n_work), 0x3FFFFFFFull) / ZR_TPOOL_CHUNK);
         HIPCHK(c, dev_alloc(&c->tb.sel, c->work_capacity));
-        HIPCHK(c, dev_alloc(&c->tb.recs, 3ull * rec_cap));
-        HIPCHK(c, dev_alloc(&c->tb.idx, rec_cap));
-        HIPCHK(c, dev_alloc(&c->tb.wave_fill, c->tb.n_waves));
+        HIPCHK(c, dev_alloc(&c->tb.recs, 3ull * c->tb.n_chunks * ZR_TPOOL_CHUNK));
+        HIPCHK(c, dev_alloc(&c->tb.idx, (size_t)c->tb.n_chunks * ZR_TPOOL_CHUNK));
+        HIPCHK(c, dev_alloc(&c->tb.chunk_fill, c->tb.n_chunks));
+        HIPCHK(c, dev_alloc(&c->tb.wave_culled, c->tb.n_waves));
         HIPCHK(c, dev_alloc(&c->tb.slow, 4ull * c->tb.slow_cap));
-        c->chunk_capacity = std::max<uint32_t>(c->chunk_capacity, rec_cap / ZR_TCHUNK + 2u * std::max(c->n_tiles, c->sn_tiles) + 1u);
+        c->chunk_capacity = std::max<uint32_t>(c->chunk_capacity, c->tb.n_chunks * (ZR_TPOOL_CHUNK / ZR_TCHUNK) + 2u * std::max(c->n_tiles, c->sn_tiles) + 1u);
         for (auto& sc : c->sc) { dev_free(sc.chunk_tab); HIPCHK(c, dev_alloc(&sc.chunk_tab, c->chunk_capacity)); }
         HIPCHK(c, dev_alloc(&c->d_pxrect, c->work_capacity)); HIPCHK(c, dev_alloc(&c->d_zmin, c->work_capacity));
         HIPCHK(c, dev_alloc(&c->d_visflag[0], c->work_capacity)); HIPCHK(c, dev_alloc(&c->d_visflag[1], c->work_capacity));
@@ -966,20 +979,16 @@ static void bin_and_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot,
 // path's one raster launch does, and are timed as the raster.
 static void tri_select(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s)
 {
-    zr_launch_select(P, c->sc[1].work, c->sc[1].rects, Z, c->tb, c->d_stats, slot, s);
+    zr_launch_select(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->tb, c->d_stats, slot, s);
 }
 static void tri_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s)
 {
     const zr_ctx::Scratch& sc = c->sc[1];
-    // the selection's size is only known on the device: big scenes launch every batch the work items could need (an empty one costs
-    // four near-empty launches); config 3 fits one
-    for (uint32_t first = 0; first < P.n_work; first += c->tb.batch) {
-        zr_launch_geom(P, c->d_objs, Z, c->tb, first, sc.tile_count, c->d_stats, slot, s);
-        zr_launch_scan(sc.tile_count, sc.tile_offset, sc.tile_cursor, sc.chunk_offset, sc.chunk_tab, c->chunk_capacity, c->n_tiles,
-                       c->tb.n_waves * c->tb.region, c->d_stats, slot, s, ZR_TCHUNK, c->tiles_x, c->cfg.tile_rank, c->cfg.tile_world);
-        zr_launch_index(c->tb, sc.tile_offset, sc.tile_cursor, s);
-        zr_launch_tile(P, sc.chunk_tab, c->tb, c->d_owned, c->n_owned, c->d_stats, slot, c->d_vis, c->raster_blocks, s);
-    }
+    if (P.n_work == 0) return;          // nothing to draw: the pass is its clear
+    zr_launch_geom(P, Z, c->tb, sc.tile_count, c->d_stats, slot, s);
+    zr_launch_scan_tri(sc.tile_count, sc.tile_offset, sc.tile_cursor, sc.chunk_tab, c->chunk_capacity, c->n_tiles, c->tb, c->d_stats, slot, s);
+    zr_launch_index(c->tb, sc.tile_offset, sc.tile_cursor, c->d_stats, slot, s);
+    zr_launch_tile(P, sc.chunk_tab, c->tb, c->d_owned, c->n_owned, c->d_stats, slot, c->d_vis, c->raster_blocks, s);
 }
 static void raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s)
 {
@@ -1071,10 +1080,11 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
     Z.pxrect = hiz_on ? c->d_pxrect : nullptr; Z.zmin = hiz_on ? c->d_zmin : nullptr;
     Z.vis_prev = c->d_visflag[c->vis_cur ^ 1]; Z.vis_now = hiz_on ? c->d_visflag[c->vis_cur] : nullptr;
     Z.phase = 0;
-    zr_launch_cull(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, c->raster_blocks * 4u, s);
+    const bool tri_bins = !(c->cfg.flags & ZR_FLAG_MESHLET_BINS) && ZR_TILE == 32;
+    if (tri_bins) zr_launch_cull_box(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, s);
+    else zr_launch_cull(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, c->raster_blocks * 4u, s);
     if (hiz_on && P.use_worklist) HIPCHK(c, hipMemsetAsync(c->d_visflag[c->vis_cur], 0, c->n_work, s));     // else k_cull clears them
     c->last_two_round = hiz_on && c->vis_history;
-    const bool tri_bins = !(c->cfg.flags & ZR_FLAG_MESHLET_BINS) && ZR_TILE == 32;
     auto bin = [&](int slot) { if (tri_bins) tri_select(c, P, Z, slot, s); else bin_and_raster(c, P, Z, slot, c->n_tiles, s); };
     auto rast = [&](int slot) { if (tri_bins) tri_raster(c, P, Z, slot, s); else raster(c, P, Z, slot, s); };
     if (c->last_two_round) {

@@ -167,8 +167,10 @@ __device__ __forceinline__ int op_min(int a, int b) { return min(a, b); }
 __device__ __forceinline__ int op_max(int a, int b) { return max(a, b); }
 __device__ __forceinline__ int op_or(int a, int b) { return a | b; }
 __device__ __forceinline__ int op_and(int a, int b) { return a & b; }
+__device__ __forceinline__ int op_add(int a, int b) { return a + b; }
 __device__ __forceinline__ int wave_min(int v) { const int idn = 0x7FFFFFFF; ZR_WAVE_REDUCE(op_min); }
 __device__ __forceinline__ int wave_max(int v) { const int idn = (int)0x80000000; ZR_WAVE_REDUCE(op_max); }
+__device__ __forceinline__ int wave_sum(int v) { const int idn = 0; ZR_WAVE_REDUCE(op_add); }
 __device__ __forceinline__ uint32_t wave_or(uint32_t u) { const int idn = 0, v = (int)u; ZR_WAVE_REDUCE(op_or); }
 __device__ __forceinline__ uint32_t wave_and(uint32_t u) { const int idn = -1, v = (int)u; ZR_WAVE_REDUCE(op_and); }
 typedef short short2_t __attribute__((ext_vector_type(2)));
@@ -286,6 +288,68 @@ __global__ __launch_bounds__(256) void k_cull_instances(ZrPass P, const ZrObject
 __device__ __forceinline__ float lane_bcast(float v, uint32_t src) { return zr_u2f((uint32_t)__builtin_amdgcn_readlane((int)zr_f2u(v), (int)src)); }
 __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
 
+// Stage A for one work item k (the calling lane's): decode, sphere vs frustum, normal cone, owned-region reject.
+struct CullItem {
+    const float4* mposv;          // first vertex of the meshlet in the flattened position array
+    const ZrObject* O;
+    uint32_t vcount, instanced, m;
+    ZrInstance I;
+};
+template <int MODE, bool WORKLIST>
+__device__ __forceinline__ bool cull_stage_a(const ZrPass& P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
+                                             uint8_t* __restrict__ vis_clear, uint32_t k, CullItem& it)
+{
+    bool alive = true;
+    const uint32_t w = WORKLIST ? work[k] : k;
+    if (!WORKLIST && vis_clear) vis_clear[w] = 0;        // this frame's visibility marks start from zero (saves a fill launch)
+    const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w);
+    const uint32_t local = w - O->work_base, nm = O->n_meshlets;
+    const uint32_t inst_i = local / nm, m = local - inst_i * nm;
+    const XkMeshlet* __restrict__ mlp = O->meshlets + m;
+    // the 64-byte record as aligned 16-byte words: [16] centre.xyz radius  [32] apex.xyz axis.x  [48] axis.yz cutoff
+    const float4* __restrict__ mq = (const float4*)mlp;
+    const float4 bs = mq[1], q2 = mq[2], q3 = mq[3];
+    const float4 cn = make_float4(q2.w, q3.x, q3.y, q3.z);      // axis.xyz, cutoff
+    it.O = O; it.m = m;
+    it.mposv = O->mpos + mlp->VertexOffset; it.vcount = mlp->VertexCount;
+    it.I = O->inst[inst_i];
+    const ZrInstance& I = it.I;
+    const uint32_t instanced = O->instanced != 0 ? 1u : 0u;
+    it.instanced = instanced;
+    // the skydome is not a shadow caster (ZE:4709-4720); with N GPUs each draws every N-th instance (see k_cull_instances)
+    if (MODE == ZR_MODE_SHADOW && ((O->flags & ZR_OBJ_SKY) || inst_i % P.inst_world != P.inst_rank)) alive = false;
+    if (alive && (P.frustum_ok | P.cone_ok | P.rect_cull)) {
+        const zf3 co = vs_position(zr3(bs.x, bs.y, bs.z), I, instanced != 0);
+        const zf4 cw4 = zr_mat4_point(P.M, co);
+        const zf3 cw = zr3(cw4.x, cw4.y, cw4.z);
+        float rw = bs.w * (instanced ? __builtin_fabsf(I.s) : 1.0f) * P.m_scale;
+        rw = __builtin_fmaf(rw, 1.001f, 1e-5f * (__builtin_fabsf(cw.x) + __builtin_fabsf(cw.y) + __builtin_fabsf(cw.z) + 1.0f));
+        if (P.frustum_ok) {
+            for (int q = 0; q < 6; ++q) {
+                const float d = __builtin_fmaf(P.planes[q][0], cw.x, __builtin_fmaf(P.planes[q][1], cw.y,
+                                __builtin_fmaf(P.planes[q][2], cw.z, P.planes[q][3])));
+                if (d < -rw) alive = false;
+            }
+        }
+        if (MODE == ZR_MODE_GBUFFER && P.cone_ok && cn.w < 1.0f && (!instanced || I.s > 0.0f)) {
+            // meshoptimizer's bounding-sphere cone test, widened by ~1 degree (0.02 L): every triangle of the
+            // cluster is back-facing for this eye  <=  dot(c - eye, axis) >= cutoff*|c - eye| + radius
+            zf3 ax = zr3(cn.x, cn.y, cn.z);
+            if (instanced) ax = zr_rowvec_mat3(ax, I.R);
+            const zf3 aw = zr3(__builtin_fmaf(P.M[8], ax.z, __builtin_fmaf(P.M[4], ax.y, P.M[0] * ax.x)),
+                               __builtin_fmaf(P.M[9], ax.z, __builtin_fmaf(P.M[5], ax.y, P.M[1] * ax.x)),
+                               __builtin_fmaf(P.M[10], ax.z, __builtin_fmaf(P.M[6], ax.y, P.M[2] * ax.x)));
+            const zf3 d = cw - zr3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+            const float L = zr_length(d);
+            if (zr_dot(d, aw) >= __builtin_fmaf(cn.w + 0.02f, L, rw)) alive = false;
+        }
+        // multi-GPU: nothing of this meshlet can land on a tile this rank owns -> no vertex of it is transformed here
+        if (alive && MODE == ZR_MODE_GBUFFER && P.rect_cull &&
+            !sphere_reaches_owned_tile(P, co, bs.w * (instanced ? __builtin_fabsf(I.s) : 1.0f))) alive = false;
+    }
+    return alive;
+}
+
 template <int MODE, bool WORKLIST>
 __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
                                               uint32_t* __restrict__ rects, uint2* __restrict__ pxrect, float* __restrict__ zmin,
@@ -298,58 +362,14 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
         const uint32_t k = base + lane;
         // ---------------------------------------------------------------- stage A: lane per meshlet-instance
         const bool mine = lane < ZR_CULL_GROUP && k < n;
-        bool alive = mine;
-        const float4* mposv = nullptr;              // first vertex of the meshlet in the flattened position array
-        uint32_t vcount = 0, instanced = 0;
-        ZrInstance I;
-        for (int i = 0; i < 9; ++i) I.R[i] = 0.0f;
-        I.t[0] = I.t[1] = I.t[2] = 0.0f; I.s = 1.0f;
-        if (alive) {
-            const uint32_t w = WORKLIST ? work[k] : k;
-            if (!WORKLIST && vis_clear) vis_clear[w] = 0;        // this frame's visibility marks start from zero (saves a fill launch)
-            const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w);
-            const uint32_t local = w - O->work_base, nm = O->n_meshlets;
-            const uint32_t inst_i = local / nm, m = local - inst_i * nm;
-            const XkMeshlet* __restrict__ mlp = O->meshlets + m;
-            // the 64-byte record as aligned 16-byte words: [16] centre.xyz radius  [32] apex.xyz axis.x  [48] axis.yz cutoff
-            const float4* __restrict__ mq = (const float4*)mlp;
-            const float4 bs = mq[1], q2 = mq[2], q3 = mq[3];
-            const float4 cn = make_float4(q2.w, q3.x, q3.y, q3.z);      // axis.xyz, cutoff
-            mposv = O->mpos + mlp->VertexOffset; vcount = mlp->VertexCount;
-            I = O->inst[inst_i];
-            instanced = O->instanced != 0 ? 1u : 0u;
-            // the skydome is not a shadow caster (ZE:4709-4720); with N GPUs each draws every N-th instance (see k_cull_instances)
-            if (MODE == ZR_MODE_SHADOW && ((O->flags & ZR_OBJ_SKY) || inst_i % P.inst_world != P.inst_rank)) alive = false;
-            if (alive && (P.frustum_ok | P.cone_ok | P.rect_cull)) {
-                const zf3 co = vs_position(zr3(bs.x, bs.y, bs.z), I, instanced != 0);
-                const zf4 cw4 = zr_mat4_point(P.M, co);
-                const zf3 cw = zr3(cw4.x, cw4.y, cw4.z);
-                float rw = bs.w * (instanced ? __builtin_fabsf(I.s) : 1.0f) * P.m_scale;
-                rw = __builtin_fmaf(rw, 1.001f, 1e-5f * (__builtin_fabsf(cw.x) + __builtin_fabsf(cw.y) + __builtin_fabsf(cw.z) + 1.0f));
-                if (P.frustum_ok) {
-                    for (int q = 0; q < 6; ++q) {
-                        const float d = __builtin_fmaf(P.planes[q][0], cw.x, __builtin_fmaf(P.planes[q][1], cw.y,
-                                        __builtin_fmaf(P.planes[q][2], cw.z, P.planes[q][3])));
-                        if (d < -rw) alive = false;
-                    }
-                }
-                if (MODE == ZR_MODE_GBUFFER && P.cone_ok && cn.w < 1.0f && (!instanced || I.s > 0.0f)) {
-                    // meshoptimizer's bounding-sphere cone test, widened by ~1 degree (0.02 L): every triangle of the
-                    // cluster is back-facing for this eye  <=  dot(c - eye, axis) >= cutoff*|c - eye| + radius
-                    zf3 ax = zr3(cn.x, cn.y, cn.z);
-                    if (instanced) ax = zr_rowvec_mat3(ax, I.R);
-                    const zf3 aw = zr3(__builtin_fmaf(P.M[8], ax.z, __builtin_fmaf(P.M[4], ax.y, P.M[0] * ax.x)),
-                                       __builtin_fmaf(P.M[9], ax.z, __builtin_fmaf(P.M[5], ax.y, P.M[1] * ax.x)),
-                                       __builtin_fmaf(P.M[10], ax.z, __builtin_fmaf(P.M[6], ax.y, P.M[2] * ax.x)));
-                    const zf3 d = cw - zr3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
-                    const float L = zr_length(d);
-                    if (zr_dot(d, aw) >= __builtin_fmaf(cn.w + 0.02f, L, rw)) alive = false;
-                }
-                // multi-GPU: nothing of this meshlet can land on a tile this rank owns -> no vertex of it is transformed here
-                if (alive && MODE == ZR_MODE_GBUFFER && P.rect_cull &&
-                    !sphere_reaches_owned_tile(P, co, bs.w * (instanced ? __builtin_fabsf(I.s) : 1.0f))) alive = false;
-            }
-        }
+        CullItem it;
+        it.mposv = nullptr; it.O = nullptr; it.vcount = 0; it.instanced = 0; it.m = 0;
+        for (int i = 0; i < 9; ++i) it.I.R[i] = 0.0f;
+        it.I.t[0] = it.I.t[1] = it.I.t[2] = 0.0f; it.I.s = 1.0f;
+        const bool alive = mine && cull_stage_a<MODE, WORKLIST>(P, objs, work, vis_clear, k, it);
+        const float4* mposv = it.mposv;
+        const uint32_t vcount = it.vcount, instanced = it.instanced;
+        const ZrInstance& I = it.I;
         uint32_t out_rect = ZR_RECT_CULLED; uint2 out_px = make_uint2(0u, 0u); float out_z = -1.0f;
         const uint32_t mp_lo = (uint32_t)(unsigned long long)mposv, mp_hi = (uint32_t)((unsigned long long)mposv >> 32);
 
@@ -424,6 +444,97 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
             rects[k] = out_rect;
             if (MODE == ZR_MODE_GBUFFER && pxrect) { pxrect[k] = out_px; zmin[k] = out_z; }
         }
+    }
+}
+
+// The triangle-binned camera pass needs no tile rectangle from the cull - k_geom tests every triangle exactly - only "is it gone" and,
+// for the Hi-Z test of round 2, a pixel box and a least depth that BOUND the meshlet's.  Those come from the eight corners of the
+// meshlet's object-space box instead of its 64 vertices, a lane per meshlet-instance instead of a wave: about a twentieth of
+// k_cull<GBUFFER>'s instructions.  The bounds are conservative by construction: a vertex lies in the box, the transforms are affine up
+// to rounding, and the rounding of both the corners' and the vertices' arithmetic is covered by an explicit margin (8 ulps of the
+// magnitudes involved, carried through the divide; at least one pixel) - culling more is never possible, only a little less.
+template <bool WORKLIST>
+__global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
+                                                  uint32_t* __restrict__ rects, uint2* __restrict__ pxrect, float* __restrict__ zmin,
+                                                  uint8_t* __restrict__ vis_clear, const ZrDevStats* __restrict__ stats, int slot)
+{
+    const uint32_t n = WORKLIST ? stats->n_vis_work[slot] : P.n_work;
+    const float rs_x = __builtin_fabsf(P.PVM[0]) + __builtin_fabsf(P.PVM[4]) + __builtin_fabsf(P.PVM[8]);
+    const float rs_y = __builtin_fabsf(P.PVM[1]) + __builtin_fabsf(P.PVM[5]) + __builtin_fabsf(P.PVM[9]);
+    const float rs_z = __builtin_fabsf(P.PVM[2]) + __builtin_fabsf(P.PVM[6]) + __builtin_fabsf(P.PVM[10]);
+    const float rs_w = __builtin_fabsf(P.PVM[3]) + __builtin_fabsf(P.PVM[7]) + __builtin_fabsf(P.PVM[11]);
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
+        CullItem it;
+        uint32_t r = ZR_RECT_CULLED; uint2 pr = make_uint2(0u, 0u); float zm = -1.0f;
+        if (cull_stage_a<ZR_MODE_GBUFFER, WORKLIST>(P, objs, work, vis_clear, k, it)) {
+            const float4 lo = it.O->mbox[2u * it.m], hi = it.O->mbox[2u * it.m + 1u];
+            const float FM = 3.402823466e38f, U = 9.5367431640625e-7f;           // 8 ulps
+            bool fin = true, clip = false;
+            float mag = 0.0f, mx = 0.0f, my = 0.0f, mz = 0.0f, mw = 0.0f, wmin = FM;
+            float nxl = FM, nxh = -FM, nyl = FM, nyh = -FM, zl = FM;
+            uint32_t out_all = 63u;        // bit q: every corner beyond plane q (-x, +x, -y, +y, near, far)
+            zf4 cl[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const zf3 wp = vs_position(zr3((q & 1) ? hi.x : lo.x, (q & 2) ? hi.y : lo.y, (q & 4) ? hi.z : lo.z), it.I, it.instanced != 0);
+                cl[q] = zr_mat4_point(P.PVM, wp);
+                mx = __builtin_fmaxf(mx, __builtin_fabsf(cl[q].x)); my = __builtin_fmaxf(my, __builtin_fabsf(cl[q].y));
+                mz = __builtin_fmaxf(mz, __builtin_fabsf(cl[q].z)); mw = __builtin_fmaxf(mw, __builtin_fabsf(cl[q].w));
+                fin = fin && __builtin_fabsf(cl[q].x) <= FM && __builtin_fabsf(cl[q].y) <= FM && __builtin_fabsf(cl[q].z) <= FM && __builtin_fabsf(cl[q].w) <= FM;
+            }
+            // what the corners' and the vertices' clip coordinates can differ from exact arithmetic by: 8 ulps of the largest terms
+            // of the two affine maps (instance: |s p| + |t|; PVM: |row| . |position| + |translation| + |result|)
+            const float pm = __builtin_fmaxf(__builtin_fabsf(lo.x), __builtin_fabsf(hi.x)) + __builtin_fmaxf(__builtin_fabsf(lo.y), __builtin_fabsf(hi.y)) +
+                             __builtin_fmaxf(__builtin_fabsf(lo.z), __builtin_fabsf(hi.z));
+            mag = it.instanced ? __builtin_fmaf(3.0f * __builtin_fabsf(it.I.s), pm, __builtin_fabsf(it.I.t[0]) + __builtin_fabsf(it.I.t[1]) + __builtin_fabsf(it.I.t[2])) : pm;
+            const float ew = U * (mag + 1.0f);
+            const float ex = __builtin_fmaf(ew, rs_x, U * (mx + __builtin_fabsf(P.PVM[12]))), ey = __builtin_fmaf(ew, rs_y, U * (my + __builtin_fabsf(P.PVM[13])));
+            const float ez = __builtin_fmaf(ew, rs_z, U * (mz + __builtin_fabsf(P.PVM[14]))), eW = __builtin_fmaf(ew, rs_w, U * (mw + __builtin_fabsf(P.PVM[15])));
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const zf4 c = cl[q];
+                const float gb = ZR_GUARD * c.w;
+                clip = clip || c.z < ez || !(c.w > eW) || __builtin_fabsf(c.x) > gb || __builtin_fabsf(c.y) > gb;
+                uint32_t o = 0;
+                if (c.x < -c.w - (ex + eW)) o |= 1u;
+                if (c.x > c.w + (ex + eW)) o |= 2u;
+                if (c.y < -c.w - (ey + eW)) o |= 4u;
+                if (c.y > c.w + (ey + eW)) o |= 8u;
+                if (c.z < -ez) o |= 16u;
+                if (c.z > c.w + (ez + eW)) o |= 32u;
+                out_all &= o;
+                wmin = __builtin_fminf(wmin, c.w);
+            }
+            if (!fin) r = 0u;                                   // not finite: drawn, never occlusion-tested (k_geom sorts it out)
+            else if (out_all) r = ZR_RECT_CULLED;               // the whole box is beyond one frustum plane
+            else if (clip) r = 0u;                              // touches the near plane / guard band: drawn, not occlusion-tested
+            else {
+                const float rwm = 1.0f / (wmin - eW);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float rw = 1.0f / cl[q].w;
+                    const float x = __builtin_fmaf(cl[q].x * rw, P.hw, P.hw), y = __builtin_fmaf(cl[q].y * rw, P.hh, P.hh);
+                    nxl = __builtin_fminf(nxl, x); nxh = __builtin_fmaxf(nxh, x); nyl = __builtin_fminf(nyl, y); nyh = __builtin_fmaxf(nyh, y);
+                    zl = __builtin_fminf(zl, cl[q].z * rw);
+                }
+                // |d(x / w)| <= (ex + |x / w| eW) / w, |x / w| <= ZR_GUARD here; one pixel on top for the snapping and the divide
+                const float px_e = __builtin_fmaf(P.hw, (ex + ZR_GUARD * eW) * rwm, 1.0f), py_e = __builtin_fmaf(P.hh, (ey + ZR_GUARD * eW) * rwm, 1.0f);
+                const float z_e = __builtin_fmaf(ez + eW, rwm, 1e-6f);
+                if (px_e < 64.0f && py_e < 64.0f) {
+                    // pixel centres the snapped vertices can bound: centre i is at i + 0.5
+                    int px0 = (int)__builtin_floorf(nxl - px_e - 0.5f) , py0 = (int)__builtin_floorf(nyl - py_e - 0.5f);
+                    int px1 = (int)__builtin_ceilf(nxh + px_e - 0.5f), py1 = (int)__builtin_ceilf(nyh + py_e - 0.5f);
+                    px0 = max(px0, 0); py0 = max(py0, 0); px1 = min(px1, (int)P.W - 1); py1 = min(py1, (int)P.H - 1);
+                    if (px0 <= px1 && py0 <= py1) {
+                        r = 0u;
+                        zm = __builtin_fmaxf(zl - z_e, 0.0f);
+                        pr = make_uint2((uint32_t)px0 | (uint32_t)py0 << 16, (uint32_t)px1 | (uint32_t)py1 << 16);
+                    }
+                } else r = 0u;
+            }
+        }
+        rects[k] = r;
+        if (pxrect) { pxrect[k] = pr; zmin[k] = zm; }
     }
 }
 
@@ -561,24 +672,19 @@ __global__ __launch_bounds__(1024) void k_bin_count(ZrPass P, const uint32_t* __
 
 // Exclusive scan of tile_count[0..n) into tile_offset[0..n] and of the per-tile work-unit counts ceil(count / chunk)
 // into chunk_offset[0..n]; lays out the rasteriser's work units (tile, first entry, end, kind); zeroes tile_count and tile_cursor
-// for the fill and resets the work counter.  Triangle-binned pass (tiles_x != 0): also notes which slow triangles this batch added.
+// for the fill and resets the work counter.
 __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
                                                uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ chunk_offset,
                                                uint4* __restrict__ chunk_tab, uint32_t chunk_cap,
-                                               uint32_t n, uint32_t capacity, ZrDevStats* __restrict__ stats, int slot,
-                                               uint32_t chunk, uint32_t tiles_x, uint32_t tile_rank, uint32_t tile_world)
+                                               uint32_t n, uint32_t capacity, ZrDevStats* __restrict__ stats, int slot, uint32_t chunk)
 {
     __shared__ uint32_t part[1024];
     __shared__ uint32_t cpart[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t b = tid * per, e = min(n, b + per);
-    // slow triangles this batch added: [what earlier batches of the round already tried, the running total)
-    const uint32_t slow_lo = tiles_x != 0u ? stats->slow_hi[slot] : 0u, slow_hi = tiles_x != 0u ? stats->n_slow[slot] : 0u;
-    (void)tile_rank; (void)tile_world;
-    auto units_of = [&](uint32_t, uint32_t c) -> uint32_t { return (c + chunk - 1u) / chunk; };
     uint32_t s = 0, cs = 0;
-    for (uint32_t i = b; i < e; ++i) { const uint32_t c = tile_count[i]; s += c; cs += units_of(i, c); }
+    for (uint32_t i = b; i < e; ++i) { const uint32_t c = tile_count[i]; s += c; cs += (c + chunk - 1u) / chunk; }
     part[tid] = s; cpart[tid] = cs;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {
@@ -593,22 +699,71 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
         tile_offset[i] = run;
         chunk_offset[i] = crun;
         // one record per raster work unit: (tile, first entry, end, kind): the rasteriser finds its unit with one load, not a search
-        const uint32_t nu = units_of(i, c), nreg = (c + chunk - 1u) / chunk;
+        const uint32_t nu = (c + chunk - 1u) / chunk;
         for (uint32_t k = 0; k < nu; ++k)
-            if (crun + k < chunk_cap)
-                chunk_tab[crun + k] = k < nreg ? make_uint4(i, run + k * chunk, run + min(c, (k + 1u) * chunk), 0u) : make_uint4(i, 0u, 0u, 1u);
+            if (crun + k < chunk_cap) chunk_tab[crun + k] = make_uint4(i, run + k * chunk, run + min(c, (k + 1u) * chunk), 0u);
         run += c; crun += nu;
         tile_count[i] = 0; tile_cursor[i] = 0;
     }
     if (tid == 1023) {
         tile_offset[n] = part[1023];
         chunk_offset[n] = cpart[1023];
-        if (tiles_x != 0u) stats->bin_entries[slot] += part[1023];       // triangle records: summed over the round's batches
-        else stats->bin_entries[slot] = part[1023];
+        stats->bin_entries[slot] = part[1023];
         stats->n_chunks[slot] = min(cpart[1023], chunk_cap);
         stats->chunk_counter[slot] = 0;
-        if (tiles_x != 0u) { stats->slow_lo[slot] = slow_lo; stats->slow_hi[slot] = slow_hi; }
         if (part[1023] > capacity) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
+    }
+}
+
+// The triangle-binned pass bins its records by (tile, walk-size class): bin_count[tile * ZR_TCLASSES + class].  A tile's records are
+// laid out class after class, so the 64 consecutive records a wave of k_tile takes are of one size - the walk of a wave lasts as long
+// as its largest triangle's.  Work units are <= chunk records of ONE tile (they may span its classes).  Also: zeroes the counts /
+// cursors, resets the work counter and the record pool, and books the meshlets k_geom's waves dropped behind the pyramid.
+__global__ __launch_bounds__(1024) void k_scan_tri(uint32_t* __restrict__ bin_count, uint32_t* __restrict__ bin_offset,
+                                                   uint32_t* __restrict__ bin_cursor, uint4* __restrict__ chunk_tab, uint32_t chunk_cap,
+                                                   uint32_t n_tiles, const uint32_t* __restrict__ wave_culled, uint32_t n_waves,
+                                                   ZrDevStats* __restrict__ stats, int slot, uint32_t chunk)
+{
+    __shared__ uint32_t culled_s;
+    if (threadIdx.x == 0) culled_s = 0;
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t cpart[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_tiles + 1023u) / 1024u;
+    const uint32_t b = min(n_tiles, tid * per), e = min(n_tiles, b + per);
+    uint4* __restrict__ cnt4 = (uint4*)bin_count;
+    uint32_t nc = 0;
+    for (uint32_t i = tid; i < n_waves; i += 1024u) nc += wave_culled[i];
+    uint32_t s = 0, cs = 0;
+    for (uint32_t i = b; i < e; ++i) { const uint4 c = cnt4[i]; const uint32_t t = c.x + c.y + c.z + c.w; s += t; cs += (t + chunk - 1u) / chunk; }
+    part[tid] = s; cpart[tid] = cs;
+    __syncthreads();
+    nc = (uint32_t)wave_sum((int)nc);
+    if ((tid & 63u) == 0 && nc) atomicAdd(&culled_s, nc);
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = (tid >= off) ? part[tid - off] : 0u, cv = (tid >= off) ? cpart[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += v; cpart[tid] += cv;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s, crun = cpart[tid] - cs;
+    for (uint32_t i = b; i < e; ++i) {
+        const uint4 c = cnt4[i];
+        const uint32_t t = c.x + c.y + c.z + c.w, nu = (t + chunk - 1u) / chunk;
+        ((uint4*)bin_offset)[i] = make_uint4(run, run + c.x, run + c.x + c.y, run + c.x + c.y + c.z);
+        for (uint32_t k = 0; k < nu; ++k)
+            if (crun + k < chunk_cap) chunk_tab[crun + k] = make_uint4(i, run + k * chunk, run + min(t, (k + 1u) * chunk), 0u);
+        run += t; crun += nu;
+        cnt4[i] = make_uint4(0u, 0u, 0u, 0u); ((uint4*)bin_cursor)[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    if (tid == 1023) {
+        stats->bin_entries[slot] = part[1023];        // triangle records of the round
+        stats->n_chunks[slot] = min(cpart[1023], chunk_cap);
+        stats->chunk_counter[slot] = 0;
+        stats->pool_used[slot] = stats->pool_next[slot]; stats->pool_next[slot] = 0;
+        if (cpart[1023] > chunk_cap) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
+        // (the scan loop's barriers ordered culled_s) meshlets of this round that k_geom dropped behind the pyramid
+        stats->hiz_culled += culled_s; stats->survivors[slot] -= culled_s;
     }
 }
 
@@ -1364,8 +1519,9 @@ __global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(ZR_RAS
 
 // Which meshlet-instances does this round draw?  (The split of the two-pass occlusion culling, as k_bin_count makes it.)
 // Compacted per workgroup: one global atomic per 1024 work items (atomics on one address run at ~10 ns apiece on this part).
-__global__ __launch_bounds__(1024) void k_select(ZrPass P, const uint32_t* __restrict__ work, const uint32_t* __restrict__ rects, ZrHiz Z,
-                                                 uint32_t* __restrict__ sel, ZrDevStats* __restrict__ stats, int slot)
+__global__ __launch_bounds__(1024) void k_select(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
+                                                 const uint32_t* __restrict__ rects, ZrHiz Z, ZrBinEntry* __restrict__ sel,
+                                                 ZrDevStats* __restrict__ stats, int slot)
 {
     __shared__ uint32_t wcount[16], wbase[16], nocc;
     const uint32_t n_vis = P.use_worklist ? stats->n_vis_work[1] : P.n_work;
@@ -1397,45 +1553,56 @@ __global__ __launch_bounds__(1024) void k_select(ZrPass P, const uint32_t* __res
         if (tot) atomicAdd(&stats->survivors[slot], tot);
     }
     __syncthreads();
-    if (take) sel[wbase[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = w;
+    if (take) {
+        // the work id is decoded here, lane-parallel: k_geom's wave starts every load of the meshlet from this one record
+        const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w);
+        const uint32_t local = w - O->work_base;
+        const uint32_t inst_i = local / O->n_meshlets, mi = local - inst_i * O->n_meshlets;
+        const XkMeshlet* __restrict__ ml = O->meshlets + mi;
+        ZrBinEntry be;
+        be.mpos = O->mpos + ml->VertexOffset; be.mtri = O->mtri + ml->BindlessContext; be.inst = O->inst + inst_i;
+        be.counts = ml->VertexCount | ml->TriangleCount << 8 | (O->instanced ? 1u << 16 : 0u);
+        be.prim_base = O->prim_base + inst_i * O->n_tris;
+        sel[wbase[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = be;
+    }
     if (threadIdx.x == 0 && nocc) atomicAdd(&stats->hiz_culled, nocc);
 }
 
 // One wave per selected meshlet-instance: vertices -> LDS, triangles -> records.
-// Records need no allocator: wave k of the grid owns record slots [k * region, (k + 1) * region) and reports its fill.
+// Records live in chunks of ZR_TPOOL_CHUNK: wave k of the grid starts in chunk k and takes further ones from a pool (one atomic per
+// ZR_TPOOL_CHUNK records); chunk_fill[] says how many records each chunk holds.  A round is ONE launch whatever the scene's size.
+// Round 2 (HIZ): a meshlet whose snapped vertex box lies behind the pyramid is dropped after the vertex phase (the test k_cull's
+// stage B makes in the meshlet-binned path, with the same box), and every triangle is tested once more by itself.
 template <bool HIZ>
-__global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ sel, uint32_t first,
-                                              uint32_t batch, ZrHiz Z, uint4* __restrict__ recs, uint32_t region,
-                                              uint32_t* __restrict__ wave_fill, uint4* __restrict__ slow, uint32_t slow_cap,
+__global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, uint4* __restrict__ recs,
+                                              uint32_t n_chunks, uint32_t* __restrict__ chunk_fill, uint32_t* __restrict__ wave_culled,
+                                              uint4* __restrict__ slow, uint32_t slow_cap,
                                               uint32_t* __restrict__ tile_count, ZrDevStats* __restrict__ stats, int slot)
 {
     __shared__ int4 vstage[4][WAVE];
     const uint32_t lane = threadIdx.x & 63u, wv = wave_uniform(threadIdx.x >> 6);
-    const uint32_t n_sel = stats->n_sel[slot];
-    const uint32_t n = min(n_sel, first + batch);
+    const uint32_t n = stats->n_sel[slot];
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const uint32_t wave_id = blockIdx.x * 4u + wv;
-    const uint32_t rec0 = wave_id * region;
-    uint32_t fill = 0;                          // wave-uniform
-    for (uint32_t i = first + wave_id; i < n; i += gridDim.x * 4u) {
-        const uint32_t w = wave_uniform(sel[i]);
-        const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w);
-        const uint32_t local = w - O->work_base, nm = O->n_meshlets;
-        const uint32_t inst_i = local / nm, m = local - inst_i * nm;
-        const XkMeshlet* __restrict__ ml = O->meshlets + m;
-        const uint32_t vcount = ml->VertexCount, tcount = ml->TriangleCount;
-        const float4* __restrict__ mp = O->mpos + ml->VertexOffset;
-        const uint2* __restrict__ tw = O->mtri + ml->BindlessContext;
-        const bool instanced = O->instanced != 0;
-        const uint32_t pbase = O->prim_base + inst_i * O->n_tris;
+    const uint32_t wave_id = blockIdx.x * 4u + wv, n_waves = gridDim.x * 4u;
+    uint32_t cur = wave_id, fill = 0, culled = 0;       // wave-uniform: the chunk being filled (n_chunks: the pool ran dry), its fill
+    for (uint32_t i = wave_id; i < n; i += n_waves) {
+        const uint4* __restrict__ rec = (const uint4*)(sel + i);
+        const uint4 e0 = rec[0], e1 = rec[1];
+        const float4* __restrict__ mp = (const float4*)(((unsigned long long)wave_uniform(e0.y) << 32) | wave_uniform(e0.x));
+        const uint2* __restrict__ tw = (const uint2*)(((unsigned long long)wave_uniform(e0.w) << 32) | wave_uniform(e0.z));
+        const ZrInstance* __restrict__ ip = (const ZrInstance*)(((unsigned long long)wave_uniform(e1.y) << 32) | wave_uniform(e1.x));
+        const uint32_t counts = wave_uniform(e1.z), pbase = wave_uniform(e1.w);
+        const uint32_t vcount = counts & 255u, tcount = (counts >> 8) & 255u;
+        const bool instanced = (counts >> 16) & 1u;
         uint2 tri_w[2];
         tri_w[0] = lane < tcount ? tw[lane] : make_uint2(0u, 0u);
         tri_w[1] = lane + WAVE < tcount ? tw[lane + WAVE] : make_uint2(0u, 0u);
         const float4 pp = lane < vcount ? mp[lane] : make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-        const ZrInstance I = O->inst[inst_i];
+        const ZrInstance I = *ip;
 
         lds_fence();   // this wave's previous readers are done with its staging area
         bool flagged;
+        int lo2 = 0x7FFF7FFF, hi2 = (int)0x80008000, zb = 0x7FFFFFFF;      // this lane's share of the meshlet's pixel box / least depth
         {
             const zf4 c = zr_mat4_point(P.PVM, vs_position(zr3(pp.x, pp.y, pp.z), I, instanced));
             const float FM = 3.402823466e38f, gb = ZR_GUARD * c.w;
@@ -1448,7 +1615,20 @@ __global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrObject* __restri
                 SV sv; sv.X = 0; sv.Y = 0; sv.z = 0.0f; sv.rw = 0.0f;
                 if (!(f & 129u)) sv = project(c, P.hw, P.hh);
                 vstage[wv][lane] = make_int4(sv.X, sv.Y, (int)zr_f2u(sv.z), (int)f);      // snapped x, y (absolute), depth, clip flags
+                if (HIZ && !flagged) {
+                    lo2 = (clamp16((sv.X - 128 + 255) >> 8) & 0xFFFF) | (clamp16((sv.Y - 128 + 255) >> 8) << 16);
+                    hi2 = (clamp16((sv.X - 128) >> 8) & 0xFFFF) | (clamp16((sv.Y - 128) >> 8) << 16);
+                    zb = (int)zr_f2u(sv.z + 0.0f);
+                }
             }
+        }
+        if (HIZ && !flagged) {       // every vertex inside the frustum: the box of the snapped vertices bounds every fragment
+            const int lo = wave_pkmin16(lo2), hi = wave_pkmax16(hi2);
+            const int px0 = max(0, (int)(short)(lo & 0xFFFF)), py0 = max(0, lo >> 16);
+            const int px1 = min((int)P.W - 1, (int)(short)(hi & 0xFFFF)), py1 = min((int)P.H - 1, hi >> 16);
+            bool gone = px0 > px1 || py0 > py1;                  // no pixel centre inside
+            if (!gone) gone = hiz_occluded(Z, make_uint2((uint32_t)px0 | (uint32_t)py0 << 16, (uint32_t)px1 | (uint32_t)py1 << 16), zr_u2f((uint32_t)wave_min(zb)));
+            if (gone) { ++culled; continue; }
         }
         lds_fence();
 
@@ -1460,7 +1640,7 @@ __global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrObject* __restri
             int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0;
             const uint32_t prim = pbase + tri_w[round].y;
             bool alive = false, is_slow = false;
-            int tx0 = 0, ty0 = 0, tx1 = -1, ty1 = -1;
+            int tx0 = 0, ty0 = 0, tx1 = -1, ty1 = -1, bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
             uint32_t i0 = 0, i1 = 0, i2 = 0;
             if (t < tcount) {
                 i0 = tri_w[round].x & 255u; i1 = (tri_w[round].x >> 8) & 255u; i2 = (tri_w[round].x >> 16) & 255u;
@@ -1484,7 +1664,7 @@ __global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrObject* __restri
                             for (int bx = x0 >> 3; bx <= (x1 >> 3); ++bx) h = __builtin_fmaxf(h, Z.lvl[0][(size_t)by * Z.hw[0] + (size_t)bx]);
                         if (tz > h) alive = false;
                     }
-                    if (alive) { tx0 = x0 / TILE; tx1 = x1 / TILE; ty0 = y0 / TILE; ty1 = y1 / TILE; }
+                    if (alive) { tx0 = x0 / TILE; tx1 = x1 / TILE; ty0 = y0 / TILE; ty1 = y1 / TILE; bx0 = x0; bx1 = x1; by0 = y0; by1 = y1; }
                 }
             }
             // ---- slow triangles: the three clip-space vertices go to the list every owned tile tries
@@ -1510,66 +1690,92 @@ __global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrObject* __restri
             const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1, ntile = alive ? nx * ny : 0;
             for (int step = 0; __ballot(step < ntile) != 0ull; ++step) {
                 bool emit = step < ntile;
-                uint32_t tile = 0;
+                uint32_t tile = 0;            // the record's bin: tile * ZR_TCLASSES + walk-size class
                 if (emit) {
-                    const uint32_t tx = (uint32_t)(tx0 + step % nx), ty = (uint32_t)(ty0 + step / nx);
-                    tile = ty * P.tiles_x + tx;
+                    const int sy = step / nx, sx = step - sy * nx;
+                    const uint32_t tx = (uint32_t)(tx0 + sx), ty = (uint32_t)(ty0 + sy);
                     if (P.tile_world > 1u && tile_owner(tx, ty, P.tile_world) != P.tile_rank) emit = false;
+                    // pixels the walk of this triangle visits in this tile (its box clamped to the tile)
+                    const int wx = min(bx1, (int)tx * TILE + TILE - 1) - max(bx0, (int)tx * TILE) + 1;
+                    const int wy = min(by1, (int)ty * TILE + TILE - 1) - max(by0, (int)ty * TILE) + 1;
+                    const int wa = wx * wy;
+                    tile = (ty * P.tiles_x + tx) * ZR_TCLASSES + (wa <= 4 ? 0u : wa <= 16 ? 1u : wa <= 64 ? 2u : 3u);
                 }
                 unsigned long long me = __ballot(emit);
                 if (!me) continue;
-                if (fill + (uint32_t)__popcll(me) > region) {          // this wave's record region is full: the frame is incomplete
+                if (cur < n_chunks && fill + (uint32_t)__popcll(me) > ZR_TPOOL_CHUNK) {      // this chunk is full: close it, take one from the pool
+                    uint32_t nx_c = 0;
+                    if (lane == 0) { chunk_fill[cur] = fill; nx_c = n_waves + atomicAdd(&stats->pool_next[slot], 1u); }
+                    cur = min((uint32_t)__builtin_amdgcn_readfirstlane((int)nx_c), n_chunks);
+                    fill = 0;
+                }
+                if (cur >= n_chunks) {          // the pool ran dry: the frame is incomplete
                     if (lane == 0) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
                     continue;
                 }
-                // count per tile: one atomic per (wave, tile), and nobody waits for it (ranks are handed out by k_index)
+                // count per tile: one add per (wave, tile), all of a step's in one instruction, and nobody waits for them (ranks are
+                // handed out by k_index)
                 unsigned long long pend = me;
+                uint32_t cnt = 0;
                 while (pend) {
                     const int leader = __builtin_ctzll(pend);
                     const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
                     const unsigned long long same = __ballot(emit && tile == tl) & pend;
-                    if ((int)lane == leader) atomicAdd(&tile_count[tl], (uint32_t)__popcll(same));
+                    if ((int)lane == leader) cnt = (uint32_t)__popcll(same);
                     pend &= ~same;
                 }
+                if (cnt) atomicAdd(&tile_count[tile], cnt);
                 if (emit) {
-                    const uint32_t pos = rec0 + fill + (uint32_t)__popcll(me & lt);
-                    recs[3u * pos] = make_uint4((uint32_t)r0.x, (uint32_t)r0.y, (uint32_t)r0.z, prim);
-                    recs[3u * pos + 1u] = make_uint4((uint32_t)r1.x, (uint32_t)r1.y, (uint32_t)r1.z, tile);
-                    recs[3u * pos + 2u] = make_uint4((uint32_t)r2.x, (uint32_t)r2.y, (uint32_t)r2.z, 0u);
+                    const uint32_t pos = cur * ZR_TPOOL_CHUNK + fill + (uint32_t)__popcll(me & lt);
+                    recs[(size_t)3u * pos] = make_uint4((uint32_t)r0.x, (uint32_t)r0.y, (uint32_t)r0.z, prim);
+                    recs[(size_t)3u * pos + 1u] = make_uint4((uint32_t)r1.x, (uint32_t)r1.y, (uint32_t)r1.z, tile);
+                    recs[(size_t)3u * pos + 2u] = make_uint4((uint32_t)r2.x, (uint32_t)r2.y, (uint32_t)r2.z, 0u);
                 }
                 fill += (uint32_t)__popcll(me);
             }
         }
     }
-    if (lane == 0) wave_fill[wave_id] = fill;
+    if (lane == 0) {
+        if (cur < n_chunks) chunk_fill[cur] = fill;
+        wave_culled[wave_id] = culled;
+    }
 }
 
 // Every record -> a place in its tile's stretch of the gather list: a cursor per tile, advanced once per (wave, distinct tile) - the
 // records of a region come meshlet by meshlet, so the 64 of a wave name a handful of tiles - because atomics on one address run at
-// about 10 ns apiece on this part and there are half a million records.  One workgroup per k_geom wave's record region.
-__global__ __launch_bounds__(256) void k_index(const uint4* __restrict__ recs, uint32_t region, const uint32_t* __restrict__ wave_fill,
+// about 10 ns apiece on this part and there are half a million records.  The lanes first sort themselves into tile groups (scalar
+// work, no memory), then every group's first lane issues its add in ONE instruction: one round trip per 64 records, not one per
+// group.  One wave per record chunk.
+__global__ __launch_bounds__(256) void k_index(const uint4* __restrict__ recs, const uint32_t* __restrict__ chunk_fill, uint32_t n_static,
+                                               uint32_t n_chunks, const ZrDevStats* __restrict__ stats, int slot,
                                                const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
                                                uint32_t* __restrict__ idx)
 {
-    const uint32_t n = wave_fill[blockIdx.x], r0 = blockIdx.x * region, lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t used = min(n_static + stats->pool_used[slot], n_chunks);
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (uint32_t j0 = (threadIdx.x >> 6) * 64u; j0 < n; j0 += 256u) {
+    for (uint32_t ch = blockIdx.x * 4u + (threadIdx.x >> 6); ch < used; ch += gridDim.x * 4u) {
+    const uint32_t n = chunk_fill[ch], r0 = ch * ZR_TPOOL_CHUNK;
+    for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
         const uint32_t j = j0 + lane, i = r0 + j;
         const bool have = j < n;
-        const uint32_t tile = have ? recs[3u * i + 1u].w : 0u;
-        uint32_t rank = 0;
+        const uint32_t tile = have ? recs[(size_t)3u * i + 1u].w : 0u;
+        const uint32_t off = have ? tile_offset[tile] : 0u;
+        uint32_t rank = 0, cnt = 0;
+        int first = (int)lane;
         unsigned long long pend = __ballot(have);
         while (pend) {
             const int leader = __builtin_ctzll(pend);
             const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
             const unsigned long long same = __ballot(have && tile == tl) & pend;
-            uint32_t b = 0;
-            if ((int)lane == leader) b = atomicAdd(&tile_cursor[tl], (uint32_t)__popcll(same));
-            b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
-            if (same >> lane & 1ull) rank = b + (uint32_t)__popcll(same & lt);
+            if (same >> lane & 1ull) { first = leader; rank = (uint32_t)__popcll(same & lt); cnt = (uint32_t)__popcll(same); }
             pend &= ~same;
         }
-        if (have) idx[tile_offset[tile] + rank] = i;
+        uint32_t b = 0;
+        if (have && first == (int)lane) b = atomicAdd(&tile_cursor[tile], cnt);
+        b = (uint32_t)__shfl((int)b, first);
+        if (have) idx[off + b + rank] = i;
+    }
     }
 }
 
@@ -1597,7 +1803,7 @@ __global__ __launch_bounds__(256) void k_tile(ZrPass P, const uint4* __restrict_
         T.px0 = 0; T.py0 = 0; T.W = (int)P.W - tpx0; T.H = (int)P.H - tpy0;
         for (uint32_t j = ct.y + tid; j < ct.z; j += 256u) {
             const uint32_t i = idx[j];
-            const uint4 q0 = recs[3u * i], q1 = recs[3u * i + 1u], q2 = recs[3u * i + 2u];
+            const uint4 q0 = recs[(size_t)3u * i], q1 = recs[(size_t)3u * i + 1u], q2 = recs[(size_t)3u * i + 2u];
             SV a, b, c;
             a.X = (int)q0.x - ox; a.Y = (int)q0.y - oy; a.z = zr_u2f(q0.z); a.rw = 0.0f;
             b.X = (int)q1.x - ox; b.Y = (int)q1.y - oy; b.z = zr_u2f(q1.z); b.rw = 0.0f;
@@ -1618,15 +1824,15 @@ __global__ __launch_bounds__(256) void k_tile(ZrPass P, const uint4* __restrict_
     }
 }
 
-// The slow triangles of the batch (they need the clipper, or have an edge of 64 px or more): every owned tile tries every one of
-// them through raster_clipped.  One workgroup per owned tile; returns at once when the batch has none (the usual case).
+// The slow triangles of the round (they need the clipper, or have an edge of 64 px or more): every owned tile tries every one of
+// them through raster_clipped.  One workgroup per owned tile; returns at once when the round has none (the usual case).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __restrict__ owned_tiles, const uint4* __restrict__ slow,
                                                    uint32_t slow_cap, const ZrDevStats* __restrict__ stats, int slot,
                                                    unsigned long long* __restrict__ vis64)
 {
     __shared__ unsigned long long keys64[TILE_PIX];
-    const uint32_t slow_lo = stats->slow_lo[slot], slow_hi = min(stats->slow_hi[slot], slow_cap);
+    const uint32_t slow_lo = 0u, slow_hi = min(stats->n_slow[slot], slow_cap);
     if (slow_lo >= slow_hi) return;
     const uint32_t tid = threadIdx.x, tile = owned_tiles[blockIdx.x];
     for (uint32_t i = tid; i < TILE_PIX; i += 256u) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
@@ -2223,6 +2429,17 @@ void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint3
         } else hipLaunchKernelGGL((k_cull<ZR_MODE_SHADOW, false>), dim3(blocks), b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot);
     }
 }
+void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, const ZrHiz& Z, ZrDevStats* stats,
+                        int slot, hipStream_t s)
+{
+    if (P.n_work == 0) return;
+    const dim3 gi((P.n_inst_total + 255) / 256), b(256);
+    const dim3 g(std::min<uint32_t>((P.n_work + 255u) / 256u, 8192u));
+    if (P.use_worklist) {
+        hipLaunchKernelGGL(k_cull_instances<ZR_MODE_GBUFFER>, gi, b, 0, s, P, objs, work, stats, slot);
+        hipLaunchKernelGGL(k_cull_box<true>, g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot);
+    } else hipLaunchKernelGGL(k_cull_box<false>, g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot);
+}
 void zr_launch_bin_count(const ZrPass& P, const uint32_t* work, uint32_t* rects, uint32_t* tile_count, const ZrHiz& Z, ZrDevStats* stats,
                          int slot, hipStream_t s)
 {
@@ -2236,10 +2453,15 @@ void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H
 }
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint4* chunk_tab,
                     uint32_t chunk_cap, uint32_t n, uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s,
-                    uint32_t chunk, uint32_t tiles_x, uint32_t tile_rank, uint32_t tile_world)
+                    uint32_t chunk)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, chunk_offset, chunk_tab, chunk_cap, n, capacity, stats, slot,
-                       chunk, tiles_x, tile_rank, tile_world);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, chunk_offset, chunk_tab, chunk_cap, n, capacity, stats, slot, chunk);
+}
+void zr_launch_scan_tri(uint32_t* bin_count, uint32_t* bin_offset, uint32_t* bin_cursor, uint4* chunk_tab, uint32_t chunk_cap, uint32_t n_tiles,
+                        const ZrTriBins& B, ZrDevStats* stats, int slot, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_scan_tri, dim3(1), dim3(1024), 0, s, bin_count, bin_offset, bin_cursor, chunk_tab, chunk_cap, n_tiles, B.wave_culled, B.n_waves,
+                       stats, slot, ZR_TCHUNK);
 }
 void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
                         uint32_t* tile_cursor, ZrBinEntry* bins, const ZrHiz& Z, ZrDevStats* stats, int slot, hipStream_t s)
@@ -2275,22 +2497,21 @@ void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4*
     else
         hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u);
 }
-void zr_launch_select(const ZrPass& P, const uint32_t* work, const uint32_t* rects, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats,
+void zr_launch_select(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats,
                       int slot, hipStream_t s)
 {
     if (P.n_work == 0) return;
-    hipLaunchKernelGGL(k_select, dim3((P.n_work + 1023) / 1024), dim3(1024), 0, s, P, work, rects, Z, B.sel, stats, slot);
+    hipLaunchKernelGGL(k_select, dim3((P.n_work + 1023) / 1024), dim3(1024), 0, s, P, objs, work, rects, Z, B.sel, stats, slot);
 }
-void zr_launch_geom(const ZrPass& P, const ZrObject* objs, const ZrHiz& Z, const ZrTriBins& B, uint32_t first, uint32_t* tile_count,
-                    ZrDevStats* stats, int slot, hipStream_t s)
+void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, uint32_t* tile_count, ZrDevStats* stats, int slot, hipStream_t s)
 {
     const dim3 g(B.n_waves / 4u), b(256);
-    if (Z.phase == 2u) hipLaunchKernelGGL(k_geom<true>, g, b, 0, s, P, objs, B.sel, first, B.batch, Z, B.recs, B.region, B.wave_fill, B.slow, B.slow_cap, tile_count, stats, slot);
-    else hipLaunchKernelGGL(k_geom<false>, g, b, 0, s, P, objs, B.sel, first, B.batch, Z, B.recs, B.region, B.wave_fill, B.slow, B.slow_cap, tile_count, stats, slot);
+    if (Z.phase == 2u) hipLaunchKernelGGL(k_geom<true>, g, b, 0, s, P, B.sel, Z, B.recs, B.n_chunks, B.chunk_fill, B.wave_culled, B.slow, B.slow_cap, tile_count, stats, slot);
+    else hipLaunchKernelGGL(k_geom<false>, g, b, 0, s, P, B.sel, Z, B.recs, B.n_chunks, B.chunk_fill, B.wave_culled, B.slow, B.slow_cap, tile_count, stats, slot);
 }
-void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* tile_cursor, hipStream_t s)
+void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* tile_cursor, const ZrDevStats* stats, int slot, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_index, dim3(B.n_waves), dim3(256), 0, s, B.recs, B.region, B.wave_fill, tile_offset, tile_cursor, B.idx);
+    hipLaunchKernelGGL(k_index, dim3(B.n_waves / 4u), dim3(256), 0, s, B.recs, B.chunk_fill, B.n_waves, B.n_chunks, stats, slot, tile_offset, tile_cursor, B.idx);
 }
 void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned,
                     ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s)

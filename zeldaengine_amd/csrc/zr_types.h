@@ -43,6 +43,7 @@ struct ZrObject {
     const XkMeshlet*  meshlets;      // device copy; BindlessContext = tri_base (triangles in earlier meshlets)
     const float4*     mpos;          // flattened meshlet vertices: mpos[VertexOffset + k] = position of meshlet vertex k
                                      // (CreateMeshVertexBuffers<XkMeshIndirect> flattens the same way, ZE:4733-4756)
+    const float4*     mbox;          // per meshlet: object-space box of its vertices, [2 m] = least, [2 m + 1] = greatest corner
     const uint32_t*   tri_meshlet;   // draw-order triangle -> meshlet index (visibility history for the Hi-Z pass)
     const uint2*      mtri;          // per meshlet triangle slot (tri_base + t): x = corners i0 | i1 << 8 | i2 << 16,
                                      // y = draw-order triangle index (primitive id within the instance)
@@ -116,8 +117,8 @@ struct ZrDevStats {
     uint32_t n_vis_work[2];          // meshlet-instances of the instances that passed the instance-level frustum test
     uint32_t hiz_culled;             // meshlet-instances rejected by the Hi-Z test
     uint32_t n_sel[3];               // triangle-binned camera pass: meshlet-instances selected for a round (slots as above)
-    uint32_t n_slow[3];              //   triangles that need the clipper / the 64-bit walk, running total of the round
-    uint32_t slow_lo[3], slow_hi[3]; //   the part of them the current batch's tile kernel has to try (set by k_scan)
+    uint32_t n_slow[3];              //   triangles of the round that need the clipper / the 64-bit walk
+    uint32_t pool_next[3], pool_used[3];   // record chunks taken from the pool: running (k_geom) / final (k_scan_tri, for k_index)
     uint32_t overflow_sticky;        // LAST member: not cleared at frame begin; set with `overflow`, cleared by zr_finish when it reports it
 };
 
@@ -170,26 +171,32 @@ void zr_launch_bin_count(const ZrPass& P, const uint32_t* work, uint32_t* rects,
 void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H, const ZrHiz& Z, hipStream_t s);
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint4* chunk_tab,
                     uint32_t chunk_cap, uint32_t n, uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s,
-                    uint32_t chunk = ZR_CHUNK, uint32_t tiles_x = 0, uint32_t tile_rank = 0, uint32_t tile_world = 0);
-// triangle-binned camera pass (k_select -> k_geom -> k_scan -> k_index -> k_tile)
+                    uint32_t chunk = ZR_CHUNK);
+// triangle-binned camera pass (k_select -> k_geom -> k_scan_tri -> k_index -> k_tile)
 struct ZrTriBins {
-    uint32_t* sel;                   // meshlet-instances of this round
-    uint4*    recs;                  // 3 x uint4 per record: (X0, Y0, z0, prim) (X1, Y1, z1, tile) (X2, Y2, z2, 0).  Every wave of k_geom
-    uint32_t  region;                //   owns `region` consecutive record slots (no allocator, no atomics) and reports how many it
-    uint32_t* wave_fill;             //   filled in wave_fill[wave]
-    uint32_t  n_waves;               // waves of the k_geom grid (= regions)
-    uint32_t* idx;                   // record indices grouped by tile
+    ZrBinEntry* sel;                 // meshlet-instances of this round, as self-contained 32-byte records
+    uint4*    recs;                  // 3 x uint4 per record: (X0, Y0, z0, prim) (X1, Y1, z1, bin) (X2, Y2, z2, 0), bin = tile * ZR_TCLASSES + walk-size
+                                     //   class.  Records live in chunks of ZR_TPOOL_CHUNK: chunk k < n_waves is where wave k of k_geom starts,
+    uint32_t  n_chunks;              //   the rest [n_waves, n_chunks) is the pool the waves take further chunks from
+    uint32_t* chunk_fill;            // records in each chunk
+    uint32_t  n_waves;               // waves of the k_geom grid
+    uint32_t* wave_culled;           // per wave: meshlets it dropped behind the Hi-Z pyramid (round 2)
+    uint32_t* idx;                   // record indices grouped by (tile, class)
     uint4*    slow; uint32_t slow_cap;      // 4 x uint4 per slow triangle: three clip-space vertices, (prim, 0, 0, 0)
-    uint32_t  batch;                 // meshlet-instances per k_geom launch (big scenes take several)
 };
+#define ZR_TPOOL_CHUNK 1024u         // records per chunk of the record pool
 #define ZR_TCHUNK 512u               // triangle records per work unit of the tile kernel
-void zr_launch_select(const ZrPass& P, const uint32_t* work, const uint32_t* rects, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats,
+#define ZR_TCLASSES 4u               // walk-size classes a tile's records are sorted into (<= 4, <= 16, <= 64, more pixels of bounding box)
+void zr_launch_scan_tri(uint32_t* bin_count, uint32_t* bin_offset, uint32_t* bin_cursor, uint4* chunk_tab, uint32_t chunk_cap, uint32_t n_tiles,
+                        const ZrTriBins& B, ZrDevStats* stats, int slot, hipStream_t s);
+void zr_launch_select(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats,
                       int slot, hipStream_t s);
-void zr_launch_geom(const ZrPass& P, const ZrObject* objs, const ZrHiz& Z, const ZrTriBins& B, uint32_t first, uint32_t* tile_count,
-                    ZrDevStats* stats, int slot, hipStream_t s);
-void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* tile_cursor, hipStream_t s);
+void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, uint32_t* tile_count, ZrDevStats* stats, int slot, hipStream_t s);
+void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* tile_cursor, const ZrDevStats* stats, int slot, hipStream_t s);
 void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned,
                     ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s);
+void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, const ZrHiz& Z, ZrDevStats* stats,
+                        int slot, hipStream_t s);
 void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
                         uint32_t* tile_cursor, ZrBinEntry* bins, const ZrHiz& Z, ZrDevStats* stats, int slot, hipStream_t s);
 void zr_launch_frame_begin(ZrDevStats* stats, const XkView* view_src_pinned, XkView* view_dst, hipStream_t s);
