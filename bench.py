@@ -5,14 +5,15 @@
 
 A step is one full frame of the hot path on synthetic, HBM-resident input, INCLUDING the engine's per-frame uniform work
 (UpdateUniformBuffer, ZE:4585-4664: the point lights ride their spiral, XkView is rebuilt and uploaded every frame):
-    meshlet cull+bin (shadow) -> shadow raster -> meshlet cull+bin (camera) -> tile raster of last frame's visible set
-    -> Hi-Z pyramid -> bin + tile raster of the rest (occlusion-tested) -> GBuffer write (resolve)
+    meshlet cull+bin (shadow) -> shadow raster -> meshlet cull (camera) -> triangle records + tile raster of last frame's visible set
+    -> Hi-Z pyramid -> triangle records + tile raster of the rest (occlusion-tested) -> GBuffer write (resolve)
     -> deferred PBR + PCF lighting [-> RCCL all-gather of the packed RGBA8 tiles + untile, N > 1].
 N > 1 partitions the SAME frame by screen tiles, so scaling is "strong".  value = W*H*steps / max-over-ranks(wall time).
 
-roofline: quoted for the pass the north star names, the GBuffer-write pass = k_raster<GBUFFER> + k_raster<GBUFFER,HiZ> +
-k_resolve_gbuffer, against the 8 TB/s HBM peak.  `achieved` = SURVEY 8(d)'s algorithmic bytes of that pass / the summed mean
-duration of its three kernels, measured live with HIP events on the stream they are launched on (the library's camera lane).
+roofline: quoted for the pass the north star names, the GBuffer-write pass = the two camera rounds (k_geom + k_scan_tri + k_index +
+k_tile [+ k_tile_slow] each) + k_resolve_gbuffer, against the 8 TB/s HBM peak.  `achieved` = SURVEY 8(d)'s algorithmic bytes of that
+pass / the summed mean duration of those kernels, measured live with HIP events on the stream they are launched on (the library's
+camera lane).
 `traffic` = the same kernels' FETCH_SIZE / WRITE_SIZE counter bytes from the committed rocprofv3 summary named in
 `traffic_source`, only when that summary was collected on this very workload (else null).  `kernels` lists every kernel the same
 way; `valu_roofline` states what actually bounds the frame (vector-ALU issue); `frame_hbm` is the whole frame's counter traffic
@@ -34,10 +35,13 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 VALU_PEAK_PER_S = 256 * 4 * 2.4e9 / 4.0     # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
 PROFILE_INDEX = os.path.join(ROOT, "profiles", "current.json")     # written by tools/make_profile_summary.py
 
-# passes that are ONE kernel launch per frame (the cull / hiz passes are groups of launch-bound kernels)
-KERNEL_OF_PASS = {"shadow": "k_raster<SHADOW>", "gbuffer": "k_raster<GBUFFER>", "gbuffer2": "k_raster<GBUFFER,HiZ>",
-                  "resolve": "k_resolve_gbuffer", "lighting": "k_lighting"}
+# the kernels of each timed pass (the cull / hiz passes are groups of launch-bound kernels).  A camera round of the triangle-binned
+# pass is k_geom (vertices -> triangle records) + k_scan_tri + k_index (records -> per-tile lists) + k_tile (+ k_tile_slow); k_scan_tri,
+# k_index, k_tile and k_tile_slow run once per round under one name, so their profile rows hold both rounds.
+KERNEL_OF_PASS = {"shadow": ("k_raster<SHADOW>",), "gbuffer": ("k_geom<false>", "k_scan_tri", "k_index", "k_tile<0>", "k_tile_slow<0>"),
+                  "gbuffer2": ("k_geom<true>",), "resolve": ("k_resolve_gbuffer",), "lighting": ("k_lighting",)}
 GBUFFER_WRITE_PASS = ("gbuffer", "gbuffer2", "resolve")
+GBUFFER_WRITE_KERNELS = "k_geom + k_scan_tri + k_index + k_tile (x2 rounds) + k_resolve_gbuffer"
 
 
 def workload_name(config, n_inst, n_work, W, H, n_point, cube_dim):
@@ -252,10 +256,16 @@ def main():
         prof = load_profile(workload) if world == 1 else None
         ptraffic = (prof or {}).get("kernels", {})
 
+        def pass_traffic(p):
+            t = [ptraffic.get(k, {}).get("hbm_bytes_per_frame") for k in KERNEL_OF_PASS[p]]
+            return int(sum(t)) if t and all(x is not None for x in t) else None
+
         def kernel_row(p, ms):
-            t = ptraffic.get(KERNEL_OF_PASS[p], {}).get("hbm_bytes_per_frame")
-            return {"kernel": KERNEL_OF_PASS[p], "ms": round(ms[p], 4), "algorithmic_bytes": int(alg[p]),
-                    "achieved_gbs": round(alg[p] / (ms[p] * 1e-3) / 1e9, 2) if ms[p] > 0 else None, "traffic": t}
+            row = {"pass": p, "kernels": list(KERNEL_OF_PASS[p]), "ms": round(ms[p], 4), "algorithmic_bytes": int(alg[p]),
+                   "achieved_gbs": round(alg[p] / (ms[p] * 1e-3) / 1e9, 2) if ms[p] > 0 else None, "traffic": pass_traffic(p)}
+            if p == "gbuffer":
+                row["traffic_note"] = "k_scan_tri / k_index / k_tile / k_tile_slow rows of the profile hold both rounds: this is the two rounds' traffic but for k_geom<true>"
+            return row
 
         def gb_pass(ms):
             t = sum(ms[p] for p in GBUFFER_WRITE_PASS)
@@ -263,10 +273,10 @@ def main():
             return t, b, (b / (t * 1e-3) / 1e9 if t > 0 else 0.0)
 
         t_gb, b_gb, gbs_gb = gb_pass(times)
-        tr = [ptraffic.get(KERNEL_OF_PASS[p], {}).get("hbm_bytes_per_frame") for p in GBUFFER_WRITE_PASS]
+        tr = [pass_traffic(p) for p in GBUFFER_WRITE_PASS]
         roofline = {
             "bound": "hbm",
-            "kernel": "GBuffer-write pass (k_raster<GBUFFER> + k_raster<GBUFFER,HiZ> + k_resolve_gbuffer)",
+            "kernel": "GBuffer-write pass (%s)" % GBUFFER_WRITE_KERNELS,
             "achieved": round(gbs_gb, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_gb / HBM_PEAK_GBS, 6),
             "traffic": int(sum(tr)) if prof and all(t is not None for t in tr) else None,
             "traffic_source": prof["_file"] if prof else None,
@@ -278,7 +288,7 @@ def main():
         if serial:
             t1, b1, g1 = gb_pass(serial["passes_ms"])
             roofline["one_stream"] = {"kernel_ms": round(t1, 4), "achieved": round(g1, 3), "frac": round(g1 / HBM_PEAK_GBS, 6),
-                                      "note": "the same three kernels alone on the GPU (ZR_FLAG_SERIAL_PASSES run below)"}
+                                      "note": "the same kernels alone on the GPU (ZR_FLAG_SERIAL_PASSES run below)"}
         valu = None
         if prof and prof.get("valu_insts_per_frame"):
             mn = prof["valu_insts_per_frame"] / VALU_PEAK_PER_S * 1e3

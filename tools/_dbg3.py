@@ -1,0 +1,11 @@
+import sys
+sys.path.insert(0, '/root/repo')
+from zeldaengine_amd import engine as gpu_engine, scenes, abi
+cfg = scenes.config3(10000, cube_dim=64)
+for flags in (0, abi.FLAG_MESHLET_BINS):
+    g = gpu_engine.Renderer(cfg["width"], cfg["height"], 1024, flags=flags)
+    gpu_engine.load_scene(g, cfg)
+    for i in range(5): g.render()
+    g.finish()
+    print(flags, g.stats())
+    g.close()

@@ -27,6 +27,8 @@ bench = json.loads([l for l in open(bench_json) if l.startswith("{")][-1])
 SHORT = {"k_raster_chunks<0, false>": "k_raster<GBUFFER>", "k_raster_chunks<0, true>": "k_raster<GBUFFER,HiZ>",
          "k_raster_chunks<1, false>": "k_raster<SHADOW>", "k_cull<0, false>": "k_cull<GBUFFER>", "k_cull<1, false>": "k_cull<SHADOW>",
          "k_cull<0, true>": "k_cull<GBUFFER,worklist>", "k_cull<1, true>": "k_cull<SHADOW,worklist>"}
+# (the triangle-binned camera pass's kernels keep their own names: k_cull_box<..>, k_select, k_geom<false|true>, k_scan_tri, k_index,
+#  k_tile<0>, k_tile_slow<0>; k_scan_tri / k_index / k_tile / k_tile_slow run once per round, so launches_per_frame = 2)
 
 
 def short(name):

@@ -187,6 +187,8 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     ok &= dev_alloc(&c->d_vis, n) == hipSuccess;
     if (ok) { zr_launch_fill64(c->d_vis, (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM, n, c->stream); ok &= hipStreamSynchronize(c->stream) == hipSuccess; }
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->raster_blocks = (uint32_t)prop.multiProcessorCount * 8u; }
+    c->shadow_blocks = c->raster_blocks;
+    if (const char* e = getenv("ZR_SHADOW_BLOCKS")) c->shadow_blocks = (uint32_t)std::max(1, atoi(e));
     {   // Hi-Z pyramid: level l = max depth per (8 << l)^2 pixel block
         size_t tot = 0;
         for (int l = 0; l < 4; ++l) { c->hiz.hw[l] = (c->W + (8u << l) - 1) / (8u << l); c->hiz.hh[l] = (c->H + (8u << l) - 1) / (8u << l); tot += (size_t)c->hiz.hw[l] * c->hiz.hh[l]; }
@@ -914,15 +916,18 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
     // the instance-level pre-pass pays for itself on big scenes; small ones go straight to one wave per meshlet-instance
     P->use_worklist = c->n_inst_total >= 65536u ? 1u : 0u;
     P->debug_skip = c->env_skip;
-    if (mode == ZR_MODE_GBUFFER && c->cfg.tile_world > 1 && !(c->cfg.flags & ZR_FLAG_NO_RECT_CULL) && ZR_TILE == 32) {
-        // the owned-region reject needs clip.x = p00 * x_view, clip.y = p11 * y_view, clip.w = -z_view and view-space radii = object radii
+    if (mode == ZR_MODE_GBUFFER && ZR_TILE == 32) {
+        // sphere_bounds() needs clip.x = p00 * x_view, clip.y = p11 * y_view, clip.z = p10 * z_view + p14, clip.w = -z_view and
+        // view-space radii = object radii
         const float* pr = u.Proj;
         const bool centred = pr[1] == 0 && pr[2] == 0 && pr[3] == 0 && pr[4] == 0 && pr[6] == 0 && pr[7] == 0 && pr[8] == 0 && pr[9] == 0 &&
                              pr[11] == -1.0f && pr[12] == 0 && pr[13] == 0 && pr[15] == 0 && std::isfinite(pr[0]) && std::isfinite(pr[5]) &&
-                             pr[0] != 0 && pr[5] != 0;
+                             pr[0] != 0 && pr[5] != 0 && std::isfinite(pr[10]) && std::isfinite(pr[14]) && pr[14] < 0;
         zr_mat4_mul(u.View, u.Model, P->VM);
         P->p00 = pr[0]; P->p11 = pr[5];
-        P->rect_cull = (centred && rigid3(u.Model) && rigid3(u.View) && finite16(P->VM)) ? 1u : 0u;
+        P->pz_a = -pr[10]; P->pz_b = pr[14];       // z_view = -d: (p10 * -d + p14) / d
+        P->sphere_ok = (centred && rigid3(u.Model) && rigid3(u.View) && finite16(P->VM)) ? 1u : 0u;
+        P->rect_cull = (P->sphere_ok && c->cfg.tile_world > 1 && !(c->cfg.flags & ZR_FLAG_NO_RECT_CULL)) ? 1u : 0u;
     }
     {
         static const float ident[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
@@ -994,7 +999,7 @@ static void raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStre
 {
     const zr_ctx::Scratch& sc = c->sc[slot ? 1 : 0];
     zr_launch_raster_chunks(P, c->d_objs, sc.chunk_tab, sc.bins, c->d_stats, slot, c->d_vis,
-                            (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), c->raster_blocks, Z, s);
+                            (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), slot == 0 ? c->shadow_blocks : c->raster_blocks, Z, s);
 }
 
 static inline float* shadow_buf(zr_ctx* c) { return c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow; }
@@ -1382,6 +1387,12 @@ extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out)
         zr_launch_count_shadow((const uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), (size_t)c->SD * c->SD, c->d_stats, c->stream);
         (void)hipStreamSynchronize(c->stream);
         (void)hipMemcpy(&c->h_stats, c->d_stats, sizeof(ZrDevStats), hipMemcpyDeviceToHost);
+    }
+    if (getenv("ZR_DUMP_STATS")) {     // diagnostics: the raw device block
+        const ZrDevStats& h = c->h_stats;
+        fprintf(stderr, "zr stats: survivors %u %u %u  bin_entries %u %u %u  n_sel %u %u %u  n_slow %u %u %u  pool_used %u %u %u  hiz_culled %u  n_chunks %u %u %u\n",
+                h.survivors[0], h.survivors[1], h.survivors[2], h.bin_entries[0], h.bin_entries[1], h.bin_entries[2], h.n_sel[0], h.n_sel[1], h.n_sel[2],
+                h.n_slow[0], h.n_slow[1], h.n_slow[2], h.pool_used[0], h.pool_used[1], h.pool_used[2], h.hiz_culled, h.n_chunks[0], h.n_chunks[1], h.n_chunks[2]);
     }
     memset(out, 0, sizeof *out);
     for (int i = 0; i < 2; ++i) {

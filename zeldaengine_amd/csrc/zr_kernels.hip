@@ -197,13 +197,13 @@ __device__ __forceinline__ int find_object_inst(const ZrObject* __restrict__ obj
 // through the eye tangent to the circle have slopes (x d +- r sqrt(x^2 + d^2 - r^2)) / (d^2 - r^2): every point of the sphere
 // projects between them; ndc = Proj[0][0] * slope (Proj[1][1] for y).  Conservative: the radius is rounded up, a slack covers the
 // arithmetic here and in the rasteriser's own transform, the pixel range gets a margin of one.  "true" whenever in doubt.
-__device__ __forceinline__ bool sphere_reaches_owned_tile(const ZrPass& P, zf3 co, float ri)
-{
+__device__ __forceinline__ bool sphere_bounds(const ZrPass& P, zf3 co, float ri, int& px0, int& py0, int& px1, int& py1, float& d_near)
+{   // false: no bound (the eye is inside, or the numbers are out of range).  An empty box (px0 > px1 or py0 > py1) = off the target.
     const zf4 cv = zr_mat4_point(P.VM, co);
     const float d = -cv.z;
     const float r = __builtin_fmaf(ri, 1.003f, 1e-6f * (__builtin_fabsf(cv.x) + __builtin_fabsf(cv.y) + __builtin_fabsf(d)) + 1e-30f);
     const float den = __builtin_fmaf(d, d, -(r * r));
-    if (!(d > r && den > 0.0f && d < 3.0e18f)) return true;
+    if (!(d > r && den > 0.0f && d < 3.0e18f)) return false;
     const float tx = r * __builtin_sqrtf(__builtin_fmaxf(__builtin_fmaf(cv.x, cv.x, den), 0.0f));
     const float ty = r * __builtin_sqrtf(__builtin_fmaxf(__builtin_fmaf(cv.y, cv.y, den), 0.0f));
     const float ax = ((cv.x * d - tx) / den) * P.p00, bx = ((cv.x * d + tx) / den) * P.p00;
@@ -214,9 +214,16 @@ __device__ __forceinline__ bool sphere_reaches_owned_tile(const ZrPass& P, zf3 c
     ny0 -= sl * (1.0f + __builtin_fabsf(ny0)); ny1 += sl * (1.0f + __builtin_fabsf(ny1));
     const float sx0 = __builtin_fmaf(nx0, P.hw, P.hw), sx1 = __builtin_fmaf(nx1, P.hw, P.hw);
     const float sy0 = __builtin_fmaf(ny0, P.hh, P.hh), sy1 = __builtin_fmaf(ny1, P.hh, P.hh);
-    if (!(sx0 >= -1.0e9f && sx1 <= 1.0e9f && sy0 >= -1.0e9f && sy1 <= 1.0e9f)) return true;      // NaN or huge
-    const int px0 = max(0, (int)__builtin_floorf(sx0) - 1), px1 = min((int)P.W - 1, (int)__builtin_floorf(sx1) + 1);
-    const int py0 = max(0, (int)__builtin_floorf(sy0) - 1), py1 = min((int)P.H - 1, (int)__builtin_floorf(sy1) + 1);
+    if (!(sx0 >= -1.0e9f && sx1 <= 1.0e9f && sy0 >= -1.0e9f && sy1 <= 1.0e9f)) return false;      // NaN or huge
+    px0 = max(0, (int)__builtin_floorf(sx0) - 1); px1 = min((int)P.W - 1, (int)__builtin_floorf(sx1) + 1);
+    py0 = max(0, (int)__builtin_floorf(sy0) - 1); py1 = min((int)P.H - 1, (int)__builtin_floorf(sy1) + 1);
+    d_near = d - r;
+    return true;
+}
+__device__ __forceinline__ bool sphere_reaches_owned_tile(const ZrPass& P, zf3 co, float ri)
+{
+    int px0, py0, px1, py1; float dn;
+    if (!sphere_bounds(P, co, ri, px0, py0, px1, py1, dn)) return true;
     if (px0 > px1 || py0 > py1) return false;                                                    // off the target altogether
     const uint32_t sh = 5u + ZR_SUPERTILE_SHIFT;      // TILE == 32 pixels: pixel -> super-tile (checked where rect_cull is set)
     for (uint32_t sy = (uint32_t)py0 >> sh; sy <= (uint32_t)py1 >> sh; ++sy)
@@ -294,6 +301,7 @@ struct CullItem {
     const ZrObject* O;
     uint32_t vcount, instanced, m;
     ZrInstance I;
+    zf3 sph_c; float sph_r;       // the meshlet's bounding sphere after the instance transform (object space of PVM)
 };
 template <int MODE, bool WORKLIST>
 __device__ __forceinline__ bool cull_stage_a(const ZrPass& P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
@@ -316,6 +324,7 @@ __device__ __forceinline__ bool cull_stage_a(const ZrPass& P, const ZrObject* __
     const ZrInstance& I = it.I;
     const uint32_t instanced = O->instanced != 0 ? 1u : 0u;
     it.instanced = instanced;
+    it.sph_c = vs_position(zr3(bs.x, bs.y, bs.z), I, instanced != 0); it.sph_r = bs.w * (instanced ? __builtin_fabsf(I.s) : 1.0f);
     // the skydome is not a shadow caster (ZE:4709-4720); with N GPUs each draws every N-th instance (see k_cull_instances)
     if (MODE == ZR_MODE_SHADOW && ((O->flags & ZR_OBJ_SKY) || inst_i % P.inst_world != P.inst_rank)) alive = false;
     if (alive && (P.frustum_ok | P.cone_ok | P.rect_cull)) {
@@ -517,17 +526,27 @@ __global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __re
                     nxl = __builtin_fminf(nxl, x); nxh = __builtin_fmaxf(nxh, x); nyl = __builtin_fminf(nyl, y); nyh = __builtin_fmaxf(nyh, y);
                     zl = __builtin_fminf(zl, cl[q].z * rw);
                 }
-                // |d(x / w)| <= (ex + |x / w| eW) / w, |x / w| <= ZR_GUARD here; one pixel on top for the snapping and the divide
-                const float px_e = __builtin_fmaf(P.hw, (ex + ZR_GUARD * eW) * rwm, 1.0f), py_e = __builtin_fmaf(P.hh, (ey + ZR_GUARD * eW) * rwm, 1.0f);
+                // |d(x / w)| <= (ex + |x / w| eW) / w, |x / w| <= ZR_GUARD here; 1/64 pixel on top for the divide, the viewport fma and the
+                // snapping to 1/256 pixel
+                const float px_e = __builtin_fmaf(P.hw, (ex + ZR_GUARD * eW) * rwm, 0.015625f), py_e = __builtin_fmaf(P.hh, (ey + ZR_GUARD * eW) * rwm, 0.015625f);
                 const float z_e = __builtin_fmaf(ez + eW, rwm, 1e-6f);
                 if (px_e < 64.0f && py_e < 64.0f) {
                     // pixel centres the snapped vertices can bound: centre i is at i + 0.5
-                    int px0 = (int)__builtin_floorf(nxl - px_e - 0.5f) , py0 = (int)__builtin_floorf(nyl - py_e - 0.5f);
-                    int px1 = (int)__builtin_ceilf(nxh + px_e - 0.5f), py1 = (int)__builtin_ceilf(nyh + py_e - 0.5f);
+                    int px0 = (int)__builtin_ceilf(nxl - px_e - 0.5f), py0 = (int)__builtin_ceilf(nyl - py_e - 0.5f);
+                    int px1 = (int)__builtin_floorf(nxh + px_e - 0.5f), py1 = (int)__builtin_floorf(nyh + py_e - 0.5f);
                     px0 = max(px0, 0); py0 = max(py0, 0); px1 = min(px1, (int)P.W - 1); py1 = min(py1, (int)P.H - 1);
+                    zm = __builtin_fmaxf(zl - z_e, 0.0f);
+                    if (P.sphere_ok) {      // the bounding sphere bounds the same vertices: the tighter of the two on every side
+                        int sx0, sy0, sx1, sy1; float dn;
+                        if (sphere_bounds(P, it.sph_c, it.sph_r, sx0, sy0, sx1, sy1, dn)) {
+                            px0 = max(px0, sx0); py0 = max(py0, sy0); px1 = min(px1, sx1); py1 = min(py1, sy1);
+                            // ndc depth of a point d in front of the eye: pz_a + pz_b / d, growing with d (pz_b < 0)
+                            const float zs = P.pz_a + P.pz_b / dn;
+                            zm = __builtin_fmaxf(zm, zs - __builtin_fmaf(1e-6f, __builtin_fabsf(P.pz_a) + __builtin_fabsf(zs), z_e));
+                        }
+                    }
                     if (px0 <= px1 && py0 <= py1) {
                         r = 0u;
-                        zm = __builtin_fmaxf(zl - z_e, 0.0f);
                         pr = make_uint2((uint32_t)px0 | (uint32_t)py0 << 16, (uint32_t)px1 | (uint32_t)py1 << 16);
                     }
                 } else r = 0u;

@@ -101,6 +101,8 @@ struct ZrPass {
     uint32_t bin_capacity;
     uint32_t images;                 // some material slot (or the skydome) holds an image: the resolve needs the texture filter
     uint32_t debug_skip;             // diagnostics only (env ZR_DEBUG_SKIP): 1 skip pixel walk, 2 skip triangle phase too
+    uint32_t sphere_ok;              // VM / p00 / p11 / pz_* hold a centred perspective with rigid model and view: sphere_bounds() applies
+    float    pz_a, pz_b;             //   ndc depth of a point d in front of the eye = pz_a + pz_b / d
     uint32_t m_identity;             // M is bit for bit the identity: M * vec4(p, 1) == p + 0.0f for finite p
     uint32_t write_overlay;          // the resolve must write the overlay plane (a skydome is drawn, or stale sky pixels must go)
 };
