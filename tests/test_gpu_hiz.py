@@ -230,3 +230,29 @@ def test_config5_reduced_against_the_oracle_with_a_moving_camera(oracle_lib, gpu
             assert st["round1_survivors"] > 0
             culled += st["hiz_culled"]
     assert culled > 0
+
+
+def test_both_camera_paths_against_the_oracle(oracle_lib, gpu_engine):
+    """The camera pass has two rasterisers: the triangle-binned one (default: k_cull_box, k_geom, k_tile) and the meshlet-binned one
+    (ZR_FLAG_MESHLET_BINS: k_cull<GBUFFER>, k_raster_chunks).  Both must give the oracle's frame over the history sequence, with and
+    without the Hi-Z rounds, and the slow-triangle list must be exercised (the ground plane crosses the near plane; the wall's
+    triangles are longer than 64 pixels)."""
+    W, H, SD = 384, 216, 256
+    o = oracle_lib.Oracle(W, H, SD)
+    gs = [gpu_engine.Renderer(W, H, SD, flags=f) for f in (0, abi.FLAG_MESHLET_BINS, abi.FLAG_NO_HIZ, abi.FLAG_MESHLET_BINS | abi.FLAG_NO_HIZ)]
+    for r in [o] + gs:
+        _crowd(r, 300, 11)
+    d, p, s = _lights()
+    for i, (pos, look) in enumerate(CAMS[:4]):
+        cam = abi.make_camera(pos, look, fov=50.0)
+        for r in [o] + gs:
+            r.update_uniforms(cam, d, p, s, 0.1 * i, 0.02 * i, 1.0 + i)
+        o.render(0)
+        for k, g in enumerate(gs):
+            g.render(); g.finish()
+            _identical(o, g, "frame %d, path %d" % (i, k))
+    st = [g.stats() for g in gs]
+    assert all(x["overflow"] == 0 for x in st)
+    assert st[0]["covered_pixels"] == st[1]["covered_pixels"] == st[2]["covered_pixels"] == st[3]["covered_pixels"]
+    for g in gs:
+        g.close()
