@@ -1,3 +1,4 @@
+"""Per-round counters of the camera pass on the benchmark scene, both rasterisers (run with ZR_DUMP_STATS=1 for the raw device block)."""
 import sys
 sys.path.insert(0, '/root/repo')
 from zeldaengine_amd import engine as gpu_engine, scenes, abi
