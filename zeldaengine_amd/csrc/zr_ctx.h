@@ -102,6 +102,11 @@ struct zr_ctx {
     // d_view, d_empty_rgba are aliases of the current frame's copies (set at frame begin, so the read-back entry points see the
     // frame rendered last).
     hipStream_t cam_s = nullptr; bool camera_on_lane = false;
+    // Experiment kept behind ZR_LANES=3 (zr_render only, not the staged entry points): the shadow pipeline and the lighting pass on
+    // streams of their own as well, so that frame N's lighting, frame N + 1's shadow pipeline and frame N + 1's camera pipeline all run
+    // side by side and the host's stream only joins the finished frame.  Measured SLOWER than two lanes: the
+    // camera pipeline - a chain of short kernels - is then starved by two heavy neighbours instead of one.
+    hipStream_t shadow_s = nullptr, light_s = nullptr; bool in_render = false, three_lanes = false, lanes3_now = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cam = nullptr;
     // End of every frame's lighting pass, one (timing-enabled) event per frame in a ring: the next-but-one frame waits for it before
     // it reuses the double-buffered copies, and consecutive ones give the per-frame GPU period (zr_get_frame_periods) for free.
@@ -111,7 +116,8 @@ struct zr_ctx {
     uint32_t* d_empty_b[2] = { nullptr, nullptr };
     bool overlay_dirty[2] = { false, false };       // Gb[i].overlay may hold skydome pixels of an earlier frame
     bool shadow_cleared[2] = { false, false };      // d_shadow_b[i] already holds depth 1.0 (cleared by the previous lighting pass)
-    unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048, shadow_blocks = 2048;
+    unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048, shadow_blocks = 2048; bool env_shadow_box = false, env_shadow_static = false, env_shadow_defer = true;
+    uint4* d_slow0 = nullptr; uint32_t slow0_cap = 1u << 18;      // shadow pass: triangles for the clipper (k_tile_slow)
     uint32_t work_capacity = 0, bin_capacity = 0; bool any_images = false;
     // two-pass Hi-Z occlusion culling of the camera pass: per work item pixel bbox + least depth (written by the cull),
     // visibility of the previous / current frame (one byte per meshlet-instance, marked by the resolve), the pyramid

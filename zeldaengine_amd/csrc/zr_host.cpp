@@ -24,6 +24,9 @@ hipError_t zr_sync_all(zr_ctx* c)
 {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess && c->cam_s) e = hipStreamSynchronize(c->cam_s);
+    if (e == hipSuccess && c->shadow_s) e = hipStreamSynchronize(c->shadow_s);
+    if (e == hipSuccess && c->light_s) e = hipStreamSynchronize(c->light_s);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // (the host's stream may have been made to wait for the lanes)
     if (e == hipSuccess) e = zr_dist_sync(c);           // the native multi-GPU host's collective stream, if any
     return e;
 }
@@ -180,6 +183,9 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         ok &= hipStreamCreateWithPriority(&c->cam_s, hipStreamNonBlocking, greatest) == hipSuccess;
+        ok &= hipStreamCreateWithPriority(&c->shadow_s, hipStreamNonBlocking, least) == hipSuccess;
+        ok &= hipStreamCreateWithPriority(&c->light_s, hipStreamNonBlocking, least) == hipSuccess;
+        if (const char* e = getenv("ZR_LANES")) c->three_lanes = atoi(e) >= 3;
     }
     ok &= hipEventCreateWithFlags(&c->ev_cam, hipEventDisableTiming) == hipSuccess;
     ok &= hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -188,6 +194,10 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     if (ok) { zr_launch_fill64(c->d_vis, (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM, n, c->stream); ok &= hipStreamSynchronize(c->stream) == hipSuccess; }
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->raster_blocks = (uint32_t)prop.multiProcessorCount * 8u; }
     c->shadow_blocks = c->raster_blocks;
+    if (const char* e = getenv("ZR_SHADOW_BOX_CULL")) c->env_shadow_box = atoi(e) != 0;
+    if (const char* e = getenv("ZR_SHADOW_STATIC")) c->env_shadow_static = atoi(e) != 0;
+    if (const char* e = getenv("ZR_SHADOW_DEFER")) c->env_shadow_defer = atoi(e) != 0;
+    if (ok) ok &= dev_alloc(&c->d_slow0, 4ull * c->slow0_cap) == hipSuccess;
     if (const char* e = getenv("ZR_SHADOW_BLOCKS")) c->shadow_blocks = (uint32_t)std::max(1, atoi(e));
     {   // Hi-Z pyramid: level l = max depth per (8 << l)^2 pixel block
         size_t tot = 0;
@@ -253,10 +263,12 @@ extern "C" void zr_destroy(zr_ctx* c)
     if (c->h_view_ring) (void)hipHostFree(c->h_view_ring);
     for (auto& e : c->view_ev) if (e) (void)hipEventDestroy(e);
     if (c->cam_s) (void)hipStreamDestroy(c->cam_s);
+    if (c->shadow_s) (void)hipStreamDestroy(c->shadow_s);
+    if (c->light_s) (void)hipStreamDestroy(c->light_s);
     if (c->ev_cam) (void)hipEventDestroy(c->ev_cam);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    dev_free(c->d_vis);
+    dev_free(c->d_vis); dev_free(c->d_slow0);
     dev_free(c->d_pxrect); dev_free(c->d_zmin); dev_free(c->d_visflag[0]); dev_free(c->d_visflag[1]); dev_free(c->d_hiz);
     dev_free(c->tb.sel); dev_free(c->tb.recs); dev_free(c->tb.idx); dev_free(c->tb.slow); dev_free(c->tb.chunk_fill); dev_free(c->tb.wave_culled);
     for (auto& fr : c->evr) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
@@ -998,8 +1010,10 @@ static void tri_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hip
 static void raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s)
 {
     const zr_ctx::Scratch& sc = c->sc[slot ? 1 : 0];
+    const bool defer = slot == 0 && c->env_shadow_defer && c->d_slow0 != nullptr;
     zr_launch_raster_chunks(P, c->d_objs, sc.chunk_tab, sc.bins, c->d_stats, slot, c->d_vis,
-                            (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), slot == 0 ? c->shadow_blocks : c->raster_blocks, Z, s);
+                            (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), slot == 0 ? c->shadow_blocks : c->raster_blocks, Z, s,
+                            defer ? c->d_slow0 : nullptr, c->slow0_cap, c->d_sowned, c->sn_tiles);
 }
 
 static inline float* shadow_buf(zr_ctx* c) { return c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow; }
@@ -1058,7 +1072,9 @@ static int shadow_pass(zr_ctx* c, hipStream_t s)
     if (c->d_shadow_ext || !c->shadow_cleared[spar]) zr_launch_fill32((uint32_t*)shadow_buf(c), 0x3F800000u, (size_t)c->SD * c->SD, s);
     c->shadow_cleared[spar] = false;
     ZrHiz Z; memset(&Z, 0, sizeof Z);
-    zr_launch_cull(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, c->raster_blocks * 4u, s);
+    P.static_units = c->env_shadow_static ? 1u : 0u;
+    if (c->env_shadow_box) zr_launch_cull_box(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, s);
+    else zr_launch_cull(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, c->raster_blocks * 4u, s);
     bin_and_raster(c, P, Z, 0, c->sn_tiles, s);
     if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
     raster(c, P, Z, 0, s);
@@ -1153,13 +1169,15 @@ static int geometry_passes(zr_ctx* c)
     const bool lanes = !(c->cfg.flags & ZR_FLAG_SERIAL_PASSES) && c->cam_s != nullptr && !c->env_serial;
     int rc;
     c->camera_on_lane = false;
+    c->lanes3_now = lanes && c->in_render && c->three_lanes && c->shadow_s && c->light_s && !c->d_shadow_ext;
     if (lanes) {
+        hipStream_t ss = c->lanes3_now ? c->shadow_s : c->stream;
         rc = frame_begin(c, c->cam_s);
         if (rc != ZR_OK) return rc;
         HIPCHK(c, hipEventRecord(c->ev_fork, c->cam_s));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fork, 0));          // the uniforms and the zeroed statistics
-        rc = shadow_pass(c, c->stream);
-        if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(ss, c->ev_fork, 0));                 // the uniforms and the zeroed statistics
+        rc = shadow_pass(c, ss);
+        if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, ss));
         if (rc == ZR_OK) rc = gbuffer_pass(c, c->cam_s);
         if (rc == ZR_OK) { HIPCHK(c, hipEventRecord(c->ev_cam, c->cam_s)); c->camera_on_lane = true; }
     } else {
@@ -1216,16 +1234,15 @@ static int empty_pixel_pass(zr_ctx* c, hipStream_t s)
     return ZR_OK;
 }
 
-static int lighting_pass(zr_ctx* c)
+static int lighting_pass(zr_ctx* c, hipStream_t s)
 {
-    hipStream_t s = c->stream;
     hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
     ZrLightParams L; light_params(c, &L);
     L.empty_rgba = c->empty_ready ? c->d_empty_rgba : nullptr;
     // The next frame's shadow pass follows on this stream and rasterises into the OTHER copy of the map, which nothing reads or
     // writes while this pass runs: clear it here.
     const int npar = (int)((c->frame_no + 1u) & 1u);
-    if (c->n_owned) { L.clear_next = (uint32_t*)c->d_shadow_b[npar]; L.clear_n = c->SD * c->SD; c->shadow_cleared[npar] = true; }
+    if (c->n_owned && s == c->stream) { L.clear_next = (uint32_t*)c->d_shadow_b[npar]; L.clear_n = c->SD * c->SD; c->shadow_cleared[npar] = true; }
     zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, shadow_buf(c), c->cube, c->d_lut, c->d_unorm_lut,
                        L.packed_out ? (c->d_tiles_ext ? c->d_tiles_ext : c->d_tiles) : c->d_color, s);
     if (c->debug_view == 9u)        // GBufferVis mosaic over the lit frame (needs the whole GBuffer: single-rank contexts only)
@@ -1243,9 +1260,14 @@ extern "C" int zr_render_lighting(zr_ctx* c)
     if (!c) return ZR_ERR_ARG;
     if (c->stage != 2) return zr_fail(c, ZR_ERR_STATE, "zr_render_lighting out of order");
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = empty_pixel_pass(c, c->stream);       // the shadow map (possibly reduced over ranks by the host) is final only now
-    if (rc == ZR_OK && c->camera_on_lane) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_cam, 0));
-    if (rc == ZR_OK) rc = lighting_pass(c);
+    hipStream_t ls = (c->lanes3_now && c->camera_on_lane) ? c->light_s : c->stream;
+    if (ls != c->stream) HIPCHK(c, hipStreamWaitEvent(ls, c->ev_join, 0));      // this frame's shadow pipeline (on its own lane)
+    int rc = empty_pixel_pass(c, ls);              // the shadow map (possibly reduced over ranks by the host) is final only now
+    if (rc == ZR_OK && c->camera_on_lane) HIPCHK(c, hipStreamWaitEvent(ls, c->ev_cam, 0));
+    const uint64_t k = c->frame_no;
+    if (rc == ZR_OK) rc = lighting_pass(c, ls);
+    // whatever the host enqueues on its stream next is ordered after the finished frame
+    if (rc == ZR_OK && ls != c->stream) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_end[k % zr_ctx::END_RING], 0));
     return rc;
 }
 
@@ -1258,8 +1280,10 @@ extern "C" int zr_render_lighting(zr_ctx* c)
 extern "C" int zr_render(zr_ctx* c)
 {
     if (!c) return ZR_ERR_ARG;
+    c->in_render = true;
     int rc = geometry_passes(c);
     if (rc == ZR_OK) rc = zr_render_lighting(c);
+    c->in_render = false;
     if (rc != ZR_OK) c->stage = 0;
     return rc;
 }

@@ -34,6 +34,9 @@
 #ifndef ZR_RASTER_WAVES
 #define ZR_RASTER_WAVES 4                    // waves per SIMD the tile rasteriser is compiled for (5 fits only with ~25 VGPRs spilled to scratch: +100 MB of traffic per frame for 2 % less time alone, nothing side by side)
 #endif
+#ifndef ZR_RASTER_WAVES_DEFER
+#define ZR_RASTER_WAVES_DEFER 6              // ... and the variant without the clipper in its loop (DEFER)
+#endif
 // Diagnostic work-skipping switches (attribution of kernel time) exist only in -DZR_DIAG builds: the product library has none.
 #ifdef ZR_DIAG
 #define ZR_DIAG_SKIP(x) (x)
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
 // k_cull<GBUFFER>'s instructions.  The bounds are conservative by construction: a vertex lies in the box, the transforms are affine up
 // to rounding, and the rounding of both the corners' and the vertices' arithmetic is covered by an explicit margin (8 ulps of the
 // magnitudes involved, carried through the divide; at least one pixel) - culling more is never possible, only a little less.
-template <bool WORKLIST>
+template <int MODE, bool WORKLIST>
 __global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
                                                   uint32_t* __restrict__ rects, uint2* __restrict__ pxrect, float* __restrict__ zmin,
                                                   uint8_t* __restrict__ vis_clear, const ZrDevStats* __restrict__ stats, int slot)
@@ -475,7 +478,8 @@ __global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __re
     for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
         CullItem it;
         uint32_t r = ZR_RECT_CULLED; uint2 pr = make_uint2(0u, 0u); float zm = -1.0f;
-        if (cull_stage_a<ZR_MODE_GBUFFER, WORKLIST>(P, objs, work, vis_clear, k, it)) {
+        const uint32_t r_all = (P.tiles_x - 1u) << 16 | (P.tiles_y - 1u) << 24;          // every tile: extents unknown
+        if (cull_stage_a<MODE, WORKLIST>(P, objs, work, vis_clear, k, it)) {
             const float4 lo = it.O->mbox[2u * it.m], hi = it.O->mbox[2u * it.m + 1u];
             const float FM = 3.402823466e38f, U = 9.5367431640625e-7f;           // 8 ulps
             bool fin = true, clip = false;
@@ -514,9 +518,9 @@ __global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __re
                 out_all &= o;
                 wmin = __builtin_fminf(wmin, c.w);
             }
-            if (!fin) r = 0u;                                   // not finite: drawn, never occlusion-tested (k_geom sorts it out)
+            if (!fin) r = r_all;                                // not finite: drawn, never occlusion-tested (the rasteriser sorts it out)
             else if (out_all) r = ZR_RECT_CULLED;               // the whole box is beyond one frustum plane
-            else if (clip) r = 0u;                              // touches the near plane / guard band: drawn, not occlusion-tested
+            else if (clip) r = r_all;                           // touches the near plane / guard band: drawn, not occlusion-tested
             else {
                 const float rwm = 1.0f / (wmin - eW);
 #pragma unroll
@@ -546,14 +550,14 @@ __global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __re
                         }
                     }
                     if (px0 <= px1 && py0 <= py1) {
-                        r = 0u;
+                        r = (uint32_t)(px0 / TILE) | (uint32_t)(py0 / TILE) << 8 | (uint32_t)(px1 / TILE) << 16 | (uint32_t)(py1 / TILE) << 24;
                         pr = make_uint2((uint32_t)px0 | (uint32_t)py0 << 16, (uint32_t)px1 | (uint32_t)py1 << 16);
                     }
-                } else r = 0u;
+                } else r = r_all;
             }
         }
         rects[k] = r;
-        if (pxrect) { pxrect[k] = pr; zmin[k] = zm; }
+        if (MODE == ZR_MODE_GBUFFER && pxrect) { pxrect[k] = pr; zmin[k] = zm; }
     }
 }
 
@@ -1349,12 +1353,15 @@ __global__ void k_fill64(unsigned long long* __restrict__ p, unsigned long long 
 // the frame-sized key buffer in HBM with global atomic min (skipped when the resident key already wins).
 //   GBUFFER: vis64[W*H] (depth bits << 32 | prim), resolved later by k_resolve_gbuffer
 //   SHADOW : the shadow map itself (float bits as uint): the merge IS the LESS_OR_EQUAL depth write
-template <int MODE, bool HIZ>
-__global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(ZR_RASTER_WAVES))) void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs,
-                                                       const uint4* __restrict__ chunk_tab,
-                                                       const ZrBinEntry* __restrict__ bins, ZrDevStats* __restrict__ stats, int slot,
-                                                       unsigned long long* __restrict__ vis64, uint32_t* __restrict__ shadow_bits,
-                                                       const float* __restrict__ hiz0, uint32_t hiz0_w, uint32_t hiz0_h)
+// DEFER: triangles that need the clipper (or the 64-bit walk) are not rasterised here but appended, with their tile, to `slow` for
+// k_tile_slow: without the call to raster_clipped in its loop the kernel needs half the registers, i.e. twice the waves per SIMD
+// fit - next to each other and next to the other lane's kernels.
+template <int MODE, bool HIZ, bool DEFER>
+__global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(DEFER ? ZR_RASTER_WAVES_DEFER : ZR_RASTER_WAVES)))
+void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* __restrict__ chunk_tab,
+                     const ZrBinEntry* __restrict__ bins, ZrDevStats* __restrict__ stats, int slot,
+                     unsigned long long* __restrict__ vis64, uint32_t* __restrict__ shadow_bits,
+                     const float* __restrict__ hiz0, uint32_t hiz0_w, uint32_t hiz0_h, uint4* __restrict__ slow, uint32_t slow_cap)
 {
     __shared__ float hz[HIZ ? (TILE / 8) * (TILE / 8) : 1];
     __shared__ unsigned long long keys64[MODE == ZR_MODE_GBUFFER ? TILE_PIX : 1];
@@ -1467,7 +1474,13 @@ __global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(ZR_RAS
                             const float4 pk = mp[li[k]];
                             cc[k] = zr_mat4_point(P.PVM, vs_position(zr3(pk.x, pk.y, pk.z), I, instanced));
                         }
-                        raster_clipped<MODE>(cc[0], cc[1], cc[2], prim, T, P.hw, P.hh, ox, oy, keys64, keys32);
+                        if (DEFER) {
+                            const uint32_t pos = atomicAdd(&stats->n_slow[slot], 1u);          // rare: one atomic apiece does
+                            if (pos < slow_cap) {
+                                for (int k = 0; k < 3; ++k) slow[4u * pos + (uint32_t)k] = make_uint4(zr_f2u(cc[k].x), zr_f2u(cc[k].y), zr_f2u(cc[k].z), zr_f2u(cc[k].w));
+                                slow[4u * pos + 3u] = make_uint4(prim, tile, 0u, 0u);
+                            } else { stats->overflow = 1u; stats->overflow_sticky = 1u; }
+                        } else raster_clipped<MODE>(cc[0], cc[1], cc[2], prim, T, P.hw, P.hh, ox, oy, keys64, keys32);
                     }
                 }
                 const unsigned long long mask = __ballot(alive);
@@ -1519,6 +1532,11 @@ __global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(ZR_RAS
                 const uint32_t k = keys32[i];
                 if (k < shadow_bits[p]) atomicMin(&shadow_bits[p], k);
             }
+        }
+        if (P.static_units) {      // one unit per workgroup (the grid covers the units): the dispatcher balances, and a retiring workgroup
+            __syncthreads();       // frees its registers for whatever the other lane has waiting
+            chunk += gridDim.x;
+            continue;
         }
         // (the next unit is claimed only when this one is done: claiming early costs more in tail balance than the atomic's latency)
         if (tid == 0) cur_chunk = gridDim.x + atomicAdd(&stats->chunk_counter[slot], 1u);
@@ -1845,35 +1863,46 @@ __global__ __launch_bounds__(256) void k_tile(ZrPass P, const uint4* __restrict_
 
 // The slow triangles of the round (they need the clipper, or have an edge of 64 px or more): every owned tile tries every one of
 // them through raster_clipped.  One workgroup per owned tile; returns at once when the round has none (the usual case).
-template <int MODE>
+template <int MODE, bool BY_TILE>
 __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __restrict__ owned_tiles, const uint4* __restrict__ slow,
                                                    uint32_t slow_cap, const ZrDevStats* __restrict__ stats, int slot,
-                                                   unsigned long long* __restrict__ vis64)
+                                                   unsigned long long* __restrict__ vis64, uint32_t* __restrict__ shadow_bits)
 {
-    __shared__ unsigned long long keys64[TILE_PIX];
+    __shared__ unsigned long long keys64[MODE == ZR_MODE_GBUFFER ? TILE_PIX : 1];
+    __shared__ uint32_t keys32[MODE == ZR_MODE_SHADOW ? TILE_PIX : 1];
     const uint32_t slow_lo = 0u, slow_hi = min(stats->n_slow[slot], slow_cap);
     if (slow_lo >= slow_hi) return;
     const uint32_t tid = threadIdx.x, tile = owned_tiles[blockIdx.x];
-    for (uint32_t i = tid; i < TILE_PIX; i += 256u) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
+    for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
+        if (MODE == ZR_MODE_GBUFFER) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
+        else keys32[i] = 0x3F800000u;
+    }
     __syncthreads();
     const int tpx0 = (int)(tile % P.tiles_x) * TILE, tpy0 = (int)(tile / P.tiles_x) * TILE;
     TileCtx T;
     T.px0 = 0; T.py0 = 0; T.W = (int)P.W - tpx0; T.H = (int)P.H - tpy0;
     for (uint32_t j = slow_lo + tid; j < slow_hi; j += 256u) {
+        const uint4 q3 = slow[4u * j + 3u];
+        if (BY_TILE && q3.y != tile) continue;          // (the meshlet-binned rasteriser lists a triangle once per tile of its meshlet)
         const uint4 q0 = slow[4u * j], q1 = slow[4u * j + 1u], q2 = slow[4u * j + 2u];
         zf4 c0, c1, c2;
         c0.x = zr_u2f(q0.x); c0.y = zr_u2f(q0.y); c0.z = zr_u2f(q0.z); c0.w = zr_u2f(q0.w);
         c1.x = zr_u2f(q1.x); c1.y = zr_u2f(q1.y); c1.z = zr_u2f(q1.z); c1.w = zr_u2f(q1.w);
         c2.x = zr_u2f(q2.x); c2.y = zr_u2f(q2.y); c2.z = zr_u2f(q2.z); c2.w = zr_u2f(q2.w);
-        raster_clipped<MODE>(c0, c1, c2, slow[4u * j + 3u].x, T, P.hw, P.hh, tpx0 * 256, tpy0 * 256, keys64, nullptr);
+        raster_clipped<MODE>(c0, c1, c2, q3.x, T, P.hw, P.hh, tpx0 * 256, tpy0 * 256, keys64, keys32);
     }
     __syncthreads();
     for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
         const int px = tpx0 + (int)(i & (TILE - 1)), py = tpy0 + (int)(i / TILE);
         if (px >= (int)P.W || py >= (int)P.H) continue;
         const size_t p = (size_t)py * P.W + (size_t)px;
-        const unsigned long long k = keys64[i];
-        if ((uint32_t)k != ZR_EMPTY_PRIM && k < vis64[p]) atomicMin(&vis64[p], k);
+        if (MODE == ZR_MODE_GBUFFER) {
+            const unsigned long long k = keys64[i];
+            if ((uint32_t)k != ZR_EMPTY_PRIM && k < vis64[p]) atomicMin(&vis64[p], k);
+        } else {
+            const uint32_t k = keys32[i];
+            if (k < shadow_bits[p]) atomicMin(&shadow_bits[p], k);
+        }
     }
 }
 
@@ -2454,10 +2483,17 @@ void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, u
     if (P.n_work == 0) return;
     const dim3 gi((P.n_inst_total + 255) / 256), b(256);
     const dim3 g(std::min<uint32_t>((P.n_work + 255u) / 256u, 8192u));
-    if (P.use_worklist) {
-        hipLaunchKernelGGL(k_cull_instances<ZR_MODE_GBUFFER>, gi, b, 0, s, P, objs, work, stats, slot);
-        hipLaunchKernelGGL(k_cull_box<true>, g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot);
-    } else hipLaunchKernelGGL(k_cull_box<false>, g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot);
+    if (P.mode == ZR_MODE_GBUFFER) {
+        if (P.use_worklist) {
+            hipLaunchKernelGGL(k_cull_instances<ZR_MODE_GBUFFER>, gi, b, 0, s, P, objs, work, stats, slot);
+            hipLaunchKernelGGL((k_cull_box<ZR_MODE_GBUFFER, true>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot);
+        } else hipLaunchKernelGGL((k_cull_box<ZR_MODE_GBUFFER, false>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot);
+    } else {
+        if (P.use_worklist) {
+            hipLaunchKernelGGL(k_cull_instances<ZR_MODE_SHADOW>, gi, b, 0, s, P, objs, work, stats, slot);
+            hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, true>), g, b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot);
+        } else hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, false>), g, b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot);
+    }
 }
 void zr_launch_bin_count(const ZrPass& P, const uint32_t* work, uint32_t* rects, uint32_t* tile_count, const ZrHiz& Z, ZrDevStats* stats,
                          int slot, hipStream_t s)
@@ -2506,15 +2542,18 @@ void zr_launch_fill64(unsigned long long* p, unsigned long long v, size_t n, hip
 }
 void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4* chunk_tab,
                              const ZrBinEntry* bins, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t* shadow_bits,
-                             uint32_t n_blocks, const ZrHiz& Z, hipStream_t s)
+                             uint32_t n_blocks, const ZrHiz& Z, hipStream_t s, uint4* slow, uint32_t slow_cap, const uint32_t* tiles, uint32_t n_tiles)
 {
     const float* none = nullptr;
     if (P.mode == ZR_MODE_GBUFFER && Z.phase == 2u)
-        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_GBUFFER, true>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, (const float*)Z.lvl[0], Z.hw[0], Z.hh[0]);
+        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_GBUFFER, true, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, (const float*)Z.lvl[0], Z.hw[0], Z.hh[0], (uint4*)nullptr, 0u);
     else if (P.mode == ZR_MODE_GBUFFER)
-        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_GBUFFER, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u);
-    else
-        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u);
+        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_GBUFFER, false, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u, (uint4*)nullptr, 0u);
+    else if (slow) {    // shadow pass: clipped triangles go through a list + k_tile_slow
+        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false, true>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u, slow, slow_cap);
+        if (n_tiles) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_SHADOW, true>), dim3(n_tiles), dim3(256), 0, s, P, tiles, slow, slow_cap, stats, slot, (unsigned long long*)nullptr, shadow_bits);
+    } else
+        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u, (uint4*)nullptr, 0u);
 }
 void zr_launch_select(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats,
                       int slot, hipStream_t s)
@@ -2536,7 +2575,7 @@ void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B,
                     ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s)
 {
     hipLaunchKernelGGL(k_tile<ZR_MODE_GBUFFER>, dim3(n_blocks), dim3(256), 0, s, P, chunk_tab, B.recs, B.idx, stats, slot, vis64);
-    if (n_owned) hipLaunchKernelGGL(k_tile_slow<ZR_MODE_GBUFFER>, dim3(n_owned), dim3(256), 0, s, P, owned_tiles, B.slow, B.slow_cap, stats, slot, vis64);
+    if (n_owned) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_GBUFFER, false>), dim3(n_owned), dim3(256), 0, s, P, owned_tiles, B.slow, B.slow_cap, stats, slot, vis64, (uint32_t*)nullptr);
 }
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, uint8_t* vis_now,

@@ -103,6 +103,7 @@ struct ZrPass {
     uint32_t debug_skip;             // diagnostics only (env ZR_DEBUG_SKIP): 1 skip pixel walk, 2 skip triangle phase too
     uint32_t sphere_ok;              // VM / p00 / p11 / pz_* hold a centred perspective with rigid model and view: sphere_bounds() applies
     float    pz_a, pz_b;             //   ndc depth of a point d in front of the eye = pz_a + pz_b / d
+    uint32_t static_units;           // rasteriser: workgroup b takes units b, b + grid, ... (no work counter)
     uint32_t m_identity;             // M is bit for bit the identity: M * vec4(p, 1) == p + 0.0f for finite p
     uint32_t write_overlay;          // the resolve must write the overlay plane (a skydome is drawn, or stale sky pixels must go)
 };
@@ -206,7 +207,8 @@ void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s);
 void zr_launch_fill64(unsigned long long* p, unsigned long long v, size_t n, hipStream_t s);
 void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4* chunk_tab,
                              const ZrBinEntry* bins, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t* shadow_bits,
-                             uint32_t n_blocks, const ZrHiz& Z, hipStream_t s);
+                             uint32_t n_blocks, const ZrHiz& Z, hipStream_t s, uint4* slow = nullptr, uint32_t slow_cap = 0, const uint32_t* tiles = nullptr,
+                             uint32_t n_tiles = 0);      // slow != nullptr (shadow pass): clipped triangles via the list + k_tile_slow
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, uint8_t* vis_now,
                                ZrDevStats* stats, hipStream_t s);
