@@ -998,14 +998,14 @@ static void tri_select(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hip
 {
     zr_launch_select(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->tb, c->d_stats, slot, s);
 }
-static void tri_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s)
+static void tri_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s, bool slow_too)
 {
     const zr_ctx::Scratch& sc = c->sc[1];
     if (P.n_work == 0) return;          // nothing to draw: the pass is its clear
     zr_launch_geom(P, Z, c->tb, sc.tile_count, c->d_stats, slot, s);
     zr_launch_scan_tri(sc.tile_count, sc.tile_offset, sc.tile_cursor, sc.chunk_tab, c->chunk_capacity, c->n_tiles, c->tb, c->d_stats, slot, s);
     zr_launch_index(c->tb, sc.tile_offset, sc.tile_cursor, c->d_stats, slot, s);
-    zr_launch_tile(P, sc.chunk_tab, c->tb, c->d_owned, c->n_owned, c->d_stats, slot, c->d_vis, c->raster_blocks, s);
+    zr_launch_tile(P, sc.chunk_tab, c->tb, c->d_owned, c->n_owned, c->d_stats, slot, c->d_vis, c->raster_blocks, s, slow_too);
 }
 static void raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s)
 {
@@ -1102,12 +1102,14 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
     Z.vis_prev = c->d_visflag[c->vis_cur ^ 1]; Z.vis_now = hiz_on ? c->d_visflag[c->vis_cur] : nullptr;
     Z.phase = 0;
     const bool tri_bins = !(c->cfg.flags & ZR_FLAG_MESHLET_BINS) && ZR_TILE == 32;
-    if (tri_bins) zr_launch_cull_box(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, s);
+    c->last_two_round = hiz_on && c->vis_history;
+    // (triangle-binned pass: the cull kernel also compacts round 1's list - the survivors that owned a pixel last frame, or all of them)
+    if (tri_bins) zr_launch_cull_box(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, s, c->tb.sel, c->last_two_round ? Z.vis_prev : nullptr);
     else zr_launch_cull(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, c->raster_blocks * 4u, s);
     if (hiz_on && P.use_worklist) HIPCHK(c, hipMemsetAsync(c->d_visflag[c->vis_cur], 0, c->n_work, s));     // else k_cull clears them
-    c->last_two_round = hiz_on && c->vis_history;
-    auto bin = [&](int slot) { if (tri_bins) tri_select(c, P, Z, slot, s); else bin_and_raster(c, P, Z, slot, c->n_tiles, s); };
-    auto rast = [&](int slot) { if (tri_bins) tri_raster(c, P, Z, slot, s); else raster(c, P, Z, slot, s); };
+    const bool two = c->last_two_round;
+    auto bin = [&](int slot) { if (!tri_bins) bin_and_raster(c, P, Z, slot, c->n_tiles, s); else if (slot == 2) tri_select(c, P, Z, slot, s); };
+    auto rast = [&](int slot) { if (tri_bins) tri_raster(c, P, Z, slot, s, slot == 2 || !two); else raster(c, P, Z, slot, s); };
     if (c->last_two_round) {
         Z.phase = 1;
         bin(1);

@@ -302,7 +302,7 @@ __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, uint32_t src) { retur
 struct CullItem {
     const float4* mposv;          // first vertex of the meshlet in the flattened position array
     const ZrObject* O;
-    uint32_t vcount, instanced, m;
+    uint32_t vcount, instanced, m, inst_i, w, tcount, tri_base;
     ZrInstance I;
     zf3 sph_c; float sph_r;       // the meshlet's bounding sphere after the instance transform (object space of PVM)
 };
@@ -321,8 +321,8 @@ __device__ __forceinline__ bool cull_stage_a(const ZrPass& P, const ZrObject* __
     const float4* __restrict__ mq = (const float4*)mlp;
     const float4 bs = mq[1], q2 = mq[2], q3 = mq[3];
     const float4 cn = make_float4(q2.w, q3.x, q3.y, q3.z);      // axis.xyz, cutoff
-    it.O = O; it.m = m;
-    it.mposv = O->mpos + mlp->VertexOffset; it.vcount = mlp->VertexCount;
+    it.O = O; it.m = m; it.inst_i = inst_i; it.w = w;
+    it.mposv = O->mpos + mlp->VertexOffset; it.vcount = mlp->VertexCount; it.tcount = mlp->TriangleCount; it.tri_base = mlp->BindlessContext;
     it.I = O->inst[inst_i];
     const ZrInstance& I = it.I;
     const uint32_t instanced = O->instanced != 0 ? 1u : 0u;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
         // ---------------------------------------------------------------- stage A: lane per meshlet-instance
         const bool mine = lane < ZR_CULL_GROUP && k < n;
         CullItem it;
-        it.mposv = nullptr; it.O = nullptr; it.vcount = 0; it.instanced = 0; it.m = 0;
+        it.mposv = nullptr; it.O = nullptr; it.vcount = 0; it.instanced = 0; it.m = 0; it.inst_i = 0; it.w = 0; it.tcount = 0; it.tri_base = 0;
         for (int i = 0; i < 9; ++i) it.I.R[i] = 0.0f;
         it.I.t[0] = it.I.t[1] = it.I.t[2] = 0.0f; it.I.s = 1.0f;
         const bool alive = mine && cull_stage_a<MODE, WORKLIST>(P, objs, work, vis_clear, k, it);
@@ -468,18 +468,24 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
 template <int MODE, bool WORKLIST>
 __global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
                                                   uint32_t* __restrict__ rects, uint2* __restrict__ pxrect, float* __restrict__ zmin,
-                                                  uint8_t* __restrict__ vis_clear, const ZrDevStats* __restrict__ stats, int slot)
+                                                  uint8_t* __restrict__ vis_clear, ZrDevStats* __restrict__ stats, int slot,
+                                                  ZrBinEntry* __restrict__ sel, const uint8_t* __restrict__ vis_prev)
 {
+    // sel != nullptr (camera pass): the survivors that round 1 draws - all of them, or with vis_prev those that owned a pixel last
+    // frame - are compacted into sel[] right here (what k_select does for round 2), one global atomic per 256 work items
+    __shared__ uint32_t wcount[4], wbase[4];
     const uint32_t n = WORKLIST ? stats->n_vis_work[slot] : P.n_work;
     const float rs_x = __builtin_fabsf(P.PVM[0]) + __builtin_fabsf(P.PVM[4]) + __builtin_fabsf(P.PVM[8]);
     const float rs_y = __builtin_fabsf(P.PVM[1]) + __builtin_fabsf(P.PVM[5]) + __builtin_fabsf(P.PVM[9]);
     const float rs_z = __builtin_fabsf(P.PVM[2]) + __builtin_fabsf(P.PVM[6]) + __builtin_fabsf(P.PVM[10]);
     const float rs_w = __builtin_fabsf(P.PVM[3]) + __builtin_fabsf(P.PVM[7]) + __builtin_fabsf(P.PVM[11]);
-    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
+    for (uint32_t k0 = blockIdx.x * 256u; k0 < n; k0 += gridDim.x * 256u) {
+        const uint32_t k = k0 + threadIdx.x;
         CullItem it;
+        it.O = nullptr; it.w = 0;
         uint32_t r = ZR_RECT_CULLED; uint2 pr = make_uint2(0u, 0u); float zm = -1.0f;
         const uint32_t r_all = (P.tiles_x - 1u) << 16 | (P.tiles_y - 1u) << 24;          // every tile: extents unknown
-        if (cull_stage_a<MODE, WORKLIST>(P, objs, work, vis_clear, k, it)) {
+        if (k < n && cull_stage_a<MODE, WORKLIST>(P, objs, work, vis_clear, k, it)) {
             const float4 lo = it.O->mbox[2u * it.m], hi = it.O->mbox[2u * it.m + 1u];
             const float FM = 3.402823466e38f, U = 9.5367431640625e-7f;           // 8 ulps
             bool fin = true, clip = false;
@@ -556,8 +562,33 @@ __global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __re
                 } else r = r_all;
             }
         }
-        rects[k] = r;
-        if (MODE == ZR_MODE_GBUFFER && pxrect) { pxrect[k] = pr; zmin[k] = zm; }
+        if (k < n) {
+            rects[k] = r;
+            if (MODE == ZR_MODE_GBUFFER && pxrect) { pxrect[k] = pr; zmin[k] = zm; }
+        }
+        if (MODE == ZR_MODE_GBUFFER && sel) {
+            const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+            const bool take = r != ZR_RECT_CULLED && (vis_prev == nullptr || vis_prev[it.w] != 0);
+            const unsigned long long m = __ballot(take);
+            if (lane == 0) wcount[wv] = (uint32_t)__popcll(m);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+                const uint32_t base = tot ? atomicAdd(&stats->n_sel[1], tot) : 0u;
+                wbase[0] = base; wbase[1] = base + wcount[0]; wbase[2] = wbase[1] + wcount[1]; wbase[3] = wbase[2] + wcount[2];
+                if (tot) atomicAdd(&stats->survivors[1], tot);
+            }
+            __syncthreads();
+            if (take) {
+                const ZrObject* __restrict__ O = it.O;
+                ZrBinEntry be;
+                be.mpos = it.mposv; be.mtri = O->mtri + it.tri_base; be.inst = O->inst + it.inst_i;
+                be.counts = it.vcount | it.tcount << 8 | (it.instanced ? 1u << 16 : 0u);
+                be.prim_base = O->prim_base + it.inst_i * O->n_tris;
+                sel[wbase[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = be;
+            }
+            __syncthreads();      // wcount / wbase are reused by the next stretch
+        }
     }
 }
 
@@ -747,11 +778,8 @@ __global__ __launch_bounds__(1024) void k_scan_tri(uint32_t* __restrict__ bin_co
                                                    uint32_t n_tiles, const uint32_t* __restrict__ wave_culled, uint32_t n_waves,
                                                    ZrDevStats* __restrict__ stats, int slot, uint32_t chunk)
 {
-    __shared__ uint32_t culled_s;
-    if (threadIdx.x == 0) culled_s = 0;
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t cpart[1024];
-    const uint32_t tid = threadIdx.x;
+    __shared__ uint32_t wtot[16], cwtot[16], ctot_s[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t per = (n_tiles + 1023u) / 1024u;
     const uint32_t b = min(n_tiles, tid * per), e = min(n_tiles, b + per);
     uint4* __restrict__ cnt4 = (uint4*)bin_count;
@@ -759,17 +787,24 @@ __global__ __launch_bounds__(1024) void k_scan_tri(uint32_t* __restrict__ bin_co
     for (uint32_t i = tid; i < n_waves; i += 1024u) nc += wave_culled[i];
     uint32_t s = 0, cs = 0;
     for (uint32_t i = b; i < e; ++i) { const uint4 c = cnt4[i]; const uint32_t t = c.x + c.y + c.z + c.w; s += t; cs += (t + chunk - 1u) / chunk; }
-    part[tid] = s; cpart[tid] = cs;
-    __syncthreads();
-    nc = (uint32_t)wave_sum((int)nc);
-    if ((tid & 63u) == 0 && nc) atomicAdd(&culled_s, nc);
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        const uint32_t v = (tid >= off) ? part[tid - off] : 0u, cv = (tid >= off) ? cpart[tid - off] : 0u;
-        __syncthreads();
-        part[tid] += v; cpart[tid] += cv;
-        __syncthreads();
+    // scan: inside the wave by shuffles, across the 16 waves through LDS - one barrier instead of twenty (this kernel is one
+    // workgroup on the camera pipeline's critical path)
+    uint32_t incl = s, cincl = cs;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, o), cv = (uint32_t)__shfl_up((int)cincl, o);
+        if ((int)lane >= o) { incl += v; cincl += cv; }
     }
-    uint32_t run = part[tid] - s, crun = cpart[tid] - cs;
+    nc = (uint32_t)wave_sum((int)nc);
+    if (lane == 63u) { wtot[wv] = incl; cwtot[wv] = cincl; }
+    if (lane == 0u) ctot_s[wv] = nc;
+    __syncthreads();
+    uint32_t wpre = 0, cwpre = 0, tot = 0, ctot = 0, culled = 0;
+    for (uint32_t i = 0; i < 16u; ++i) {
+        const uint32_t a = wtot[i], c = cwtot[i];
+        if (i < wv) { wpre += a; cwpre += c; }
+        tot += a; ctot += c; culled += ctot_s[i];
+    }
+    uint32_t run = wpre + incl - s, crun = cwpre + cincl - cs;
     for (uint32_t i = b; i < e; ++i) {
         const uint4 c = cnt4[i];
         const uint32_t t = c.x + c.y + c.z + c.w, nu = (t + chunk - 1u) / chunk;
@@ -779,14 +814,14 @@ __global__ __launch_bounds__(1024) void k_scan_tri(uint32_t* __restrict__ bin_co
         run += t; crun += nu;
         cnt4[i] = make_uint4(0u, 0u, 0u, 0u); ((uint4*)bin_cursor)[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-    if (tid == 1023) {
-        stats->bin_entries[slot] = part[1023];        // triangle records of the round
-        stats->n_chunks[slot] = min(cpart[1023], chunk_cap);
+    if (tid == 0) {
+        stats->bin_entries[slot] = tot;               // triangle records of the round
+        stats->n_chunks[slot] = min(ctot, chunk_cap);
         stats->chunk_counter[slot] = 0;
         stats->pool_used[slot] = stats->pool_next[slot]; stats->pool_next[slot] = 0;
-        if (cpart[1023] > chunk_cap) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
-        // (the scan loop's barriers ordered culled_s) meshlets of this round that k_geom dropped behind the pyramid
-        stats->hiz_culled += culled_s; stats->survivors[slot] -= culled_s;
+        if (ctot > chunk_cap) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
+        // meshlets of this round that k_geom dropped behind the pyramid
+        stats->hiz_culled += culled; stats->survivors[slot] -= culled;
     }
 }
 
@@ -1711,8 +1746,8 @@ __global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrBinEntry* __rest
                 if (lane == (uint32_t)__builtin_ctzll(ms)) base = atomicAdd(&stats->n_slow[slot], (uint32_t)__popcll(ms));
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(ms));
                 if (is_slow) {
-                    const uint32_t pos = base + (uint32_t)__popcll(ms & lt);
-                    if (pos < slow_cap) {
+                    const uint32_t pos_r = base + (uint32_t)__popcll(ms & lt), pos = pos_r + (slot == 2 ? slow_cap / 2u : 0u);
+                    if (pos_r < slow_cap / 2u) {
                         const uint32_t li[3] = { i0, i1, i2 };
                         for (int k = 0; k < 3; ++k) {
                             const float4 pk = mp[li[k]];
@@ -1870,8 +1905,11 @@ __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __r
 {
     __shared__ unsigned long long keys64[MODE == ZR_MODE_GBUFFER ? TILE_PIX : 1];
     __shared__ uint32_t keys32[MODE == ZR_MODE_SHADOW ? TILE_PIX : 1];
-    const uint32_t slow_lo = 0u, slow_hi = min(stats->n_slow[slot], slow_cap);
-    if (slow_lo >= slow_hi) return;
+    // camera pass: round 1's triangles sit in the first half of the list, round 2's in the second; one launch after round 2 draws both
+    // (slot = 2), or round 1's alone in a one-round frame (slot = 1)
+    const uint32_t half = BY_TILE ? slow_cap : slow_cap / 2u;
+    const uint32_t n_a = min(stats->n_slow[BY_TILE ? slot : 1], half), n_b = (!BY_TILE && slot == 2) ? min(stats->n_slow[2], half) : 0u;
+    if (n_a + n_b == 0u) return;
     const uint32_t tid = threadIdx.x, tile = owned_tiles[blockIdx.x];
     for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
         if (MODE == ZR_MODE_GBUFFER) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
@@ -1881,7 +1919,8 @@ __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __r
     const int tpx0 = (int)(tile % P.tiles_x) * TILE, tpy0 = (int)(tile / P.tiles_x) * TILE;
     TileCtx T;
     T.px0 = 0; T.py0 = 0; T.W = (int)P.W - tpx0; T.H = (int)P.H - tpy0;
-    for (uint32_t j = slow_lo + tid; j < slow_hi; j += 256u) {
+    for (uint32_t jj = tid; jj < n_a + n_b; jj += 256u) {
+        const uint32_t j = jj < n_a ? jj : half + (jj - n_a);
         const uint4 q3 = slow[4u * j + 3u];
         if (BY_TILE && q3.y != tile) continue;          // (the meshlet-binned rasteriser lists a triangle once per tile of its meshlet)
         const uint4 q0 = slow[4u * j], q1 = slow[4u * j + 1u], q2 = slow[4u * j + 2u];
@@ -2478,7 +2517,7 @@ void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint3
     }
 }
 void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, const ZrHiz& Z, ZrDevStats* stats,
-                        int slot, hipStream_t s)
+                        int slot, hipStream_t s, ZrBinEntry* sel, const uint8_t* vis_prev)
 {
     if (P.n_work == 0) return;
     const dim3 gi((P.n_inst_total + 255) / 256), b(256);
@@ -2486,13 +2525,13 @@ void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, u
     if (P.mode == ZR_MODE_GBUFFER) {
         if (P.use_worklist) {
             hipLaunchKernelGGL(k_cull_instances<ZR_MODE_GBUFFER>, gi, b, 0, s, P, objs, work, stats, slot);
-            hipLaunchKernelGGL((k_cull_box<ZR_MODE_GBUFFER, true>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot);
-        } else hipLaunchKernelGGL((k_cull_box<ZR_MODE_GBUFFER, false>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot);
+            hipLaunchKernelGGL((k_cull_box<ZR_MODE_GBUFFER, true>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot, sel, vis_prev);
+        } else hipLaunchKernelGGL((k_cull_box<ZR_MODE_GBUFFER, false>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot, sel, vis_prev);
     } else {
         if (P.use_worklist) {
             hipLaunchKernelGGL(k_cull_instances<ZR_MODE_SHADOW>, gi, b, 0, s, P, objs, work, stats, slot);
-            hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, true>), g, b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot);
-        } else hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, false>), g, b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot);
+            hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, true>), g, b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot, (ZrBinEntry*)nullptr, (const uint8_t*)nullptr);
+        } else hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, false>), g, b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot, (ZrBinEntry*)nullptr, (const uint8_t*)nullptr);
     }
 }
 void zr_launch_bin_count(const ZrPass& P, const uint32_t* work, uint32_t* rects, uint32_t* tile_count, const ZrHiz& Z, ZrDevStats* stats,
@@ -2572,10 +2611,10 @@ void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* 
     hipLaunchKernelGGL(k_index, dim3(B.n_waves / 4u), dim3(256), 0, s, B.recs, B.chunk_fill, B.n_waves, B.n_chunks, stats, slot, tile_offset, tile_cursor, B.idx);
 }
 void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned,
-                    ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s)
+                    ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s, bool slow_too)
 {
     hipLaunchKernelGGL(k_tile<ZR_MODE_GBUFFER>, dim3(n_blocks), dim3(256), 0, s, P, chunk_tab, B.recs, B.idx, stats, slot, vis64);
-    if (n_owned) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_GBUFFER, false>), dim3(n_owned), dim3(256), 0, s, P, owned_tiles, B.slow, B.slow_cap, stats, slot, vis64, (uint32_t*)nullptr);
+    if (n_owned && slow_too) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_GBUFFER, false>), dim3(n_owned), dim3(256), 0, s, P, owned_tiles, B.slow, B.slow_cap, stats, slot, vis64, (uint32_t*)nullptr);
 }
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, uint8_t* vis_now,
