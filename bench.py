@@ -38,7 +38,7 @@ PROFILE_INDEX = os.path.join(ROOT, "profiles", "current.json")     # written by 
 # the kernels of each timed pass (the cull / hiz passes are groups of launch-bound kernels).  A camera round of the triangle-binned
 # pass is k_geom (vertices -> triangle records) + k_scan_tri + k_index (records -> per-tile lists) + k_tile (+ k_tile_slow); k_scan_tri,
 # k_index, k_tile and k_tile_slow run once per round under one name, so their profile rows hold both rounds.
-KERNEL_OF_PASS = {"shadow": ("k_raster<SHADOW>",), "gbuffer": ("k_geom<false>", "k_scan_tri", "k_index", "k_tile<0>", "k_tile_slow<0>"),
+KERNEL_OF_PASS = {"shadow": ("k_raster<SHADOW>", "k_tile_slow<SHADOW>"), "gbuffer": ("k_geom<false>", "k_scan_tri", "k_index", "k_tile<0>", "k_tile_slow<GBUFFER>"),
                   "gbuffer2": ("k_geom<true>",), "resolve": ("k_resolve_gbuffer",), "lighting": ("k_lighting",)}
 GBUFFER_WRITE_PASS = ("gbuffer", "gbuffer2", "resolve")
 GBUFFER_WRITE_KERNELS = "k_geom + k_scan_tri + k_index + k_tile (x2 rounds) + k_resolve_gbuffer"
@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--python-dist", action="store_true", help="N > 1: torch.distributed frame loop (dist.py) instead of the library's native RCCL host")
     ap.add_argument("--timing-interval", type=int, default=0,
                     help="per-kernel hipEvents are recorded on every n-th timed frame (each record is a ~6 us stream bubble); "
-                         "0 = steps // 12 clamped to 1..8")
+                         "0 = steps // 12 clamped to 5..8 (a short run still leaves four frames in five undisturbed)")
     ap.add_argument("--cube-dim", type=int, default=1024, help="cubemap face edge (the engine's is 1024: 11 mips)")
     args = ap.parse_args()
 
@@ -155,7 +155,7 @@ def main():
 
     dr = make_renderer(cfg)
     r = dr.r
-    interval = args.timing_interval if args.timing_interval > 0 else max(1, min(8, args.steps // 12))
+    interval = args.timing_interval if args.timing_interval > 0 else max(min(5, args.steps), min(8, args.steps // 12))
     interval = max(1, min(interval, args.steps))
     r.set_timing_interval(interval)
 
@@ -237,7 +237,7 @@ def main():
             dt = make_renderer(cfg_t)
             dt.r.set_timing_interval(0)
             k = max(10, min(args.steps, 60))
-            el = timed_loop(dt, k, 5, uniforms_static)
+            el = timed_loop(dt, k, 10, uniforms_static)
             extras["value_textured"] = round(W * H * k / el / 1e6, 3)
             extras["textured_note"] = "same scene with seven non-constant 512^2 material textures (trilinear + anisotropic sampling in the resolve), %d frames" % k
             dt.r.close()

@@ -25,7 +25,11 @@ shutil.copy(glob.glob(stats_dir + "/**/*kernel_stats.csv", recursive=True)[0], o
 bench = json.loads([l for l in open(bench_json) if l.startswith("{")][-1])
 
 SHORT = {"k_raster_chunks<0, false>": "k_raster<GBUFFER>", "k_raster_chunks<0, true>": "k_raster<GBUFFER,HiZ>",
-         "k_raster_chunks<1, false>": "k_raster<SHADOW>", "k_cull<0, false>": "k_cull<GBUFFER>", "k_cull<1, false>": "k_cull<SHADOW>",
+         "k_raster_chunks<1, false>": "k_raster<SHADOW>", "k_raster_chunks<1, false, true>": "k_raster<SHADOW>", "k_raster_chunks<1, false, false>": "k_raster<SHADOW>",
+         "k_raster_chunks<0, false, false>": "k_raster<GBUFFER>", "k_raster_chunks<0, true, false>": "k_raster<GBUFFER,HiZ>",
+         "k_tile_slow<0, false>": "k_tile_slow<GBUFFER>", "k_tile_slow<1, true>": "k_tile_slow<SHADOW>",
+         "k_cull_box<0, false>": "k_cull_box<GBUFFER>", "k_cull_box<1, false>": "k_cull_box<SHADOW>",
+         "k_cull_box<0, true>": "k_cull_box<GBUFFER,worklist>", "k_cull_box<1, true>": "k_cull_box<SHADOW,worklist>", "k_cull<0, false>": "k_cull<GBUFFER>", "k_cull<1, false>": "k_cull<SHADOW>",
          "k_cull<0, true>": "k_cull<GBUFFER,worklist>", "k_cull<1, true>": "k_cull<SHADOW,worklist>"}
 # (the triangle-binned camera pass's kernels keep their own names: k_cull_box<..>, k_select, k_geom<false|true>, k_scan_tri, k_index,
 #  k_tile<0>, k_tile_slow<0>; k_scan_tri / k_index / k_tile / k_tile_slow run once per round, so launches_per_frame = 2)
