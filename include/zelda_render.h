@@ -77,14 +77,14 @@ typedef struct zr_material { zr_image tex[XK_PBR_SAMPLER_NUMBER]; } zr_material;
 typedef struct zr_camera { float Position[3]; float Lookat[3]; float Speed, FOV, zNear, zFar; } zr_camera;
 
 /* Per-pass GPU timings of the last zr_render, milliseconds (hipEvents on the render stream). */
-enum { ZR_PASS_CULL_SHADOW = 0,   /* k_fill32 + k_cull<SHADOW> + k_bin_count + k_scan + k_bin_fill */
-       ZR_PASS_SHADOW,            /* k_raster_chunks<SHADOW> */
-       ZR_PASS_CULL_CAMERA,       /* k_cull_box + k_select (round 1: last frame's visible set)
+enum { ZR_PASS_CULL_SHADOW = 0,   /* k_cull_box<SHADOW> + k_bin_count + k_scan + k_bin_fill (the map's clear rides in the previous lighting pass) */
+       ZR_PASS_SHADOW,            /* k_raster_chunks<SHADOW> + k_tile_slow<SHADOW> (clipped triangles) */
+       ZR_PASS_CULL_CAMERA,       /* k_cull_box<GBUFFER> (also compacts round 1's list: last frame's visible set)
                                      [ZR_FLAG_MESHLET_BINS: k_cull<GBUFFER> + k_bin_count + k_scan + k_bin_fill] */
-       ZR_PASS_GBUFFER,           /* round 1 (the whole pass when the frame runs in one round): k_geom + k_scan_tri + k_index + k_tile + k_tile_slow
+       ZR_PASS_GBUFFER,           /* round 1 (the whole pass when the frame runs in one round): k_geom + k_scan_tri + k_index + k_tile
                                      [ZR_FLAG_MESHLET_BINS: k_raster_chunks<GBUFFER>] */
        ZR_PASS_HIZ,               /* k_hiz_build + round 2's k_select [.. k_bin_count + k_scan + k_bin_fill] (0 in a one-round frame) */
-       ZR_PASS_GBUFFER2,          /* round 2: k_geom<Hi-Z> + k_scan_tri + k_index + k_tile + k_tile_slow [.. k_raster_chunks<GBUFFER, Hi-Z>] */
+       ZR_PASS_GBUFFER2,          /* round 2: k_geom<Hi-Z> + k_scan_tri + k_index + k_tile + k_tile_slow (both rounds' clipped triangles) [.. k_raster_chunks<GBUFFER, Hi-Z>] */
        ZR_PASS_RESOLVE,           /* k_resolve_gbuffer: the GBuffer write */
        ZR_PASS_LIGHTING,          /* k_lighting */
        ZR_PASS_COMPOSITE, ZR_PASS_TOTAL, ZR_PASS_COUNT };
