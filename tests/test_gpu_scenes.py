@@ -409,3 +409,39 @@ def test_anisotropic_filtering_at_grazing_angles(oracle_lib, gpu_engine):
     bc = o.gbuffer(4)
     assert len(np.unique(bc)) > 50                             # filtered greys, not just the two stripe colours
     _identical(o, g, "anisotropic")
+
+
+def test_record_pool_and_slow_list_overflow_are_reported(oracle_lib, gpu_engine, monkeypatch):
+    """The triangle-binned camera pass keeps its records in a pool of chunks and its clipped triangles in a list; either running dry
+    must surface as ZR_ERR_OVERFLOW at zr_finish (never as a silently incomplete frame), and the same scene must render exactly once
+    the capacity is there again."""
+    import math
+    W, H, SD = 320, 200, 128
+
+    def scene(r):
+        r.set_cubemap(scenes.synthetic_cubemap(8))
+        r.object_add(r.mesh_create(*scenes.grid_plane(40.0, 6, 0.0)))              # crosses the near plane: clipped triangles
+        r.object_add(r.mesh_create(*scenes.uv_sphere()), None, scenes.generate_instances(400, 0.5, 6.0, 0.3, 0.8, seed=3))
+        _std_frame()(r)
+
+    o = oracle_lib.Oracle(W, H, SD)
+    scene(o)
+    o.render()
+    for var, val in (("ZR_TB_CHUNKS", "8"), ("ZR_TB_SLOW_CAP", "2")):
+        monkeypatch.setenv(var, val)
+        g = gpu_engine.Renderer(W, H, SD)
+        scene(g)
+        g.render()
+        with pytest.raises(gpu_engine.ZeldaRenderError) as e:
+            g.finish()
+        assert e.value.code == abi.ERR_OVERFLOW, (var, e.value)
+        g.close()
+        monkeypatch.delenv(var)
+    g = gpu_engine.Renderer(W, H, SD)
+    scene(g)
+    g.render(); g.render(); g.finish()
+    o.render()
+    d = compare_all(o, g)
+    assert not {k: v for k, v in d.items() if v}, d
+    assert g.stats()["overflow"] == 0
+    g.close()

@@ -676,6 +676,8 @@ static int finalize_scene(zr_ctx* c)
         // capacity as for the meshlet bins: 8 records per meshlet-instance of the scene, at least 32 Mi (1.5 GiB)
         c->tb.n_waves = 8192; c->tb.slow_cap = 1u << 18;
         c->tb.n_chunks = (uint32_t)(std::min<uint64_t>(std::max<uint64_t>(32ull << 20, 8ull * c->n_work), 0x3FFFFFFFull) / ZR_TPOOL_CHUNK);
+        if (const char* e = getenv("ZR_TB_CHUNKS")) c->tb.n_chunks = (uint32_t)std::max(1, atoi(e));      // (tests: a pool that runs dry)
+        if (const char* e = getenv("ZR_TB_SLOW_CAP")) c->tb.slow_cap = (uint32_t)std::max(2, atoi(e));
         HIPCHK(c, dev_alloc(&c->tb.sel, c->work_capacity));
         HIPCHK(c, dev_alloc(&c->tb.recs, 3ull * c->tb.n_chunks * ZR_TPOOL_CHUNK));
         HIPCHK(c, dev_alloc(&c->tb.idx, (size_t)c->tb.n_chunks * ZR_TPOOL_CHUNK));
