@@ -202,9 +202,12 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     {   // Hi-Z pyramid: level l = max depth per (8 << l)^2 pixel block
         size_t tot = 0;
         for (int l = 0; l < 4; ++l) { c->hiz.hw[l] = (c->W + (8u << l) - 1) / (8u << l); c->hiz.hh[l] = (c->H + (8u << l) - 1) / (8u << l); tot += (size_t)c->hiz.hw[l] * c->hiz.hh[l]; }
+        c->hiz.fw = (c->W + 3u) / 4u; c->hiz.fh = (c->H + 3u) / 4u;
+        tot += (size_t)c->hiz.fw * c->hiz.fh;
         ok &= dev_alloc(&c->d_hiz, tot) == hipSuccess;
         float* p = c->d_hiz;
         for (int l = 0; l < 4; ++l) { c->hiz.lvl[l] = p; p += (size_t)c->hiz.hw[l] * c->hiz.hh[l]; }
+        c->hiz.fine = p;
     }
     if (ok) {
         // The runtime backs an event with a signal on its FIRST record and grows that pool in batches, which blocks the host for

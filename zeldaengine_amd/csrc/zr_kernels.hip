@@ -598,12 +598,12 @@ __global__ __launch_bounds__(256) void k_hiz_build(const unsigned long long* __r
 {
     __shared__ float l0[8][8];
     const uint32_t rx = blockIdx.x, ry = blockIdx.y, tid = threadIdx.x;
-    // 256 threads: thread t handles pixel-block (t & 7, (t >> 3) & 7) quarter (t >> 6): 4 threads per 8x8 block, 16 pixels each
+    // 256 threads: thread t handles pixel-block (t & 7, (t >> 3) & 7) quarter (t >> 6): 4 threads per 8x8 block, a 4x4 sub-block each
     const uint32_t bx = tid & 7u, by = (tid >> 3) & 7u, q = tid >> 6;
     float m = 0.0f;
     bool any = false;
     for (uint32_t i = 0; i < 16u; ++i) {
-        const uint32_t px = rx * 64u + bx * 8u + (i & 7u), py = ry * 64u + by * 8u + q * 2u + (i >> 3);
+        const uint32_t px = rx * 64u + bx * 8u + (q & 1u) * 4u + (i & 3u), py = ry * 64u + by * 8u + (q >> 1) * 4u + (i >> 2);
         if (px < W && py < H) {
             // a tile of another rank never receives a fragment here: it must not keep the meshlets that straddle it alive
             const bool mine = Z.tile_world <= 1u || tile_owner(px / TILE, py / TILE, Z.tile_world) == Z.tile_rank;
@@ -612,6 +612,10 @@ __global__ __launch_bounds__(256) void k_hiz_build(const unsigned long long* __r
         }
     }
     if (!any) m = 0.0f;
+    {   // the finest level: this thread's 4 x 4 pixels
+        const uint32_t fx = rx * 16u + bx * 2u + (q & 1u), fy = ry * 16u + by * 2u + (q >> 1);
+        if (fx < Z.fw && fy < Z.fh) Z.fine[(size_t)fy * Z.fw + fx] = m;
+    }
     // combine the 4 quarters (lanes tid, tid+64, tid+128, tid+192) through LDS
     __shared__ float part[4][64];
     part[q][tid & 63u] = m;
@@ -650,13 +654,13 @@ __device__ __forceinline__ bool hiz_occluded(const ZrHiz& Z, uint2 pr, float zmi
     if (!(zmin >= 0.0f)) return false;
     const uint32_t x0 = pr.x & 0xFFFFu, y0 = pr.x >> 16, x1 = pr.y & 0xFFFFu, y1 = pr.y >> 16;
     const uint32_t ext = max(x1 - x0, y1 - y0);
-    uint32_t l = 0;
-    while (l < 3u && (ext >> (3u + l)) >= 3u) ++l;        // the box then spans at most 4 texels of level l per axis
-    const uint32_t sh = 3u + l;
+    uint32_t l = 0;                                        // 0: the 4 x 4 pixel level, 1..4: lvl[0..3]
+    while (l < 4u && (ext >> (2u + l)) >= 3u) ++l;        // the box then spans at most 4 texels of that level per axis
+    const uint32_t sh = 2u + l;
     const uint32_t tx0 = x0 >> sh, ty0 = y0 >> sh, tx1 = x1 >> sh, ty1 = y1 >> sh;
     if (tx1 - tx0 > 3u || ty1 - ty0 > 3u) return false;     // wider than 4x4 texels of the coarsest level: not tested
-    const float* __restrict__ L = Z.lvl[l];
-    const uint32_t hw = Z.hw[l];
+    const float* __restrict__ L = l == 0u ? Z.fine : Z.lvl[l - 1u];
+    const uint32_t hw = l == 0u ? Z.fw : Z.hw[l - 1u];
     // 16 independent loads (clamped repeats at the far edges) instead of a data-dependent loop: one memory latency, not sixteen
     float hmax = 0.0f;
 #pragma unroll
@@ -1699,7 +1703,16 @@ __global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrBinEntry* __rest
             const int px0 = max(0, (int)(short)(lo & 0xFFFF)), py0 = max(0, lo >> 16);
             const int px1 = min((int)P.W - 1, (int)(short)(hi & 0xFFFF)), py1 = min((int)P.H - 1, hi >> 16);
             bool gone = px0 > px1 || py0 > py1;                  // no pixel centre inside
-            if (!gone) gone = hiz_occluded(Z, make_uint2((uint32_t)px0 | (uint32_t)py0 << 16, (uint32_t)px1 | (uint32_t)py1 << 16), zr_u2f((uint32_t)wave_min(zb)));
+            if (!gone) {
+                const float zm = zr_u2f((uint32_t)wave_min(zb));
+                const uint32_t fx0 = (uint32_t)px0 >> 2, fy0 = (uint32_t)py0 >> 2, fx1 = (uint32_t)px1 >> 2, fy1 = (uint32_t)py1 >> 2;
+                if (fx1 - fx0 < 8u && fy1 - fy0 < 8u) {
+                    // a box of up to 32 x 32 pixels: its <= 8 x 8 blocks of the 4 x 4 level, a lane each - one load, one wave reduction
+                    const uint32_t x = fx0 + (lane & 7u), y = fy0 + (lane >> 3);
+                    const float v = (x <= fx1 && y <= fy1) ? Z.fine[(size_t)y * Z.fw + x] : 0.0f;
+                    gone = zm >= 0.0f && zm > wave_fmax(v);
+                } else gone = hiz_occluded(Z, make_uint2((uint32_t)px0 | (uint32_t)py0 << 16, (uint32_t)px1 | (uint32_t)py1 << 16), zm);
+            }
             if (gone) { ++culled; continue; }
         }
         lds_fence();
@@ -1728,12 +1741,18 @@ __global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrBinEntry* __rest
                     const int y0 = max((imin3(r0.y, r1.y, r2.y) - 128 + 255) >> 8, 0), y1 = min((imax3(r0.y, r1.y, r2.y) - 128) >> 8, (int)P.H - 1);
                     alive = A < 0 && x0 <= x1 && y0 <= y1;
                     if (HIZ && alive) {
-                        // max depth already in the key buffer over the 8 x 8 pixel blocks the box touches (blocks of other ranks' tiles
-                        // hold 0): a triangle whose least vertex depth lies behind it cannot win a pixel
+                        // max depth already in the key buffer over the pixel blocks the box touches (4 x 4 blocks for a box under 16 pixels,
+                        // else 8 x 8; blocks of other ranks' tiles hold 0): a triangle whose least vertex depth lies behind it cannot win a
+                        // pixel
                         const float tz = __builtin_fminf(__builtin_fminf(zr_u2f((uint32_t)r0.z), zr_u2f((uint32_t)r1.z)), zr_u2f((uint32_t)r2.z));
                         float h = 0.0f;
-                        for (int by = y0 >> 3; by <= (y1 >> 3); ++by)
-                            for (int bx = x0 >> 3; bx <= (x1 >> 3); ++bx) h = __builtin_fmaxf(h, Z.lvl[0][(size_t)by * Z.hw[0] + (size_t)bx]);
+                        if (max(x1 - x0, y1 - y0) < 16) {
+                            for (int by = y0 >> 2; by <= (y1 >> 2); ++by)
+                                for (int bx = x0 >> 2; bx <= (x1 >> 2); ++bx) h = __builtin_fmaxf(h, Z.fine[(size_t)by * Z.fw + (size_t)bx]);
+                        } else {
+                            for (int by = y0 >> 3; by <= (y1 >> 3); ++by)
+                                for (int bx = x0 >> 3; bx <= (x1 >> 3); ++bx) h = __builtin_fmaxf(h, Z.lvl[0][(size_t)by * Z.hw[0] + (size_t)bx]);
+                        }
                         if (tz > h) alive = false;
                     }
                     if (alive) { tx0 = x0 / TILE; tx1 = x1 / TILE; ty0 = y0 / TILE; ty1 = y1 / TILE; bx0 = x0; bx1 = x1; by0 = y0; by1 = y1; }

@@ -128,8 +128,9 @@ struct ZrDevStats {
 // Two-pass Hi-Z occlusion culling of the camera pass (config 5; conservative).
 // Hi-Z level l holds, per (8 << l) x (8 << l) pixel block, the MAX depth currently in the key buffer (1.0 where empty).
 struct ZrHiz {
-    float*    lvl[4];                // device arrays, level l is hw[l] x hh[l]
+    float*    lvl[4];                // device arrays, level l is hw[l] x hh[l]: max depth per (8 << l)^2 pixel block
     uint32_t  hw[4], hh[4];
+    float*    fine; uint32_t fw, fh; // one level below: max depth per 4 x 4 pixel block (small meshlets and single triangles are tested here)
     uint2*    pxrect;                // per work item: snapped pixel bbox (x0 | y0 << 16, x1 | y1 << 16)
     float*    zmin;                  // per work item: least NDC depth of the meshlet's vertices, < 0: do not occlusion-test
     const uint8_t* vis_prev;         // per meshlet-instance: owned a pixel of the previous frame
