@@ -116,7 +116,7 @@ struct zr_ctx {
     uint32_t* d_empty_b[2] = { nullptr, nullptr };
     bool overlay_dirty[2] = { false, false };       // Gb[i].overlay may hold skydome pixels of an earlier frame
     bool shadow_cleared[2] = { false, false };      // d_shadow_b[i] already holds depth 1.0 (cleared by the previous lighting pass)
-    unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048, shadow_blocks = 2048; bool env_shadow_box = true, env_shadow_static = false, env_shadow_defer = true;
+    unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048, shadow_blocks = 2048; bool env_shadow_box = true, env_shadow_defer = true;
     uint4* d_slow0 = nullptr; uint32_t slow0_cap = 1u << 18;      // shadow pass: triangles for the clipper (k_tile_slow)
     uint32_t work_capacity = 0, bin_capacity = 0; bool any_images = false;
     // two-pass Hi-Z occlusion culling of the camera pass: per work item pixel bbox + least depth (written by the cull),

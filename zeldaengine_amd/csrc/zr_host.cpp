@@ -195,7 +195,6 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->raster_blocks = (uint32_t)prop.multiProcessorCount * 8u; }
     c->shadow_blocks = c->raster_blocks;
     if (const char* e = getenv("ZR_SHADOW_BOX_CULL")) c->env_shadow_box = atoi(e) != 0;
-    if (const char* e = getenv("ZR_SHADOW_STATIC")) c->env_shadow_static = atoi(e) != 0;
     if (const char* e = getenv("ZR_SHADOW_DEFER")) c->env_shadow_defer = atoi(e) != 0;
     if (ok) ok &= dev_alloc(&c->d_slow0, 4ull * c->slow0_cap) == hipSuccess;
     if (const char* e = getenv("ZR_SHADOW_BLOCKS")) c->shadow_blocks = (uint32_t)std::max(1, atoi(e));
@@ -1077,7 +1076,6 @@ static int shadow_pass(zr_ctx* c, hipStream_t s)
     if (c->d_shadow_ext || !c->shadow_cleared[spar]) zr_launch_fill32((uint32_t*)shadow_buf(c), 0x3F800000u, (size_t)c->SD * c->SD, s);
     c->shadow_cleared[spar] = false;
     ZrHiz Z; memset(&Z, 0, sizeof Z);
-    P.static_units = c->env_shadow_static ? 1u : 0u;
     if (c->env_shadow_box) zr_launch_cull_box(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, s);
     else zr_launch_cull(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, c->raster_blocks * 4u, s);
     bin_and_raster(c, P, Z, 0, c->sn_tiles, s);

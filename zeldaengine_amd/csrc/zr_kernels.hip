@@ -653,9 +653,9 @@ __device__ __forceinline__ bool hiz_occluded(const ZrHiz& Z, uint2 pr, float zmi
 {
     if (!(zmin >= 0.0f)) return false;
     const uint32_t x0 = pr.x & 0xFFFFu, y0 = pr.x >> 16, x1 = pr.y & 0xFFFFu, y1 = pr.y >> 16;
-    const uint32_t ext = max(x1 - x0, y1 - y0);
     uint32_t l = 0;                                        // 0: the 4 x 4 pixel level, 1..4: lvl[0..3]
-    while (l < 4u && (ext >> (2u + l)) >= 3u) ++l;        // the box then spans at most 4 texels of that level per axis
+    // the finest level at which the box spans at most 4 texels per axis
+    while (l < 4u && (((x1 >> (2u + l)) - (x0 >> (2u + l))) > 3u || ((y1 >> (2u + l)) - (y0 >> (2u + l))) > 3u)) ++l;
     const uint32_t sh = 2u + l;
     const uint32_t tx0 = x0 >> sh, ty0 = y0 >> sh, tx1 = x1 >> sh, ty1 = y1 >> sh;
     if (tx1 - tx0 > 3u || ty1 - ty0 > 3u) return false;     // wider than 4x4 texels of the coarsest level: not tested
@@ -1571,11 +1571,6 @@ void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* _
                 const uint32_t k = keys32[i];
                 if (k < shadow_bits[p]) atomicMin(&shadow_bits[p], k);
             }
-        }
-        if (P.static_units) {      // one unit per workgroup (the grid covers the units): the dispatcher balances, and a retiring workgroup
-            __syncthreads();       // frees its registers for whatever the other lane has waiting
-            chunk += gridDim.x;
-            continue;
         }
         // (the next unit is claimed only when this one is done: claiming early costs more in tail balance than the atomic's latency)
         if (tid == 0) cur_chunk = gridDim.x + atomicAdd(&stats->chunk_counter[slot], 1u);

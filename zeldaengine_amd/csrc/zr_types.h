@@ -103,7 +103,6 @@ struct ZrPass {
     uint32_t debug_skip;             // diagnostics only (env ZR_DEBUG_SKIP): 1 skip pixel walk, 2 skip triangle phase too
     uint32_t sphere_ok;              // VM / p00 / p11 / pz_* hold a centred perspective with rigid model and view: sphere_bounds() applies
     float    pz_a, pz_b;             //   ndc depth of a point d in front of the eye = pz_a + pz_b / d
-    uint32_t static_units;           // rasteriser: workgroup b takes units b, b + grid, ... (no work counter)
     uint32_t m_identity;             // M is bit for bit the identity: M * vec4(p, 1) == p + 0.0f for finite p
     uint32_t write_overlay;          // the resolve must write the overlay plane (a skydome is drawn, or stale sky pixels must go)
 };
@@ -189,7 +188,11 @@ struct ZrTriBins {
     uint4*    slow; uint32_t slow_cap;      // 4 x uint4 per slow triangle: three clip-space vertices, (prim, 0, 0, 0)
 };
 #define ZR_TPOOL_CHUNK 1024u         // records per chunk of the record pool
+#ifdef ZR_TCHUNK_AB
+#define ZR_TCHUNK ZR_TCHUNK_AB
+#else
 #define ZR_TCHUNK 512u               // triangle records per work unit of the tile kernel
+#endif
 #define ZR_TCLASSES 4u               // walk-size classes a tile's records are sorted into (<= 4, <= 16, <= 64, more pixels of bounding box)
 void zr_launch_scan_tri(uint32_t* bin_count, uint32_t* bin_offset, uint32_t* bin_cursor, uint4* chunk_tab, uint32_t chunk_cap, uint32_t n_tiles,
                         const ZrTriBins& B, ZrDevStats* stats, int slot, hipStream_t s);
