@@ -145,7 +145,7 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     if (ok && !owned.empty()) ok &= hipMemcpy(c->d_owned, owned.data(), owned.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     if (ok) ok &= hipMemcpy(c->d_sowned, sowned.data(), sowned.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
     if (ok) ok &= hipMemset(c->d_tiles, 0, (size_t)c->slots_per_rank * ZR_TILE * ZR_TILE * 4) == hipSuccess;
-    const uint32_t mt = (c->n_tiles > c->sn_tiles ? c->n_tiles : c->sn_tiles) * ZR_TCLASSES + 4;    // (the triangle-binned pass bins by tile x class)
+    const uint32_t mt = (c->n_tiles > c->sn_tiles ? c->n_tiles : c->sn_tiles) * ZR_TSTRIDE + 1;     // (the triangle-binned pass spreads its counters)
     for (auto& sc : c->sc) {
         ok &= dev_alloc(&sc.tile_count, mt) == hipSuccess;
         ok &= dev_alloc(&sc.tile_offset, mt) == hipSuccess;

@@ -773,12 +773,13 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
     }
 }
 
-// The triangle-binned pass bins its records by (tile, walk-size class): bin_count[tile * ZR_TCLASSES + class].  A tile's records are
-// laid out class after class, so the 64 consecutive records a wave of k_tile takes are of one size - the walk of a wave lasts as long
-// as its largest triangle's.  Work units are <= chunk records of ONE tile (they may span its classes).  Also: zeroes the counts /
-// cursors, resets the work counter and the record pool, and books the meshlets k_geom's waves dropped behind the pyramid.
-__global__ __launch_bounds__(1024) void k_scan_tri(uint32_t* __restrict__ bin_count, uint32_t* __restrict__ bin_offset,
-                                                   uint32_t* __restrict__ bin_cursor, uint4* __restrict__ chunk_tab, uint32_t chunk_cap,
+// The triangle-binned pass: exclusive scan of the per-tile record counts into tile_offset, work units of <= chunk records of ONE
+// tile (the counters and cursors of the tiles sit ZR_TSTRIDE words apart: atomics on one cache line queue up behind each other, and
+// neighbouring tiles are hit together); also zeroes the counts / cursors, resets the work counter and the record pool, and books the meshlets k_geom's waves dropped
+// behind the pyramid.  (Sorting a tile's records by walk size - four classes by box area, or by longest side with every class padded
+// to whole waves - was tried: k_tile executed the same instructions, k_geom and k_index paid for four times the bins.)
+__global__ __launch_bounds__(1024) void k_scan_tri(uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
+                                                   uint32_t* __restrict__ tile_cursor, uint4* __restrict__ chunk_tab, uint32_t chunk_cap,
                                                    uint32_t n_tiles, const uint32_t* __restrict__ wave_culled, uint32_t n_waves,
                                                    ZrDevStats* __restrict__ stats, int slot, uint32_t chunk)
 {
@@ -786,11 +787,10 @@ __global__ __launch_bounds__(1024) void k_scan_tri(uint32_t* __restrict__ bin_co
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t per = (n_tiles + 1023u) / 1024u;
     const uint32_t b = min(n_tiles, tid * per), e = min(n_tiles, b + per);
-    uint4* __restrict__ cnt4 = (uint4*)bin_count;
     uint32_t nc = 0;
     for (uint32_t i = tid; i < n_waves; i += 1024u) nc += wave_culled[i];
     uint32_t s = 0, cs = 0;
-    for (uint32_t i = b; i < e; ++i) { const uint4 c = cnt4[i]; const uint32_t t = c.x + c.y + c.z + c.w; s += t; cs += (t + chunk - 1u) / chunk; }
+    for (uint32_t i = b; i < e; ++i) { const uint32_t t = tile_count[i * ZR_TSTRIDE]; s += t; cs += (t + chunk - 1u) / chunk; }
     // scan: inside the wave by shuffles, across the 16 waves through LDS - one barrier instead of twenty (this kernel is one
     // workgroup on the camera pipeline's critical path)
     uint32_t incl = s, cincl = cs;
@@ -810,13 +810,12 @@ __global__ __launch_bounds__(1024) void k_scan_tri(uint32_t* __restrict__ bin_co
     }
     uint32_t run = wpre + incl - s, crun = cwpre + cincl - cs;
     for (uint32_t i = b; i < e; ++i) {
-        const uint4 c = cnt4[i];
-        const uint32_t t = c.x + c.y + c.z + c.w, nu = (t + chunk - 1u) / chunk;
-        ((uint4*)bin_offset)[i] = make_uint4(run, run + c.x, run + c.x + c.y, run + c.x + c.y + c.z);
+        const uint32_t t = tile_count[i * ZR_TSTRIDE], nu = (t + chunk - 1u) / chunk;
+        tile_offset[i] = run;
         for (uint32_t k = 0; k < nu; ++k)
             if (crun + k < chunk_cap) chunk_tab[crun + k] = make_uint4(i, run + k * chunk, run + min(t, (k + 1u) * chunk), 0u);
         run += t; crun += nu;
-        cnt4[i] = make_uint4(0u, 0u, 0u, 0u); ((uint4*)bin_cursor)[i] = make_uint4(0u, 0u, 0u, 0u);
+        tile_count[i * ZR_TSTRIDE] = 0; tile_cursor[i * ZR_TSTRIDE] = 0;
     }
     if (tid == 0) {
         stats->bin_entries[slot] = tot;               // triangle records of the round
@@ -1720,7 +1719,7 @@ __global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrBinEntry* __rest
             int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0;
             const uint32_t prim = pbase + tri_w[round].y;
             bool alive = false, is_slow = false;
-            int tx0 = 0, ty0 = 0, tx1 = -1, ty1 = -1, bx0 = 0, by0 = 0, bx1 = 0, by1 = 0;
+            int tx0 = 0, ty0 = 0, tx1 = -1, ty1 = -1;
             uint32_t i0 = 0, i1 = 0, i2 = 0;
             if (t < tcount) {
                 i0 = tri_w[round].x & 255u; i1 = (tri_w[round].x >> 8) & 255u; i2 = (tri_w[round].x >> 16) & 255u;
@@ -1750,7 +1749,7 @@ __global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrBinEntry* __rest
                         }
                         if (tz > h) alive = false;
                     }
-                    if (alive) { tx0 = x0 / TILE; tx1 = x1 / TILE; ty0 = y0 / TILE; ty1 = y1 / TILE; bx0 = x0; bx1 = x1; by0 = y0; by1 = y1; }
+                    if (alive) { tx0 = x0 / TILE; tx1 = x1 / TILE; ty0 = y0 / TILE; ty1 = y1 / TILE; }
                 }
             }
             // ---- slow triangles: the three clip-space vertices go to the list every owned tile tries
@@ -1776,16 +1775,12 @@ __global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrBinEntry* __rest
             const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1, ntile = alive ? nx * ny : 0;
             for (int step = 0; __ballot(step < ntile) != 0ull; ++step) {
                 bool emit = step < ntile;
-                uint32_t tile = 0;            // the record's bin: tile * ZR_TCLASSES + walk-size class
+                uint32_t tile = 0;            // the record's tile
                 if (emit) {
                     const int sy = step / nx, sx = step - sy * nx;
                     const uint32_t tx = (uint32_t)(tx0 + sx), ty = (uint32_t)(ty0 + sy);
                     if (P.tile_world > 1u && tile_owner(tx, ty, P.tile_world) != P.tile_rank) emit = false;
-                    // pixels the walk of this triangle visits in this tile (its box clamped to the tile)
-                    const int wx = min(bx1, (int)tx * TILE + TILE - 1) - max(bx0, (int)tx * TILE) + 1;
-                    const int wy = min(by1, (int)ty * TILE + TILE - 1) - max(by0, (int)ty * TILE) + 1;
-                    const int wa = wx * wy;
-                    tile = (ty * P.tiles_x + tx) * ZR_TCLASSES + (wa <= 4 ? 0u : wa <= 16 ? 1u : wa <= 64 ? 2u : 3u);
+                    tile = ty * P.tiles_x + tx;
                 }
                 unsigned long long me = __ballot(emit);
                 if (!me) continue;
@@ -1810,7 +1805,7 @@ __global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrBinEntry* __rest
                     if ((int)lane == leader) cnt = (uint32_t)__popcll(same);
                     pend &= ~same;
                 }
-                if (cnt) atomicAdd(&tile_count[tile], cnt);
+                if (cnt) atomicAdd(&tile_count[tile * ZR_TSTRIDE], cnt);
                 if (emit) {
                     const uint32_t pos = cur * ZR_TPOOL_CHUNK + fill + (uint32_t)__popcll(me & lt);
                     recs[(size_t)3u * pos] = make_uint4((uint32_t)r0.x, (uint32_t)r0.y, (uint32_t)r0.z, prim);
@@ -1828,7 +1823,7 @@ __global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrBinEntry* __rest
 }
 
 // Every record -> a place in its tile's stretch of the gather list: a cursor per tile, advanced once per (wave, distinct tile) - the
-// records of a region come meshlet by meshlet, so the 64 of a wave name a handful of tiles - because atomics on one address run at
+// records of a chunk come meshlet by meshlet, so the 64 of a wave name a handful of tiles - because atomics on one address run at
 // about 10 ns apiece on this part and there are half a million records.  The lanes first sort themselves into tile groups (scalar
 // work, no memory), then every group's first lane issues its add in ONE instruction: one round trip per 64 records, not one per
 // group.  One wave per record chunk.
@@ -1858,7 +1853,7 @@ __global__ __launch_bounds__(256) void k_index(const uint4* __restrict__ recs, c
             pend &= ~same;
         }
         uint32_t b = 0;
-        if (have && first == (int)lane) b = atomicAdd(&tile_cursor[tile], cnt);
+        if (have && first == (int)lane) b = atomicAdd(&tile_cursor[tile * ZR_TSTRIDE], cnt);
         b = (uint32_t)__shfl((int)b, first);
         if (have) idx[off + b + rank] = i;
     }

@@ -178,22 +178,24 @@ void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_
 // triangle-binned camera pass (k_select -> k_geom -> k_scan_tri -> k_index -> k_tile)
 struct ZrTriBins {
     ZrBinEntry* sel;                 // meshlet-instances of this round, as self-contained 32-byte records
-    uint4*    recs;                  // 3 x uint4 per record: (X0, Y0, z0, prim) (X1, Y1, z1, bin) (X2, Y2, z2, 0), bin = tile * ZR_TCLASSES + walk-size
-                                     //   class.  Records live in chunks of ZR_TPOOL_CHUNK: chunk k < n_waves is where wave k of k_geom starts,
+    uint4*    recs;                  // 3 x uint4 per record: (X0, Y0, z0, prim) (X1, Y1, z1, tile) (X2, Y2, z2, 0)
+                                     //   Records live in chunks of ZR_TPOOL_CHUNK: chunk k < n_waves is where wave k of k_geom starts,
     uint32_t  n_chunks;              //   the rest [n_waves, n_chunks) is the pool the waves take further chunks from
     uint32_t* chunk_fill;            // records in each chunk
     uint32_t  n_waves;               // waves of the k_geom grid
     uint32_t* wave_culled;           // per wave: meshlets it dropped behind the Hi-Z pyramid (round 2)
-    uint32_t* idx;                   // record indices grouped by (tile, class)
+    uint32_t* idx;                   // record indices grouped by tile
     uint4*    slow; uint32_t slow_cap;      // 4 x uint4 per slow triangle: three clip-space vertices, (prim, 0, 0, 0)
 };
 #define ZR_TPOOL_CHUNK 1024u         // records per chunk of the record pool
+#ifndef ZR_TSTRIDE
+#define ZR_TSTRIDE 4u                 // words between the per-tile record counters (and cursors) of neighbouring tiles
+#endif
 #ifdef ZR_TCHUNK_AB
 #define ZR_TCHUNK ZR_TCHUNK_AB
 #else
 #define ZR_TCHUNK 512u               // triangle records per work unit of the tile kernel
 #endif
-#define ZR_TCLASSES 4u               // walk-size classes a tile's records are sorted into (<= 4, <= 16, <= 64, more pixels of bounding box)
 void zr_launch_scan_tri(uint32_t* bin_count, uint32_t* bin_offset, uint32_t* bin_cursor, uint4* chunk_tab, uint32_t chunk_cap, uint32_t n_tiles,
                         const ZrTriBins& B, ZrDevStats* stats, int slot, hipStream_t s);
 void zr_launch_select(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats,
