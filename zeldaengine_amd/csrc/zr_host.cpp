@@ -52,6 +52,14 @@ static uint8_t srgb_encode8(float l)
 
 template <typename T> static hipError_t dev_alloc(T** p, size_t n) { return hipMalloc((void**)p, (n ? n : 1) * sizeof(T)); }
 template <typename T> static void dev_free(T*& p) { if (p) { (void)hipFree((void*)p); p = nullptr; } }
+// Images that kernels gather from at random (material textures, skydome, background): allocated in whole 2 MiB units, so that the
+// driver maps them with large page fragments whatever the allocator's pools look like at the time - a 1.4 MiB texture that lands
+// in 4 KiB-mapped memory costs the sampled resolve a third of its speed (seen as two modes of `value_textured`, run to run).
+static hipError_t dev_alloc_image(uint8_t** p, size_t bytes)
+{
+    const size_t unit = (size_t)2 << 20;
+    return hipMalloc((void**)p, (bytes + unit - 1) / unit * unit);
+}
 
 // ------------------------------------------------------------------------------------------------ lifetime
 
@@ -183,9 +191,11 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         ok &= hipStreamCreateWithPriority(&c->cam_s, hipStreamNonBlocking, greatest) == hipSuccess;
-        ok &= hipStreamCreateWithPriority(&c->shadow_s, hipStreamNonBlocking, least) == hipSuccess;
-        ok &= hipStreamCreateWithPriority(&c->light_s, hipStreamNonBlocking, least) == hipSuccess;
         if (const char* e = getenv("ZR_LANES")) c->three_lanes = atoi(e) >= 3;
+        if (c->three_lanes) {      // (only then: every stream takes one of the process's few hardware queues)
+            ok &= hipStreamCreateWithPriority(&c->shadow_s, hipStreamNonBlocking, least) == hipSuccess;
+            ok &= hipStreamCreateWithPriority(&c->light_s, hipStreamNonBlocking, least) == hipSuccess;
+        }
     }
     ok &= hipEventCreateWithFlags(&c->ev_cam, hipEventDisableTiming) == hipSuccess;
     ok &= hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -508,7 +518,7 @@ int zr_object_add_internal(zr_ctx* c, uint32_t mesh_id, const ZrMaterialHost& ma
         if (mat.image[t].empty()) continue;
         std::vector<uint8_t> chain; uint32_t levels = 1;
         build_mip_chain(c, mat.image[t], mat.w[t], mat.h[t], t == 0, &chain, &levels);
-        hipError_t e = dev_alloc(&o.d_tex[t], chain.size());
+        hipError_t e = dev_alloc_image(&o.d_tex[t], chain.size());
         if (e == hipSuccess) e = hipMemcpy(o.d_tex[t], chain.data(), chain.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) { cleanup(); return zr_fail(c, ZR_ERR_DEVICE, hipGetErrorString(e)); }
         o.tex_w[t] = mat.w[t]; o.tex_h[t] = mat.h[t]; o.tex_levels[t] = levels;
@@ -705,7 +715,7 @@ static int upload_texture(zr_ctx* c, const zr_image* tex, bool srgb, uint8_t** d
     if (tex->width == 0 || tex->height == 0 || tex->width > 16384 || tex->height > 16384) return zr_fail(c, ZR_ERR_ARG, "bad image size");
     std::vector<uint8_t> img(tex->rgba8, tex->rgba8 + (size_t)tex->width * tex->height * 4), chain;
     build_mip_chain(c, img, tex->width, tex->height, srgb, &chain, levels);
-    HIPCHK(c, dev_alloc(d, chain.size()));
+    HIPCHK(c, dev_alloc_image(d, chain.size()));
     HIPCHK(c, hipMemcpy(*d, chain.data(), chain.size(), hipMemcpyHostToDevice));
     *w = tex->width; *h = tex->height;
     return ZR_OK;
