@@ -1416,8 +1416,10 @@ void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* _
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = wave_uniform(tid >> 6);
     const uint32_t n_chunks = stats->n_chunks[slot];
 
-    // the first chunk of a workgroup is its own index (no atomic: an empty pass costs nothing), later ones come from the counter
+    // the first two chunks of a workgroup are its own index and that + the grid (no atomic: an empty pass costs nothing), later ones
+    // come from the counter
     uint32_t chunk = blockIdx.x;
+    bool first = true;
     for (;;) {
         if (chunk >= n_chunks) break;
         for (uint32_t i = tid; i < TILE_PIX; i += RTHREADS) {
@@ -1572,7 +1574,9 @@ void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* _
             }
         }
         // (the next unit is claimed only when this one is done: claiming early costs more in tail balance than the atomic's latency)
-        if (tid == 0) cur_chunk = gridDim.x + atomicAdd(&stats->chunk_counter[slot], 1u);
+        // ... and the second unit of a workgroup is fixed like the first (b + grid): claims on one counter queue up for ~10 ns apiece
+        if (first) { first = false; __syncthreads(); chunk += gridDim.x; continue; }
+        if (tid == 0) cur_chunk = 2u * gridDim.x + atomicAdd(&stats->chunk_counter[slot], 1u);
         __syncthreads();   // keys are re-cleared at the top of the loop
         chunk = cur_chunk;
     }
@@ -1872,6 +1876,7 @@ __global__ __launch_bounds__(256) void k_tile(ZrPass P, const uint4* __restrict_
     const uint32_t tid = threadIdx.x;
     const uint32_t n_units = stats->n_chunks[slot];
     uint32_t unit = blockIdx.x;
+    bool first = true;
     for (;;) {
         if (unit >= n_units) break;
         for (uint32_t i = tid; i < TILE_PIX; i += 256u) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
@@ -1899,7 +1904,10 @@ __global__ __launch_bounds__(256) void k_tile(ZrPass P, const uint4* __restrict_
             const unsigned long long k = keys64[i];
             if ((uint32_t)k != ZR_EMPTY_PRIM && k < vis64[p]) atomicMin(&vis64[p], k);
         }
-        if (tid == 0) cur_unit = gridDim.x + atomicAdd(&stats->chunk_counter[slot], 1u);
+        // the second unit of a workgroup is fixed too (b + grid): when the grid's first units end together, 2 048 claims on one
+        // counter would queue up for ~10 ns apiece; only later units (hot frames) come from the counter
+        if (first) { first = false; __syncthreads(); unit += gridDim.x; continue; }
+        if (tid == 0) cur_unit = 2u * gridDim.x + atomicAdd(&stats->chunk_counter[slot], 1u);
         __syncthreads();
         unit = cur_unit;
     }
