@@ -576,7 +576,6 @@ __global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __re
                 const uint32_t tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
                 const uint32_t base = tot ? atomicAdd(&stats->n_sel[1], tot) : 0u;
                 wbase[0] = base; wbase[1] = base + wcount[0]; wbase[2] = wbase[1] + wcount[1]; wbase[3] = wbase[2] + wcount[2];
-                if (tot) atomicAdd(&stats->survivors[1], tot);
             }
             __syncthreads();
             if (take) {
@@ -823,8 +822,8 @@ __global__ __launch_bounds__(1024) void k_scan_tri(uint32_t* __restrict__ tile_c
         stats->chunk_counter[slot] = 0;
         stats->pool_used[slot] = stats->pool_next[slot]; stats->pool_next[slot] = 0;
         if (ctot > chunk_cap) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
-        // meshlets of this round that k_geom dropped behind the pyramid
-        stats->hiz_culled += culled; stats->survivors[slot] -= culled;
+        // the round's survivors: what was selected minus the meshlets k_geom dropped behind the pyramid
+        stats->hiz_culled += culled; stats->survivors[slot] = stats->n_sel[slot] - culled;
     }
 }
 
@@ -1624,7 +1623,6 @@ __global__ __launch_bounds__(1024) void k_select(ZrPass P, const ZrObject* __res
         for (int i = 0; i < 16; ++i) { wbase[i] = tot; tot += wcount[i]; }
         const uint32_t base = tot ? atomicAdd(&stats->n_sel[slot], tot) : 0u;
         for (int i = 0; i < 16; ++i) wbase[i] += base;
-        if (tot) atomicAdd(&stats->survivors[slot], tot);
     }
     __syncthreads();
     if (take) {
