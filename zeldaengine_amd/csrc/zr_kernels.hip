@@ -1592,32 +1592,41 @@ void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* _
 
 // Which meshlet-instances does this round draw?  (The split of the two-pass occlusion culling, as k_bin_count makes it.)
 // Compacted per workgroup: one global atomic per 1024 work items (atomics on one address run at ~10 ns apiece on this part).
-__global__ __launch_bounds__(1024) void k_select(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
-                                                 const uint32_t* __restrict__ rects, ZrHiz Z, ZrBinEntry* __restrict__ sel,
-                                                 ZrDevStats* __restrict__ stats, int slot)
+#define ZR_SELECT_THREADS 256
+__global__ __launch_bounds__(256) void k_select(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
+                                                const uint32_t* __restrict__ rects, ZrHiz Z, ZrBinEntry* __restrict__ sel,
+                                                ZrDevStats* __restrict__ stats, int slot)
 {
+    // 1024 work items per workgroup of 256 threads: beside the other lane's kernels a small workgroup finds room where 1024 threads
+    // wait for a whole CU (this kernel sits on the camera pipeline's critical path), and the compaction still costs one atomic per 1024
     __shared__ uint32_t wcount[16], wbase[16], nocc;
     const uint32_t n_vis = P.use_worklist ? stats->n_vis_work[1] : P.n_work;
     if (blockIdx.x * 1024u >= n_vis) return;
-    const uint32_t k = blockIdx.x * 1024u + threadIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     if (threadIdx.x == 0) nocc = 0;
-    bool take = false, occluded = false;
-    uint32_t w = 0;
-    if (k < n_vis) {
-        w = P.use_worklist ? work[k] : k;
-        take = rects[k] != ZR_RECT_CULLED;
-        if (take && Z.phase) {
-            const bool was_visible = Z.vis_prev[w] != 0;
-            if (Z.phase == 1u) take = was_visible;
-            else if (was_visible) take = false;
-            else if (hiz_occluded(Z, Z.pxrect[k], Z.zmin[k])) { take = false; occluded = true; }
+    bool take[4]; uint32_t w[4]; unsigned long long m[4];
+    uint32_t n_occ = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t k = blockIdx.x * 1024u + (uint32_t)j * 256u + threadIdx.x;
+        take[j] = false; w[j] = 0;
+        bool occluded = false;
+        if (k < n_vis) {
+            w[j] = P.use_worklist ? work[k] : k;
+            take[j] = rects[k] != ZR_RECT_CULLED;
+            if (take[j] && Z.phase) {
+                const bool was_visible = Z.vis_prev[w[j]] != 0;
+                if (Z.phase == 1u) take[j] = was_visible;
+                else if (was_visible) take[j] = false;
+                else if (hiz_occluded(Z, Z.pxrect[k], Z.zmin[k])) { take[j] = false; occluded = true; }
+            }
         }
+        m[j] = __ballot(take[j]);
+        if (lane == 0) wcount[j * 4 + (int)wv] = (uint32_t)__popcll(m[j]);
+        n_occ += (uint32_t)__popcll(__ballot(occluded));
     }
-    const unsigned long long m = __ballot(take);
-    if (lane == 0) wcount[wv] = (uint32_t)__popcll(m);
     __syncthreads();
-    const unsigned long long mo = __ballot(occluded);
-    if (lane == 0 && mo) atomicAdd(&nocc, (uint32_t)__popcll(mo));
+    if (lane == 0 && n_occ) atomicAdd(&nocc, n_occ);
     if (threadIdx.x == 0) {
         uint32_t tot = 0;
         for (int i = 0; i < 16; ++i) { wbase[i] = tot; tot += wcount[i]; }
@@ -1625,17 +1634,19 @@ __global__ __launch_bounds__(1024) void k_select(ZrPass P, const ZrObject* __res
         for (int i = 0; i < 16; ++i) wbase[i] += base;
     }
     __syncthreads();
-    if (take) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (!take[j]) continue;
         // the work id is decoded here, lane-parallel: k_geom's wave starts every load of the meshlet from this one record
-        const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w);
-        const uint32_t local = w - O->work_base;
+        const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w[j]);
+        const uint32_t local = w[j] - O->work_base;
         const uint32_t inst_i = local / O->n_meshlets, mi = local - inst_i * O->n_meshlets;
         const XkMeshlet* __restrict__ ml = O->meshlets + mi;
         ZrBinEntry be;
         be.mpos = O->mpos + ml->VertexOffset; be.mtri = O->mtri + ml->BindlessContext; be.inst = O->inst + inst_i;
         be.counts = ml->VertexCount | ml->TriangleCount << 8 | (O->instanced ? 1u << 16 : 0u);
         be.prim_base = O->prim_base + inst_i * O->n_tris;
-        sel[wbase[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = be;
+        sel[wbase[j * 4 + (int)wv] + (uint32_t)__popcll(m[j] & ((1ull << lane) - 1ull))] = be;
     }
     if (threadIdx.x == 0 && nocc) atomicAdd(&stats->hiz_culled, nocc);
 }
@@ -2613,7 +2624,7 @@ void zr_launch_select(const ZrPass& P, const ZrObject* objs, const uint32_t* wor
                       int slot, hipStream_t s)
 {
     if (P.n_work == 0) return;
-    hipLaunchKernelGGL(k_select, dim3((P.n_work + 1023) / 1024), dim3(1024), 0, s, P, objs, work, rects, Z, B.sel, stats, slot);
+    hipLaunchKernelGGL(k_select, dim3((P.n_work + 1023) / 1024), dim3(ZR_SELECT_THREADS), 0, s, P, objs, work, rects, Z, B.sel, stats, slot);
 }
 void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, uint32_t* tile_count, ZrDevStats* stats, int slot, hipStream_t s)
 {
