@@ -942,7 +942,7 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
     // the instance-level pre-pass pays for itself on big scenes; small ones go straight to one wave per meshlet-instance
     P->use_worklist = c->n_inst_total >= 65536u ? 1u : 0u;
     P->debug_skip = c->env_skip;
-    if (mode == ZR_MODE_GBUFFER && ZR_TILE == 32) {
+    if (ZR_TILE == 32) {      // (both passes: the shadow pass uses it for the instance-level "no texel centre" reject)
         // sphere_bounds() needs clip.x = p00 * x_view, clip.y = p11 * y_view, clip.z = p10 * z_view + p14, clip.w = -z_view and
         // view-space radii = object radii
         const float* pr = u.Proj;
@@ -953,7 +953,7 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
         P->p00 = pr[0]; P->p11 = pr[5];
         P->pz_a = -pr[10]; P->pz_b = pr[14];       // z_view = -d: (p10 * -d + p14) / d
         P->sphere_ok = (centred && rigid3(u.Model) && rigid3(u.View) && finite16(P->VM)) ? 1u : 0u;
-        P->rect_cull = (P->sphere_ok && c->cfg.tile_world > 1 && !(c->cfg.flags & ZR_FLAG_NO_RECT_CULL)) ? 1u : 0u;
+        P->rect_cull = (mode == ZR_MODE_GBUFFER && P->sphere_ok && c->cfg.tile_world > 1 && !(c->cfg.flags & ZR_FLAG_NO_RECT_CULL)) ? 1u : 0u;
     }
     {
         static const float ident[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };

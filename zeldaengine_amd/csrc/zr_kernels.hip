@@ -200,8 +200,8 @@ __device__ __forceinline__ int find_object_inst(const ZrObject* __restrict__ obj
 // through the eye tangent to the circle have slopes (x d +- r sqrt(x^2 + d^2 - r^2)) / (d^2 - r^2): every point of the sphere
 // projects between them; ndc = Proj[0][0] * slope (Proj[1][1] for y).  Conservative: the radius is rounded up, a slack covers the
 // arithmetic here and in the rasteriser's own transform, the pixel range gets a margin of one.  "true" whenever in doubt.
-__device__ __forceinline__ bool sphere_bounds(const ZrPass& P, zf3 co, float ri, int& px0, int& py0, int& px1, int& py1, float& d_near)
-{   // false: no bound (the eye is inside, or the numbers are out of range).  An empty box (px0 > px1 or py0 > py1) = off the target.
+__device__ __forceinline__ bool sphere_screen(const ZrPass& P, zf3 co, float ri, float& sx0, float& sy0, float& sx1, float& sy1, float& d_near)
+{   // false: no bound (the eye is inside, or the numbers are out of range).  Screen-space extent (pixels, y down) of the sphere.
     const zf4 cv = zr_mat4_point(P.VM, co);
     const float d = -cv.z;
     const float r = __builtin_fmaf(ri, 1.003f, 1e-6f * (__builtin_fabsf(cv.x) + __builtin_fabsf(cv.y) + __builtin_fabsf(d)) + 1e-30f);
@@ -215,13 +215,29 @@ __device__ __forceinline__ bool sphere_bounds(const ZrPass& P, zf3 co, float ri,
     const float sl = 1e-5f;
     nx0 -= sl * (1.0f + __builtin_fabsf(nx0)); nx1 += sl * (1.0f + __builtin_fabsf(nx1));
     ny0 -= sl * (1.0f + __builtin_fabsf(ny0)); ny1 += sl * (1.0f + __builtin_fabsf(ny1));
-    const float sx0 = __builtin_fmaf(nx0, P.hw, P.hw), sx1 = __builtin_fmaf(nx1, P.hw, P.hw);
-    const float sy0 = __builtin_fmaf(ny0, P.hh, P.hh), sy1 = __builtin_fmaf(ny1, P.hh, P.hh);
+    sx0 = __builtin_fmaf(nx0, P.hw, P.hw); sx1 = __builtin_fmaf(nx1, P.hw, P.hw);
+    sy0 = __builtin_fmaf(ny0, P.hh, P.hh); sy1 = __builtin_fmaf(ny1, P.hh, P.hh);
     if (!(sx0 >= -1.0e9f && sx1 <= 1.0e9f && sy0 >= -1.0e9f && sy1 <= 1.0e9f)) return false;      // NaN or huge
-    px0 = max(0, (int)__builtin_floorf(sx0) - 1); px1 = min((int)P.W - 1, (int)__builtin_floorf(sx1) + 1);
-    py0 = max(0, (int)__builtin_floorf(sy0) - 1); py1 = min((int)P.H - 1, (int)__builtin_floorf(sy1) + 1);
     d_near = d - r;
     return true;
+}
+__device__ __forceinline__ bool sphere_bounds(const ZrPass& P, zf3 co, float ri, int& px0, int& py0, int& px1, int& py1, float& d_near)
+{   // false: no bound.  An empty box (px0 > px1 or py0 > py1) = off the target.  One pixel of margin on every side.
+    float sx0, sy0, sx1, sy1;
+    if (!sphere_screen(P, co, ri, sx0, sy0, sx1, sy1, d_near)) return false;
+    px0 = max(0, (int)__builtin_floorf(sx0) - 1); px1 = min((int)P.W - 1, (int)__builtin_floorf(sx1) + 1);
+    py0 = max(0, (int)__builtin_floorf(sy0) - 1); py1 = min((int)P.H - 1, (int)__builtin_floorf(sy1) + 1);
+    return true;
+}
+// The sphere's screen extent holds no pixel centre of the target (centre i lies at i + 0.5; 1/32 pixel of slack covers the snapping
+// of vertices to 1/256 pixel and the rasteriser's own rounding): nothing inside it can produce a fragment.
+__device__ __forceinline__ bool sphere_holds_no_centre(const ZrPass& P, zf3 co, float ri)
+{
+    float sx0, sy0, sx1, sy1, dn;
+    if (!sphere_screen(P, co, ri, sx0, sy0, sx1, sy1, dn)) return false;
+    const int px0 = max(0, (int)__builtin_ceilf(sx0 - 0.53125f)), px1 = min((int)P.W - 1, (int)__builtin_floorf(sx1 - 0.46875f));
+    const int py0 = max(0, (int)__builtin_ceilf(sy0 - 0.53125f)), py1 = min((int)P.H - 1, (int)__builtin_floorf(sy1 - 0.46875f));
+    return px0 > px1 || py0 > py1;
 }
 __device__ __forceinline__ bool sphere_reaches_owned_tile(const ZrPass& P, zf3 co, float ri)
 {
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(256) void k_cull_instances(ZrPass P, const ZrObject
         // the skydome is not a shadow caster (ZE:4709-4720); with N GPUs each draws every N-th instance into its own copy of
         // the shadow map and the copies are min-reduced (depth test LESS_OR_EQUAL is a min, so the split is exact)
         if (MODE == ZR_MODE_SHADOW && ((O->flags & ZR_OBJ_SKY) || inst_i % P.inst_world != P.inst_rank)) vis = false;
-        if (vis && (P.frustum_ok | P.rect_cull)) {
+        if (vis && (P.frustum_ok | P.rect_cull | P.sphere_ok)) {
             const ZrInstance I = O->inst[inst_i];
             const bool instanced = O->instanced != 0;
             const zf3 co = vs_position(zr3(O->mesh_center[0], O->mesh_center[1], O->mesh_center[2]), I, instanced);
@@ -265,6 +281,8 @@ __global__ __launch_bounds__(256) void k_cull_instances(ZrPass P, const ZrObject
             }
             if (vis && MODE == ZR_MODE_GBUFFER && P.rect_cull &&
                 !sphere_reaches_owned_tile(P, co, O->mesh_radius * (instanced ? __builtin_fabsf(I.s) : 1.0f))) vis = false;
+            // a whole instance between the pixel (texel) centres: a million instances under a 1024^2 shadow map are mostly that
+            if (vis && P.sphere_ok && P.frustum_ok && sphere_holds_no_centre(P, co, O->mesh_radius * (instanced ? __builtin_fabsf(I.s) : 1.0f))) vis = false;
         }
         if (vis) { nm = O->n_meshlets; wbase = O->work_base + inst_i * nm; }
     }
