@@ -2,13 +2,22 @@
 //
 //   k_instance_prep   XkInstanceData -> ZrInstance (rotation matrix), once per zr_object_add
 //   k_cull_instances  big scenes only: whole-mesh sphere vs frustum per instance -> compacted work list
-//   k_cull<MODE>      a wave owns a few meshlet-instances: lane-per-meshlet bounds tests (frustum, normal cone), then
-//                     wave-per-survivor lane-per-vertex transform -> exact snapped screen box -> tile rect (+ Hi-Z inputs)
+//   k_cull_box<MODE>  lane per meshlet-instance: bounds tests (frustum, normal cone, owned region), then the 8 corners of the
+//                     meshlet's object-space box through the vertex transform -> a tile rect / pixel box / least depth that BOUND
+//                     the exact ones; the camera pass's round-1 list is compacted here too
+//   k_cull<MODE>      (shadow pass with ZR_SHADOW_BOX_CULL=0, camera pass with ZR_FLAG_MESHLET_BINS) the exact version: lane-per-
+//                     meshlet bounds tests, then wave-per-survivor lane-per-vertex transform -> exact snapped screen box
+//   shadow pass (and the camera pass with ZR_FLAG_MESHLET_BINS): meshlet-level binning
 //   k_bin_count / k_scan / k_bin_fill   per-tile lists of self-contained 32-byte meshlet records (LDS histograms)
-//   k_raster_chunks<MODE, HIZ>  persistent workgroups pull chunks (<= ZR_CHUNK entries of one 32x32 tile's list): per wave,
+//   k_raster_chunks<MODE, HIZ, DEFER>  persistent workgroups pull chunks (<= ZR_CHUNK entries of one 32x32 tile's list): per wave,
 //                     stage a meshlet's transformed vertices in LDS, test its <=128 triangles (2 per lane), compact the
 //                     survivors, rasterise them lane-per-triangle into the tile's LDS depth/visibility keys with ds_min;
-//                     merge touched keys into HBM (atomic min)
+//                     merge touched keys into HBM (atomic min); DEFER: clipped triangles go to a list for k_tile_slow
+//   camera pass: triangle-level binning
+//   k_select          round 2: the meshlet-instances the Hi-Z pyramid does not hide -> 32-byte records
+//   k_geom<HIZ>       wave per meshlet-instance: vertices once, exact per-triangle tests, one 48-byte record per (triangle, tile)
+//   k_scan_tri / k_index   per-tile offsets and work units; record indices grouped by tile
+//   k_tile / k_tile_slow   lane per record: edge set-up + walk into the tile's LDS keys; clipped triangles through raster_clipped
 //   k_hiz_build       max-depth pyramid of the key buffer after round 1 (two-pass occlusion culling of the camera pass)
 //   k_resolve_gbuffer BaseScene.frag per pixel from the key buffer; SoA GBuffer planes, coalesced row stores; marks the
 //                     meshlet-instances that own a pixel (next frame's round 1)
