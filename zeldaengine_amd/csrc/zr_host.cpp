@@ -318,7 +318,10 @@ extern "C" int zr_tile_partition(uint32_t width, uint32_t height, uint32_t world
 extern "C" int zr_set_stream(zr_ctx* c, void* s)
 {
     if (!c) return ZR_ERR_ARG;
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    hipStream_t ns = s ? (hipStream_t)s : c->own_stream;
+    // frames in flight are ordered by their place on the host's stream (frame_begin relies on it): a change of stream drains them
+    if (ns != c->stream && c->rendered) { HIPCHK(c, hipSetDevice(c->device)); HIPCHK(c, zr_sync_all(c)); }
+    c->stream = ns;
     return ZR_OK;
 }
 
@@ -1053,7 +1056,9 @@ static int frame_begin(zr_ctx* c, hipStream_t s)
     const int par = (int)(c->frame_no & 1u);
     c->G = c->Gb[par]; c->d_shadow = c->d_shadow_b[par]; c->d_view = c->d_view_b[par]; c->d_empty_rgba = c->d_empty_b[par];
     if (s != c->stream) {
-        if (c->frame_no >= 2) HIPCHK(c, hipStreamWaitEvent(s, c->ev_end[(c->frame_no - 2) % zr_ctx::END_RING], 0));
+        // (two lanes: the shadow pipeline of the previous frame ran on the host's stream AFTER the lighting pass of the frame before
+        // it, so waiting for the former covers the latter - one barrier packet less on the lane the frame rate hangs on)
+        if (c->frame_no >= 2 && c->lanes3_now) HIPCHK(c, hipStreamWaitEvent(s, c->ev_end[(c->frame_no - 2) % zr_ctx::END_RING], 0));
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0));
     }
     c->timing_now = c->timing_interval != 0 && c->frame_no % c->timing_interval == 0;     // pass events cost ~6 us of stream bubble each
