@@ -1690,6 +1690,7 @@ __global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrBinEntry* __rest
                                               uint32_t* __restrict__ tile_count, ZrDevStats* __restrict__ stats, int slot)
 {
     __shared__ int4 vstage[4][WAVE];
+    __shared__ float hzs[HIZ ? 4 : 1][WAVE];
     const uint32_t lane = threadIdx.x & 63u, wv = wave_uniform(threadIdx.x >> 6);
     const uint32_t n = stats->n_sel[slot];
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -1732,6 +1733,8 @@ __global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrBinEntry* __rest
                 }
             }
         }
+        bool hz_local = false;           // wave-uniform: hzs[wv] holds this meshlet's 4 x 4-pixel blocks, (hz_x0, hz_y0) the first one
+        int hz_x0 = 0, hz_y0 = 0;
         if (HIZ && !flagged) {       // every vertex inside the frustum: the box of the snapped vertices bounds every fragment
             const int lo = wave_pkmin16(lo2), hi = wave_pkmax16(hi2);
             const int px0 = max(0, (int)(short)(lo & 0xFFFF)), py0 = max(0, lo >> 16);
@@ -1741,9 +1744,12 @@ __global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrBinEntry* __rest
                 const float zm = zr_u2f((uint32_t)wave_min(zb));
                 const uint32_t fx0 = (uint32_t)px0 >> 2, fy0 = (uint32_t)py0 >> 2, fx1 = (uint32_t)px1 >> 2, fy1 = (uint32_t)py1 >> 2;
                 if (fx1 - fx0 < 8u && fy1 - fy0 < 8u) {
-                    // a box of up to 32 x 32 pixels: its <= 8 x 8 blocks of the 4 x 4 level, a lane each - one load, one wave reduction
+                    // a box of up to 32 x 32 pixels: its <= 8 x 8 blocks of the 4 x 4 level, a lane each - one load, one wave reduction;
+                    // the values stay in LDS for the per-triangle tests below (no dependent global load per triangle)
                     const uint32_t x = fx0 + (lane & 7u), y = fy0 + (lane >> 3);
                     const float v = (x <= fx1 && y <= fy1) ? Z.fine[(size_t)y * Z.fw + x] : 0.0f;
+                    hzs[wv][lane] = v;
+                    hz_x0 = (int)fx0; hz_y0 = (int)fy0; hz_local = true;
                     gone = zm >= 0.0f && zm > wave_fmax(v);
                 } else gone = hiz_occluded(Z, make_uint2((uint32_t)px0 | (uint32_t)py0 << 16, (uint32_t)px1 | (uint32_t)py1 << 16), zm);
             }
@@ -1780,7 +1786,10 @@ __global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrBinEntry* __rest
                         // pixel
                         const float tz = __builtin_fminf(__builtin_fminf(zr_u2f((uint32_t)r0.z), zr_u2f((uint32_t)r1.z)), zr_u2f((uint32_t)r2.z));
                         float h = 0.0f;
-                        if (max(x1 - x0, y1 - y0) < 16) {
+                        if (hz_local) {       // (a triangle's box lies inside its meshlet's)
+                            for (int by = (y0 >> 2) - hz_y0; by <= (y1 >> 2) - hz_y0; ++by)
+                                for (int bx = (x0 >> 2) - hz_x0; bx <= (x1 >> 2) - hz_x0; ++bx) h = __builtin_fmaxf(h, hzs[wv][by * 8 + bx]);
+                        } else if (max(x1 - x0, y1 - y0) < 16) {
                             for (int by = y0 >> 2; by <= (y1 >> 2); ++by)
                                 for (int bx = x0 >> 2; bx <= (x1 >> 2); ++bx) h = __builtin_fmaxf(h, Z.fine[(size_t)by * Z.fw + (size_t)bx]);
                         } else {
