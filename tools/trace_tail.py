@@ -17,8 +17,8 @@ def short(n):
     return n.split("(")[0].replace("void ", "").strip()
 
 
-# a frame starts at the shadow-map clear (k_fill32)
-starts = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]) == "k_fill32"]
+# a frame starts at k_frame_begin
+starts = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]) == "k_frame_begin"]
 starts = starts[-frames - 1:]
 acc = defaultdict(lambda: [0.0, 0.0, 0])
 order = []

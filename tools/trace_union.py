@@ -7,7 +7,7 @@ for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 short = lambda n: n.split("(")[0].replace("void ", "").strip()
-starts = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]) == "k_fill32"][-frames - 1:]
+starts = [i for i, r in enumerate(rows) if short(r["Kernel_Name"]) == "k_frame_begin"][-frames - 1:]
 a, b = starts[0], starts[-1]
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows[a:b])
 busy = 0; cs, ce = iv[0]
