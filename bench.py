@@ -155,6 +155,7 @@ def main():
 
     dr = make_renderer(cfg)
     r = dr.r
+    fallback = getattr(dr, "native_fallback", None)
     interval = args.timing_interval if args.timing_interval > 0 else max(min(5, args.steps), min(8, args.steps // 12))
     interval = max(1, min(interval, args.steps))
     r.set_timing_interval(interval)
@@ -308,7 +309,9 @@ def main():
             "config": {"workload": workload, "resolution": [W, H],
                        "parallelism": ("screen super-tiles over %d ranks, %s, %s" % (world, "shadow casters i%%%d + MIN all-reduce" % world if args.split_shadow
                                        else "shadow map replicated (all-gather of the composite is the only collective)",
-                                       "torch.distributed loop" if (args.python_dist or rehearsal) else "native RCCL host (zr_dist_*)")) if world > 1 else "single GPU"},
+                                       "torch.distributed loop" if (args.python_dist or rehearsal) else
+                                       ("torch.distributed loop (the native RCCL host could not be brought up: %s)" % fallback if fallback
+                                        else "native RCCL host (zr_dist_*)"))) if world > 1 else "single GPU"},
             "roofline": roofline,
             "kernels": [kernel_row(p, times) for p in KERNEL_OF_PASS],
             "valu_roofline": valu,

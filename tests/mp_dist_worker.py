@@ -18,7 +18,15 @@ def main():
     dist.init_process_group("gloo")
     cfg = scenes.config3(300, 416, 250)
     split = os.environ.get("ZR_TEST_SPLIT_SHADOW") == "1"     # default: all-gather of the composite is the only collective
-    dr = zdist.DistributedRenderer(cfg["width"], cfg["height"], 256, device_index=0, rank=rank, world=world, split_shadow=split)
+    if os.environ.get("ZR_TEST_NATIVE") == "1":
+        # the native RCCL host cannot come up with every rank on one GPU (RCCL wants a device per rank): all ranks must notice, agree
+        # and fall back to the torch.distributed loop together
+        dr = zdist.make_distributed(cfg["width"], cfg["height"], 256, device_index=0, rank=rank, world=world, split_shadow=split, native=True)
+        fb = getattr(dr, "native_fallback", None)
+        print("rank %d native_fallback: %s" % (rank, fb), flush=True)
+        assert isinstance(dr, zdist.DistributedRenderer) and fb, "expected the agreed fallback on a one-GPU box"
+    else:
+        dr = zdist.DistributedRenderer(cfg["width"], cfg["height"], 256, device_index=0, rank=rank, world=world, split_shadow=split)
     engine.load_scene(dr.r, cfg)
     for _ in range(5):                  # both halves of the double buffers, occlusion history in use
         dr.frame()

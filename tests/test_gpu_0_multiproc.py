@@ -21,3 +21,18 @@ def test_ranks_composite_the_single_gpu_frame(world, split):
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     text = out.stdout.decode(errors="replace")
     assert out.returncode == 0 and "MP_DIST_OK" in text, text[-3000:]
+
+
+def test_native_host_falls_back_together_when_rccl_refuses():
+    """bench.py's N > 1 default is the library's own RCCL host.  On a one-GPU box RCCL refuses two ranks on one device
+    (ncclCommInitRank: invalid usage): every rank must notice, agree over torch.distributed and fall back to the torch loop - and
+    still composite the single-GPU frame.  (On a real N-GPU node the same call brings the native host up.)"""
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["ZR_TEST_SPLIT_SHADOW"] = "0"
+    env["ZR_TEST_NATIVE"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(HERE, "mp_dist_worker.py")]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    text = out.stdout.decode(errors="replace")
+    assert out.returncode == 0 and "MP_DIST_OK" in text and "native_fallback" in text, text[-3000:]

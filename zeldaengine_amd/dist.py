@@ -149,31 +149,76 @@ class DistributedRenderer:
 
 
 def make_distributed(width, height, shadow_dim=1024, device_index=0, rank=0, world=1, flags=0, split_shadow=False, native=False):
-    """One rank of the partition.  native=True: the library's own RCCL host (zr_dist_*, no Python or torch in the frame loop)."""
+    """One rank of the partition.  native=True: the library's own RCCL host (zr_dist_*, no Python or torch in the frame loop).  When
+    that host cannot be brought up on EVERY rank (librccl missing, communicator refused), all ranks fall back together to the
+    torch.distributed loop and the renderer carries the reason in `.native_fallback`."""
     if native and world > 1:
-        return NativeDistributedRenderer(width, height, shadow_dim, device_index, rank, world, flags, split_shadow)
+        dr, why = _try_native(width, height, shadow_dim, device_index, rank, world, flags, split_shadow)
+        if dr is not None:
+            return dr
+        d = DistributedRenderer(width, height, shadow_dim, device_index, rank, world, flags, split_shadow=split_shadow)
+        d.native_fallback = why
+        return d
     return DistributedRenderer(width, height, shadow_dim, device_index, rank, world, flags, split_shadow=split_shadow)
+
+
+def _try_native(width, height, shadow_dim, device_index, rank, world, flags, split_shadow):
+    """-> (NativeDistributedRenderer, None) or (None, reason); every rank returns the same kind (the outcome is agreed over
+    torch.distributed, which is initialised when world > 1)."""
+    import torch
+    import torch.distributed as dist
+    from . import engine
+    uid, err = None, ""
+    if rank == 0:
+        try:
+            uid = engine.dist_unique_id()
+        except Exception as e:      # noqa: BLE001
+            err = "zr_dist_unique_id: %s" % e
+    box = [uid, err]
+    dist.broadcast_object_list(box, src=0)
+    uid, err = box
+    if uid is None:
+        return None, err
+    dr, ok = None, 1
+    try:
+        dr = NativeDistributedRenderer(width, height, shadow_dim, device_index, rank, world, flags, split_shadow, unique_id=uid)
+    except Exception as e:          # noqa: BLE001
+        ok, err = 0, "rank %d: %s" % (rank, e)
+    dev = torch.device("cuda", device_index) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if int(t.item()) == 0:
+        if dr is not None:
+            dr.close()
+        return None, err or "the native RCCL host failed on another rank"
+    return dr, None
 
 
 class NativeDistributedRenderer:
     """One rank of the partition with the library's own RCCL host (zr_dist_*).  torch.distributed (already initialised when
     world > 1) is used ONCE, to hand rank 0's ncclUniqueId to the other ranks; frames are enqueued by one C call each."""
 
-    def __init__(self, width, height, shadow_dim=1024, device_index=0, rank=0, world=1, flags=0, split_shadow=False):
+    def __init__(self, width, height, shadow_dim=1024, device_index=0, rank=0, world=1, flags=0, split_shadow=False, unique_id=None):
         import torch
         from . import abi, engine
         self.torch = torch
         self.rank, self.world = rank, world
         if world == 1:
             flags |= abi.FLAG_PACKED_TILES
+        uid = unique_id
+        if uid is None:
+            uid = engine.dist_unique_id() if rank == 0 else bytes(128)
+            if world > 1:
+                import torch.distributed as dist
+                box = [uid]
+                dist.broadcast_object_list(box, src=0)
+                uid = box[0]
         self.r = engine.Renderer(width, height, shadow_dim, device=device_index, tile_rank=rank, tile_world=world, flags=flags)
-        uid = engine.dist_unique_id() if rank == 0 else bytes(128)
-        if world > 1:
-            import torch.distributed as dist
-            box = [uid]
-            dist.broadcast_object_list(box, src=0)
-            uid = box[0]
-        self.r.dist_init(uid, rank, world, split_shadow)
+        try:
+            self.r.dist_init(uid, rank, world, split_shadow)
+        except Exception:
+            self.r.close()
+            raise
 
     def frame(self):
         self.r.dist_frame()
