@@ -256,3 +256,26 @@ def test_both_camera_paths_against_the_oracle(oracle_lib, gpu_engine):
     assert st[0]["covered_pixels"] == st[1]["covered_pixels"] == st[2]["covered_pixels"] == st[3]["covered_pixels"]
     for g in gs:
         g.close()
+
+
+def test_record_pool_chunks_beyond_the_first(gpu_engine):
+    """With NO_HIZ every frame is one round over all frustum / cone survivors: at 60 000 instances a wave of k_geom handles ~60
+    meshlet-instances and fills its first record chunk (1 024 records) several times over, so the chunks it takes from the pool, their
+    fill counts and k_index's walk over them are exercised.  Too big for the scalar oracle: the triangle-binned frame must equal the
+    meshlet-binned rasteriser's in every target."""
+    cfg = scenes.config3(60000, 1920, 1080)
+    frames = []
+    for flags in (abi.FLAG_NO_HIZ, abi.FLAG_NO_HIZ | abi.FLAG_MESHLET_BINS):
+        g = gpu_engine.Renderer(cfg["width"], cfg["height"], 1024, flags=flags)
+        from zeldaengine_amd import engine as eng
+        eng.load_scene(g, cfg)
+        g.render(); g.render(); g.finish()
+        frames.append((g.color(), [g.gbuffer(t) for t in range(6)], g.shadowmap(), g.stats()))
+        g.close()
+    a, b = frames
+    assert a[3]["overflow"] == 0 and b[3]["overflow"] == 0
+    assert a[3]["bin_entries"][1] > 8192 * 1024 // 2, a[3]          # records: well beyond what the waves' first chunks hold on average
+    assert np.array_equal(a[0], b[0])
+    for t in range(6):
+        assert np.array_equal(a[1][t].view(np.uint8), b[1][t].view(np.uint8)), "GBuffer target %d" % t
+    assert a[3]["covered_pixels"] == b[3]["covered_pixels"]
