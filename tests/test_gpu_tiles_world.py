@@ -318,3 +318,36 @@ def test_native_rccl_host_world_of_one(gpu_engine):
     with pytest.raises(gpu_engine.ZeldaRenderError):
         g.dist_init(bytes(128), 1, 2)
     g.close()
+
+
+def test_tile_partition_with_clipped_triangles_and_hiz_rounds(gpu_engine):
+    """Three rank contexts, a scene whose ground plane crosses the near plane and whose wall has triangles longer than 64 pixels
+    (the triangle-binned pass's slow list, tried by every owned tile), three frames with the camera moving (Hi-Z rounds with a
+    stale history on every rank): the ranks' packed tiles must be the single-GPU frame's, frame after frame."""
+    W, H, SD, world = 416, 250, 128, 3
+
+    def scene(r):
+        r.set_cubemap(scenes.synthetic_cubemap(16))
+        r.object_add(r.mesh_create(*scenes.grid_plane(60.0, 8, 0.0)))
+        r.object_add(r.mesh_create(*scenes.box((3.0, 0.15, 1.6), (0.0, 0.0, 1.6))))
+        r.object_add(r.mesh_create(*scenes.uv_sphere()), None, scenes.generate_instances(400, 1.0, 14.0, 0.3, 0.7, seed=5))
+
+    single = gpu_engine.Renderer(W, H, SD)
+    ranks = [gpu_engine.Renderer(W, H, SD, tile_rank=r, tile_world=world) for r in range(world)]
+    for g in [single] + ranks:
+        scene(g)
+    w = scenes.sample_world()
+    d, _, s = scenes.lights_from_world(w)
+    w["PointLights"] = scenes.sample_point_lights(8)
+    _, p, _ = scenes.lights_from_world(w)
+    for i, (pos, look) in enumerate([((0.0, -6.0, 1.2), (0.0, 0.0, 1.0)), ((2.5, -5.0, 1.6), (0.0, 0.0, 1.0)), ((6.0, 1.0, 4.0), (0.0, 0.0, 0.5))]):
+        cam = abi.make_camera(pos, look, fov=50.0)
+        for g in [single] + ranks:
+            g.update_uniforms(cam, d, p, s, 0.1 * i, 0.02 * i, 1.0 + i)
+            g.render()
+        want = single.color()
+        for r, g in enumerate(ranks):
+            assert np.array_equal(g.read_tiles(), zdist.pack_tiles(want, r, world)), "frame %d, rank %d" % (i, r)
+            assert g.stats()["overflow"] == 0
+    for g in [single] + ranks:
+        g.close()
