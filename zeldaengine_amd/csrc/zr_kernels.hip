@@ -2133,7 +2133,10 @@ __device__ __forceinline__ float shadow_tap(const float* __restrict__ S, int SD,
 
 // BaseLighting.frag:147-254 for every pixel of the owned tiles (the full-screen quad of ZE:3531-3540)
 template <bool LIGHT_LIST, bool BACKGROUND>
-__global__ __launch_bounds__(256) void k_lighting(ZrLightParams L, const XkView* __restrict__ view,
+#ifndef ZR_LIGHT_WAVES
+#define ZR_LIGHT_WAVES 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZR_LIGHT_WAVES, ZR_LIGHT_WAVES))) void k_lighting(ZrLightParams L, const XkView* __restrict__ view,
                                                   const uint32_t* __restrict__ owned_tiles, GBufferPtrs G,
                                                   const float* __restrict__ shadowmap, CubeDesc C,
                                                   const float* __restrict__ srgb_lut, const float* __restrict__ unorm_lut,
