@@ -1684,7 +1684,8 @@ __global__ __launch_bounds__(256) void k_select(ZrPass P, const ZrObject* __rest
 // Round 2 (HIZ): a meshlet whose snapped vertex box lies behind the pyramid is dropped after the vertex phase (the test k_cull's
 // stage B makes in the meshlet-binned path, with the same box), and every triangle is tested once more by itself.
 template <bool HIZ>
-__global__ __launch_bounds__(256) void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, uint4* __restrict__ recs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))      // (the Hi-Z variant would take 67 VGPRs: 7 waves)
+void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, uint4* __restrict__ recs,
                                               uint32_t n_chunks, uint32_t* __restrict__ chunk_fill, uint32_t* __restrict__ wave_culled,
                                               uint4* __restrict__ slow, uint32_t slow_cap,
                                               uint32_t* __restrict__ tile_count, ZrDevStats* __restrict__ stats, int slot)
@@ -2133,10 +2134,9 @@ __device__ __forceinline__ float shadow_tap(const float* __restrict__ S, int SD,
 
 // BaseLighting.frag:147-254 for every pixel of the owned tiles (the full-screen quad of ZE:3531-3540)
 template <bool LIGHT_LIST, bool BACKGROUND>
-#ifndef ZR_LIGHT_WAVES
-#define ZR_LIGHT_WAVES 4
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZR_LIGHT_WAVES, ZR_LIGHT_WAVES))) void k_lighting(ZrLightParams L, const XkView* __restrict__ view,
+// (compiled for exactly 4 waves per SIMD: left to itself the allocator takes 127 VGPRs, told so it makes do with 97 - the same four
+// waves, but 120 registers per SIMD left for the other lane's kernels; 5 or 6 waves (95 / 80 VGPRs) are faster alone, not beside)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lighting(ZrLightParams L, const XkView* __restrict__ view,
                                                   const uint32_t* __restrict__ owned_tiles, GBufferPtrs G,
                                                   const float* __restrict__ shadowmap, CubeDesc C,
                                                   const float* __restrict__ srgb_lut, const float* __restrict__ unorm_lut,
