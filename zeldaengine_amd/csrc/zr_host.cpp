@@ -1152,7 +1152,7 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
         c->overlay_dirty[par] = sky;
     }
     if (ev) HIPCHK(c, hipEventRecord(ev[6], s));
-    zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_lut, Z.vis_now, c->d_stats, s);
+    zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_lut, c->d_unorm_lut, Z.vis_now, c->d_stats, s);
     if (ev) HIPCHK(c, hipEventRecord(ev[7], s));
     if (hiz_on) { c->vis_history = true; c->vis_cur ^= 1; } else c->vis_history = false;
     HIPCHK(c, hipGetLastError());

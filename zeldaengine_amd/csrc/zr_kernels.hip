@@ -1182,7 +1182,9 @@ __device__ __forceinline__ zf3 compute_normal(zf3 pos_dx, zf3 pos_dy, float s1, 
 
 // ---- material sampling: texture(sampler2D, uv) with LINEAR mag/min/mip, REPEAT (RHICreateSampler, ZE:6523-6557) ----
 __device__ __forceinline__ int tex_idx_clamp(float f, int hi) { f = __builtin_fminf(__builtin_fmaxf(f, 0.0f), (float)hi); return (int)f; }
-__device__ __forceinline__ float tex_decode(uint32_t v, bool srgb, const float* __restrict__ lut) { return srgb ? lut[v] : (float)v / 255.0f; }
+// `lut` = 512 floats: [0, 256) the sRGB decode table, [256, 512) c / 255 (UNORM load, the IEEE quotient formed once on the host): a
+// sampled texel costs a table read per channel instead of a division per channel (192 of them per pixel with seven images)
+__device__ __forceinline__ float tex_decode(uint32_t v, bool srgb, const float* __restrict__ lut) { return lut[(srgb ? 0u : 256u) + v]; }
 __device__ __forceinline__ zf4 tex_fetch(const uint8_t* __restrict__ lvl, uint32_t w, int x, int y, bool srgb, const float* __restrict__ lut)
 {
     const uint32_t t = *(const uint32_t*)(lvl + ((size_t)y * w + (size_t)x) * 4);
@@ -1228,9 +1230,13 @@ __device__ __forceinline__ zf4 tex_trilinear(const ZrTex& T, float lambda, float
 // scheme is the one the Vulkan specification describes: N = min(ceil(Pmax / Pmin), 16) trilinear taps spread along the major
 // screen axis at lambda = log2(Pmax / N), averaged; N = 1 is plain trilinear filtering.
 #define ZR_MAX_ANISO 16
-__device__ __forceinline__ zf4 tex_sample_image(const ZrTex& T, bool srgb, const float* __restrict__ lut,
-                                             float u, float v, float dudx, float dvdx, float dudy, float dvdy)
+// The filter footprint depends on the image's size and mip count and on the derivatives only: a material's seven textures are
+// usually of one size, so the resolve forms it once per pixel and size, not once per slot.
+struct TexFootprint { uint32_t w, h, levels; int N; float lambda, du, dv; };
+__device__ __forceinline__ TexFootprint tex_footprint(const ZrTex& T, float dudx, float dvdx, float dudy, float dvdy)
 {
+    TexFootprint F;
+    F.w = T.w; F.h = T.h; F.levels = T.levels;
     const float W = (float)T.w, H = (float)T.h;
     const float ax = dudx * W, ay = dvdx * H, bx = dudy * W, by = dvdy * H;
     const float rx2 = __builtin_fmaf(ax, ax, ay * ay), ry2 = __builtin_fmaf(bx, bx, by * by);
@@ -1240,17 +1246,41 @@ __device__ __forceinline__ zf4 tex_sample_image(const ZrTex& T, bool srgb, const
     while (N < ZR_MAX_ANISO && (float)(N * N) * rmin2 < rmax2) ++N;
     float lambda = 0.5f * zr_log2(rmax2);
     if (N > 1) lambda = lambda - zr_log2((float)N);
-    lambda = __builtin_fminf(__builtin_fmaxf(lambda, 0.0f), (float)(T.levels - 1u));
-    if (N == 1) return tex_trilinear(T, lambda, u, v, srgb, lut);
-    const float du = xmajor ? dudx : dudy, dv = xmajor ? dvdx : dvdy;
+    F.lambda = __builtin_fminf(__builtin_fmaxf(lambda, 0.0f), (float)(T.levels - 1u));
+    F.N = N;
+    F.du = xmajor ? dudx : dudy; F.dv = xmajor ? dvdx : dvdy;
+    return F;
+}
+__device__ __forceinline__ zf4 tex_sample_footprint(const ZrTex& T, const TexFootprint& F, bool srgb, const float* __restrict__ lut, float u, float v)
+{
+    const int N = F.N;
+    if (N == 1) return tex_trilinear(T, F.lambda, u, v, srgb, lut);
     zf4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
     for (int i = 1; i <= N; ++i) {
         const float off = (float)i / (float)(N + 1) - 0.5f;
-        const zf4 s = tex_trilinear(T, lambda, __builtin_fmaf(du, off, u), __builtin_fmaf(dv, off, v), srgb, lut);
+        const zf4 s = tex_trilinear(T, F.lambda, __builtin_fmaf(F.du, off, u), __builtin_fmaf(F.dv, off, v), srgb, lut);
         acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
     }
     zf4 r; r.x = acc.x / (float)N; r.y = acc.y / (float)N; r.z = acc.z / (float)N; r.w = acc.w / (float)N;
     return r;
+}
+__device__ __forceinline__ zf4 tex_sample_image(const ZrTex& T, bool srgb, const float* __restrict__ lut,
+                                             float u, float v, float dudx, float dvdx, float dudy, float dvdy)
+{
+    const TexFootprint F = tex_footprint(T, dudx, dvdx, dudy, dvdy);
+    return tex_sample_footprint(T, F, srgb, lut, u, v);
+}
+// the same, reusing (or replacing) the caller's footprint when the image has the size it was formed for
+template <bool IMAGES>
+__device__ __forceinline__ zf4 tex_sample_shared(const ZrTex& T, const float* __restrict__ constant, bool srgb, const float* __restrict__ lut,
+                                                 float u, float v, float dudx, float dvdx, float dudy, float dvdy, TexFootprint& F)
+{
+    if (!IMAGES || T.data == nullptr) {      // constant slot: decoded once on the host
+        zf4 r; r.x = constant[0]; r.y = constant[1]; r.z = constant[2]; r.w = constant[3];
+        return r;
+    }
+    if (F.w != T.w || F.h != T.h || F.levels != T.levels) F = tex_footprint(T, dudx, dvdx, dudy, dvdy);
+    return tex_sample_footprint(T, F, srgb, lut, u, v);
 }
 // IMAGES = false: the caller knows that no slot of the scene holds an image (every material constant, the common synthetic
 // case): the filter is not even instantiated, which keeps eight inlined copies of it out of the kernel's registers.
@@ -1363,13 +1393,15 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
         w_sc = O->c_scene_color; w_gB = O->c_gB; w_gC = O->c_gC;
         ts = zr3(O->ts_const[0], O->ts_const[1], O->ts_const[2]);
     } else {
-        const zf4 tb = tex_sample<IMAGES>(O->tex[0], O->texc[0], true, lut, u0, v0, s1, t1, s2, t2);
-        const zf4 tme = tex_sample<IMAGES>(O->tex[1], O->texc[1], false, lut, u0, v0, s1, t1, s2, t2);
-        const zf4 tro = tex_sample<IMAGES>(O->tex[2], O->texc[2], false, lut, u0, v0, s1, t1, s2, t2);
-        const zf4 tno = tex_sample<IMAGES>(O->tex[3], O->texc[3], false, lut, u0, v0, s1, t1, s2, t2);
-        const zf4 tao = tex_sample<IMAGES>(O->tex[4], O->texc[4], false, lut, u0, v0, s1, t1, s2, t2);
-        const zf4 tem = tex_sample<IMAGES>(O->tex[5], O->texc[5], false, lut, u0, v0, s1, t1, s2, t2);
-        const zf4 tms = tex_sample<IMAGES>(O->tex[6], O->texc[6], false, lut, u0, v0, s1, t1, s2, t2);
+        TexFootprint F;
+        F.w = F.h = F.levels = 0u; F.N = 1; F.lambda = 0.0f; F.du = F.dv = 0.0f;      // formed by the first slot that holds an image
+        const zf4 tb = tex_sample_shared<IMAGES>(O->tex[0], O->texc[0], true, lut, u0, v0, s1, t1, s2, t2, F);
+        const zf4 tme = tex_sample_shared<IMAGES>(O->tex[1], O->texc[1], false, lut, u0, v0, s1, t1, s2, t2, F);
+        const zf4 tro = tex_sample_shared<IMAGES>(O->tex[2], O->texc[2], false, lut, u0, v0, s1, t1, s2, t2, F);
+        const zf4 tno = tex_sample_shared<IMAGES>(O->tex[3], O->texc[3], false, lut, u0, v0, s1, t1, s2, t2, F);
+        const zf4 tao = tex_sample_shared<IMAGES>(O->tex[4], O->texc[4], false, lut, u0, v0, s1, t1, s2, t2, F);
+        const zf4 tem = tex_sample_shared<IMAGES>(O->tex[5], O->texc[5], false, lut, u0, v0, s1, t1, s2, t2, F);
+        const zf4 tms = tex_sample_shared<IMAGES>(O->tex[6], O->texc[6], false, lut, u0, v0, s1, t1, s2, t2, F);
         const float Rough = __builtin_fmaxf(0.01f, tro.x);
         w_sc = zr_unorm(tem.x, 255.0f) | zr_unorm(tem.y, 255.0f) << 8 | zr_unorm(tem.z, 255.0f) << 16 | zr_unorm(tms.x, 255.0f) << 24;
         w_gB = zr_unorm(tme.x, 255.0f) | zr_unorm(1.0f, 255.0f) << 8 | zr_unorm(Rough, 255.0f) << 16 | 255u << 24;
@@ -2013,11 +2045,14 @@ template <bool IMAGES>
 __global__ __launch_bounds__(256) void k_resolve_gbuffer(ZrPass P, const ZrObject* __restrict__ objs,
                                                          const uint32_t* __restrict__ owned_tiles,
                                                          unsigned long long* __restrict__ vis64, GBufferPtrs G,
-                                                         const float* __restrict__ srgb_lut, uint8_t* __restrict__ vis_now,
-                                                         ZrDevStats* __restrict__ stats)
+                                                         const float* __restrict__ srgb_lut, const float* __restrict__ unorm_lut,
+                                                         uint8_t* __restrict__ vis_now, ZrDevStats* __restrict__ stats)
 {
     __shared__ uint32_t covered_s;
+    __shared__ float tlut[IMAGES ? 512 : 1];       // texel decode tables of the sampler (see tex_decode)
     const uint32_t tid = threadIdx.x;
+    if (IMAGES) { tlut[tid] = srgb_lut[tid]; tlut[256u + tid] = unorm_lut[tid]; }      // (256 threads; the barrier below orders it)
+    const float* __restrict__ dlut = IMAGES ? tlut : srgb_lut;
     const uint32_t tile = owned_tiles[blockIdx.x];
     const int tx0 = (int)(tile % P.tiles_x) * TILE, ty0 = (int)(tile / P.tiles_x) * TILE;
     if (tid == 0) covered_s = 0;
@@ -2030,7 +2065,7 @@ __global__ __launch_bounds__(256) void k_resolve_gbuffer(ZrPass P, const ZrObjec
         const size_t p = (size_t)py * P.W + (size_t)px;
         const unsigned long long k = vis64[p];
         vis64[p] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
-        ncov += resolve_pixel<IMAGES>(P, objs, (uint32_t)k, zr_u2f((uint32_t)(k >> 32)), px, py, G, srgb_lut, vis_now) ? 1u : 0u;
+        ncov += resolve_pixel<IMAGES>(P, objs, (uint32_t)k, zr_u2f((uint32_t)(k >> 32)), px, py, G, dlut, vis_now) ? 1u : 0u;
     }
     if (ncov) atomicAdd(&covered_s, ncov);
     __syncthreads();
@@ -2143,9 +2178,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                   uint32_t* __restrict__ out)
 {
     // UNORM loads are IEEE quotients c / 255 and c / 1023: 14 per pixel, served from an LDS copy of the host-built table
-    __shared__ float u8[256];
+    __shared__ float tl[512];            // [0, 256) sRGB decode (24 cubemap fetches per pixel), [256, 512) c / 255: tex_decode's layout
     __shared__ float u10[1024];
-    __shared__ float slut[256];          // sRGB decode table of the cubemap fetches (24 per pixel)
+    float* const slut = tl; float* const u8 = tl + 256;
     for (uint32_t i = threadIdx.x; i < 256u; i += 256u) { u8[i] = unorm_lut[i]; slut[i] = srgb_lut[i]; }
     for (uint32_t i = threadIdx.x; i < 1024u; i += 256u) u10[i] = unorm_lut[256u + i];
     __syncthreads();
@@ -2228,7 +2263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 else if (BACKGROUND && L.bg_enabled && 1.0f <= G.depth[p]) {
                     const float u = ((float)px + 0.5f) / (float)L.W, v = ((float)py + 0.5f) / (float)L.H;
                     const float one4[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
-                    const zf4 bgc = tex_sample<true>(L.bg, one4, true, srgb_lut, u, v, 1.0f / (float)L.W, 0.0f, 0.0f, 1.0f / (float)L.H);
+                    const zf4 bgc = tex_sample<true>(L.bg, one4, true, tl, u, v, 1.0f / (float)L.W, 0.0f, 0.0f, 1.0f / (float)L.H);
                     rgba = zr_unorm(zr_pow(bgc.x, 0.4545f), 255.0f) | zr_unorm(zr_pow(bgc.y, 0.4545f), 255.0f) << 8 |
                            zr_unorm(zr_pow(bgc.z, 0.4545f), 255.0f) << 16 | 255u << 24;
                 }
@@ -2682,12 +2717,12 @@ void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B,
     if (n_owned && slow_too) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_GBUFFER, false>), dim3(n_owned), dim3(256), 0, s, P, owned_tiles, B.slow, B.slow_cap, stats, slot, vis64, (uint32_t*)nullptr);
 }
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
-                               unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, uint8_t* vis_now,
+                               unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, const float* unorm_lut, uint8_t* vis_now,
                                ZrDevStats* stats, hipStream_t s)
 {
     if (n_owned == 0) return;
-    if (P.images) hipLaunchKernelGGL(k_resolve_gbuffer<true>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, vis_now, stats);
-    else hipLaunchKernelGGL(k_resolve_gbuffer<false>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, vis_now, stats);
+    if (P.images) hipLaunchKernelGGL(k_resolve_gbuffer<true>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats);
+    else hipLaunchKernelGGL(k_resolve_gbuffer<false>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats);
 }
 void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, hipStream_t s)
 {

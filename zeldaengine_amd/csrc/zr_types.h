@@ -216,7 +216,7 @@ void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4*
                              uint32_t n_blocks, const ZrHiz& Z, hipStream_t s, uint4* slow = nullptr, uint32_t slow_cap = 0, const uint32_t* tiles = nullptr,
                              uint32_t n_tiles = 0);      // slow != nullptr (shadow pass): clipped triangles via the list + k_tile_slow
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
-                               unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, uint8_t* vis_now,
+                               unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, const float* unorm_lut, uint8_t* vis_now,
                                ZrDevStats* stats, hipStream_t s);
 void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, hipStream_t s);
 void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32_t* owned_tiles, uint32_t n_owned,
