@@ -1196,8 +1196,14 @@ __device__ __forceinline__ zf4 tex_fetch(const uint8_t* __restrict__ lvl, uint32
 __device__ __forceinline__ zf4 tex_bilinear(const ZrTex& T, int level, float u, float v, bool srgb, const float* __restrict__ lut)
 {
     size_t off = 0;
-    for (int l = 0; l < level; ++l) { uint32_t lw = T.w >> l, lh = T.h >> l; if (!lw) lw = 1; if (!lh) lh = 1; off += (size_t)lw * lh * 4; }
-    uint32_t w = T.w >> level, h = T.h >> level; if (!w) w = 1; if (!h) h = 1;
+    uint32_t w = T.w >> level, h = T.h >> level;
+    if (w != 0u && h != 0u && (T.w & (T.w - 1u)) == 0u && (T.h & (T.h - 1u)) == 0u) {
+        // power-of-two image, level above the 1 x N tail: sum_{l < level} (w h) >> 2 l = (w h - (w h >> 2 level)) * 4 / 3 texels, exactly
+        const uint32_t sz = T.w * T.h;                    // (images are at most 16384^2 texels: 2^28)
+        off = (size_t)((sz - (sz >> (2 * level))) / 3u) * 16u;
+    } else
+        for (int l = 0; l < level; ++l) { uint32_t lw = T.w >> l, lh = T.h >> l; if (!lw) lw = 1; if (!lh) lh = 1; off += (size_t)lw * lh * 4; }
+    if (!w) w = 1; if (!h) h = 1;
     const uint8_t* __restrict__ lvl = T.data + off;
     const float ur = u - __builtin_floorf(u), vr = v - __builtin_floorf(v);
     const float x = __builtin_fmaf(ur, (float)w, -0.5f), y = __builtin_fmaf(vr, (float)h, -0.5f);
