@@ -112,6 +112,11 @@ def main():
     ap.add_argument("--cube-dim", type=int, default=1024, help="cubemap face edge (the engine's is 1024: 11 mips)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: start the N ranks as a CHILD process (torch.distributed.run, one rank per GPU) and relay
+        # its output and exit code.  This parent never touches the GPU (nothing of torch or HIP is imported here) and never exec()s.
+        raise SystemExit(launch_ranks(args.gpus))
+
     import torch
     from zeldaengine_amd import abi, dist as zdist, engine, scenes
 
@@ -123,20 +128,26 @@ def main():
     rehearsal = os.environ.get("ZR_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback")
+    if world > 1 and not rehearsal and torch.cuda.device_count() < world:
+        # RCCL refuses two ranks on one device (and would hang the others inside ncclCommInitRank): say so before any collective
+        raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s); one process per GPU needs %d (ZR_BENCH_REHEARSAL=1 runs every rank "
+                         "on cuda:0 over gloo to rehearse the frame loop: its numbers mean nothing)" % (world, torch.cuda.device_count(), world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        # Control plane (the ncclUniqueId hand-over, the timing barrier, the MAX over ranks) on gloo with CPU tensors; the frame's
+        # collectives are the library's own RCCL communicator (zr_dist_*).  torch's RCCL communicator ("nccl" IS RCCL on ROCm) is created
+        # lazily, i.e. only if the torch.distributed frame loop runs (--python-dist, or the agreed fallback): one communicator per rank.
+        dist.init_process_group("gloo" if rehearsal else "cpu:gloo,cuda:nccl")
+
+    def barrier():
+        if world > 1:
+            dist.all_reduce(torch.zeros(1, dtype=torch.int32))      # a CPU tensor: gloo
 
     n_point = 256 if args.config == 5 else 16
     if args.config == 3:
@@ -178,8 +189,7 @@ def main():
             dr_.frame()
         dr_.synchronize()
         torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
+        barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for i in range(steps):
@@ -187,12 +197,11 @@ def main():
             dr_.frame()
         dr_.synchronize()                # render stream + camera lane + collective stream
         torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
+        barrier()
         torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            t = torch.tensor([el], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         return el
@@ -331,8 +340,24 @@ def main():
         print(json.dumps(line), flush=True)
     dr.close()
     if world > 1:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
+
+
+def launch_ranks(n):
+    """Start `python -m torch.distributed.run --nnodes=1 --nproc-per-node n bench.py <same arguments>` as a child, pass its stdout /
+    stderr through, return its exit code (what the driver's launcher does for N > 1)."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:       # a free rendezvous port on the loopback
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(n_inst, cube_dim):

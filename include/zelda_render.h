@@ -54,8 +54,8 @@ typedef struct zr_ctx zr_ctx;
 #define ZR_FLAG_NO_HIZ          8u  /* disable two-pass Hi-Z occlusion culling of the camera pass (parity A/B) */
 #define ZR_FLAG_SERIAL_PASSES   16u /* zr_render: shadow and camera pipelines on the one stream instead of side by side */
 #define ZR_FLAG_PACKED_TILES    32u /* tile_world == 1: still light into the packed tile buffer (the multi-GPU data path on one GPU) */
-#define ZR_FLAG_MESHLET_BINS   128u /* camera pass: the meshlet-binned rasteriser of round 1 (every (meshlet, tile) entry re-transforms and
-                                     * re-tests the meshlet) instead of the triangle-binned one (A/B; the shadow pass always uses it) */
+#define ZR_FLAG_MESHLET_BINS   128u /* -DZR_DIAG builds only (zr_create: ZR_ERR_UNSUPPORTED otherwise): camera pass through the meshlet-binned
+                                     * rasteriser the shadow pass uses, instead of the triangle-binned one (A/B measurements) */
 #define ZR_FLAG_NO_RECT_CULL    64u /* tile_world > 1: do not reject meshlets by the rank's owned screen region before stage B (parity A/B) */
 
 typedef struct zr_config {
@@ -131,6 +131,10 @@ int  zr_mesh_get_meshlets(zr_ctx* ctx, uint32_t mesh_id, XkMeshlet* m, uint32_t*
 /* n_inst == 0: non-instanced draw (Base.vert); n_inst >= 1: instanced draw (BaseInstanced.vert). */
 int  zr_object_add(zr_ctx* ctx, uint32_t mesh_id, const zr_material* mat,
                    const XkInstanceData* inst, uint32_t n_inst);
+/* Capacities of the camera pass's triangle-record pool (in chunks of 1024 records) and of its clipped-triangle list; 0 = defaults
+ * (8 records per meshlet-instance of the scene, at least 32 Mi records; 2^18 triangles).  A frame that outgrows either reports
+ * ZR_ERR_OVERFLOW at zr_finish.  Takes effect at the next frame (the pools are re-made). */
+int  zr_set_limits(zr_ctx* ctx, uint32_t record_chunks, uint32_t slow_triangles);
 int  zr_scene_clear(zr_ctx* ctx);                   /* CleanupBasePass, ZE:4142 (also drops meshes and Profabs) */
 int  zr_object_count(zr_ctx* ctx, uint32_t* n);
 /* Copy out the instance array of object `index` (add order); *n = 0 for a non-instanced draw.  dst may be NULL. */
@@ -224,6 +228,12 @@ int  zr_color_device_ptr(zr_ctx* ctx, void** dev_ptr);
 #define ZR_DIST_SPLIT_SHADOW 1u
 int  zr_dist_unique_id(void* id, size_t bytes);                       /* bytes must be 128 */
 int  zr_dist_init(zr_ctx* ctx, const void* id, size_t bytes, uint32_t rank, uint32_t world, uint32_t dist_flags);
+/* The same bring-up in two steps, for hosts that can agree between them: zr_dist_prepare is LOCAL (librccl, collective stream, packed /
+ * gathered buffers) and may fail on one rank alone; zr_dist_connect calls ncclCommInitRank, which is itself a collective - a rank that
+ * never reaches it leaves the others blocked inside it - so call it only after every rank reported a successful prepare.
+ * zr_dist_init = prepare + connect.  A failed connect leaves a plain single-context renderer behind (whole shadow map). */
+int  zr_dist_prepare(zr_ctx* ctx, uint32_t rank, uint32_t world, uint32_t dist_flags);
+int  zr_dist_connect(zr_ctx* ctx, const void* id, size_t bytes);
 int  zr_dist_frame(zr_ctx* ctx);
 
 /* --- world JSON + livelink (replaces XkWorld::Load ZE:1051-1147, socket thread ZE:1617-1710) --- */

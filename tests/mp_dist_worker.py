@@ -21,6 +21,11 @@ def main():
     if os.environ.get("ZR_TEST_NATIVE") == "1":
         # the native RCCL host cannot come up with every rank on one GPU (RCCL wants a device per rank): all ranks must notice, agree
         # and fall back to the torch.distributed loop together
+        if os.environ.get("ZR_TEST_NATIVE_FAIL_RANK") == str(rank):
+            # ONE rank cannot even prepare (no librccl / no memory there): the others must not be left inside ncclCommInitRank
+            def broken(self, *a, **k):
+                raise RuntimeError("injected: this rank cannot prepare the native host")
+            engine.Renderer.dist_prepare = broken
         dr = zdist.make_distributed(cfg["width"], cfg["height"], 256, device_index=0, rank=rank, world=world, split_shadow=split, native=True)
         fb = getattr(dr, "native_fallback", None)
         print("rank %d native_fallback: %s" % (rank, fb), flush=True)

@@ -36,3 +36,18 @@ def test_native_host_falls_back_together_when_rccl_refuses():
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     text = out.stdout.decode(errors="replace")
     assert out.returncode == 0 and "MP_DIST_OK" in text and "native_fallback" in text, text[-3000:]
+
+
+def test_native_host_falls_back_together_when_one_rank_cannot_prepare():
+    """ncclCommInitRank is a collective: if one rank fails before it, the others would block inside it for ever.  The bring-up
+    therefore agrees on the local half (zr_dist_prepare) first: with rank 1 unable to prepare, both ranks must fall back - promptly."""
+    env = dict(os.environ)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["ZR_TEST_SPLIT_SHADOW"] = "0"
+    env["ZR_TEST_NATIVE"] = "1"
+    env["ZR_TEST_NATIVE_FAIL_RANK"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29548", os.path.join(HERE, "mp_dist_worker.py")]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    text = out.stdout.decode(errors="replace")
+    assert out.returncode == 0 and "MP_DIST_OK" in text and "injected" in text, text[-3000:]

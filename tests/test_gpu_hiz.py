@@ -232,14 +232,14 @@ def test_config5_reduced_against_the_oracle_with_a_moving_camera(oracle_lib, gpu
     assert culled > 0
 
 
-def test_both_camera_paths_against_the_oracle(oracle_lib, gpu_engine):
-    """The camera pass has two rasterisers: the triangle-binned one (default: k_cull_box, k_geom, k_tile) and the meshlet-binned one
-    (ZR_FLAG_MESHLET_BINS: k_cull<GBUFFER>, k_raster_chunks).  Both must give the oracle's frame over the history sequence, with and
-    without the Hi-Z rounds, and the slow-triangle list must be exercised (the ground plane crosses the near plane; the wall's
-    triangles are longer than 64 pixels)."""
+def test_camera_pass_against_the_oracle_with_and_without_hiz_rounds(oracle_lib, gpu_engine):
+    """The triangle-binned camera pass (k_cull_box, k_geom, k_index, k_tile) over the history sequence, with and without the Hi-Z rounds:
+    both must give the oracle's frame, and the slow-triangle list must be exercised (the ground plane crosses the near plane; the
+    wall's triangles are longer than 64 pixels).  (The meshlet-binned A/B rasteriser for the camera pass exists in -DZR_DIAG builds only:
+    the product library refuses ZR_FLAG_MESHLET_BINS.)"""
     W, H, SD = 384, 216, 256
     o = oracle_lib.Oracle(W, H, SD)
-    gs = [gpu_engine.Renderer(W, H, SD, flags=f) for f in (0, abi.FLAG_MESHLET_BINS, abi.FLAG_NO_HIZ, abi.FLAG_MESHLET_BINS | abi.FLAG_NO_HIZ)]
+    gs = [gpu_engine.Renderer(W, H, SD, flags=f) for f in (0, abi.FLAG_NO_HIZ)]
     for r in [o] + gs:
         _crowd(r, 300, 11)
     d, p, s = _lights()
@@ -253,29 +253,29 @@ def test_both_camera_paths_against_the_oracle(oracle_lib, gpu_engine):
             _identical(o, g, "frame %d, path %d" % (i, k))
     st = [g.stats() for g in gs]
     assert all(x["overflow"] == 0 for x in st)
-    assert st[0]["covered_pixels"] == st[1]["covered_pixels"] == st[2]["covered_pixels"] == st[3]["covered_pixels"]
+    assert st[0]["covered_pixels"] == st[1]["covered_pixels"]
     for g in gs:
         g.close()
+    with pytest.raises(gpu_engine.ZeldaRenderError):
+        gpu_engine.Renderer(W, H, SD, flags=abi.FLAG_MESHLET_BINS)
 
 
-def test_record_pool_chunks_beyond_the_first(gpu_engine):
+def test_record_pool_chunks_beyond_the_first(oracle_lib, gpu_engine):
     """With NO_HIZ every frame is one round over all frustum / cone survivors: at 60 000 instances a wave of k_geom handles ~60
     meshlet-instances and fills its first record chunk (1 024 records) several times over, so the chunks it takes from the pool, their
-    fill counts and k_index's walk over them are exercised.  Too big for the scalar oracle: the triangle-binned frame must equal the
-    meshlet-binned rasteriser's in every target."""
+    fill counts and k_index's walk over them are exercised.  Checked against the scalar oracle (57.6 M triangles: ~20 s of CPU)."""
+    from zeldaengine_amd import engine as eng
     cfg = scenes.config3(60000, 1920, 1080)
-    frames = []
-    for flags in (abi.FLAG_NO_HIZ, abi.FLAG_NO_HIZ | abi.FLAG_MESHLET_BINS):
-        g = gpu_engine.Renderer(cfg["width"], cfg["height"], 1024, flags=flags)
-        from zeldaengine_amd import engine as eng
-        eng.load_scene(g, cfg)
-        g.render(); g.render(); g.finish()
-        frames.append((g.color(), [g.gbuffer(t) for t in range(6)], g.shadowmap(), g.stats()))
-        g.close()
-    a, b = frames
-    assert a[3]["overflow"] == 0 and b[3]["overflow"] == 0
-    assert a[3]["bin_entries"][1] > 8192 * 1024 // 2, a[3]          # records: well beyond what the waves' first chunks hold on average
-    assert np.array_equal(a[0], b[0])
-    for t in range(6):
-        assert np.array_equal(a[1][t].view(np.uint8), b[1][t].view(np.uint8)), "GBuffer target %d" % t
-    assert a[3]["covered_pixels"] == b[3]["covered_pixels"]
+    g = gpu_engine.Renderer(cfg["width"], cfg["height"], 1024, flags=abi.FLAG_NO_HIZ)
+    eng.load_scene(g, cfg)
+    g.render(); g.render(); g.finish()
+    st = g.stats()
+    assert st["overflow"] == 0
+    assert st["bin_entries"][1] > 8192 * 1024 // 2, st           # records: well beyond what the waves' first chunks hold on average
+    o = oracle_lib.Oracle(cfg["width"], cfg["height"], 1024)
+    oracle_lib.load_scene(o, cfg)
+    o.set_threads(16)
+    o.render()
+    _identical(o, g, "60 000 instances, one round")
+    assert st["covered_pixels"] == o.covered_pixels()
+    g.close()

@@ -230,3 +230,34 @@ def test_native_headless_driver_takes_the_scene_from_the_livelink(gpu_engine, tm
     g.world_load_json(json.dumps(world))
     g.render(); g.render(); g.finish()
     assert np.array_equal(got, g.color()[..., :3])
+
+
+def test_hostile_inputs_are_errors_not_crashes(gpu_engine, tmp_path):
+    """A corrupt `.meshlet` header must not be able to ask for gigabytes (every section count is checked against the bytes the file
+    still holds), and file names in a world payload - the livelink is unauthenticated - must stay inside the content tree."""
+    import struct
+    root = str(tmp_path)
+    _, world = _content_tree(root)
+    g = gpu_engine.Renderer(64, 64, 64)
+    g.set_asset_root(root)
+    for payload in (struct.pack("<Q", (1 << 31)),                                        # 2^31 meshlets = 128 GiB, 8 bytes on disk
+                    struct.pack("<Q", 3) + b"\0" * 64,                                   # three records promised, one present
+                    struct.pack("<Q", 0) * 4 + struct.pack("<Q", (1 << 31) - 1)):        # empty sections, then a huge index count
+        p = os.path.join(root, "bad.meshlet")
+        open(p, "wb").write(payload)
+        with pytest.raises(gpu_engine.ZeldaRenderError) as e:
+            g.load_meshlet_file(p)
+        assert e.value.code == abi.ERR_IO
+    for key, section, bad in (("BackgroundFileName", "Background", "/etc/passwd"), ("BackgroundFileName", "Background", "../../secret.png"),
+                              ("SkydomeFileName", "Skydome", "Content/../../x.png")):
+        w = json.loads(json.dumps(world)); w[section][key] = bad
+        with pytest.raises(gpu_engine.ZeldaRenderError) as e:
+            g.world_load_json(json.dumps(w))
+        assert e.value.code == abi.ERR_ARG, (bad, e.value)
+    w = json.loads(json.dumps(world)); w["Objects"][0]["ProfabName"] = "../Content"
+    with pytest.raises(gpu_engine.ZeldaRenderError) as e:
+        g.world_load_json(json.dumps(w))
+    assert e.value.code == abi.ERR_ARG
+    g.world_load_json(json.dumps(world))          # and the sound world still loads on the same context
+    g.render(); g.finish()
+    g.close()

@@ -427,16 +427,19 @@ def test_record_pool_and_slow_list_overflow_are_reported(oracle_lib, gpu_engine,
     o = oracle_lib.Oracle(W, H, SD)
     scene(o)
     o.render()
-    for var, val in (("ZR_TB_CHUNKS", "8"), ("ZR_TB_SLOW_CAP", "2")):
-        monkeypatch.setenv(var, val)
+    for limits in ((8, 0), (0, 2)):                    # (record chunks, clipped triangles); 0 = default
         g = gpu_engine.Renderer(W, H, SD)
+        g.set_limits(*limits)
         scene(g)
         g.render()
         with pytest.raises(gpu_engine.ZeldaRenderError) as e:
             g.finish()
-        assert e.value.code == abi.ERR_OVERFLOW, (var, e.value)
+        assert e.value.code == abi.ERR_OVERFLOW, (limits, e.value)
+        g.set_limits(0, 0)                             # the same context with the default pools: the frame is whole again
+        g.render(); g.render(); g.finish()
+        d = compare_all(o, g)
+        assert not {k: v for k, v in d.items() if v}, (limits, d)
         g.close()
-        monkeypatch.delenv(var)
     g = gpu_engine.Renderer(W, H, SD)
     scene(g)
     g.render(); g.render(); g.finish()

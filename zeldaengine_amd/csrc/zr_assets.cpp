@@ -64,6 +64,22 @@ static bool search_asset_dir(const std::string& dir, const std::string& file_wit
     return false;
 }
 
+// Names that arrive in a (possibly unauthenticated) world payload - CubemapFileNames, SkydomeFileName, BackgroundFileName, ProfabName -
+// must stay inside the content tree: no absolute path, no ".." component, no NUL.
+bool zr_payload_name_ok(const std::string& name)
+{
+    if (name.empty() || name[0] == '/' || name[0] == '\\' || name.find('\0') != std::string::npos) return false;
+    if (name.size() > 1 && name[1] == ':') return false;                       // drive letter
+    size_t b = 0;
+    while (b <= name.size()) {
+        size_t e = name.find_first_of("/\\", b);
+        if (e == std::string::npos) e = name.size();
+        if (name.compare(b, e - b, "..") == 0) return false;
+        b = e + 1;
+    }
+    return true;
+}
+
 std::string zr_asset_search(const zr_ctx* c, const std::string& name)
 {
     std::error_code ec;
@@ -77,7 +93,7 @@ std::string zr_asset_search(const zr_ctx* c, const std::string& name)
     return literal;                                            // as the engine: the caller then fails to open it
 }
 
-extern "C" int zr_set_asset_root(zr_ctx* c, const char* dir)
+static int zr_set_asset_root_impl(zr_ctx* c, const char* dir)
 {
     if (!c) return ZR_ERR_ARG;
     c->asset_root = dir ? dir : "";
@@ -85,8 +101,12 @@ extern "C" int zr_set_asset_root(zr_ctx* c, const char* dir)
     c->assets_on = dir != nullptr;
     return ZR_OK;
 }
+extern "C" int zr_set_asset_root(zr_ctx* c, const char* dir)
+{
+    return zr_guard(c, [&]() { return zr_set_asset_root_impl(c, dir); });
+}
 
-extern "C" int zr_asset_path_search(zr_ctx* c, const char* name, char* dst, size_t cap, size_t* len)
+static int zr_asset_path_search_impl(zr_ctx* c, const char* name, char* dst, size_t cap, size_t* len)
 {
     if (!c || !name || !len) return ZR_ERR_ARG;
     const std::string r = zr_asset_search(c, name);
@@ -96,6 +116,10 @@ extern "C" int zr_asset_path_search(zr_ctx* c, const char* name, char* dst, size
         memcpy(dst, r.data(), r.size());
     }
     return ZR_OK;
+}
+extern "C" int zr_asset_path_search(zr_ctx* c, const char* name, char* dst, size_t cap, size_t* len)
+{
+    return zr_guard(c, [&]() { return zr_asset_path_search_impl(c, name, dst, cap, len); });
 }
 
 // ------------------------------------------------------------------------------------------------ OBJ
@@ -174,7 +198,7 @@ bool zr_obj_ingest(const std::string& path, std::vector<XkVertex>* v, std::vecto
     return true;
 }
 
-extern "C" int zr_load_obj(const char* path, XkVertex* v, uint32_t* nv, uint32_t* idx, uint32_t* ni)
+static int zr_load_obj_impl(const char* path, XkVertex* v, uint32_t* nv, uint32_t* idx, uint32_t* ni)
 {
     if (!path || !nv || !ni) return ZR_ERR_ARG;
     std::vector<XkVertex> vv; std::vector<uint32_t> ii; std::string err;
@@ -183,6 +207,10 @@ extern "C" int zr_load_obj(const char* path, XkVertex* v, uint32_t* nv, uint32_t
     if (idx) { if (*ni < ii.size()) return ZR_ERR_ARG; memcpy(idx, ii.data(), ii.size() * 4); }
     *nv = (uint32_t)vv.size(); *ni = (uint32_t)ii.size();
     return ZR_OK;
+}
+extern "C" int zr_load_obj(const char* path, XkVertex* v, uint32_t* nv, uint32_t* idx, uint32_t* ni)
+{
+    return zr_guard(nullptr, [&]() { return zr_load_obj_impl(path, v, nv, idx, ni); });
 }
 
 // ------------------------------------------------------------------------------------------------ PNG
@@ -304,7 +332,7 @@ bool zr_png_load(const std::string& path, std::vector<uint8_t>* rgba, uint32_t* 
     return true;
 }
 
-extern "C" int zr_load_png_rgba8(const char* path, uint8_t* dst, size_t cap, uint32_t* w, uint32_t* h)
+static int zr_load_png_rgba8_impl(const char* path, uint8_t* dst, size_t cap, uint32_t* w, uint32_t* h)
 {
     if (!path || !w || !h) return ZR_ERR_ARG;
     std::vector<uint8_t> px; std::string err;
@@ -312,12 +340,16 @@ extern "C" int zr_load_png_rgba8(const char* path, uint8_t* dst, size_t cap, uin
     if (dst) { if (cap < px.size()) return ZR_ERR_ARG; memcpy(dst, px.data(), px.size()); }
     return ZR_OK;
 }
+extern "C" int zr_load_png_rgba8(const char* path, uint8_t* dst, size_t cap, uint32_t* w, uint32_t* h)
+{
+    return zr_guard(nullptr, [&]() { return zr_load_png_rgba8_impl(path, dst, cap, w, h); });
+}
 
 // ------------------------------------------------------------------------------------------------ .meshlet
 
 // LoadMeshletAsset, ZE:7046-7169: five sections, each a size_t count + the raw array (Meshlet 64 B, u32, u8, Vertex 32 B, u32);
 // vertices become XkVertex with colour (1, 1, 1).  Then CreateMeshVertexBuffers<XkMeshIndirect> = zr_mesh_set_meshlets.
-extern "C" int zr_load_meshlet_file(zr_ctx* c, const char* path, uint32_t* mesh_id)
+static int zr_load_meshlet_file_impl(zr_ctx* c, const char* path, uint32_t* mesh_id)
 {
     if (!c || !path || !mesh_id) return ZR_ERR_ARG;
     const std::string full = rooted(c, path);
@@ -325,10 +357,17 @@ extern "C" int zr_load_meshlet_file(zr_ctx* c, const char* path, uint32_t* mesh_
     if (!in) return zr_fail(c, ZR_ERR_IO, "[LoadMeshletAsset] cannot open " + full);
     struct FileVertex { float x, y, z, nx, ny, nz, u, v; };
     std::vector<XkMeshlet> ml; std::vector<uint32_t> mv, indices; std::vector<uint8_t> mt; std::vector<FileVertex> fv;
+    // a section's count is checked against the bytes the file still holds BEFORE anything is allocated: a corrupt header cannot ask for
+    // gigabytes
+    in.seekg(0, std::ios::end);
+    const uint64_t file_bytes = (uint64_t)std::max<std::streamoff>(0, in.tellg());
+    in.seekg(0, std::ios::beg);
     auto section = [&](auto& vec) -> bool {
         uint64_t n = 0;
         in.read((char*)&n, 8);
         if (!in || n > (1ull << 31)) return false;
+        const uint64_t at = (uint64_t)std::max<std::streamoff>(0, in.tellg());
+        if (at > file_bytes || n * sizeof(vec[0]) > file_bytes - at) return false;
         vec.resize((size_t)n);
         in.read((char*)vec.data(), (std::streamsize)(n * sizeof(vec[0])));
         return (bool)in || n == 0;
@@ -347,6 +386,10 @@ extern "C" int zr_load_meshlet_file(zr_ctx* c, const char* path, uint32_t* mesh_
     if (rc) return rc;
     return zr_mesh_set_meshlets(c, *mesh_id, ml.data(), (uint32_t)ml.size(), mv.data(), mv.size(), mt.data(), mt.size());
 }
+extern "C" int zr_load_meshlet_file(zr_ctx* c, const char* path, uint32_t* mesh_id)
+{
+    return zr_guard(c, [&]() { return zr_load_meshlet_file_impl(c, path, mesh_id); });
+}
 
 // ------------------------------------------------------------------------------------------------ Profabs + overrides
 
@@ -354,6 +397,7 @@ static bool load_image(zr_ctx* c, const std::string& path, std::vector<uint8_t>*
 {
     std::string err; uint32_t w = 0, h = 0;
     if (!zr_png_load(path, px, &w, &h, &err)) { zr_fail(c, ZR_ERR_IO, err); return false; }
+    if (w > 8192u || h > 8192u) { zr_fail(c, ZR_ERR_IO, "[WORLD] image larger than 8192 x 8192: " + path); return false; }      // (the engine's own: 1024^2 faces)
     im->rgba8 = px->data(); im->width = w; im->height = h;
     return true;
 }
@@ -365,6 +409,7 @@ int zr_profab_from_disk(zr_ctx* c, const std::string& name, int* found)
 {
     *found = 0;
     std::error_code ec;
+    if (!zr_payload_name_ok(name)) return zr_fail(c, ZR_ERR_ARG, "[WORLD] ProfabName must be a plain name inside Profabs/: " + name);
     const std::string set = rooted(c, "Profabs") + "/" + name, models = set + "/models/", textures = set + "/textures/";
     if (!fs::is_directory(models, ec) || !fs::is_directory(textures, ec)) return ZR_OK;
     std::vector<fs::path> files;
@@ -396,6 +441,9 @@ int zr_profab_from_disk(zr_ctx* c, const std::string& name, int* found)
 int zr_world_apply_overrides(zr_ctx* c, const ZrWorld& w)
 {
     if (!c->assets_on) return ZR_OK;                  // no content tree given: the host sets these through zr_set_cubemap / _skydome / _background
+    if (w.OverrideCubemap) for (const std::string& n : w.CubemapFileNames) if (!zr_payload_name_ok(n)) return zr_fail(c, ZR_ERR_ARG, "[WORLD] file names in a world must be relative to the content tree: " + n);
+    if (w.OverrideSkydome && !zr_payload_name_ok(w.SkydomeFileName)) return zr_fail(c, ZR_ERR_ARG, "[WORLD] file names in a world must be relative to the content tree: " + w.SkydomeFileName);
+    if (w.OverrideBackground && !zr_payload_name_ok(w.BackgroundFileName)) return zr_fail(c, ZR_ERR_ARG, "[WORLD] file names in a world must be relative to the content tree: " + w.BackgroundFileName);
     if (w.OverrideCubemap) {
         std::vector<uint8_t> px[6]; const uint8_t* faces[6]; uint32_t dim = 0;
         for (int f = 0; f < 6; ++f) {
@@ -427,7 +475,7 @@ int zr_world_apply_overrides(zr_ctx* c, const ZrWorld& w)
 // ------------------------------------------------------------------------------------------------ World.json on disk
 
 // XkWorld::Load() from FilePath (ZE:1057-1068; default "Content/World.json", ZE:1027)
-extern "C" int zr_world_load_file(zr_ctx* c, const char* path)
+static int zr_world_load_file_impl(zr_ctx* c, const char* path)
 {
     if (!c) return ZR_ERR_ARG;
     const std::string full = rooted(c, path ? path : "Content/World.json");
@@ -437,9 +485,13 @@ extern "C" int zr_world_load_file(zr_ctx* c, const char* path)
     const std::string text = ss.str();
     return zr_world_load_json(c, text.data(), text.size());
 }
+extern "C" int zr_world_load_file(zr_ctx* c, const char* path)
+{
+    return zr_guard(c, [&]() { return zr_world_load_file_impl(c, path); });
+}
 
 // XkWorld::Save(), ZE:1149-1263
-extern "C" int zr_world_save_file(zr_ctx* c, const char* path)
+static int zr_world_save_file_impl(zr_ctx* c, const char* path)
 {
     if (!c) return ZR_ERR_ARG;
     size_t n = 0;
@@ -453,4 +505,8 @@ extern "C" int zr_world_save_file(zr_ctx* c, const char* path)
     if (!out) return zr_fail(c, ZR_ERR_IO, "[WORLD] cannot write " + full);
     out.write(text.data(), (std::streamsize)text.size());
     return out ? ZR_OK : zr_fail(c, ZR_ERR_IO, "[WORLD] short write to " + full);
+}
+extern "C" int zr_world_save_file(zr_ctx* c, const char* path)
+{
+    return zr_guard(c, [&]() { return zr_world_save_file_impl(c, path); });
 }

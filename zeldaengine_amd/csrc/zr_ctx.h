@@ -4,6 +4,8 @@
 #include <atomic>
 #include <map>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -119,6 +121,7 @@ struct zr_ctx {
     unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048, shadow_blocks = 2048; bool env_shadow_box = true, env_shadow_defer = true;
     uint4* d_slow0 = nullptr; uint32_t slow0_cap = 1u << 18;      // shadow pass: triangles for the clipper (k_tile_slow)
     uint32_t work_capacity = 0, bin_capacity = 0; bool any_images = false;
+    uint32_t limit_record_chunks = 0, limit_slow_triangles = 0;      // zr_set_limits (0 = defaults)
     // two-pass Hi-Z occlusion culling of the camera pass: per work item pixel bbox + least depth (written by the cull),
     // visibility of the previous / current frame (one byte per meshlet-instance, marked by the resolve), the pyramid
     uint2* d_pxrect = nullptr; float* d_zmin = nullptr; uint8_t* d_visflag[2] = { nullptr, nullptr };
@@ -146,7 +149,15 @@ struct zr_ctx {
     int ll_listen_fd = -1; bool ll_pending = false, ll_bind_any = false; ZrWorld ll_world; uint16_t ll_port = 0;
 };
 
-int zr_fail(zr_ctx* c, int code, const std::string& msg);
+int zr_fail(zr_ctx* c, int code, const std::string& msg);      // records the message (never throws), returns code
+// No exception crosses the C-ABI: entry points that build host-side containers run their body through this.
+template <typename F> static inline int zr_guard(zr_ctx* c, F&& body) noexcept
+{
+    try { return body(); }
+    catch (const std::bad_alloc&) { return zr_fail(c, ZR_ERR_OOM, "out of host memory"); }
+    catch (const std::exception& e) { return zr_fail(c, ZR_ERR_IO, e.what()); }
+    catch (...) { return zr_fail(c, ZR_ERR_IO, "unexpected exception"); }
+}
 hipError_t zr_sync_all(zr_ctx* c);     // every stream the library enqueues on
 // helpers implemented in zr_host.cpp and used by zr_world.cpp
 float zr_srgb_decode8(uint32_t c);

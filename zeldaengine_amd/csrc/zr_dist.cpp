@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <new>
 
 struct ZrDist {
     void* lib = nullptr;
@@ -80,7 +81,10 @@ void zr_dist_destroy(zr_ctx* c)
         if (d->rendered[b]) (void)hipEventDestroy(d->rendered[b]);
         if (d->consumed[b]) (void)hipEventDestroy(d->consumed[b]);
     }
-    if (d->shadow) { if (c->d_shadow_ext == d->shadow) c->d_shadow_ext = nullptr; (void)hipFree(d->shadow); }
+    if (d->shadow) {
+        if (c->d_shadow_ext == d->shadow) { c->d_shadow_ext = nullptr; c->shadow_rank = 0; c->shadow_world = 1; }      // back to the whole map
+        (void)hipFree(d->shadow);
+    }
     if (d->shadow_reduced) (void)hipEventDestroy(d->shadow_reduced);
     if (d->comm_s) (void)hipStreamDestroy(d->comm_s);
     if (c->d_tiles_ext == d->tiles[0] || c->d_tiles_ext == d->tiles[1]) c->d_tiles_ext = nullptr;
@@ -90,17 +94,21 @@ void zr_dist_destroy(zr_ctx* c)
 
 hipError_t zr_dist_sync(zr_ctx* c) { return (c->dist && c->dist->comm_s) ? hipStreamSynchronize(c->dist->comm_s) : hipSuccess; }
 
-extern "C" int zr_dist_init(zr_ctx* c, const void* id, size_t bytes, uint32_t rank, uint32_t world, uint32_t dist_flags)
+// Bring-up in two steps so that a host can AGREE between them: zr_dist_prepare is local (librccl, the collective stream, the packed /
+// gathered buffers) and may fail on one rank alone; ncclCommInitRank inside zr_dist_connect is itself a collective - a rank that never
+// reaches it leaves the others blocked inside it - so a host calls it only after every rank has reported a successful prepare.
+extern "C" int zr_dist_prepare(zr_ctx* c, uint32_t rank, uint32_t world, uint32_t dist_flags)
 {
     if (!c) return ZR_ERR_ARG;
-    if (!id || bytes != sizeof(ncclUniqueId) || world == 0 || rank >= world) return zr_fail(c, ZR_ERR_ARG, "zr_dist_init: bad id / rank / world");
-    if (c->dist) return zr_fail(c, ZR_ERR_STATE, "zr_dist_init: already initialised");
+    if (world == 0 || rank >= world) return zr_fail(c, ZR_ERR_ARG, "zr_dist_prepare: bad rank / world");
+    if (c->dist) return zr_fail(c, ZR_ERR_STATE, "zr_dist_prepare: already initialised");
     if (rank != c->cfg.tile_rank || world != c->cfg.tile_world)
-        return zr_fail(c, ZR_ERR_ARG, "zr_dist_init: rank / world differ from the context's tile_rank / tile_world");
+        return zr_fail(c, ZR_ERR_ARG, "zr_dist_prepare: rank / world differ from the context's tile_rank / tile_world");
     if (world == 1 && !(c->cfg.flags & ZR_FLAG_PACKED_TILES))
-        return zr_fail(c, ZR_ERR_ARG, "zr_dist_init: a world of one needs ZR_FLAG_PACKED_TILES (the packed tile path)");
+        return zr_fail(c, ZR_ERR_ARG, "zr_dist_prepare: a world of one needs ZR_FLAG_PACKED_TILES (the packed tile path)");
     HIPCHK(c, hipSetDevice(c->device));
-    ZrDist* d = new ZrDist();
+    ZrDist* d = new (std::nothrow) ZrDist();
+    if (!d) return zr_fail(c, ZR_ERR_OOM, "zr_dist_prepare: out of memory");
     c->dist = d;
     std::string err;
     if (!load_rccl(d, &err)) { zr_dist_destroy(c); return zr_fail(c, ZR_ERR_UNSUPPORTED, err); }
@@ -109,22 +117,48 @@ extern "C" int zr_dist_init(zr_ctx* c, const void* id, size_t bytes, uint32_t ra
     auto bail = [&](int code, const std::string& m) { zr_dist_destroy(c); return zr_fail(c, code, m); };
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (hipStreamCreateWithPriority(&d->comm_s, hipStreamNonBlocking, least) != hipSuccess) return bail(ZR_ERR_DEVICE, "zr_dist_init: stream");
+    if (hipStreamCreateWithPriority(&d->comm_s, hipStreamNonBlocking, least) != hipSuccess) return bail(ZR_ERR_DEVICE, "zr_dist_prepare: stream");
     for (int b = 0; b < 2; ++b) {
         if (hipMalloc((void**)&d->tiles[b], d->tile_bytes) != hipSuccess || hipMalloc((void**)&d->gathered[b], d->tile_bytes * world) != hipSuccess ||
             hipMemset(d->tiles[b], 0, d->tile_bytes) != hipSuccess ||
             hipEventCreateWithFlags(&d->rendered[b], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&d->consumed[b], hipEventDisableTiming) != hipSuccess) return bail(ZR_ERR_DEVICE, "zr_dist_init: buffers");
+            hipEventCreateWithFlags(&d->consumed[b], hipEventDisableTiming) != hipSuccess) return bail(ZR_ERR_DEVICE, "zr_dist_prepare: buffers");
     }
     if (d->split_shadow) {
         if (hipMalloc((void**)&d->shadow, (size_t)c->SD * c->SD * 4) != hipSuccess ||
-            hipEventCreateWithFlags(&d->shadow_reduced, hipEventDisableTiming) != hipSuccess) return bail(ZR_ERR_DEVICE, "zr_dist_init: shadow buffer");
-        c->d_shadow_ext = d->shadow; c->shadow_rank = rank; c->shadow_world = world;
+            hipEventCreateWithFlags(&d->shadow_reduced, hipEventDisableTiming) != hipSuccess) return bail(ZR_ERR_DEVICE, "zr_dist_prepare: shadow buffer");
     }
-    ncclUniqueId u; memcpy(&u, id, sizeof u);
-    const ncclResult_t r = d->CommInitRank(&d->comm, (int)world, u, (int)rank);
-    if (r != ncclSuccess) return bail(ZR_ERR_DEVICE, std::string("ncclCommInitRank: ") + d->GetErrorString(r));
     return ZR_OK;
+}
+
+extern "C" int zr_dist_connect(zr_ctx* c, const void* id, size_t bytes)
+{
+    if (!c) return ZR_ERR_ARG;
+    ZrDist* d = c->dist;
+    if (!d) return zr_fail(c, ZR_ERR_STATE, "zr_dist_connect: zr_dist_prepare first");
+    if (d->comm) return zr_fail(c, ZR_ERR_STATE, "zr_dist_connect: already connected");
+    if (!id || bytes != sizeof(ncclUniqueId)) return zr_fail(c, ZR_ERR_ARG, "zr_dist_connect: bad id");
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId u; memcpy(&u, id, sizeof u);
+    const ncclResult_t r = d->CommInitRank(&d->comm, (int)d->world, u, (int)d->rank);
+    if (r != ncclSuccess) {
+        const std::string m = std::string("ncclCommInitRank: ") + d->GetErrorString(r);
+        d->comm = nullptr;
+        zr_dist_destroy(c);
+        return zr_fail(c, ZR_ERR_DEVICE, m);
+    }
+    // only a connected context draws a share of the shadow casters: a host that keeps using a context whose bring-up failed through
+    // plain zr_render must get the whole map
+    if (d->split_shadow) { c->d_shadow_ext = d->shadow; c->shadow_rank = d->rank; c->shadow_world = d->world; }
+    return ZR_OK;
+}
+
+extern "C" int zr_dist_init(zr_ctx* c, const void* id, size_t bytes, uint32_t rank, uint32_t world, uint32_t dist_flags)
+{
+    if (!c) return ZR_ERR_ARG;
+    if (!id || bytes != sizeof(ncclUniqueId)) return zr_fail(c, ZR_ERR_ARG, "zr_dist_init: bad id");
+    const int rc = zr_dist_prepare(c, rank, world, dist_flags);
+    return rc != ZR_OK ? rc : zr_dist_connect(c, id, bytes);
 }
 
 // One frame of this rank: render -> (all-gather + untile on the collective stream, overlapped with the next frame's rendering).
@@ -132,7 +166,7 @@ extern "C" int zr_dist_frame(zr_ctx* c)
 {
     if (!c) return ZR_ERR_ARG;
     ZrDist* d = c->dist;
-    if (!d) return zr_fail(c, ZR_ERR_STATE, "zr_dist_frame: zr_dist_init first");
+    if (!d || !d->comm) return zr_fail(c, ZR_ERR_STATE, "zr_dist_frame: zr_dist_init (or zr_dist_prepare + zr_dist_connect) first");
     HIPCHK(c, hipSetDevice(c->device));
     const int b = (int)(d->k & 1u);
     d->k++;

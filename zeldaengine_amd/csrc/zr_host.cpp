@@ -17,7 +17,11 @@
     return zr_fail((c), ZR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e)); } while (0)
 #define ARGCHK(c, cond) do { if (!(cond)) return zr_fail((c), ZR_ERR_ARG, "bad argument: " #cond); } while (0)
 
-int zr_fail(zr_ctx* c, int code, const std::string& msg) { if (c) c->err = msg; return code; }
+int zr_fail(zr_ctx* c, int code, const std::string& msg)
+{
+    if (c) { try { c->err = msg; } catch (...) { c->err.clear(); } }      // (called from catch blocks: must not throw itself)
+    return code;
+}
 
 // Everything the library has enqueued: the host's stream (shadow pipeline, lighting) and its own camera lane.
 hipError_t zr_sync_all(zr_ctx* c)
@@ -180,8 +184,13 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         if ((e = getenv("ZR_DEBUG_SKIP_LIGHT"))) c->env_skip_light = (uint32_t)atoi(e);     // bits: 1 PCF, 2 lights, 4 reflection
         if ((e = getenv("ZR_LIGHT_LIST_MIN"))) c->env_light_list_min = atoi(e);
         c->env_no_empty_px = getenv("ZR_NO_EMPTY_PIXEL") != nullptr;
+        c->env_serial = getenv("ZR_SERIAL_PASSES") != nullptr;      // same frame, one stream (= ZR_FLAG_SERIAL_PASSES)
+        if ((e = getenv("ZR_LANES"))) c->three_lanes = atoi(e) >= 3;
+        if ((e = getenv("ZR_SHADOW_BOX_CULL"))) c->env_shadow_box = atoi(e) != 0;
+        if ((e = getenv("ZR_SHADOW_DEFER"))) c->env_shadow_defer = atoi(e) != 0;
+#else
+        if (c->cfg.flags & ZR_FLAG_MESHLET_BINS) { delete c; return ZR_ERR_UNSUPPORTED; }      // the A/B rasteriser exists in -DZR_DIAG builds only
 #endif
-        c->env_serial = getenv("ZR_SERIAL_PASSES") != nullptr;      // same frame, one stream (= ZR_FLAG_SERIAL_PASSES): profiling only
     }
     ok &= hipHostMalloc((void**)&c->h_view_ring, sizeof(XkView) * zr_ctx::VIEW_RING, hipHostMallocDefault) == hipSuccess;
     for (auto& e : c->view_ev) ok &= hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
@@ -191,7 +200,6 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         ok &= hipStreamCreateWithPriority(&c->cam_s, hipStreamNonBlocking, greatest) == hipSuccess;
-        if (const char* e = getenv("ZR_LANES")) c->three_lanes = atoi(e) >= 3;
         if (c->three_lanes) {      // (only then: every stream takes one of the process's few hardware queues)
             ok &= hipStreamCreateWithPriority(&c->shadow_s, hipStreamNonBlocking, least) == hipSuccess;
             ok &= hipStreamCreateWithPriority(&c->light_s, hipStreamNonBlocking, least) == hipSuccess;
@@ -204,10 +212,10 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     if (ok) { zr_launch_fill64(c->d_vis, (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM, n, c->stream); ok &= hipStreamSynchronize(c->stream) == hipSuccess; }
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->raster_blocks = (uint32_t)prop.multiProcessorCount * 8u; }
     c->shadow_blocks = c->raster_blocks;
-    if (const char* e = getenv("ZR_SHADOW_BOX_CULL")) c->env_shadow_box = atoi(e) != 0;
-    if (const char* e = getenv("ZR_SHADOW_DEFER")) c->env_shadow_defer = atoi(e) != 0;
     if (ok) ok &= dev_alloc(&c->d_slow0, 4ull * c->slow0_cap) == hipSuccess;
+#ifdef ZR_DIAG
     if (const char* e = getenv("ZR_SHADOW_BLOCKS")) c->shadow_blocks = (uint32_t)std::max(1, atoi(e));
+#endif
     {   // Hi-Z pyramid: level l = max depth per (8 << l)^2 pixel block
         size_t tot = 0;
         for (int l = 0; l < 4; ++l) { c->hiz.hw[l] = (c->W + (8u << l) - 1) / (8u << l); c->hiz.hh[l] = (c->H + (8u << l) - 1) / (8u << l); tot += (size_t)c->hiz.hw[l] * c->hiz.hh[l]; }
@@ -298,7 +306,7 @@ extern "C" uint32_t zr_tile_owner(uint32_t tx, uint32_t ty, uint32_t world)
     return world <= 1 ? 0u : ((tx >> ZR_SUPERTILE_SHIFT) + (ty >> ZR_SUPERTILE_SHIFT) * ZR_SUPERTILE_SKEW) % world;
 }
 
-extern "C" int zr_tile_partition(uint32_t width, uint32_t height, uint32_t world, uint32_t rank, uint32_t* owned, uint32_t* n_owned,
+static int zr_tile_partition_impl(uint32_t width, uint32_t height, uint32_t world, uint32_t rank, uint32_t* owned, uint32_t* n_owned,
                                  uint32_t* slots_per_rank)
 {
     if (!width || !height || !world || rank >= world || !n_owned || !slots_per_rank) return ZR_ERR_ARG;
@@ -314,6 +322,10 @@ extern "C" int zr_tile_partition(uint32_t width, uint32_t height, uint32_t world
     for (uint32_t k : counts) *slots_per_rank = std::max(*slots_per_rank, k);
     return ZR_OK;
 }
+extern "C" int zr_tile_partition(uint32_t width, uint32_t height, uint32_t world, uint32_t rank, uint32_t* owned, uint32_t* n_owned, uint32_t* slots_per_rank)
+{
+    return zr_guard(nullptr, [&]() { return zr_tile_partition_impl(width, height, world, rank, owned, n_owned, slots_per_rank); });
+}
 
 extern "C" int zr_set_stream(zr_ctx* c, void* s)
 {
@@ -327,7 +339,7 @@ extern "C" int zr_set_stream(zr_ctx* c, void* s)
 
 // ------------------------------------------------------------------------------------------------ scene
 
-extern "C" int zr_mesh_create(zr_ctx* c, const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, uint32_t* mesh_id)
+static int zr_mesh_create_impl(zr_ctx* c, const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, uint32_t* mesh_id)
 {
     if (!c) return ZR_ERR_ARG;
     ARGCHK(c, v && idx && mesh_id && nv > 0 && ni > 0 && ni % 3 == 0);
@@ -337,6 +349,10 @@ extern "C" int zr_mesh_create(zr_ctx* c, const XkVertex* v, uint32_t nv, const u
     c->meshes.push_back(std::move(m));
     *mesh_id = (uint32_t)c->meshes.size() - 1;
     return ZR_OK;
+}
+extern "C" int zr_mesh_create(zr_ctx* c, const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, uint32_t* mesh_id)
+{
+    return zr_guard(c, [&]() { return zr_mesh_create_impl(c, v, nv, idx, ni, mesh_id); });
 }
 
 static int validate_meshlets(zr_ctx* c, const ZrMesh& m, const XkMeshlet* ml, uint32_t nm, size_t nmv, const uint32_t* mv,
@@ -355,7 +371,7 @@ static int validate_meshlets(zr_ctx* c, const ZrMesh& m, const XkMeshlet* ml, ui
     return ZR_OK;
 }
 
-extern "C" int zr_mesh_set_meshlets(zr_ctx* c, uint32_t mesh_id, const XkMeshlet* ml, uint32_t nm,
+static int zr_mesh_set_meshlets_impl(zr_ctx* c, uint32_t mesh_id, const XkMeshlet* ml, uint32_t nm,
                                     const uint32_t* mv, size_t nmv, const uint8_t* mt, size_t nmt)
 {
     if (!c) return ZR_ERR_ARG;
@@ -397,8 +413,12 @@ extern "C" int zr_mesh_set_meshlets(zr_ctx* c, uint32_t mesh_id, const XkMeshlet
     m.has_meshlets = true;
     return ZR_OK;
 }
+extern "C" int zr_mesh_set_meshlets(zr_ctx* c, uint32_t mesh_id, const XkMeshlet* ml, uint32_t nm, const uint32_t* mv, size_t nmv, const uint8_t* mt, size_t nmt)
+{
+    return zr_guard(c, [&]() { return zr_mesh_set_meshlets_impl(c, mesh_id, ml, nm, mv, nmv, mt, nmt); });
+}
 
-extern "C" int zr_mesh_build_meshlets(zr_ctx* c, uint32_t mesh_id, uint32_t max_v, uint32_t max_t, float cone_weight)
+static int zr_mesh_build_meshlets_impl(zr_ctx* c, uint32_t mesh_id, uint32_t max_v, uint32_t max_t, float cone_weight)
 {
     if (!c) return ZR_ERR_ARG;
     ARGCHK(c, mesh_id < c->meshes.size());
@@ -411,10 +431,14 @@ extern "C" int zr_mesh_build_meshlets(zr_ctx* c, uint32_t mesh_id, uint32_t max_
     m.has_meshlets = true;
     return ZR_OK;
 }
+extern "C" int zr_mesh_build_meshlets(zr_ctx* c, uint32_t mesh_id, uint32_t max_v, uint32_t max_t, float cone_weight)
+{
+    return zr_guard(c, [&]() { return zr_mesh_build_meshlets_impl(c, mesh_id, max_v, max_t, cone_weight); });
+}
 
 // Context-free form of the clusteriser: the ZeldaMeshlet tool's BuildMeshlets (ZM:132-172) as a library call.  Pure host
 // code (runs without a GPU).  Pass NULL outputs to query the sizes.  tri_order[k] = index-buffer triangle of slot k.
-extern "C" int zr_meshlets_build(const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, uint32_t max_v, uint32_t max_t,
+static int zr_meshlets_build_impl(const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, uint32_t max_v, uint32_t max_t,
                                  float cone_weight, XkMeshlet* ml, uint32_t* nm, uint32_t* mv, size_t* nmv, uint8_t* mt, size_t* nmt,
                                  uint32_t* tri_order)
 {
@@ -432,8 +456,12 @@ extern "C" int zr_meshlets_build(const XkVertex* v, uint32_t nv, const uint32_t*
     if (tri_order) memcpy(tri_order, ms.tri_order.data(), ms.tri_order.size() * 4);
     return ZR_OK;
 }
+extern "C" int zr_meshlets_build(const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, uint32_t max_v, uint32_t max_t, float cone_weight, XkMeshlet* ml, uint32_t* nm, uint32_t* mv, size_t* nmv, uint8_t* mt, size_t* nmt, uint32_t* tri_order)
+{
+    return zr_guard(nullptr, [&]() { return zr_meshlets_build_impl(v, nv, idx, ni, max_v, max_t, cone_weight, ml, nm, mv, nmv, mt, nmt, tri_order); });
+}
 
-extern "C" int zr_mesh_get_meshlets(zr_ctx* c, uint32_t mesh_id, XkMeshlet* ml, uint32_t* nm, uint32_t* mv, size_t* nmv,
+static int zr_mesh_get_meshlets_impl(zr_ctx* c, uint32_t mesh_id, XkMeshlet* ml, uint32_t* nm, uint32_t* mv, size_t* nmv,
                                     uint8_t* mt, size_t* nmt)
 {
     if (!c) return ZR_ERR_ARG;
@@ -447,6 +475,10 @@ extern "C" int zr_mesh_get_meshlets(zr_ctx* c, uint32_t mesh_id, XkMeshlet* ml, 
     if (mv) memcpy(mv, m.ms.mverts.data(), m.ms.mverts.size() * 4);
     if (mt) memcpy(mt, m.ms.mtris.data(), m.ms.mtris.size());
     return ZR_OK;
+}
+extern "C" int zr_mesh_get_meshlets(zr_ctx* c, uint32_t mesh_id, XkMeshlet* ml, uint32_t* nm, uint32_t* mv, size_t* nmv, uint8_t* mt, size_t* nmt)
+{
+    return zr_guard(c, [&]() { return zr_mesh_get_meshlets_impl(c, mesh_id, ml, nm, mv, nmv, mt, nmt); });
 }
 
 int zr_material_prepare(zr_ctx* c, const zr_material* mat, ZrMaterialHost* out)
@@ -542,7 +574,7 @@ int zr_object_add_internal(zr_ctx* c, uint32_t mesh_id, const ZrMaterialHost& ma
     return ZR_OK;
 }
 
-extern "C" int zr_object_add(zr_ctx* c, uint32_t mesh_id, const zr_material* mat, const XkInstanceData* inst, uint32_t n_inst)
+static int zr_object_add_impl(zr_ctx* c, uint32_t mesh_id, const zr_material* mat, const XkInstanceData* inst, uint32_t n_inst)
 {
     if (!c) return ZR_ERR_ARG;
     ARGCHK(c, mesh_id < c->meshes.size() && (n_inst == 0 || inst));
@@ -550,6 +582,20 @@ extern "C" int zr_object_add(zr_ctx* c, uint32_t mesh_id, const zr_material* mat
     int rc = zr_material_prepare(c, mat, &m);
     if (rc) return rc;
     return zr_object_add_internal(c, mesh_id, m, inst, n_inst);
+}
+extern "C" int zr_object_add(zr_ctx* c, uint32_t mesh_id, const zr_material* mat, const XkInstanceData* inst, uint32_t n_inst)
+{
+    return zr_guard(c, [&]() { return zr_object_add_impl(c, mesh_id, mat, inst, n_inst); });
+}
+
+// Capacities of the triangle-record pool (chunks of ZR_TPOOL_CHUNK records) and of the clipped-triangle list, for hosts that size them
+// themselves (0 = the default: 8 records per meshlet-instance, at least 32 Mi; 2^18 triangles).  Takes effect at the next scene upload.
+extern "C" int zr_set_limits(zr_ctx* c, uint32_t record_chunks, uint32_t slow_triangles)
+{
+    if (!c) return ZR_ERR_ARG;
+    c->limit_record_chunks = record_chunks; c->limit_slow_triangles = slow_triangles;
+    c->work_capacity = 0; c->scene_dirty = true;          // the pools are re-made by the next frame
+    return ZR_OK;
 }
 
 extern "C" int zr_scene_clear(zr_ctx* c)
@@ -674,13 +720,16 @@ static int finalize_scene(zr_ctx* c)
     if (c->n_work > c->work_capacity) {
         for (auto& sc : c->sc) { dev_free(sc.rects); dev_free(sc.bins); dev_free(sc.work); dev_free(sc.chunk_tab); }
         dev_free(c->d_pxrect); dev_free(c->d_zmin); dev_free(c->d_visflag[0]); dev_free(c->d_visflag[1]);
-        c->work_capacity = c->n_work;
+        // (a failed allocation below returns with scene_dirty still set and work_capacity 0: the next frame tries again instead of
+        // launching on freed buffers)
+        const uint32_t cap_w = c->n_work;
+        c->work_capacity = 0;
         const uint64_t cap = std::max<uint64_t>(1u << 20, 8ull * c->n_work);
         c->bin_capacity = (uint32_t)std::min<uint64_t>(cap, 0x3FFFFFFFull);
         c->chunk_capacity = c->bin_capacity / ZR_CHUNK + std::max(c->n_tiles, c->sn_tiles) + 1u;
         for (auto& sc : c->sc) {
-            HIPCHK(c, dev_alloc(&sc.rects, c->work_capacity));
-            HIPCHK(c, dev_alloc(&sc.work, c->work_capacity));
+            HIPCHK(c, dev_alloc(&sc.rects, cap_w));
+            HIPCHK(c, dev_alloc(&sc.work, cap_w));
             HIPCHK(c, dev_alloc(&sc.bins, c->bin_capacity));
             HIPCHK(c, dev_alloc(&sc.chunk_tab, c->chunk_capacity));
         }
@@ -691,9 +740,9 @@ static int finalize_scene(zr_ctx* c)
         // capacity as for the meshlet bins: 8 records per meshlet-instance of the scene, at least 32 Mi (1.5 GiB)
         c->tb.n_waves = 8192; c->tb.slow_cap = 1u << 18;
         c->tb.n_chunks = (uint32_t)(std::min<uint64_t>(std::max<uint64_t>(32ull << 20, 8ull * c->n_work), 0x3FFFFFFFull) / ZR_TPOOL_CHUNK);
-        if (const char* e = getenv("ZR_TB_CHUNKS")) c->tb.n_chunks = (uint32_t)std::max(1, atoi(e));      // (tests: a pool that runs dry)
-        if (const char* e = getenv("ZR_TB_SLOW_CAP")) c->tb.slow_cap = (uint32_t)std::max(2, atoi(e));
-        HIPCHK(c, dev_alloc(&c->tb.sel, c->work_capacity));
+        if (c->limit_record_chunks) c->tb.n_chunks = c->limit_record_chunks;      // zr_set_limits (a host sizing the pools; the overflow tests)
+        if (c->limit_slow_triangles) c->tb.slow_cap = std::max(2u, c->limit_slow_triangles);
+        HIPCHK(c, dev_alloc(&c->tb.sel, cap_w));
         HIPCHK(c, dev_alloc(&c->tb.recs, 3ull * c->tb.n_chunks * ZR_TPOOL_CHUNK));
         HIPCHK(c, dev_alloc(&c->tb.idx, (size_t)c->tb.n_chunks * ZR_TPOOL_CHUNK));
         HIPCHK(c, dev_alloc(&c->tb.chunk_fill, c->tb.n_chunks));
@@ -701,8 +750,9 @@ static int finalize_scene(zr_ctx* c)
         HIPCHK(c, dev_alloc(&c->tb.slow, 4ull * c->tb.slow_cap));
         c->chunk_capacity = std::max<uint32_t>(c->chunk_capacity, c->tb.n_chunks * (ZR_TPOOL_CHUNK / ZR_TCHUNK) + 2u * std::max(c->n_tiles, c->sn_tiles) + 1u);
         for (auto& sc : c->sc) { dev_free(sc.chunk_tab); HIPCHK(c, dev_alloc(&sc.chunk_tab, c->chunk_capacity)); }
-        HIPCHK(c, dev_alloc(&c->d_pxrect, c->work_capacity)); HIPCHK(c, dev_alloc(&c->d_zmin, c->work_capacity));
-        HIPCHK(c, dev_alloc(&c->d_visflag[0], c->work_capacity)); HIPCHK(c, dev_alloc(&c->d_visflag[1], c->work_capacity));
+        HIPCHK(c, dev_alloc(&c->d_pxrect, cap_w)); HIPCHK(c, dev_alloc(&c->d_zmin, cap_w));
+        HIPCHK(c, dev_alloc(&c->d_visflag[0], cap_w)); HIPCHK(c, dev_alloc(&c->d_visflag[1], cap_w));
+        c->work_capacity = cap_w;              // every buffer is there
     }
     c->any_images = false;
     for (const ZrObject& d : tab) for (int t = 0; t < 7; ++t) if (d.tex[t].data) c->any_images = true;
@@ -724,7 +774,7 @@ static int upload_texture(zr_ctx* c, const zr_image* tex, bool srgb, uint8_t** d
     return ZR_OK;
 }
 
-extern "C" int zr_set_skydome(zr_ctx* c, const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const zr_image* tex)
+static int zr_set_skydome_impl(zr_ctx* c, const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const zr_image* tex)
 {
     if (!c) return ZR_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -748,8 +798,12 @@ extern "C" int zr_set_skydome(zr_ctx* c, const XkVertex* v, uint32_t nv, const u
     c->sky_set = true;
     return ZR_OK;
 }
+extern "C" int zr_set_skydome(zr_ctx* c, const XkVertex* v, uint32_t nv, const uint32_t* idx, uint32_t ni, const zr_image* tex)
+{
+    return zr_guard(c, [&]() { return zr_set_skydome_impl(c, v, nv, idx, ni, tex); });
+}
 
-extern "C" int zr_set_background(zr_ctx* c, const zr_image* tex)
+static int zr_set_background_impl(zr_ctx* c, const zr_image* tex)
 {
     if (!c) return ZR_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -760,6 +814,10 @@ extern "C" int zr_set_background(zr_ctx* c, const zr_image* tex)
     if (rc) return rc;
     c->bg_set = true;
     return ZR_OK;
+}
+extern "C" int zr_set_background(zr_ctx* c, const zr_image* tex)
+{
+    return zr_guard(c, [&]() { return zr_set_background_impl(c, tex); });
 }
 
 extern "C" int zr_set_sky_flags(zr_ctx* c, int sky, int bg)
@@ -772,7 +830,7 @@ extern "C" int zr_set_sky_flags(zr_ctx* c, int sky, int bg)
 
 // ------------------------------------------------------------------------------------------------ cubemap
 
-extern "C" int zr_set_cubemap(zr_ctx* c, const uint8_t* const faces[6], uint32_t dim)
+static int zr_set_cubemap_impl(zr_ctx* c, const uint8_t* const faces[6], uint32_t dim)
 {
     if (!c) return ZR_ERR_ARG;
     static const uint8_t grey[4] = { 127, 127, 127, 255 };
@@ -820,6 +878,10 @@ extern "C" int zr_set_cubemap(zr_ctx* c, const uint8_t* const faces[6], uint32_t
     c->view.LightsCount[3] = (int32_t)levels;       // CubemapMaxMips, ZE:4308
     c->view_dirty = true;
     return ZR_OK;
+}
+extern "C" int zr_set_cubemap(zr_ctx* c, const uint8_t* const faces[6], uint32_t dim)
+{
+    return zr_guard(c, [&]() { return zr_set_cubemap_impl(c, faces, dim); });
 }
 
 // ------------------------------------------------------------------------------------------------ uniforms
@@ -1091,8 +1153,11 @@ static int shadow_pass(zr_ctx* c, hipStream_t s)
     if (c->d_shadow_ext || !c->shadow_cleared[spar]) zr_launch_fill32((uint32_t*)shadow_buf(c), 0x3F800000u, (size_t)c->SD * c->SD, s);
     c->shadow_cleared[spar] = false;
     ZrHiz Z; memset(&Z, 0, sizeof Z);
-    if (c->env_shadow_box) zr_launch_cull_box(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, s);
-    else zr_launch_cull(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, c->raster_blocks * 4u, s);
+#ifdef ZR_DIAG
+    if (!c->env_shadow_box) zr_launch_cull(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, c->raster_blocks * 4u, s);
+    else
+#endif
+    zr_launch_cull_box(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, s);
     bin_and_raster(c, P, Z, 0, c->sn_tiles, s);
     if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
     raster(c, P, Z, 0, s);
@@ -1119,11 +1184,19 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
     Z.pxrect = hiz_on ? c->d_pxrect : nullptr; Z.zmin = hiz_on ? c->d_zmin : nullptr;
     Z.vis_prev = c->d_visflag[c->vis_cur ^ 1]; Z.vis_now = hiz_on ? c->d_visflag[c->vis_cur] : nullptr;
     Z.phase = 0;
-    const bool tri_bins = !(c->cfg.flags & ZR_FLAG_MESHLET_BINS) && ZR_TILE == 32;
+#ifdef ZR_DIAG
+    const bool tri_bins = !(c->cfg.flags & ZR_FLAG_MESHLET_BINS) && ZR_TILE == 32;      // A/B: the meshlet-binned rasteriser for the camera pass too
+#else
+    constexpr bool tri_bins = true;
+    static_assert(ZR_TILE == 32, "the triangle-binned camera pass is written for 32 x 32 tiles");
+#endif
     c->last_two_round = hiz_on && c->vis_history;
     // (triangle-binned pass: the cull kernel also compacts round 1's list - the survivors that owned a pixel last frame, or all of them)
-    if (tri_bins) zr_launch_cull_box(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, s, c->tb.sel, c->last_two_round ? Z.vis_prev : nullptr);
-    else zr_launch_cull(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, c->raster_blocks * 4u, s);
+#ifdef ZR_DIAG
+    if (!tri_bins) zr_launch_cull(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, c->raster_blocks * 4u, s);
+    else
+#endif
+    zr_launch_cull_box(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, s, c->tb.sel, c->last_two_round ? Z.vis_prev : nullptr);
     if (hiz_on && P.use_worklist) HIPCHK(c, hipMemsetAsync(c->d_visflag[c->vis_cur], 0, c->n_work, s));     // else k_cull clears them
     const bool two = c->last_two_round;
     auto bin = [&](int slot) { if (!tri_bins) bin_and_raster(c, P, Z, slot, c->n_tiles, s); else if (slot == 2) tri_select(c, P, Z, slot, s); };
@@ -1159,7 +1232,7 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
     return ZR_OK;
 }
 
-extern "C" int zr_render_shadow(zr_ctx* c)
+static int zr_render_shadow_impl(zr_ctx* c)
 {
     if (!c) return ZR_ERR_ARG;
     c->camera_on_lane = false;
@@ -1168,6 +1241,10 @@ extern "C" int zr_render_shadow(zr_ctx* c)
     if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, c->stream));
     if (rc == ZR_OK) c->stage = 1;
     return rc;
+}
+extern "C" int zr_render_shadow(zr_ctx* c)
+{
+    return zr_guard(c, [&]() { return zr_render_shadow_impl(c); });
 }
 
 extern "C" int zr_render_gbuffer(zr_ctx* c)
@@ -1211,10 +1288,14 @@ static int geometry_passes(zr_ctx* c)
     return rc;
 }
 
-extern "C" int zr_render_geometry(zr_ctx* c)
+static int zr_render_geometry_impl(zr_ctx* c)
 {
     if (!c) return ZR_ERR_ARG;
     return geometry_passes(c);
+}
+extern "C" int zr_render_geometry(zr_ctx* c)
+{
+    return zr_guard(c, [&]() { return zr_render_geometry_impl(c); });
 }
 
 extern "C" int zr_stream_wait_shadow(zr_ctx* c, void* hip_stream)
@@ -1297,7 +1378,7 @@ extern "C" int zr_render_lighting(zr_ctx* c)
 // frame's lighting.  zr_render therefore runs two lanes: the camera pipeline on the library's high-priority stream cam_s, and
 // shadow pipeline -> lighting on the host's stream.  Whatever the host enqueues on its stream after zr_render is ordered after
 // the finished frame, as before.  ZR_FLAG_SERIAL_PASSES keeps everything on the one stream, as the staged entry points do.
-extern "C" int zr_render(zr_ctx* c)
+static int zr_render_impl(zr_ctx* c)
 {
     if (!c) return ZR_ERR_ARG;
     c->in_render = true;
@@ -1306,6 +1387,10 @@ extern "C" int zr_render(zr_ctx* c)
     c->in_render = false;
     if (rc != ZR_OK) c->stage = 0;
     return rc;
+}
+extern "C" int zr_render(zr_ctx* c)
+{
+    return zr_guard(c, [&]() { return zr_render_impl(c); });
 }
 
 // Multi-GPU shadow pass: this context draws instances i with i % world == rank (non-instanced draws count as instance 0).
@@ -1432,12 +1517,14 @@ extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out)
         (void)hipStreamSynchronize(c->stream);
         (void)hipMemcpy(&c->h_stats, c->d_stats, sizeof(ZrDevStats), hipMemcpyDeviceToHost);
     }
+#ifdef ZR_DIAG
     if (getenv("ZR_DUMP_STATS")) {     // diagnostics: the raw device block
         const ZrDevStats& h = c->h_stats;
         fprintf(stderr, "zr stats: survivors %u %u %u  bin_entries %u %u %u  n_sel %u %u %u  n_slow %u %u %u  pool_used %u %u %u  hiz_culled %u  n_chunks %u %u %u\n",
                 h.survivors[0], h.survivors[1], h.survivors[2], h.bin_entries[0], h.bin_entries[1], h.bin_entries[2], h.n_sel[0], h.n_sel[1], h.n_sel[2],
                 h.n_slow[0], h.n_slow[1], h.n_slow[2], h.pool_used[0], h.pool_used[1], h.pool_used[2], h.hiz_culled, h.n_chunks[0], h.n_chunks[1], h.n_chunks[2]);
     }
+#endif
     memset(out, 0, sizeof *out);
     for (int i = 0; i < 2; ++i) {
         out->work_items[i] = c->last_work[i]; out->survivors[i] = c->h_stats.survivors[i]; out->bin_entries[i] = c->h_stats.bin_entries[i];

@@ -389,6 +389,7 @@ __device__ __forceinline__ bool cull_stage_a(const ZrPass& P, const ZrObject* __
     return alive;
 }
 
+#ifdef ZR_DIAG      // the exact 64-lane cull: A/B builds only (ZR_SHADOW_BOX_CULL=0, ZR_FLAG_MESHLET_BINS)
 template <int MODE, bool WORKLIST>
 __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
                                               uint32_t* __restrict__ rects, uint2* __restrict__ pxrect, float* __restrict__ zmin,
@@ -485,6 +486,8 @@ __global__ __launch_bounds__(256) void k_cull(ZrPass P, const ZrObject* __restri
         }
     }
 }
+
+#endif   // ZR_DIAG
 
 // The triangle-binned camera pass needs no tile rectangle from the cull - k_geom tests every triangle exactly - only "is it gone" and,
 // for the Hi-Z test of round 2, a pixel box and a least depth that BOUND the meshlet's.  Those come from the eight corners of the
@@ -2602,6 +2605,7 @@ void zr_launch_instance_prep(const XkInstanceData* in, ZrInstance* out, uint32_t
 {
     hipLaunchKernelGGL(k_instance_prep, dim3((n + 255) / 256), dim3(256), 0, s, in, out, n, instanced);
 }
+#ifdef ZR_DIAG
 void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, const ZrHiz& Z, ZrDevStats* stats,
                     int slot, uint32_t n_waves, hipStream_t s)
 {
@@ -2622,6 +2626,7 @@ void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint3
         } else hipLaunchKernelGGL((k_cull<ZR_MODE_SHADOW, false>), dim3(blocks), b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot);
     }
 }
+#endif
 void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, const ZrHiz& Z, ZrDevStats* stats,
                         int slot, hipStream_t s, ZrBinEntry* sel, const uint8_t* vis_prev)
 {
@@ -2690,11 +2695,18 @@ void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4*
                              uint32_t n_blocks, const ZrHiz& Z, hipStream_t s, uint4* slow, uint32_t slow_cap, const uint32_t* tiles, uint32_t n_tiles)
 {
     const float* none = nullptr;
-    if (P.mode == ZR_MODE_GBUFFER && Z.phase == 2u)
+#ifdef ZR_DIAG      // the camera pass through this rasteriser: A/B builds only (ZR_FLAG_MESHLET_BINS)
+    if (P.mode == ZR_MODE_GBUFFER && Z.phase == 2u) {
         hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_GBUFFER, true, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, (const float*)Z.lvl[0], Z.hw[0], Z.hh[0], (uint4*)nullptr, 0u);
-    else if (P.mode == ZR_MODE_GBUFFER)
+        return;
+    }
+    if (P.mode == ZR_MODE_GBUFFER) {
         hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_GBUFFER, false, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u, (uint4*)nullptr, 0u);
-    else if (slow) {    // shadow pass: clipped triangles go through a list + k_tile_slow
+        return;
+    }
+#endif
+    if (P.mode == ZR_MODE_GBUFFER) return;      // (not reached: the product's camera pass is triangle-binned)
+    if (slow) {    // shadow pass: clipped triangles go through a list + k_tile_slow
         hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false, true>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u, slow, slow_cap);
         if (n_tiles) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_SHADOW, true>), dim3(n_tiles), dim3(256), 0, s, P, tiles, slow, slow_cap, stats, slot, (unsigned long long*)nullptr, shadow_bits);
     } else

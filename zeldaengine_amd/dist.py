@@ -162,10 +162,24 @@ def make_distributed(width, height, shadow_dim=1024, device_index=0, rank=0, wor
     return DistributedRenderer(width, height, shadow_dim, device_index, rank, world, flags, split_shadow=split_shadow)
 
 
-def _try_native(width, height, shadow_dim, device_index, rank, world, flags, split_shadow):
-    """-> (NativeDistributedRenderer, None) or (None, reason); every rank returns the same kind (the outcome is agreed over
-    torch.distributed, which is initialised when world > 1)."""
+def _agree(ok):
+    """MIN over ranks of a flag, on whatever the process group offers (a CPU tensor when gloo is there: no RCCL communicator of
+    torch's is created for it)."""
     import torch
+    import torch.distributed as dist
+    backend = str(dist.get_backend())
+    dev = torch.device("cpu") if "gloo" in backend else torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item()) == 1
+
+
+def _try_native(width, height, shadow_dim, device_index, rank, world, flags, split_shadow):
+    """-> (NativeDistributedRenderer, None) or (None, reason); every rank returns the same kind.
+
+    ncclCommInitRank is a collective: a rank that fails BEFORE it (no context, no librccl, no memory) would leave the others blocked
+    inside it.  So the bring-up has two agreed steps: (1) everything local - the id on rank 0, the renderer, zr_dist_prepare - then a
+    MIN over ranks; only if every rank got that far (2) zr_dist_connect, and a second MIN on its outcome."""
     import torch.distributed as dist
     from . import engine
     uid, err = None, ""
@@ -176,21 +190,25 @@ def _try_native(width, height, shadow_dim, device_index, rank, world, flags, spl
             err = "zr_dist_unique_id: %s" % e
     box = [uid, err]
     dist.broadcast_object_list(box, src=0)
-    uid, err = box
-    if uid is None:
-        return None, err
-    dr, ok = None, 1
-    try:
-        dr = NativeDistributedRenderer(width, height, shadow_dim, device_index, rank, world, flags, split_shadow, unique_id=uid)
-    except Exception as e:          # noqa: BLE001
-        ok, err = 0, "rank %d: %s" % (rank, e)
-    dev = torch.device("cuda", device_index) if dist.get_backend() == "nccl" else torch.device("cpu")
-    t = torch.tensor([ok], dtype=torch.int32, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    if int(t.item()) == 0:
+    uid, err0 = box
+    dr, err = None, ""
+    if uid is not None:
+        try:
+            dr = NativeDistributedRenderer(width, height, shadow_dim, device_index, rank, world, flags, split_shadow, connect=False)
+        except Exception as e:          # noqa: BLE001
+            err = "rank %d: %s" % (rank, e)
+    if not _agree(dr is not None):
         if dr is not None:
             dr.close()
-        return None, err or "the native RCCL host failed on another rank"
+        return None, err0 or err or "the native RCCL host could not be prepared on another rank"
+    try:
+        dr.connect(uid)
+        ok = True
+    except Exception as e:              # noqa: BLE001
+        ok, err = False, "rank %d: %s" % (rank, e)
+    if not _agree(ok):
+        dr.close()
+        return None, err or "ncclCommInitRank failed on another rank"
     return dr, None
 
 
@@ -198,24 +216,34 @@ class NativeDistributedRenderer:
     """One rank of the partition with the library's own RCCL host (zr_dist_*).  torch.distributed (already initialised when
     world > 1) is used ONCE, to hand rank 0's ncclUniqueId to the other ranks; frames are enqueued by one C call each."""
 
-    def __init__(self, width, height, shadow_dim=1024, device_index=0, rank=0, world=1, flags=0, split_shadow=False, unique_id=None):
+    def __init__(self, width, height, shadow_dim=1024, device_index=0, rank=0, world=1, flags=0, split_shadow=False, unique_id=None,
+                 connect=True):
         import torch
         from . import abi, engine
         self.torch = torch
         self.rank, self.world = rank, world
         if world == 1:
             flags |= abi.FLAG_PACKED_TILES
-        uid = unique_id
-        if uid is None:
-            uid = engine.dist_unique_id() if rank == 0 else bytes(128)
-            if world > 1:
-                import torch.distributed as dist
-                box = [uid]
-                dist.broadcast_object_list(box, src=0)
-                uid = box[0]
         self.r = engine.Renderer(width, height, shadow_dim, device=device_index, tile_rank=rank, tile_world=world, flags=flags)
         try:
-            self.r.dist_init(uid, rank, world, split_shadow)
+            self.r.dist_prepare(rank, world, split_shadow)          # local: may fail on this rank alone
+        except Exception:
+            self.r.close()
+            raise
+        if connect:                                                  # (hosts that agree between the two steps pass connect=False)
+            uid = unique_id
+            if uid is None:
+                uid = engine.dist_unique_id() if rank == 0 else bytes(128)
+                if world > 1:
+                    import torch.distributed as dist
+                    box = [uid]
+                    dist.broadcast_object_list(box, src=0)
+                    uid = box[0]
+            self.connect(uid)
+
+    def connect(self, unique_id):
+        try:
+            self.r.dist_connect(unique_id)                           # ncclCommInitRank: collective
         except Exception:
             self.r.close()
             raise

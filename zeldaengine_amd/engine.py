@@ -49,6 +49,7 @@ def lib():
         "zr_meshlets_build": [vp, u32, vp, u32, u32, u32, C.c_float, vp, C.POINTER(u32), vp, C.POINTER(sz), vp, C.POINTER(sz), vp],
         "zr_object_add": [vp, u32, vp, vp, u32],
         "zr_scene_clear": [vp],
+        "zr_set_limits": [vp, u32, u32],
         "zr_object_count": [vp, C.POINTER(u32)],
         "zr_object_get_instances": [vp, u32, C.POINTER(u32), vp, C.POINTER(u32)],
         "zr_set_cubemap": [vp, vp, u32],
@@ -82,6 +83,8 @@ def lib():
         "zr_tile_partition": [u32, u32, u32, u32, vp, C.POINTER(u32), C.POINTER(u32)],
         "zr_dist_unique_id": [vp, sz],
         "zr_dist_init": [vp, vp, sz, u32, u32, u32],
+        "zr_dist_prepare": [vp, u32, u32, u32],
+        "zr_dist_connect": [vp, vp, sz],
         "zr_dist_frame": [vp],
         "zr_profab_register": [vp, C.c_char_p, u32, vp],
         "zr_world_load_json": [vp, C.c_char_p, sz],
@@ -284,6 +287,10 @@ class Renderer:
     def scene_clear(self):
         self._chk(self.L.zr_scene_clear(self.h))
 
+    def set_limits(self, record_chunks=0, slow_triangles=0):
+        """Capacities of the triangle-record pool (chunks of 1024) and the clipped-triangle list; 0 = defaults."""
+        self._chk(self.L.zr_set_limits(self.h, record_chunks, slow_triangles))
+
     def object_count(self):
         n = C.c_uint32()
         self._chk(self.L.zr_object_count(self.h, C.byref(n)))
@@ -455,6 +462,15 @@ class Renderer:
         """Native multi-GPU host: the library calls RCCL itself (zr_dist_frame = render + all-gather + composite)."""
         self._dist_id = bytes(unique_id)
         self._chk(self.L.zr_dist_init(self.h, self._dist_id, len(self._dist_id), rank, world, 1 if split_shadow else 0))
+
+    def dist_prepare(self, rank, world, split_shadow=False):
+        """The local half of dist_init (librccl, collective stream, buffers): safe to fail on one rank alone."""
+        self._chk(self.L.zr_dist_prepare(self.h, rank, world, 1 if split_shadow else 0))
+
+    def dist_connect(self, unique_id):
+        """ncclCommInitRank: a collective - call it only when every rank's dist_prepare succeeded."""
+        self._dist_id = bytes(unique_id)
+        self._chk(self.L.zr_dist_connect(self.h, self._dist_id, len(self._dist_id)))
 
     def dist_frame(self):
         self._chk(self.L.zr_dist_frame(self.h))

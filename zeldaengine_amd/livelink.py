@@ -21,13 +21,13 @@ def sendDataToEngine(data, port=DEFAULT_PORT, host="localhost", timeout=5.0):
             s.settimeout(timeout)
             s.connect((host, port))
             s.sendall(payload)
-            response = s.recv(1024)
-            print("Received:", response.decode())
-            return response
+            reply = s.recv(1024)             # the engine half-closes without a payload: b''
+            print("livelink: %d bytes delivered to %s:%d, reply %r" % (len(payload), host, port, reply))
+            return reply
     except ConnectionRefusedError:
-        print(f"Connection to port {port} failed. Make sure there's a server listening on this port.")
-    except Exception as e:      # noqa: BLE001  (the reference client swallows and prints, ZeldaUntitled.py:25-26)
-        print(f"An error occurred: {e}")
+        print("livelink: nobody is listening on %s:%d (is the engine / zr_livelink_serve running?)" % (host, port))
+    except OSError as e:        # like the reference client, a failed delivery is reported, not raised (ZeldaUntitled.py:23-26)
+        print("livelink: delivery to %s:%d failed: %s" % (host, port, e))
     return None
 
 
