@@ -110,6 +110,7 @@ def main():
                     help="per-kernel hipEvents are recorded on every n-th timed frame (each record is a ~6 us stream bubble); "
                          "0 = steps // 12 clamped to 5..8 (a short run still leaves four frames in five undisturbed)")
     ap.add_argument("--cube-dim", type=int, default=1024, help="cubemap face edge (the engine's is 1024: 11 mips)")
+    ap.add_argument("--serial", action="store_true", help="profiling: the whole frame on ONE stream (ZR_FLAG_SERIAL_PASSES), every kernel alone on the GPU")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -164,7 +165,7 @@ def main():
         engine.load_scene(dr_.r, cfg_)
         return dr_
 
-    dr = make_renderer(cfg)
+    dr = make_renderer(cfg, flags=abi.FLAG_SERIAL_PASSES if args.serial else 0)
     r = dr.r
     fallback = getattr(dr, "native_fallback", None)
     interval = args.timing_interval if args.timing_interval > 0 else max(min(5, args.steps), min(8, args.steps // 12))

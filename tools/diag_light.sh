@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 for sk in 0 1 2 4 7; do
   R=$GRAFT_REPO_ROOT
   rm -rf $R/gpurun_out/dl
-  ZR_DEBUG_SKIP_LIGHT=$sk ZR_SERIAL_PASSES=1 ZELDA_RENDER_LIB=$R/zeldaengine_amd/libzr_diag.so timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -d $R/gpurun_out/dl -o d -- python3 $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-extras > /dev/null 2>&1
+  ZR_DEBUG_SKIP_LIGHT=$sk ZELDA_RENDER_LIB=$R/zeldaengine_amd/libzr_diag.so timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -d $R/gpurun_out/dl -o d -- python3 $R/bench.py --serial --steps 12 --warmup 4 --no-cpu-baseline --no-extras > /dev/null 2>&1
   python3 - $sk $R <<'PY'
 import csv, glob, sys
 sk, R = sys.argv[1], sys.argv[2]

@@ -1,7 +1,7 @@
 # usage (GPU box): bash tools/kstats.sh [bench args]   -> one-stream per-kernel average durations (rocprofv3 --kernel-trace --stats)
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_ks
-ZR_SERIAL_PASSES=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_ks -o s -- python3 $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-extras "$@" > /dev/null 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_ks -o s -- python3 $GRAFT_REPO_ROOT/bench.py --serial --steps 40 --warmup 10 --no-cpu-baseline --no-extras "$@" > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT; python - <<PY
 import csv, glob
 f = glob.glob("gpurun_out/prof_ks/**/*kernel_stats.csv", recursive=True)[0]
