@@ -155,7 +155,7 @@ def test_config4_scale_culling_paths_agree(gpu_engine):
         assert np.array_equal(a[1][t].view(np.uint8), b[1][t].view(np.uint8)), "GBuffer target %d" % t
     assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
     assert a[3]["covered_pixels"] == b[3]["covered_pixels"] and a[3]["overflow"] == 0 and b[3]["overflow"] == 0
-    assert a[3]["hiz_culled"] > 100000 and a[3]["survivors"][1] < b[3]["survivors"][1] // 4
+    assert a[3]["hiz_culled"] > 100000 and a[3]["survivors"][1] < b[3]["survivors"][1] // 3
 
 
 def test_soak_two_frames_in_flight(oracle_lib, gpu_engine):
@@ -201,7 +201,7 @@ def test_config5_full_size_culling_paths_agree(gpu_engine):
         assert np.array_equal(a[1][t].view(np.uint8), b[1][t].view(np.uint8)), "GBuffer target %d" % t
     assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
     assert a[3]["covered_pixels"] == b[3]["covered_pixels"] and a[3]["overflow"] == 0 and b[3]["overflow"] == 0
-    assert a[3]["round1_survivors"] > 0 and a[3]["hiz_culled"] > 100000 and a[3]["survivors"][1] < b[3]["survivors"][1] // 4
+    assert a[3]["round1_survivors"] > 0 and a[3]["hiz_culled"] > 100000 and a[3]["survivors"][1] < b[3]["survivors"][1] // 1.9
     assert len(np.unique(a[0].reshape(-1, 4), axis=0)) > 1000       # a lit frame, not a constant
 
 
@@ -233,13 +233,13 @@ def test_config5_reduced_against_the_oracle_with_a_moving_camera(oracle_lib, gpu
 
 
 def test_camera_pass_against_the_oracle_with_and_without_hiz_rounds(oracle_lib, gpu_engine):
-    """The triangle-binned camera pass (k_cull_box, k_geom, k_index, k_tile) over the history sequence, with and without the Hi-Z rounds:
-    both must give the oracle's frame, and the slow-triangle list must be exercised (the ground plane crosses the near plane; the
+    """The triangle-binned camera pass (k_cull_box, k_geom, k_index, k_tile, k_retest) over the history sequence - with the Hi-Z rounds and
+    round 1's guess from last frame's pyramid, without the guess, without the rounds: all must give the oracle's frame, and the slow-triangle list must be exercised (the ground plane crosses the near plane; the
     wall's triangles are longer than 64 pixels).  (The meshlet-binned A/B rasteriser for the camera pass exists in -DZR_DIAG builds only:
     the product library refuses ZR_FLAG_MESHLET_BINS.)"""
     W, H, SD = 384, 216, 256
     o = oracle_lib.Oracle(W, H, SD)
-    gs = [gpu_engine.Renderer(W, H, SD, flags=f) for f in (0, abi.FLAG_NO_HIZ)]
+    gs = [gpu_engine.Renderer(W, H, SD, flags=f) for f in (0, abi.FLAG_NO_HIZ, abi.FLAG_NO_PREDICT)]
     for r in [o] + gs:
         _crowd(r, 300, 11)
     d, p, s = _lights()
@@ -253,7 +253,10 @@ def test_camera_pass_against_the_oracle_with_and_without_hiz_rounds(oracle_lib, 
             _identical(o, g, "frame %d, path %d" % (i, k))
     st = [g.stats() for g in gs]
     assert all(x["overflow"] == 0 for x in st)
-    assert st[0]["covered_pixels"] == st[1]["covered_pixels"]
+    assert st[0]["covered_pixels"] == st[1]["covered_pixels"] == st[2]["covered_pixels"]
+    # round 1's guess (last frame's pyramid) was in use on the default context, put triangles off, and k_retest had to draw some of them
+    # after all (the camera moves between these frames); without the guess nothing is deferred
+    assert st[0]["deferred_triangles"] > 0 and st[2]["deferred_triangles"] == 0 and st[1]["deferred_triangles"] == 0
     for g in gs:
         g.close()
     with pytest.raises(gpu_engine.ZeldaRenderError):
@@ -271,7 +274,7 @@ def test_record_pool_chunks_beyond_the_first(oracle_lib, gpu_engine):
     g.render(); g.render(); g.finish()
     st = g.stats()
     assert st["overflow"] == 0
-    assert st["bin_entries"][1] > 8192 * 1024 // 2, st           # records: well beyond what the waves' first chunks hold on average
+    assert st["bin_entries"][1] > 8192 * 256 * 2, st            # records: well beyond what the waves' own chunks (256 each) hold
     o = oracle_lib.Oracle(cfg["width"], cfg["height"], 1024)
     oracle_lib.load_scene(o, cfg)
     o.set_threads(16)

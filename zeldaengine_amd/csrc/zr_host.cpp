@@ -163,7 +163,8 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         ok &= dev_alloc(&sc.tile_offset, mt) == hipSuccess;
         ok &= dev_alloc(&sc.tile_cursor, mt) == hipSuccess;
         ok &= dev_alloc(&sc.chunk_offset, mt) == hipSuccess;
-        if (ok) ok &= hipMemset(sc.tile_count, 0, mt * 4) == hipSuccess;
+        if (ok) ok &= hipMemset(sc.tile_count, 0, mt * 4) == hipSuccess;       // k_geom counts into zeroes, k_index advances cursors from zero:
+        if (ok) ok &= hipMemset(sc.tile_cursor, 0, mt * 4) == hipSuccess;      // k_tile leaves both that way for the next round
     }
     {   // the clear values of ZE:3427-3433, as resolve_pixel writes them for an empty pixel
         ok &= dev_alloc(&c->d_clear_px, 64) == hipSuccess;
@@ -246,6 +247,12 @@ static void free_mesh_buffers(ZrMesh& m)
     m.uploaded = false;
 }
 
+static void free_tri_bins(zr_ctx* c)
+{
+    dev_free(c->tb.sel); dev_free(c->tb.recA); dev_free(c->tb.recB); dev_free(c->tb.rtile); dev_free(c->tb.srtA); dev_free(c->tb.srtB);
+    dev_free(c->tb.slow); dev_free(c->tb.chunk_fill); dev_free(c->tb.wave_culled); dev_free(c->tb.wave_direct); dev_free(c->tb.wave_retest);
+}
+
 static void free_scene(zr_ctx* c)
 {
     for (auto& o : c->objects) { dev_free(o.d_inst); for (auto& t : o.d_tex) dev_free(t); }
@@ -290,7 +297,7 @@ extern "C" void zr_destroy(zr_ctx* c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     dev_free(c->d_vis); dev_free(c->d_slow0);
     dev_free(c->d_pxrect); dev_free(c->d_zmin); dev_free(c->d_visflag[0]); dev_free(c->d_visflag[1]); dev_free(c->d_hiz);
-    dev_free(c->tb.sel); dev_free(c->tb.recs); dev_free(c->tb.idx); dev_free(c->tb.slow); dev_free(c->tb.chunk_fill); dev_free(c->tb.wave_culled);
+    free_tri_bins(c);
     for (auto& fr : c->evr) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ev_end) if (e) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -588,8 +595,9 @@ extern "C" int zr_object_add(zr_ctx* c, uint32_t mesh_id, const zr_material* mat
     return zr_guard(c, [&]() { return zr_object_add_impl(c, mesh_id, mat, inst, n_inst); });
 }
 
-// Capacities of the triangle-record pool (chunks of ZR_TPOOL_CHUNK records) and of the clipped-triangle list, for hosts that size them
-// themselves (0 = the default: 8 records per meshlet-instance, at least 32 Mi; 2^18 triangles).  Takes effect at the next scene upload.
+// Capacities of the triangle-record pool (chunks of ZR_TPOOL_CHUNK = 256 records, the 3 x 8192 chunks the waves of k_geom start in included)
+// and of the clipped-triangle list, for hosts that size them themselves (0 = the default: 8 records per meshlet-instance, at least 32 Mi,
+// plus the waves' own chunks; 2^18 triangles).  Takes effect at the next frame.
 extern "C" int zr_set_limits(zr_ctx* c, uint32_t record_chunks, uint32_t slow_triangles)
 {
     if (!c) return ZR_ERR_ARG;
@@ -733,22 +741,31 @@ static int finalize_scene(zr_ctx* c)
             HIPCHK(c, dev_alloc(&sc.bins, c->bin_capacity));
             HIPCHK(c, dev_alloc(&sc.chunk_tab, c->chunk_capacity));
         }
-        // triangle-binned camera pass: triangle records live in chunks of ZR_TPOOL_CHUNK; every wave of k_geom's fixed grid starts in
-        // its own chunk and takes further ones from the pool (a pool that runs dry is reported like a bin overflow).  1.5 GB of
-        // 288: HBM is not scarce.
-        dev_free(c->tb.sel); dev_free(c->tb.recs); dev_free(c->tb.idx); dev_free(c->tb.slow); dev_free(c->tb.chunk_fill); dev_free(c->tb.wave_culled);
-        // capacity as for the meshlet bins: 8 records per meshlet-instance of the scene, at least 32 Mi (1.5 GiB)
+        // triangle-binned camera pass: triangle records (32 B + a 4-byte tile id) live in chunks of ZR_TPOOL_CHUNK; every wave of k_geom's
+        // fixed grid starts in two chunks of its own (drawn / deferred records) and takes further ones from the pool (a pool that runs dry
+        // is reported like a bin overflow); k_index moves the drawn ones into a second array in tile order.  Sized from the scene:
+        // 8 records per meshlet-instance, at least 32 Mi (3 x 8192 x 256 on top are the waves' own chunks: drawn, deferred, round 2) - 68 bytes
+        // apiece, 2.6 GB of 288 reserved, touched as far as a frame needs.
+        free_tri_bins(c);
         c->tb.n_waves = 8192; c->tb.slow_cap = 1u << 18;
-        c->tb.n_chunks = (uint32_t)(std::min<uint64_t>(std::max<uint64_t>(32ull << 20, 8ull * c->n_work), 0x3FFFFFFFull) / ZR_TPOOL_CHUNK);
-        if (c->limit_record_chunks) c->tb.n_chunks = c->limit_record_chunks;      // zr_set_limits (a host sizing the pools; the overflow tests)
+        const uint64_t n_rec = std::min<uint64_t>(std::max<uint64_t>(32ull << 20, 8ull * c->n_work) + 3ull * c->tb.n_waves * ZR_TPOOL_CHUNK, 0x3FFFFFFFull);
+        c->tb.n_chunks = (uint32_t)(n_rec / ZR_TPOOL_CHUNK);
+        if (c->limit_record_chunks) c->tb.n_chunks = c->limit_record_chunks;      // zr_set_limits (a host sizing the pool; the overflow tests)
         if (c->limit_slow_triangles) c->tb.slow_cap = std::max(2u, c->limit_slow_triangles);
+        c->tb.sorted_cap = (uint32_t)std::min<uint64_t>((uint64_t)c->tb.n_chunks * ZR_TPOOL_CHUNK, 0x7FFFFFFFull);
         HIPCHK(c, dev_alloc(&c->tb.sel, cap_w));
-        HIPCHK(c, dev_alloc(&c->tb.recs, 3ull * c->tb.n_chunks * ZR_TPOOL_CHUNK));
-        HIPCHK(c, dev_alloc(&c->tb.idx, (size_t)c->tb.n_chunks * ZR_TPOOL_CHUNK));
+        HIPCHK(c, dev_alloc(&c->tb.recA, (size_t)c->tb.n_chunks * ZR_TPOOL_CHUNK));
+        HIPCHK(c, dev_alloc(&c->tb.recB, (size_t)c->tb.n_chunks * ZR_TPOOL_CHUNK));
+        HIPCHK(c, dev_alloc(&c->tb.rtile, (size_t)c->tb.n_chunks * ZR_TPOOL_CHUNK));
+        HIPCHK(c, dev_alloc(&c->tb.srtA, c->tb.sorted_cap));
+        HIPCHK(c, dev_alloc(&c->tb.srtB, c->tb.sorted_cap));
         HIPCHK(c, dev_alloc(&c->tb.chunk_fill, c->tb.n_chunks));
+        HIPCHK(c, hipMemset(c->tb.chunk_fill, 0, (size_t)c->tb.n_chunks * 4));
         HIPCHK(c, dev_alloc(&c->tb.wave_culled, c->tb.n_waves));
+        HIPCHK(c, dev_alloc(&c->tb.wave_direct, c->tb.n_waves));
+        HIPCHK(c, dev_alloc(&c->tb.wave_retest, 2ull * c->tb.n_waves));
         HIPCHK(c, dev_alloc(&c->tb.slow, 4ull * c->tb.slow_cap));
-        c->chunk_capacity = std::max<uint32_t>(c->chunk_capacity, c->tb.n_chunks * (ZR_TPOOL_CHUNK / ZR_TCHUNK) + 2u * std::max(c->n_tiles, c->sn_tiles) + 1u);
+        c->chunk_capacity = std::max<uint32_t>(c->chunk_capacity, c->tb.sorted_cap / ZR_TCHUNK + 2u * std::max(c->n_tiles, c->sn_tiles) + 1u);
         for (auto& sc : c->sc) { dev_free(sc.chunk_tab); HIPCHK(c, dev_alloc(&sc.chunk_tab, c->chunk_capacity)); }
         HIPCHK(c, dev_alloc(&c->d_pxrect, cap_w)); HIPCHK(c, dev_alloc(&c->d_zmin, cap_w));
         HIPCHK(c, dev_alloc(&c->d_visflag[0], cap_w)); HIPCHK(c, dev_alloc(&c->d_visflag[1], cap_w));
@@ -757,6 +774,7 @@ static int finalize_scene(zr_ctx* c)
     c->any_images = false;
     for (const ZrObject& d : tab) for (int t = 0; t < 7; ++t) if (d.tex[t].data) c->any_images = true;
     c->vis_history = false;         // work item numbering changed: last frame's visibility says nothing about this scene
+    c->hiz_valid = false;
     c->scene_dirty = false;
     return ZR_OK;
 }
@@ -1077,14 +1095,18 @@ static void tri_select(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hip
 {
     zr_launch_select(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->tb, c->d_stats, slot, s);
 }
-static void tri_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s, bool slow_too)
+// Round 1 (or the only round): records -> tile order -> tile raster.  Round 2: the few triangles the pyramid lets through are rasterised
+// where they are found (k_geom<true>), then round 1's deferred triangles are looked at again (k_retest).  One k_tile_slow after the
+// last round draws the clipped / long triangles of both.
+static void tri_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s, bool last)
 {
     const zr_ctx::Scratch& sc = c->sc[1];
     if (P.n_work == 0) return;          // nothing to draw: the pass is its clear
-    zr_launch_geom(P, Z, c->tb, sc.tile_count, c->d_stats, slot, s);
-    zr_launch_scan_tri(sc.tile_count, sc.tile_offset, sc.tile_cursor, sc.chunk_tab, c->chunk_capacity, c->n_tiles, c->tb, c->d_stats, slot, s);
-    zr_launch_index(c->tb, sc.tile_offset, sc.tile_cursor, c->d_stats, slot, s);
-    zr_launch_tile(P, sc.chunk_tab, c->tb, c->d_owned, c->n_owned, c->d_stats, slot, c->d_vis, c->raster_blocks, s, slow_too);
+    zr_launch_geom(P, Z, c->tb, sc.tile_count, c->d_stats, slot, c->d_vis, s);
+    if (slot == 2 && c->predict_now) zr_launch_retest(P, Z, c->tb, c->d_stats, c->d_vis, s);      // round 1's deferred triangles
+    zr_launch_index(c->tb, c->n_tiles, sc.tile_count, sc.tile_cursor, sc.chunk_tab, c->chunk_capacity, c->d_stats, slot, s);
+    zr_launch_tile(P, sc.chunk_tab, c->tb, sc.tile_count, sc.tile_cursor, c->n_tiles, c->d_stats, slot, c->d_vis, c->raster_blocks, s);
+    if (last) zr_launch_tile_slow_camera(P, c->tb, c->d_owned, c->n_owned, c->d_stats, slot, c->d_vis, slot == 2 && c->predict_now, s);
 }
 static void raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s)
 {
@@ -1199,6 +1221,10 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
     zr_launch_cull_box(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, s, c->tb.sel, c->last_two_round ? Z.vis_prev : nullptr);
     if (hiz_on && P.use_worklist) HIPCHK(c, hipMemsetAsync(c->d_visflag[c->vis_cur], 0, c->n_work, s));     // else k_cull clears them
     const bool two = c->last_two_round;
+    // round 1 may consult LAST frame's pyramid (still in the arrays) to put off triangles that were hidden then; k_retest settles them
+    // against this frame's.  Only a guess is needed (any subset may be drawn first), so a stale pyramid costs time, never pixels.
+    c->predict_now = tri_bins && two && c->hiz_valid && !(c->cfg.flags & ZR_FLAG_NO_PREDICT);
+    Z.predict = c->predict_now ? 1u : 0u;
     auto bin = [&](int slot) { if (!tri_bins) bin_and_raster(c, P, Z, slot, c->n_tiles, s); else if (slot == 2) tri_select(c, P, Z, slot, s); };
     auto rast = [&](int slot) { if (tri_bins) tri_raster(c, P, Z, slot, s, slot == 2 || !two); else raster(c, P, Z, slot, s); };
     if (c->last_two_round) {
@@ -1208,7 +1234,8 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
         rast(1);
         if (ev) HIPCHK(c, hipEventRecord(ev[4], s));
         zr_launch_hiz_build(c->d_vis, c->W, c->H, Z, s);
-        Z.phase = 2;
+        c->hiz_valid = true;
+        Z.phase = 2; Z.predict = 0u;
         bin(2);
         if (ev) HIPCHK(c, hipEventRecord(ev[5], s));
         rast(2);
@@ -1227,7 +1254,8 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
     if (ev) HIPCHK(c, hipEventRecord(ev[6], s));
     zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_lut, c->d_unorm_lut, Z.vis_now, c->d_stats, s);
     if (ev) HIPCHK(c, hipEventRecord(ev[7], s));
-    if (hiz_on) { c->vis_history = true; c->vis_cur ^= 1; } else c->vis_history = false;
+    if (hiz_on) { c->vis_history = true; c->vis_cur ^= 1; } else { c->vis_history = false; c->hiz_valid = false; }
+    if (!two) c->hiz_valid = false;        // a one-round frame builds no pyramid: what the arrays hold is two frames old or older
     HIPCHK(c, hipGetLastError());
     return ZR_OK;
 }
@@ -1531,6 +1559,7 @@ extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out)
     }
     out->survivors[1] += c->h_stats.survivors[2]; out->bin_entries[1] += c->h_stats.bin_entries[2];    // both rounds of the camera pass
     out->hiz_culled = c->h_stats.hiz_culled; out->round1_survivors = c->last_two_round ? c->h_stats.survivors[1] : 0;
+    out->deferred_triangles = c->h_stats.n_deferred; out->deferred_drawn = c->h_stats.n_retest_kept; out->direct_triangles = c->h_stats.bin_entries[2];
     out->covered_pixels = c->h_stats.covered; out->covered_shadow_texels = c->h_stats.covered_shadow; out->overflow = c->h_stats.overflow;
     return rc;
 }

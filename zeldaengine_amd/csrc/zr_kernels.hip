@@ -15,9 +15,12 @@
 //                     merge touched keys into HBM (atomic min); DEFER: clipped triangles go to a list for k_tile_slow
 //   camera pass: triangle-level binning
 //   k_select          round 2: the meshlet-instances the Hi-Z pyramid does not hide -> 32-byte records
-//   k_geom<HIZ>       wave per meshlet-instance: vertices once, exact per-triangle tests, one 48-byte record per (triangle, tile)
-//   k_scan_tri / k_index   per-tile offsets and work units; record indices grouped by tile
-//   k_tile / k_tile_slow   lane per record: edge set-up + walk into the tile's LDS keys; clipped triangles through raster_clipped
+//   k_geom<false>     round 1, wave per meshlet-instance: vertices once, exact per-triangle tests, one 32-byte record per (triangle, tile);
+//                     triangles last frame's pyramid hides are deferred to k_retest instead
+//   k_index           per-tile offsets and work units (every workgroup scans the counts itself), records MOVED into tile order
+//   k_tile / k_tile_slow   lane per record, streamed: edge set-up + walk into the tile's LDS keys; clipped triangles through raster_clipped
+//   k_geom<true>      round 2: as round 1 + this frame's pyramid per meshlet and per triangle; survivors rasterised directly (atomicMin)
+//   k_retest          round 1's deferred triangles against this frame's pyramid, survivors rasterised directly
 //   k_hiz_build       max-depth pyramid of the key buffer after round 1 (two-pass occlusion culling of the camera pass)
 //   k_resolve_gbuffer BaseScene.frag per pixel from the key buffer; SoA GBuffer planes, coalesced row stores; marks the
 //                     meshlet-instances that own a pixel (next frame's round 1)
@@ -799,61 +802,6 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
         stats->n_chunks[slot] = min(cpart[1023], chunk_cap);
         stats->chunk_counter[slot] = 0;
         if (part[1023] > capacity) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
-    }
-}
-
-// The triangle-binned pass: exclusive scan of the per-tile record counts into tile_offset, work units of <= chunk records of ONE
-// tile (the counters and cursors of the tiles sit ZR_TSTRIDE words apart: atomics on one cache line queue up behind each other, and
-// neighbouring tiles are hit together); also zeroes the counts / cursors, resets the work counter and the record pool, and books the meshlets k_geom's waves dropped
-// behind the pyramid.  (Sorting a tile's records by walk size - four classes by box area, or by longest side with every class padded
-// to whole waves - was tried: k_tile executed the same instructions, k_geom and k_index paid for four times the bins.)
-__global__ __launch_bounds__(1024) void k_scan_tri(uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
-                                                   uint32_t* __restrict__ tile_cursor, uint4* __restrict__ chunk_tab, uint32_t chunk_cap,
-                                                   uint32_t n_tiles, const uint32_t* __restrict__ wave_culled, uint32_t n_waves,
-                                                   ZrDevStats* __restrict__ stats, int slot, uint32_t chunk)
-{
-    __shared__ uint32_t wtot[16], cwtot[16], ctot_s[16];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const uint32_t per = (n_tiles + 1023u) / 1024u;
-    const uint32_t b = min(n_tiles, tid * per), e = min(n_tiles, b + per);
-    uint32_t nc = 0;
-    for (uint32_t i = tid; i < n_waves; i += 1024u) nc += wave_culled[i];
-    uint32_t s = 0, cs = 0;
-    for (uint32_t i = b; i < e; ++i) { const uint32_t t = tile_count[i * ZR_TSTRIDE]; s += t; cs += (t + chunk - 1u) / chunk; }
-    // scan: inside the wave by shuffles, across the 16 waves through LDS - one barrier instead of twenty (this kernel is one
-    // workgroup on the camera pipeline's critical path)
-    uint32_t incl = s, cincl = cs;
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = (uint32_t)__shfl_up((int)incl, o), cv = (uint32_t)__shfl_up((int)cincl, o);
-        if ((int)lane >= o) { incl += v; cincl += cv; }
-    }
-    nc = (uint32_t)wave_sum((int)nc);
-    if (lane == 63u) { wtot[wv] = incl; cwtot[wv] = cincl; }
-    if (lane == 0u) ctot_s[wv] = nc;
-    __syncthreads();
-    uint32_t wpre = 0, cwpre = 0, tot = 0, ctot = 0, culled = 0;
-    for (uint32_t i = 0; i < 16u; ++i) {
-        const uint32_t a = wtot[i], c = cwtot[i];
-        if (i < wv) { wpre += a; cwpre += c; }
-        tot += a; ctot += c; culled += ctot_s[i];
-    }
-    uint32_t run = wpre + incl - s, crun = cwpre + cincl - cs;
-    for (uint32_t i = b; i < e; ++i) {
-        const uint32_t t = tile_count[i * ZR_TSTRIDE], nu = (t + chunk - 1u) / chunk;
-        tile_offset[i] = run;
-        for (uint32_t k = 0; k < nu; ++k)
-            if (crun + k < chunk_cap) chunk_tab[crun + k] = make_uint4(i, run + k * chunk, run + min(t, (k + 1u) * chunk), 0u);
-        run += t; crun += nu;
-        tile_count[i * ZR_TSTRIDE] = 0; tile_cursor[i * ZR_TSTRIDE] = 0;
-    }
-    if (tid == 0) {
-        stats->bin_entries[slot] = tot;               // triangle records of the round
-        stats->n_chunks[slot] = min(ctot, chunk_cap);
-        stats->chunk_counter[slot] = 0;
-        stats->pool_used[slot] = stats->pool_next[slot]; stats->pool_next[slot] = 0;
-        if (ctot > chunk_cap) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
-        // the round's survivors: what was selected minus the meshlets k_geom dropped behind the pyramid
-        stats->hiz_culled += culled; stats->survivors[slot] = stats->n_sel[slot] - culled;
     }
 }
 
@@ -1719,25 +1667,167 @@ __global__ __launch_bounds__(256) void k_select(ZrPass P, const ZrObject* __rest
     if (threadIdx.x == 0 && nocc) atomicAdd(&stats->hiz_culled, nocc);
 }
 
-// One wave per selected meshlet-instance: vertices -> LDS, triangles -> records.
-// Records live in chunks of ZR_TPOOL_CHUNK: wave k of the grid starts in chunk k and takes further ones from a pool (one atomic per
-// ZR_TPOOL_CHUNK records); chunk_fill[] says how many records each chunk holds.  A round is ONE launch whatever the scene's size.
-// Round 2 (HIZ): a meshlet whose snapped vertex box lies behind the pyramid is dropped after the vertex phase (the test k_cull's
-// stage B makes in the meshlet-binned path, with the same box), and every triangle is tested once more by itself.
+// ---- triangle records ----
+// 32 bytes per (triangle, tile): three snapped vertices RELATIVE TO THE TILE'S ORIGIN as int16 pairs (a small triangle - every edge under
+// 64 px - that reaches the tile has its vertices within [-16384, 24576] sub-pixel units of it) with their depth bits, and the primitive id:
+//   plane A: (X0 | Y0 << 16, z0, X1 | Y1 << 16, z1)      plane B: (X2 | Y2 << 16, z2, prim, 0)
+// plus the tile id in a separate dword stream (k_index reads 4 bytes per record, not the record, to find where it goes).  Records live
+// in chunks of ZR_TPOOL_CHUNK, structure-of-arrays inside a chunk (every store and load of a wave is one contiguous run).
+// Two kinds of chunks: DRAWN records go through k_index / k_tile now; DEFERRED ones (round 1 predicted them hidden, see k_geom) wait for
+// k_retest.  chunk_fill[c] = records | kind << 31.
+#define ZR_CHUNK_DEFERRED 0x80000000u
+#define ZR_CHUNK_ROUND2   0x40000000u       // drawn records of round 2 (k_index / k_tile run once per round)
+#define ZR_CHUNK_COUNT(cf) ((cf) & 0x3FFFFFFFu)
+__device__ __forceinline__ uint32_t pack_xy(int X, int Y) { return ((uint32_t)X & 0xFFFFu) | ((uint32_t)Y << 16); }
+struct RecWriter {                 // wave-uniform state of one record stream of a wave
+    uint32_t cur, fill;            // the chunk being filled (>= n_chunks: the pool ran dry) and its fill
+};
+// room for `n` more records (wave-uniform): closes the chunk and takes one from the pool when it would overflow; false: pool dry
+__device__ __forceinline__ bool rec_reserve(RecWriter& W, uint32_t n, uint32_t kind, uint32_t lane, const ZrTriBins& B, ZrDevStats* __restrict__ stats, int slot)
+{
+    if (W.cur < B.n_chunks && W.fill + n > ZR_TPOOL_CHUNK) {
+        uint32_t nx_c = 0;
+        if (lane == 0) { B.chunk_fill[W.cur] = W.fill | kind; nx_c = 3u * B.n_waves + atomicAdd(&stats->pool_next[1], 1u); }      // (one pool for both rounds)
+        W.cur = min((uint32_t)__builtin_amdgcn_readfirstlane((int)nx_c), B.n_chunks);
+        W.fill = 0;
+    }
+    if (W.cur >= B.n_chunks) { if (lane == 0) { stats->overflow = 1u; stats->overflow_sticky = 1u; } return false; }
+    return true;
+}
+__device__ __forceinline__ void rec_store(const ZrTriBins& B, uint32_t pos, const int4& r0, const int4& r1, const int4& r2, uint32_t prim, uint32_t tile, int tx, int ty)
+{
+    const int ox = tx * (TILE * 256), oy = ty * (TILE * 256);
+    B.recA[pos] = make_uint4(pack_xy(r0.x - ox, r0.y - oy), (uint32_t)r0.z, pack_xy(r1.x - ox, r1.y - oy), (uint32_t)r1.z);
+    B.recB[pos] = make_uint4(pack_xy(r2.x - ox, r2.y - oy), (uint32_t)r2.z, prim, 0u);
+    B.rtile[pos] = tile;
+}
+struct RecTri { SV a, b, c; uint32_t prim; };
+__device__ __forceinline__ RecTri rec_load(const uint4 qa, const uint4 qb)
+{
+    RecTri t;
+    t.a.X = (int)(short)(qa.x & 0xFFFFu); t.a.Y = (int)qa.x >> 16; t.a.z = zr_u2f(qa.y); t.a.rw = 0.0f;
+    t.b.X = (int)(short)(qa.z & 0xFFFFu); t.b.Y = (int)qa.z >> 16; t.b.z = zr_u2f(qa.w); t.b.rw = 0.0f;
+    t.c.X = (int)(short)(qb.x & 0xFFFFu); t.c.Y = (int)qb.x >> 16; t.c.z = zr_u2f(qb.y); t.c.rw = 0.0f;
+    t.prim = qb.z;
+    return t;
+}
+
+// Up to 64 small triangles (every edge under 64 px; lane l holds triangle l, `draw` says whether it is to be drawn) straight into the
+// frame's key buffer, FLATTENED: the pixels of all their clipped boxes form one sequence, and the wave takes 64 of them per step, whatever
+// triangle they belong to (owner found by a search over the running sum of the box areas; the owner's set-up travels by ds_bpermute).
+// Every lane is busy on every step and the guarding reads of the key buffer are 64 independent loads per step - a lane-per-triangle walk
+// waits for one such read per pixel, and unguarded atomics (most of these fragments lose: the triangles that reach this path are the ones a
+// conservative pyramid test could not reject) run at ~16 G/s when scattered like this.
+// Same integers and floats as raster_sub<GBUFFER, SMALL> on absolute coordinates: an edge value is E(origin) + steps * increment (exact
+// integer arithmetic either way, all below 2^31: the box is clipped to the target and the edges are under 2^14), the depth is the same
+// fma chain from the same operands.  Only for the FEW triangles of round 2 / k_retest: device-scope atomics are slow.
+__device__ __forceinline__ void raster_flat(const ZrPass& P, const SV& v0, const SV& v1, const SV& v2, uint32_t prim, bool draw, uint32_t lane,
+                                            unsigned long long* __restrict__ vis64)
+{
+    // ---- per-triangle set-up, in the owner's lane
+    int x0 = 0, y0 = 0, bw = 0, area = 0, E0 = 0, E1 = 0, E2 = 0, sx0 = 0, sx1 = 0, sx2 = 0, sy0 = 0, sy1 = 0, sy2 = 0;
+    float gx = 0.0f, gy = 0.0f, zlo = 0.0f, zhi = 0.0f;
+    if (draw) {
+        const int dX1 = v1.X - v0.X, dY1 = v1.Y - v0.Y, dX2 = v2.X - v0.X, dY2 = v2.Y - v0.Y;
+        const int A = dX1 * dY2 - dX2 * dY1;
+        x0 = max((imin3(v0.X, v1.X, v2.X) - 128 + 255) >> 8, 0); const int x1 = min((imax3(v0.X, v1.X, v2.X) - 128) >> 8, (int)P.W - 1);
+        y0 = max((imin3(v0.Y, v1.Y, v2.Y) - 128 + 255) >> 8, 0); const int y1 = min((imax3(v0.Y, v1.Y, v2.Y) - 128) >> 8, (int)P.H - 1);
+        if (A < 0 && x0 <= x1 && y0 <= y1) {              // (A >= 0: degenerate or back-facing, ZE:5113-5123)
+            bw = x1 - x0 + 1; area = bw * (y1 - y0 + 1);
+            const int ex0 = -(v2.X - v1.X), ey0 = -(v2.Y - v1.Y), ex1 = -(v0.X - v2.X), ey1 = -(v0.Y - v2.Y), ex2 = -(v1.X - v0.X), ey2 = -(v1.Y - v0.Y);
+            const int Px0 = x0 * 256 + 128, Py0 = y0 * 256 + 128;
+            const int tl0 = ((ey0 < 0) || (ey0 == 0 && ex0 > 0)) ? 0 : 1, tl1 = ((ey1 < 0) || (ey1 == 0 && ex1 > 0)) ? 0 : 1;
+            const int tl2 = ((ey2 < 0) || (ey2 == 0 && ex2 > 0)) ? 0 : 1;
+            E0 = ex0 * (Py0 - v1.Y) - ey0 * (Px0 - v1.X) - tl0;
+            E1 = ex1 * (Py0 - v2.Y) - ey1 * (Px0 - v2.X) - tl1;
+            E2 = ex2 * (Py0 - v0.Y) - ey2 * (Px0 - v0.X) - tl2;
+            sx0 = -ey0 * 256; sx1 = -ey1 * 256; sx2 = -ey2 * 256; sy0 = ex0 * 256; sy1 = ex1 * 256; sy2 = ex2 * 256;
+            const float invA = 1.0f / (float)A;
+            const float a1 = (float)(v2.Y - v0.Y) * invA, b1 = (float)(v0.X - v2.X) * invA;
+            const float a2 = (float)(v0.Y - v1.Y) * invA, b2 = (float)(v1.X - v0.X) * invA;
+            const float dz1 = v1.z - v0.z, dz2 = v2.z - v0.z;
+            gx = __builtin_fmaf(a2, dz2, a1 * dz1); gy = __builtin_fmaf(b2, dz2, b1 * dz1);
+            zlo = __builtin_fminf(__builtin_fminf(v0.z, v1.z), v2.z); zhi = __builtin_fmaxf(__builtin_fmaxf(v0.z, v1.z), v2.z);
+        }
+    }
+    // ---- running sum of the box areas over the lanes (inclusive), total in every lane
+    int incl = area;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+    const int total = __shfl(incl, 63);
+    for (int f0 = 0; f0 < total; f0 += 64) {
+        const int f = f0 + (int)lane;
+        // owner = the first lane whose inclusive sum exceeds f (lanes with an empty box never own anything)
+        int lo = 0, hi = 63;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) { const int mid = (lo + hi) >> 1; if (__shfl(incl, mid) > f) hi = mid; else lo = mid + 1; }
+        const int o = lo;
+        const int o_incl = __shfl(incl, o), o_area = __shfl(area, o), o_bw = __shfl(bw, o);
+        const int o_x0 = __shfl(x0, o), o_y0 = __shfl(y0, o);
+        const int oE0 = __shfl(E0, o), oE1 = __shfl(E1, o), oE2 = __shfl(E2, o);
+        const int osx0 = __shfl(sx0, o), osx1 = __shfl(sx1, o), osx2 = __shfl(sx2, o), osy0 = __shfl(sy0, o), osy1 = __shfl(sy1, o), osy2 = __shfl(sy2, o);
+        const int oX = __shfl(v0.X, o), oY = __shfl(v0.Y, o);
+        const float oz = __shfl(v0.z, o), ogx = __shfl(gx, o), ogy = __shfl(gy, o), ozlo = __shfl(zlo, o), ozhi = __shfl(zhi, o);
+        const uint32_t oprim = (uint32_t)__shfl((int)prim, o);
+        if (f >= total) continue;
+        const int local = f - (o_incl - o_area);           // index inside the owner's box, row-major
+        const int ry = local / o_bw, rx = local - ry * o_bw;
+        const int x = o_x0 + rx, y = o_y0 + ry;
+        const int e0 = oE0 + osx0 * rx + osy0 * ry, e1 = oE1 + osx1 * rx + osy1 * ry, e2 = oE2 + osx2 * rx + osy2 * ry;
+        if ((e0 | e1 | e2) < 0) continue;
+        if (P.tile_world > 1u && tile_owner((uint32_t)x / TILE, (uint32_t)y / TILE, P.tile_world) != P.tile_rank) continue;
+        const float fx = (float)(x * 256 + 128 - oX), fy = (float)(y * 256 + 128 - oY);
+        float z = __builtin_fmaf(ogy, fy, __builtin_fmaf(ogx, fx, oz));
+        z = __builtin_fminf(__builtin_fmaxf(z, ozlo), ozhi);
+        z = z + 0.0f;
+        if (z >= 0.0f && z < 1.0f) {
+            const unsigned long long k = (unsigned long long)zr_f2u(z) << 32 | oprim;
+            unsigned long long* q = vis64 + ((size_t)y * P.W + (size_t)x);
+            if (k < *q) atomicMin(q, k);
+        }
+    }
+}
+
+// Max depth already in the key buffer (per the pyramid Z) over the pixel blocks a snapped box touches: 4 x 4 blocks for a box under 16
+// pixels, else 8 x 8 (blocks of other ranks' tiles hold 0).  A triangle whose least vertex depth lies behind it cannot win a pixel.
+__device__ __forceinline__ float pyramid_max(const ZrHiz& Z, int x0, int y0, int x1, int y1)
+{
+    float h = 0.0f;
+    if (max(x1 - x0, y1 - y0) < 16) {
+        for (int by = y0 >> 2; by <= (y1 >> 2); ++by)
+            for (int bx = x0 >> 2; bx <= (x1 >> 2); ++bx) h = __builtin_fmaxf(h, Z.fine[(size_t)by * Z.fw + (size_t)bx]);
+    } else {
+        for (int by = y0 >> 3; by <= (y1 >> 3); ++by)
+            for (int bx = x0 >> 3; bx <= (x1 >> 3); ++bx) h = __builtin_fmaxf(h, Z.lvl[0][(size_t)by * Z.hw[0] + (size_t)bx]);
+    }
+    return h;
+}
+
+// One wave per selected meshlet-instance: vertices -> LDS, then a lane per triangle.
+// ROUND 1 (HIZ = false) turns triangles into records, one per (triangle, owned tile), in the wave's own chunks (wave k starts in chunk
+// k and takes further ones from a pool: one atomic per ZR_TPOOL_CHUNK records; a round is ONE launch whatever the scene's size).  With
+// Z.predict (a pyramid of the PREVIOUS frame exists) a triangle that pyramid hides is not drawn now but DEFERRED - one record in the
+// wave's deferred chunks (wave k: chunk n_waves + k) - and k_retest looks at it again once this frame's pyramid stands.  Any guess is
+// allowed here: round 1 only has to put good occluders down, the depth test and k_retest decide the pixels.  With a still camera the
+// guess is as good as round 2's own test, so round 1 draws little more than what ends up visible - at triangle, not meshlet granularity.
+// ROUND 2 (HIZ = true): a meshlet whose snapped vertex box lies behind this frame's pyramid is dropped after the vertex phase, every
+// triangle is tested once more by itself, and the few that remain are rasterised straight into the key buffer (raster_direct): no
+// records, no binning chain behind this launch.
 template <bool HIZ>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))      // (the Hi-Z variant would take 67 VGPRs: 7 waves)
-void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, uint4* __restrict__ recs,
-                                              uint32_t n_chunks, uint32_t* __restrict__ chunk_fill, uint32_t* __restrict__ wave_culled,
-                                              uint4* __restrict__ slow, uint32_t slow_cap,
-                                              uint32_t* __restrict__ tile_count, ZrDevStats* __restrict__ stats, int slot)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, uint32_t* __restrict__ tile_count,
+            ZrDevStats* __restrict__ stats, int slot, unsigned long long* __restrict__ vis64)
 {
     __shared__ int4 vstage[4][WAVE];
-    __shared__ float hzs[HIZ ? 4 : 1][WAVE];
+    __shared__ float hzs[4][WAVE];
     const uint32_t lane = threadIdx.x & 63u, wv = wave_uniform(threadIdx.x >> 6);
     const uint32_t n = stats->n_sel[slot];
     const unsigned long long lt = (1ull << lane) - 1ull;
     const uint32_t wave_id = blockIdx.x * 4u + wv, n_waves = gridDim.x * 4u;
-    uint32_t cur = wave_id, fill = 0, culled = 0;       // wave-uniform: the chunk being filled (n_chunks: the pool ran dry), its fill
+    const bool pyramid = HIZ || Z.predict != 0u;          // a pyramid is consulted: this frame's (round 2) or last frame's (round 1's guess)
+    if (HIZ && wave_id == 0u && lane == 0u) stats->survivors[slot] = n;      // (k_tile_slow takes the meshlets dropped behind the pyramid off)
+    RecWriter Wd, Wq;                                    // drawn / deferred streams (round 2 draws into a chunk range of its own)
+    Wd.cur = (HIZ ? 2u * n_waves : 0u) + wave_id; Wd.fill = 0; Wq.cur = n_waves + wave_id; Wq.fill = 0;
+    uint32_t culled = 0, n_direct = 0;
     for (uint32_t i = wave_id; i < n; i += n_waves) {
         const uint4* __restrict__ rec = (const uint4*)(sel + i);
         const uint4 e0 = rec[0], e1 = rec[1];
@@ -1768,7 +1858,7 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, uint4* __rest
                 SV sv; sv.X = 0; sv.Y = 0; sv.z = 0.0f; sv.rw = 0.0f;
                 if (!(f & 129u)) sv = project(c, P.hw, P.hh);
                 vstage[wv][lane] = make_int4(sv.X, sv.Y, (int)zr_f2u(sv.z), (int)f);      // snapped x, y (absolute), depth, clip flags
-                if (HIZ && !flagged) {
+                if (pyramid && !flagged) {
                     lo2 = (clamp16((sv.X - 128 + 255) >> 8) & 0xFFFF) | (clamp16((sv.Y - 128 + 255) >> 8) << 16);
                     hi2 = (clamp16((sv.X - 128) >> 8) & 0xFFFF) | (clamp16((sv.Y - 128) >> 8) << 16);
                     zb = (int)zr_f2u(sv.z + 0.0f);
@@ -1777,13 +1867,12 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, uint4* __rest
         }
         bool hz_local = false;           // wave-uniform: hzs[wv] holds this meshlet's 4 x 4-pixel blocks, (hz_x0, hz_y0) the first one
         int hz_x0 = 0, hz_y0 = 0;
-        if (HIZ && !flagged) {       // every vertex inside the frustum: the box of the snapped vertices bounds every fragment
+        if (pyramid && !flagged) {      // every vertex inside the frustum: the box of the snapped vertices bounds every fragment
             const int lo = wave_pkmin16(lo2), hi = wave_pkmax16(hi2);
             const int px0 = max(0, (int)(short)(lo & 0xFFFF)), py0 = max(0, lo >> 16);
             const int px1 = min((int)P.W - 1, (int)(short)(hi & 0xFFFF)), py1 = min((int)P.H - 1, hi >> 16);
             bool gone = px0 > px1 || py0 > py1;                  // no pixel centre inside
             if (!gone) {
-                const float zm = zr_u2f((uint32_t)wave_min(zb));
                 const uint32_t fx0 = (uint32_t)px0 >> 2, fy0 = (uint32_t)py0 >> 2, fx1 = (uint32_t)px1 >> 2, fy1 = (uint32_t)py1 >> 2;
                 if (fx1 - fx0 < 8u && fy1 - fy0 < 8u) {
                     // a box of up to 32 x 32 pixels: its <= 8 x 8 blocks of the 4 x 4 level, a lane each - one load, one wave reduction;
@@ -1792,10 +1881,14 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, uint4* __rest
                     const float v = (x <= fx1 && y <= fy1) ? Z.fine[(size_t)y * Z.fw + x] : 0.0f;
                     hzs[wv][lane] = v;
                     hz_x0 = (int)fx0; hz_y0 = (int)fy0; hz_local = true;
-                    gone = zm >= 0.0f && zm > wave_fmax(v);
-                } else gone = hiz_occluded(Z, make_uint2((uint32_t)px0 | (uint32_t)py0 << 16, (uint32_t)px1 | (uint32_t)py1 << 16), zm);
+                    if (HIZ) { const float zm = zr_u2f((uint32_t)wave_min(zb)); gone = zm >= 0.0f && zm > wave_fmax(v); }
+                } else if (HIZ) {
+                    const float zm = zr_u2f((uint32_t)wave_min(zb));
+                    gone = hiz_occluded(Z, make_uint2((uint32_t)px0 | (uint32_t)py0 << 16, (uint32_t)px1 | (uint32_t)py1 << 16), zm);
+                }
             }
-            if (gone) { ++culled; continue; }
+            // (round 1 keeps a meshlet whose box holds no pixel centre: its triangles fail their own test below, nothing is deferred)
+            if (HIZ && gone) { ++culled; continue; }
         }
         lds_fence();
 
@@ -1806,8 +1899,8 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, uint4* __rest
             const uint32_t t = t0 + lane;
             int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0;
             const uint32_t prim = pbase + tri_w[round].y;
-            bool alive = false, is_slow = false;
-            int tx0 = 0, ty0 = 0, tx1 = -1, ty1 = -1;
+            bool alive = false, is_slow = false, hidden = false;
+            int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
             uint32_t i0 = 0, i1 = 0, i2 = 0;
             if (t < tcount) {
                 i0 = tri_w[round].x & 255u; i1 = (tri_w[round].x >> 8) & 255u; i2 = (tri_w[round].x >> 16) & 255u;
@@ -1817,30 +1910,23 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, uint4* __rest
                 if (cls == 2) is_slow = true;
                 else if (cls == 1) {
                     // the tests of tri_prefilter / raster_sub that do not depend on the tile: facing + degenerate (edges below 2^14:
-                    // the area fits 32 bits), pixel centres of the TARGET inside the snapped box, and in round 2 the Hi-Z test
+                    // the area fits 32 bits), pixel centres of the TARGET inside the snapped box, then the pyramid
                     const int A = (r1.x - r0.x) * (r2.y - r0.y) - (r2.x - r0.x) * (r1.y - r0.y);
-                    const int x0 = max((imin3(r0.x, r1.x, r2.x) - 128 + 255) >> 8, 0), x1 = min((imax3(r0.x, r1.x, r2.x) - 128) >> 8, (int)P.W - 1);
-                    const int y0 = max((imin3(r0.y, r1.y, r2.y) - 128 + 255) >> 8, 0), y1 = min((imax3(r0.y, r1.y, r2.y) - 128) >> 8, (int)P.H - 1);
+                    x0 = max((imin3(r0.x, r1.x, r2.x) - 128 + 255) >> 8, 0); x1 = min((imax3(r0.x, r1.x, r2.x) - 128) >> 8, (int)P.W - 1);
+                    y0 = max((imin3(r0.y, r1.y, r2.y) - 128 + 255) >> 8, 0); y1 = min((imax3(r0.y, r1.y, r2.y) - 128) >> 8, (int)P.H - 1);
                     alive = A < 0 && x0 <= x1 && y0 <= y1;
-                    if (HIZ && alive) {
-                        // max depth already in the key buffer over the pixel blocks the box touches (4 x 4 blocks for a box under 16 pixels,
-                        // else 8 x 8; blocks of other ranks' tiles hold 0): a triangle whose least vertex depth lies behind it cannot win a
-                        // pixel
+                    if (pyramid && alive && !flagged) {
                         const float tz = __builtin_fminf(__builtin_fminf(zr_u2f((uint32_t)r0.z), zr_u2f((uint32_t)r1.z)), zr_u2f((uint32_t)r2.z));
                         float h = 0.0f;
                         if (hz_local) {       // (a triangle's box lies inside its meshlet's)
                             for (int by = (y0 >> 2) - hz_y0; by <= (y1 >> 2) - hz_y0; ++by)
                                 for (int bx = (x0 >> 2) - hz_x0; bx <= (x1 >> 2) - hz_x0; ++bx) h = __builtin_fmaxf(h, hzs[wv][by * 8 + bx]);
-                        } else if (max(x1 - x0, y1 - y0) < 16) {
-                            for (int by = y0 >> 2; by <= (y1 >> 2); ++by)
-                                for (int bx = x0 >> 2; bx <= (x1 >> 2); ++bx) h = __builtin_fmaxf(h, Z.fine[(size_t)by * Z.fw + (size_t)bx]);
-                        } else {
-                            for (int by = y0 >> 3; by <= (y1 >> 3); ++by)
-                                for (int bx = x0 >> 3; bx <= (x1 >> 3); ++bx) h = __builtin_fmaxf(h, Z.lvl[0][(size_t)by * Z.hw[0] + (size_t)bx]);
-                        }
-                        if (tz > h) alive = false;
+                        } else h = pyramid_max(Z, x0, y0, x1, y1);
+                        hidden = tz > h;
+                    } else if (HIZ && alive) {   // (a flagged meshlet's unclipped triangle: vertices in front of the near plane, depths valid)
+                        const float tz = __builtin_fminf(__builtin_fminf(zr_u2f((uint32_t)r0.z), zr_u2f((uint32_t)r1.z)), zr_u2f((uint32_t)r2.z));
+                        hidden = tz > pyramid_max(Z, x0, y0, x1, y1);
                     }
-                    if (alive) { tx0 = x0 / TILE; tx1 = x1 / TILE; ty0 = y0 / TILE; ty1 = y1 / TILE; }
                 }
             }
             // ---- slow triangles: the three clip-space vertices go to the list every owned tile tries
@@ -1850,43 +1936,48 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, uint4* __rest
                 if (lane == (uint32_t)__builtin_ctzll(ms)) base = atomicAdd(&stats->n_slow[slot], (uint32_t)__popcll(ms));
                 base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(ms));
                 if (is_slow) {
-                    const uint32_t pos_r = base + (uint32_t)__popcll(ms & lt), pos = pos_r + (slot == 2 ? slow_cap / 2u : 0u);
-                    if (pos_r < slow_cap / 2u) {
+                    const uint32_t pos_r = base + (uint32_t)__popcll(ms & lt), pos = pos_r + (slot == 2 ? B.slow_cap / 2u : 0u);
+                    if (pos_r < B.slow_cap / 2u) {
                         const uint32_t li[3] = { i0, i1, i2 };
                         for (int k = 0; k < 3; ++k) {
                             const float4 pk = mp[li[k]];
                             const zf4 cc = zr_mat4_point(P.PVM, vs_position(zr3(pk.x, pk.y, pk.z), I, instanced));
-                            slow[4u * pos + (uint32_t)k] = make_uint4(zr_f2u(cc.x), zr_f2u(cc.y), zr_f2u(cc.z), zr_f2u(cc.w));
+                            B.slow[4u * pos + (uint32_t)k] = make_uint4(zr_f2u(cc.x), zr_f2u(cc.y), zr_f2u(cc.z), zr_f2u(cc.w));
                         }
-                        slow[4u * pos + 3u] = make_uint4(prim, 0u, 0u, 0u);
+                        B.slow[4u * pos + 3u] = make_uint4(prim, 0u, 0u, 0u);
                     } else { stats->overflow = 1u; stats->overflow_sticky = 1u; }
                 }
             }
-            // ---- one record per (triangle, owned tile); ranks within a tile come from one atomic per (wave, tile)
-            const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1, ntile = alive ? nx * ny : 0;
+            if (HIZ) n_direct += (uint32_t)__popcll(__ballot(alive && !hidden));
+            // ---- round 1, deferred: one record per triangle, filed under the first tile of its box
+            const unsigned long long mq = HIZ ? 0ull : __ballot(alive && hidden);
+            if (mq && rec_reserve(Wq, (uint32_t)__popcll(mq), ZR_CHUNK_DEFERRED, lane, B, stats, slot)) {
+                if (alive && hidden) {
+                    const uint32_t tile = (uint32_t)(y0 / TILE) * P.tiles_x + (uint32_t)(x0 / TILE);
+                    rec_store(B, Wq.cur * ZR_TPOOL_CHUNK + Wq.fill + (uint32_t)__popcll(mq & lt), r0, r1, r2, prim, tile, x0 / TILE, y0 / TILE);
+                }
+                Wq.fill += (uint32_t)__popcll(mq);
+            }
+            // ---- drawn (round 1: what last frame's pyramid does not hide; round 2: what this frame's does not): one record per
+            // (triangle, owned tile); ranks within a tile are handed out by k_index
+            const bool draw = alive && !hidden;
+            const int tx0 = x0 / TILE, ty0 = y0 / TILE;
+            const int nx = draw ? x1 / TILE - tx0 + 1 : 0, ny = draw ? y1 / TILE - ty0 + 1 : 0, ntile = nx * ny;
             for (int step = 0; __ballot(step < ntile) != 0ull; ++step) {
                 bool emit = step < ntile;
                 uint32_t tile = 0;            // the record's tile
+                int rtx = 0, rty = 0;
                 if (emit) {
-                    const int sy = step / nx, sx = step - sy * nx;
-                    const uint32_t tx = (uint32_t)(tx0 + sx), ty = (uint32_t)(ty0 + sy);
-                    if (P.tile_world > 1u && tile_owner(tx, ty, P.tile_world) != P.tile_rank) emit = false;
-                    tile = ty * P.tiles_x + tx;
+                    // (a small triangle spans at most 3 x 3 tiles: the step's row by comparisons, not by a division)
+                    const int sy = (step >= nx) + (step >= 2 * nx), sx = step - sy * nx;
+                    rtx = tx0 + sx; rty = ty0 + sy;
+                    if (P.tile_world > 1u && tile_owner((uint32_t)rtx, (uint32_t)rty, P.tile_world) != P.tile_rank) emit = false;
+                    tile = (uint32_t)rty * P.tiles_x + (uint32_t)rtx;
                 }
-                unsigned long long me = __ballot(emit);
+                const unsigned long long me = __ballot(emit);
                 if (!me) continue;
-                if (cur < n_chunks && fill + (uint32_t)__popcll(me) > ZR_TPOOL_CHUNK) {      // this chunk is full: close it, take one from the pool
-                    uint32_t nx_c = 0;
-                    if (lane == 0) { chunk_fill[cur] = fill; nx_c = n_waves + atomicAdd(&stats->pool_next[slot], 1u); }
-                    cur = min((uint32_t)__builtin_amdgcn_readfirstlane((int)nx_c), n_chunks);
-                    fill = 0;
-                }
-                if (cur >= n_chunks) {          // the pool ran dry: the frame is incomplete
-                    if (lane == 0) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
-                    continue;
-                }
-                // count per tile: one add per (wave, tile), all of a step's in one instruction, and nobody waits for them (ranks are
-                // handed out by k_index)
+                if (!rec_reserve(Wd, (uint32_t)__popcll(me), HIZ ? ZR_CHUNK_ROUND2 : 0u, lane, B, stats, slot)) continue;
+                // count per tile: one add per (wave, tile), all of a step's in one instruction, and nobody waits for them
                 unsigned long long pend = me;
                 uint32_t cnt = 0;
                 while (pend) {
@@ -1897,71 +1988,115 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, uint4* __rest
                     pend &= ~same;
                 }
                 if (cnt) atomicAdd(&tile_count[tile * ZR_TSTRIDE], cnt);
-                if (emit) {
-                    const uint32_t pos = cur * ZR_TPOOL_CHUNK + fill + (uint32_t)__popcll(me & lt);
-                    recs[(size_t)3u * pos] = make_uint4((uint32_t)r0.x, (uint32_t)r0.y, (uint32_t)r0.z, prim);
-                    recs[(size_t)3u * pos + 1u] = make_uint4((uint32_t)r1.x, (uint32_t)r1.y, (uint32_t)r1.z, tile);
-                    recs[(size_t)3u * pos + 2u] = make_uint4((uint32_t)r2.x, (uint32_t)r2.y, (uint32_t)r2.z, 0u);
-                }
-                fill += (uint32_t)__popcll(me);
+                if (emit) rec_store(B, Wd.cur * ZR_TPOOL_CHUNK + Wd.fill + (uint32_t)__popcll(me & lt), r0, r1, r2, prim, tile, rtx, rty);
+                Wd.fill += (uint32_t)__popcll(me);
             }
         }
     }
     if (lane == 0) {
-        if (cur < n_chunks) chunk_fill[cur] = fill;
-        wave_culled[wave_id] = culled;
+        if (Wd.cur < B.n_chunks) B.chunk_fill[Wd.cur] = Wd.fill | (HIZ ? ZR_CHUNK_ROUND2 : 0u);
+        if (!HIZ && Wq.cur < B.n_chunks) B.chunk_fill[Wq.cur] = Wq.fill | ZR_CHUNK_DEFERRED;
+        B.wave_culled[wave_id] = HIZ ? culled : 0u;
+        B.wave_direct[wave_id] = n_direct;
     }
 }
 
-// Every record -> a place in its tile's stretch of the gather list: a cursor per tile, advanced once per (wave, distinct tile) - the
-// records of a chunk come meshlet by meshlet, so the 64 of a wave name a handful of tiles - because atomics on one address run at
-// about 10 ns apiece on this part and there are half a million records.  The lanes first sort themselves into tile groups (scalar
-// work, no memory), then every group's first lane issues its add in ONE instruction: one round trip per 64 records, not one per
-// group.  One wave per record chunk.
-__global__ __launch_bounds__(256) void k_index(const uint4* __restrict__ recs, const uint32_t* __restrict__ chunk_fill, uint32_t n_static,
-                                               uint32_t n_chunks, const ZrDevStats* __restrict__ stats, int slot,
-                                               const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
-                                               uint32_t* __restrict__ idx)
+// Every DRAWN record -> its place in its tile's stretch of the sorted record array, and the record itself is MOVED there, so that k_tile
+// streams its work unit instead of gathering it.  First every workgroup scans the per-tile counts into offsets for itself (LDS, the
+// counts sit in L2; the separate one-workgroup scan launch of round 2 cost 8 us of pure latency on the camera pipeline's critical path);
+// workgroup 0 also lays out k_tile's work units and the round's statistics.  Then a cursor per tile is advanced once per (wave, distinct
+// tile) - the 64 records of a wave come meshlet by meshlet, so they name a handful of tiles - because atomics on one address run at
+// about 10 ns apiece on this part and there are half a million records: the lanes first sort themselves into tile groups (scalar work,
+// no memory), then every group's first lane issues its add in ONE instruction.  One wave per record chunk.
+__global__ __launch_bounds__(256) void k_index(ZrTriBins B, ZrDevStats* __restrict__ stats, int slot, uint32_t n_tiles,
+                                               const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_cursor,
+                                               uint4* __restrict__ chunk_tab, uint32_t chunk_cap, uint32_t unit)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t used = min(n_static + stats->pool_used[slot], n_chunks);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    for (uint32_t ch = blockIdx.x * 4u + (threadIdx.x >> 6); ch < used; ch += gridDim.x * 4u) {
-    const uint32_t n = chunk_fill[ch], r0 = ch * ZR_TPOOL_CHUNK;
-    for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
-        const uint32_t j = j0 + lane, i = r0 + j;
-        const bool have = j < n;
-        const uint32_t tile = have ? recs[(size_t)3u * i + 1u].w : 0u;
-        const uint32_t off = have ? tile_offset[tile] : 0u;
-        uint32_t rank = 0, cnt = 0;
-        int first = (int)lane;
-        unsigned long long pend = __ballot(have);
-        while (pend) {
-            const int leader = __builtin_ctzll(pend);
-            const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
-            const unsigned long long same = __ballot(have && tile == tl) & pend;
-            if (same >> lane & 1ull) { first = leader; rank = (uint32_t)__popcll(same & lt); cnt = (uint32_t)__popcll(same); }
-            pend &= ~same;
+    extern __shared__ uint32_t toff[];                     // the tiles' counts, then the exclusive offsets of their stretches
+    __shared__ uint32_t wtot[4], cwtot[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    {
+        for (uint32_t i = tid; i < n_tiles; i += 256u) toff[i] = tile_count[i * ZR_TSTRIDE];      // coalesced (16-byte stride), from L2
+        __syncthreads();
+        const uint32_t per = (n_tiles + 255u) / 256u;
+        const uint32_t b = min(n_tiles, tid * per), e = min(n_tiles, b + per);
+        uint32_t s = 0, cs = 0;
+        for (uint32_t i = b; i < e; ++i) { const uint32_t t = toff[i]; s += t; cs += (t + unit - 1u) / unit; }
+        uint32_t incl = s, cincl = cs;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, o), cv = (uint32_t)__shfl_up((int)cincl, o);
+            if ((int)lane >= o) { incl += v; cincl += cv; }
         }
-        uint32_t b = 0;
-        if (have && first == (int)lane) b = atomicAdd(&tile_cursor[tile * ZR_TSTRIDE], cnt);
-        b = (uint32_t)__shfl((int)b, first);
-        if (have) idx[off + b + rank] = i;
+        if (lane == 63u) { wtot[wv] = incl; cwtot[wv] = cincl; }
+        __syncthreads();
+        uint32_t wpre = 0, cwpre = 0, tot = 0, ctot = 0;
+        for (uint32_t i = 0; i < 4u; ++i) { if (i < wv) { wpre += wtot[i]; cwpre += cwtot[i]; } tot += wtot[i]; ctot += cwtot[i]; }
+        uint32_t run = wpre + incl - s, crun = cwpre + cincl - cs;
+        for (uint32_t i = b; i < e; ++i) {
+            const uint32_t t = toff[i], nu = (t + unit - 1u) / unit;
+            toff[i] = run;                 // (this thread's own stretch of the array: nobody else reads it before the barrier)
+            if (blockIdx.x == 0)          // k_tile's work units: (tile, first record, end) - one load there, not a search
+                for (uint32_t k = 0; k < nu; ++k)
+                    if (crun + k < chunk_cap) chunk_tab[crun + k] = make_uint4(i, run + k * unit, run + min(t, (k + 1u) * unit), 0u);
+            run += t; crun += nu;
+        }
+        if (blockIdx.x == 0 && tid == 0) {
+            stats->bin_entries[slot] = tot;               // drawn triangle records of the round
+            stats->n_chunks[slot] = min(ctot, chunk_cap);
+            stats->chunk_counter[slot] = 0;
+            stats->survivors[slot] = stats->n_sel[slot];
+            if (ctot > chunk_cap || tot > B.sorted_cap) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
+        }
+        __syncthreads();
     }
+    const uint32_t used = max(3u * B.n_waves, min(3u * B.n_waves + stats->pool_next[1], B.n_chunks));
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t my_kind = slot == 2 ? ZR_CHUNK_ROUND2 : 0u, own0 = slot == 2 ? 2u * B.n_waves : 0u;
+    for (uint32_t w = blockIdx.x * 4u + wv; w < B.n_waves + (used - 3u * B.n_waves); w += gridDim.x * 4u) {
+        const uint32_t ch = w < B.n_waves ? own0 + w : 3u * B.n_waves + (w - B.n_waves);      // the round's own chunks, then the pool
+        const uint32_t cf = B.chunk_fill[ch];
+        if ((cf & (ZR_CHUNK_DEFERRED | ZR_CHUNK_ROUND2)) != my_kind) continue;
+        const uint32_t n = ZR_CHUNK_COUNT(cf), r0 = ch * ZR_TPOOL_CHUNK;
+        for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
+            const uint32_t j = j0 + lane, i = r0 + j;
+            const bool have = j < n;
+            const uint32_t tile = have ? B.rtile[i] : 0u;
+            uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
+            if (have) { qa = B.recA[i]; qb = B.recB[i]; }
+            const uint32_t off = have ? toff[tile] : 0u;
+            uint32_t rank = 0, cnt = 0;
+            int first = (int)lane;
+            unsigned long long pend = __ballot(have);
+            while (pend) {
+                const int leader = __builtin_ctzll(pend);
+                const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
+                const unsigned long long same = __ballot(have && tile == tl) & pend;
+                if (same >> lane & 1ull) { first = leader; rank = (uint32_t)__popcll(same & lt); cnt = (uint32_t)__popcll(same); }
+                pend &= ~same;
+            }
+            uint32_t b = 0;
+            if (have && first == (int)lane) b = atomicAdd(&tile_cursor[tile * ZR_TSTRIDE], cnt);
+            b = (uint32_t)__shfl((int)b, first);
+            const uint32_t dst = off + b + rank;
+            if (have && dst < B.sorted_cap) { B.srtA[dst] = qa; B.srtB[dst] = qb; }
+        }
     }
 }
 
-// Persistent workgroups pull work units: <= ZR_TCHUNK records of one tile; lane per triangle: edge setup + walk into the tile's LDS
-// keys; touched keys are merged into the frame key buffer.  Nothing else: no vertices, no tests, no call in the loop.
+// Persistent workgroups pull work units: <= ZR_TCHUNK records of one tile, contiguous in the sorted array; lane per triangle: edge setup
+// + walk into the tile's LDS keys; touched keys are merged into the frame key buffer.  Nothing else: no vertices, no tests, no gather.
+// The kernel also leaves the per-tile counters and the record pool as the next round's k_geom wants them (zero).
 template <int MODE>
-__global__ __launch_bounds__(256) void k_tile(ZrPass P, const uint4* __restrict__ chunk_tab, const uint4* __restrict__ recs,
-                                              const uint32_t* __restrict__ idx, ZrDevStats* __restrict__ stats, int slot,
+__global__ __launch_bounds__(256) void k_tile(ZrPass P, const uint4* __restrict__ chunk_tab, ZrTriBins B, uint32_t* __restrict__ tile_count,
+                                              uint32_t* __restrict__ tile_cursor, uint32_t n_tiles, ZrDevStats* __restrict__ stats, int slot,
                                               unsigned long long* __restrict__ vis64)
 {
     __shared__ unsigned long long keys64[TILE_PIX];
     __shared__ uint32_t cur_unit;
     const uint32_t tid = threadIdx.x;
     const uint32_t n_units = stats->n_chunks[slot];
+    for (uint32_t i = blockIdx.x * 256u + tid; i < n_tiles; i += gridDim.x * 256u) { tile_count[i * ZR_TSTRIDE] = 0u; tile_cursor[i * ZR_TSTRIDE] = 0u; }
+    if (blockIdx.x == 0 && tid == 0) { stats->pool_used[slot] = stats->pool_next[slot]; }
     uint32_t unit = blockIdx.x;
     bool first = true;
     for (;;) {
@@ -1971,17 +2106,11 @@ __global__ __launch_bounds__(256) void k_tile(ZrPass P, const uint4* __restrict_
         const uint4 ct = chunk_tab[unit];
         const uint32_t tile = ct.x;
         const int tpx0 = (int)(tile % P.tiles_x) * TILE, tpy0 = (int)(tile / P.tiles_x) * TILE;
-        const int ox = tpx0 * 256, oy = tpy0 * 256;
         TileCtx T;
         T.px0 = 0; T.py0 = 0; T.W = (int)P.W - tpx0; T.H = (int)P.H - tpy0;
-        for (uint32_t j = ct.y + tid; j < ct.z; j += 256u) {
-            const uint32_t i = idx[j];
-            const uint4 q0 = recs[(size_t)3u * i], q1 = recs[(size_t)3u * i + 1u], q2 = recs[(size_t)3u * i + 2u];
-            SV a, b, c;
-            a.X = (int)q0.x - ox; a.Y = (int)q0.y - oy; a.z = zr_u2f(q0.z); a.rw = 0.0f;
-            b.X = (int)q1.x - ox; b.Y = (int)q1.y - oy; b.z = zr_u2f(q1.z); b.rw = 0.0f;
-            c.X = (int)q2.x - ox; c.Y = (int)q2.y - oy; c.z = zr_u2f(q2.z); c.rw = 0.0f;
-            raster_sub<MODE, true>(a, b, c, q0.w, T, keys64, nullptr);
+        for (uint32_t j = ct.y + tid; j < min(ct.z, B.sorted_cap); j += 256u) {
+            const RecTri t = rec_load(B.srtA[j], B.srtB[j]);
+            raster_sub<MODE, true>(t.a, t.b, t.c, t.prim, T, keys64, nullptr);
         }
         __syncthreads();
         for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
@@ -1989,7 +2118,7 @@ __global__ __launch_bounds__(256) void k_tile(ZrPass P, const uint4* __restrict_
             if (px >= (int)P.W || py >= (int)P.H) continue;
             const size_t p = (size_t)py * P.W + (size_t)px;
             const unsigned long long k = keys64[i];
-            if ((uint32_t)k != ZR_EMPTY_PRIM && k < vis64[p]) atomicMin(&vis64[p], k);
+            if ((uint32_t)k != ZR_EMPTY_PRIM) atomicMin(&vis64[p], k);      // (no read-and-compare first: the key buffer is empty but for this tile's other units)
         }
         // the second unit of a workgroup is fixed too (b + grid): when the grid's first units end together, 2 048 claims on one
         // counter would queue up for ~10 ns apiece; only later units (hot frames) come from the counter
@@ -2000,12 +2129,53 @@ __global__ __launch_bounds__(256) void k_tile(ZrPass P, const uint4* __restrict_
     }
 }
 
+// Round 1's deferred triangles against THIS frame's pyramid (exactly round 2's per-triangle test: a lower bound of the fragments' depth
+// against a max of depths already in the key buffer, so nothing that could win a pixel is dropped); what the pyramid lets through after
+// all is rasterised straight into the key buffer (raster_flat).  With a still camera nearly everything deferred stays hidden: the kernel
+// streams 36 bytes per record and a few pyramid texels.  One wave per deferred chunk (a wave of round 1 leaves ~80 records in its own):
+// the kernel is bound by the latency of its dependent loads, so it wants many short waves.
+__global__ __launch_bounds__(256) void k_retest(ZrPass P, ZrHiz Z, ZrTriBins B, ZrDevStats* __restrict__ stats, unsigned long long* __restrict__ vis64)
+{
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t used = max(3u * B.n_waves, min(3u * B.n_waves + stats->pool_next[1], B.n_chunks));
+    uint32_t kept = 0, seen = 0;
+    for (uint32_t w = blockIdx.x * 4u + wv; w < B.n_waves + (used - 3u * B.n_waves); w += gridDim.x * 4u) {
+        const uint32_t ch = w < B.n_waves ? B.n_waves + w : 3u * B.n_waves + (w - B.n_waves);      // the waves' deferred chunks, then the pool
+        const uint32_t cf = B.chunk_fill[ch];
+        if (!(cf & ZR_CHUNK_DEFERRED)) continue;
+        const uint32_t n = ZR_CHUNK_COUNT(cf), r0 = ch * ZR_TPOOL_CHUNK;
+        for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
+            const uint32_t j = j0 + lane, i = r0 + j;
+            bool draw = false;
+            RecTri t; t.a.X = t.a.Y = t.b.X = t.b.Y = t.c.X = t.c.Y = 0; t.a.z = t.b.z = t.c.z = 0.0f; t.a.rw = t.b.rw = t.c.rw = 0.0f; t.prim = 0u;
+            if (j < n) {
+                const uint32_t tile = B.rtile[i];
+                t = rec_load(B.recA[i], B.recB[i]);
+                const int ox = (int)(tile % P.tiles_x) * (TILE * 256), oy = (int)(tile / P.tiles_x) * (TILE * 256);
+                t.a.X += ox; t.a.Y += oy; t.b.X += ox; t.b.Y += oy; t.c.X += ox; t.c.Y += oy;
+                ++seen;
+                const int x0 = max((imin3(t.a.X, t.b.X, t.c.X) - 128 + 255) >> 8, 0), x1 = min((imax3(t.a.X, t.b.X, t.c.X) - 128) >> 8, (int)P.W - 1);
+                const int y0 = max((imin3(t.a.Y, t.b.Y, t.c.Y) - 128 + 255) >> 8, 0), y1 = min((imax3(t.a.Y, t.b.Y, t.c.Y) - 128) >> 8, (int)P.H - 1);
+                const float tz = __builtin_fminf(__builtin_fminf(t.a.z, t.b.z), t.c.z);
+                draw = !(tz > pyramid_max(Z, x0, y0, x1, y1));
+                if (draw) ++kept;
+            }
+            if (__ballot(draw)) raster_flat(P, t.a, t.b, t.c, t.prim, draw, lane, vis64);      // the whole wave, pixel by pixel
+        }
+    }
+    // (per-wave counts, summed by k_tile_slow: 8 192 atomics on one address would queue up for ~10 ns apiece and hold the kernel's end)
+    kept = (uint32_t)wave_sum((int)kept); seen = (uint32_t)wave_sum((int)seen);
+    if (lane == 0) { const uint32_t w_ = blockIdx.x * 4u + wv; B.wave_retest[2u * w_] = seen; B.wave_retest[2u * w_ + 1u] = kept; }
+}
+
 // The slow triangles of the round (they need the clipper, or have an edge of 64 px or more): every owned tile tries every one of
 // them through raster_clipped.  One workgroup per owned tile; returns at once when the round has none (the usual case).
 template <int MODE, bool BY_TILE>
 __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __restrict__ owned_tiles, const uint4* __restrict__ slow,
-                                                   uint32_t slow_cap, const ZrDevStats* __restrict__ stats, int slot,
-                                                   unsigned long long* __restrict__ vis64, uint32_t* __restrict__ shadow_bits)
+                                                   uint32_t slow_cap, ZrDevStats* __restrict__ stats, int slot,
+                                                   unsigned long long* __restrict__ vis64, uint32_t* __restrict__ shadow_bits,
+                                                   const uint32_t* __restrict__ wave_culled, const uint32_t* __restrict__ wave_direct,
+                                                   const uint32_t* __restrict__ wave_retest, uint32_t n_waves)
 {
     __shared__ unsigned long long keys64[MODE == ZR_MODE_GBUFFER ? TILE_PIX : 1];
     __shared__ uint32_t keys32[MODE == ZR_MODE_SHADOW ? TILE_PIX : 1];
@@ -2013,6 +2183,22 @@ __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __r
     // (slot = 2), or round 1's alone in a one-round frame (slot = 1)
     const uint32_t half = BY_TILE ? slow_cap : slow_cap / 2u;
     const uint32_t n_a = min(stats->n_slow[BY_TILE ? slot : 1], half), n_b = (!BY_TILE && slot == 2) ? min(stats->n_slow[2], half) : 0u;
+    if (!BY_TILE && slot == 2 && wave_culled && blockIdx.x * 256u < n_waves) {
+        // round 2 has no binning chain behind it any more: its books are closed here (meshlets k_geom dropped behind the pyramid, triangles
+        // it handed to k_retest, what k_retest saw and kept) - a slice of the per-wave counts per workgroup
+        const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+        uint32_t nc = 0, nd = 0, ns = 0, nk = 0;
+        if (i < n_waves) {
+            nc = wave_culled[i]; nd = wave_direct[i];
+            if (wave_retest) { ns = wave_retest[2u * i]; nk = wave_retest[2u * i + 1u]; }
+        }
+        nc = (uint32_t)wave_sum((int)nc); nd = (uint32_t)wave_sum((int)nd); ns = (uint32_t)wave_sum((int)ns); nk = (uint32_t)wave_sum((int)nk);
+        if ((threadIdx.x & 63u) == 0u) {
+            if (nc) { atomicAdd(&stats->hiz_culled, nc); atomicSub(&stats->survivors[2], nc); }
+            if (ns) atomicAdd(&stats->n_deferred, ns);
+            if (nk) atomicAdd(&stats->n_retest_kept, nk);
+        }
+    }
     if (n_a + n_b == 0u) return;
     const uint32_t tid = threadIdx.x, tile = owned_tiles[blockIdx.x];
     for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
@@ -2662,12 +2848,6 @@ void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_
 {
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, chunk_offset, chunk_tab, chunk_cap, n, capacity, stats, slot, chunk);
 }
-void zr_launch_scan_tri(uint32_t* bin_count, uint32_t* bin_offset, uint32_t* bin_cursor, uint4* chunk_tab, uint32_t chunk_cap, uint32_t n_tiles,
-                        const ZrTriBins& B, ZrDevStats* stats, int slot, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_scan_tri, dim3(1), dim3(1024), 0, s, bin_count, bin_offset, bin_cursor, chunk_tab, chunk_cap, n_tiles, B.wave_culled, B.n_waves,
-                       stats, slot, ZR_TCHUNK);
-}
 void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
                         uint32_t* tile_cursor, ZrBinEntry* bins, const ZrHiz& Z, ZrDevStats* stats, int slot, hipStream_t s)
 {
@@ -2708,7 +2888,8 @@ void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4*
     if (P.mode == ZR_MODE_GBUFFER) return;      // (not reached: the product's camera pass is triangle-binned)
     if (slow) {    // shadow pass: clipped triangles go through a list + k_tile_slow
         hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false, true>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u, slow, slow_cap);
-        if (n_tiles) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_SHADOW, true>), dim3(n_tiles), dim3(256), 0, s, P, tiles, slow, slow_cap, stats, slot, (unsigned long long*)nullptr, shadow_bits);
+        if (n_tiles) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_SHADOW, true>), dim3(n_tiles), dim3(256), 0, s, P, tiles, slow, slow_cap, stats, slot, (unsigned long long*)nullptr, shadow_bits,
+                                        (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
     } else
         hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u, (uint4*)nullptr, 0u);
 }
@@ -2718,21 +2899,31 @@ void zr_launch_select(const ZrPass& P, const ZrObject* objs, const uint32_t* wor
     if (P.n_work == 0) return;
     hipLaunchKernelGGL(k_select, dim3((P.n_work + 1023) / 1024), dim3(ZR_SELECT_THREADS), 0, s, P, objs, work, rects, Z, B.sel, stats, slot);
 }
-void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, uint32_t* tile_count, ZrDevStats* stats, int slot, hipStream_t s)
+void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, uint32_t* tile_count, ZrDevStats* stats, int slot, unsigned long long* vis64, hipStream_t s)
 {
     const dim3 g(B.n_waves / 4u), b(256);
-    if (Z.phase == 2u) hipLaunchKernelGGL(k_geom<true>, g, b, 0, s, P, B.sel, Z, B.recs, B.n_chunks, B.chunk_fill, B.wave_culled, B.slow, B.slow_cap, tile_count, stats, slot);
-    else hipLaunchKernelGGL(k_geom<false>, g, b, 0, s, P, B.sel, Z, B.recs, B.n_chunks, B.chunk_fill, B.wave_culled, B.slow, B.slow_cap, tile_count, stats, slot);
+    if (Z.phase == 2u) hipLaunchKernelGGL(k_geom<true>, g, b, 0, s, P, B.sel, Z, B, tile_count, stats, slot, vis64);
+    else hipLaunchKernelGGL(k_geom<false>, g, b, 0, s, P, B.sel, Z, B, tile_count, stats, slot, vis64);
 }
-void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* tile_cursor, const ZrDevStats* stats, int slot, hipStream_t s)
+void zr_launch_index(const ZrTriBins& B, uint32_t n_tiles, const uint32_t* tile_count, uint32_t* tile_cursor, uint4* chunk_tab, uint32_t chunk_cap,
+                     ZrDevStats* stats, int slot, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_index, dim3(B.n_waves / 4u), dim3(256), 0, s, B.recs, B.chunk_fill, B.n_waves, B.n_chunks, stats, slot, tile_offset, tile_cursor, B.idx);
+    hipLaunchKernelGGL(k_index, dim3(B.n_waves / 4u), dim3(256), n_tiles * sizeof(uint32_t), s, B, stats, slot, n_tiles, tile_count, tile_cursor, chunk_tab, chunk_cap, ZR_TCHUNK);
 }
-void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned,
-                    ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s, bool slow_too)
+void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B, uint32_t* tile_count, uint32_t* tile_cursor, uint32_t n_tiles,
+                    ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_tile<ZR_MODE_GBUFFER>, dim3(n_blocks), dim3(256), 0, s, P, chunk_tab, B.recs, B.idx, stats, slot, vis64);
-    if (n_owned && slow_too) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_GBUFFER, false>), dim3(n_owned), dim3(256), 0, s, P, owned_tiles, B.slow, B.slow_cap, stats, slot, vis64, (uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_tile<ZR_MODE_GBUFFER>, dim3(n_blocks), dim3(256), 0, s, P, chunk_tab, B, tile_count, tile_cursor, n_tiles, stats, slot, vis64);
+}
+void zr_launch_retest(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats, unsigned long long* vis64, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_retest, dim3(B.n_waves / 4u), dim3(256), 0, s, P, Z, B, stats, vis64);
+}
+void zr_launch_tile_slow_camera(const ZrPass& P, const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned, ZrDevStats* stats, int slot,
+                                unsigned long long* vis64, bool retested, hipStream_t s)
+{
+    if (n_owned) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_GBUFFER, false>), dim3(n_owned), dim3(256), 0, s, P, owned_tiles, B.slow, B.slow_cap, stats, slot, vis64,
+                                    (uint32_t*)nullptr, B.wave_culled, B.wave_direct, retested ? B.wave_retest : (const uint32_t*)nullptr, B.n_waves);
 }
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, const float* unorm_lut, uint8_t* vis_now,
