@@ -39,9 +39,9 @@ PROFILE_INDEX = os.path.join(ROOT, "profiles", "current.json")     # written by 
 # pass is k_geom (vertices -> triangle records) + k_scan_tri + k_index (records -> per-tile lists) + k_tile (+ k_tile_slow); k_scan_tri,
 # k_index, k_tile and k_tile_slow run once per round under one name, so their profile rows hold both rounds.
 KERNEL_OF_PASS = {"shadow": ("k_raster<SHADOW>", "k_tile_slow<SHADOW>"), "gbuffer": ("k_geom<false>", "k_index", "k_tile<0>"),
-                  "gbuffer2": ("k_geom<true>", "k_retest", "k_tile_slow<GBUFFER>"), "resolve": ("k_resolve_gbuffer",), "lighting": ("k_lighting",)}
+                  "gbuffer2": ("k_geom<true>", "k_tile_slow<GBUFFER>"), "resolve": ("k_resolve_gbuffer",), "lighting": ("k_lighting",)}
 GBUFFER_WRITE_PASS = ("gbuffer", "gbuffer2", "resolve")
-GBUFFER_WRITE_KERNELS = "round 1: k_geom + k_index + k_tile; round 2: k_geom (direct) + k_retest + k_tile_slow; k_resolve_gbuffer"
+GBUFFER_WRITE_KERNELS = "k_geom + k_index + k_tile (x2 rounds) + k_tile_slow + k_resolve_gbuffer"
 
 
 def workload_name(config, n_inst, n_work, W, H, n_point, cube_dim):
@@ -110,7 +110,7 @@ def main():
                     help="per-kernel hipEvents are recorded on every n-th timed frame (each record is a ~6 us stream bubble); "
                          "0 = steps // 12 clamped to 5..8 (a short run still leaves four frames in five undisturbed)")
     ap.add_argument("--cube-dim", type=int, default=1024, help="cubemap face edge (the engine's is 1024: 11 mips)")
-    ap.add_argument("--flags", type=int, default=0, help="experiments: extra zr_config flags (e.g. 256 = ZR_FLAG_NO_PREDICT, 8 = ZR_FLAG_NO_HIZ)")
+    ap.add_argument("--flags", type=int, default=0, help="experiments: extra zr_config flags (e.g. 8 = ZR_FLAG_NO_HIZ)")
     ap.add_argument("--serial", action="store_true", help="profiling: the whole frame on ONE stream (ZR_FLAG_SERIAL_PASSES), every kernel alone on the GPU")
     args = ap.parse_args()
 

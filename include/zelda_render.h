@@ -56,8 +56,6 @@ typedef struct zr_ctx zr_ctx;
 #define ZR_FLAG_PACKED_TILES    32u /* tile_world == 1: still light into the packed tile buffer (the multi-GPU data path on one GPU) */
 #define ZR_FLAG_MESHLET_BINS   128u /* -DZR_DIAG builds only (zr_create: ZR_ERR_UNSUPPORTED otherwise): camera pass through the meshlet-binned
                                      * rasteriser the shadow pass uses, instead of the triangle-binned one (A/B measurements) */
-#define ZR_FLAG_NO_PREDICT     256u /* camera pass, round 1: draw every triangle of last frame's visible meshlets instead of deferring those last frame's
-                                     * depth pyramid hid (parity A/B: the frame is the same either way) */
 #define ZR_FLAG_NO_RECT_CULL    64u /* tile_world > 1: do not reject meshlets by the rank's owned screen region before stage B (parity A/B) */
 
 typedef struct zr_config {
@@ -101,9 +99,6 @@ typedef struct zr_stats {
     uint32_t overflow;          /* nonzero: a bin list overflowed; frame invalid */
     uint32_t hiz_culled;        /* camera meshlet-instances rejected by the Hi-Z occlusion test (0 on a scene's first frame) */
     uint64_t round1_survivors;  /* of survivors[1]: drawn in round 1 (visible last frame); 0 when the frame ran in one round */
-    uint64_t deferred_triangles;/* round 1: triangles put off because last frame's depth pyramid hid them ... */
-    uint64_t deferred_drawn;    /* ... and those of them this frame's pyramid let through after all (k_retest) */
-    uint64_t direct_triangles;  /* round 2: triangle records drawn (what this frame's pyramid did not hide of the meshlets not seen last frame) */
 } zr_stats;
 
 /* --- lifetime (replaces InitVulkan/Cleanup, ZE:1714, 3747) --- */
@@ -137,7 +132,7 @@ int  zr_mesh_get_meshlets(zr_ctx* ctx, uint32_t mesh_id, XkMeshlet* m, uint32_t*
 int  zr_object_add(zr_ctx* ctx, uint32_t mesh_id, const zr_material* mat,
                    const XkInstanceData* inst, uint32_t n_inst);
 /* Capacities of the camera pass's triangle-record pool (in chunks of 256 records of 68 bytes) and of its clipped-triangle list; 0 =
- * defaults (8 records per meshlet-instance of the scene, at least 32 Mi, plus 3 x 8192 chunks the rasteriser's waves start in; 2^18
+ * defaults (8 records per meshlet-instance of the scene, at least 32 Mi, plus 8192 chunks the rasteriser's waves start in; 2^18
  * triangles).  A frame that outgrows either reports ZR_ERR_OVERFLOW at zr_finish.  Takes effect at the next frame (the pools are re-made). */
 int  zr_set_limits(zr_ctx* ctx, uint32_t record_chunks, uint32_t slow_triangles);
 int  zr_scene_clear(zr_ctx* ctx);                   /* CleanupBasePass, ZE:4142 (also drops meshes and Profabs) */

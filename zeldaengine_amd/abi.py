@@ -54,8 +54,7 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("work_items", C.c_uint64 * 2), ("survivors", C.c_uint64 * 2), ("bin_entries", C.c_uint64 * 2),
                 ("covered_pixels", C.c_uint64), ("covered_shadow_texels", C.c_uint64), ("overflow", C.c_uint32), ("hiz_culled", C.c_uint32),
-                ("round1_survivors", C.c_uint64), ("deferred_triangles", C.c_uint64), ("deferred_drawn", C.c_uint64),
-                ("direct_triangles", C.c_uint64)]
+                ("round1_survivors", C.c_uint64)]
 
 
 PASS_NAMES = ["cull_shadow", "shadow", "cull_camera", "gbuffer", "hiz", "gbuffer2", "resolve", "lighting", "composite", "total"]
@@ -69,7 +68,6 @@ FLAG_SERIAL_PASSES = 16
 FLAG_PACKED_TILES = 32
 FLAG_NO_RECT_CULL = 64
 FLAG_MESHLET_BINS = 128
-FLAG_NO_PREDICT = 256
 
 OK, ERR_ARG, ERR_DEVICE, ERR_OOM, ERR_PARSE, ERR_IO, ERR_STATE, ERR_OVERFLOW, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8
 

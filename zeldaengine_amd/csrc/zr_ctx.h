@@ -126,8 +126,6 @@ struct zr_ctx {
     // visibility of the previous / current frame (one byte per meshlet-instance, marked by the resolve), the pyramid
     uint2* d_pxrect = nullptr; float* d_zmin = nullptr; uint8_t* d_visflag[2] = { nullptr, nullptr };
     float* d_hiz = nullptr; ZrHiz hiz = {}; int vis_cur = 0; bool vis_history = false, last_two_round = false;
-    bool hiz_valid = false, predict_now = false;     // the pyramid arrays hold the previous frame's pyramid / round 1 uses it as a guess
-    float last_pvm[16] = { 0 };                      // the camera pass's transform of the previous frame
     ZrDevStats* d_stats = nullptr; ZrDevStats h_stats = {};
     uint64_t last_work[2] = { 0, 0 };
 

@@ -200,6 +200,22 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         // pools, so the camera lane - the frame's critical path anyway - is created with the highest priority.
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+#ifdef ZR_DIAG
+        // experiment: CU partition between the lanes.  ZR_CU_MASK_CAM / ZR_CU_MASK_HOST = "lo-hi" CU ranges (of 256), or "xN:k" = the first k
+        // CUs of every group of N; the host's stream is then the library's own masked stream (only when the caller sets none)
+        auto make_masked = [&](const char* spec, hipStream_t* out) -> bool {
+            uint32_t mask[8] = { 0 };
+            int a = 0, b = 0;
+            if (sscanf(spec, "x%d:%d", &a, &b) == 2 && a > 0) { for (int i = 0; i < 256; ++i) if (i % a < b) mask[i >> 5] |= 1u << (i & 31); }
+            else if (sscanf(spec, "%d-%d", &a, &b) == 2) { for (int i = a; i <= b && i < 256; ++i) if (i >= 0) mask[i >> 5] |= 1u << (i & 31); }
+            else return false;
+            return hipExtStreamCreateWithCUMask(out, 8, mask) == hipSuccess;
+        };
+        const char* mc = getenv("ZR_CU_MASK_CAM"); const char* mh = getenv("ZR_CU_MASK_HOST");
+        if (mh) { hipStream_t hs = nullptr; if (make_masked(mh, &hs)) { (void)hipStreamDestroy(c->own_stream); c->own_stream = hs; c->stream = hs; } }
+        if (mc && make_masked(mc, &c->cam_s)) { }
+        else
+#endif
         ok &= hipStreamCreateWithPriority(&c->cam_s, hipStreamNonBlocking, greatest) == hipSuccess;
         if (c->three_lanes) {      // (only then: every stream takes one of the process's few hardware queues)
             ok &= hipStreamCreateWithPriority(&c->shadow_s, hipStreamNonBlocking, least) == hipSuccess;
@@ -250,7 +266,7 @@ static void free_mesh_buffers(ZrMesh& m)
 static void free_tri_bins(zr_ctx* c)
 {
     dev_free(c->tb.sel); dev_free(c->tb.recA); dev_free(c->tb.recB); dev_free(c->tb.rtile); dev_free(c->tb.srtA); dev_free(c->tb.srtB);
-    dev_free(c->tb.slow); dev_free(c->tb.chunk_fill); dev_free(c->tb.wave_culled); dev_free(c->tb.wave_direct); dev_free(c->tb.wave_retest);
+    dev_free(c->tb.slow); dev_free(c->tb.chunk_fill); dev_free(c->tb.wave_culled);
 }
 
 static void free_scene(zr_ctx* c)
@@ -595,7 +611,7 @@ extern "C" int zr_object_add(zr_ctx* c, uint32_t mesh_id, const zr_material* mat
     return zr_guard(c, [&]() { return zr_object_add_impl(c, mesh_id, mat, inst, n_inst); });
 }
 
-// Capacities of the triangle-record pool (chunks of ZR_TPOOL_CHUNK = 256 records, the 3 x 8192 chunks the waves of k_geom start in included)
+// Capacities of the triangle-record pool (chunks of ZR_TPOOL_CHUNK = 256 records, the 8192 chunks the waves of k_geom start in included)
 // and of the clipped-triangle list, for hosts that size them themselves (0 = the default: 8 records per meshlet-instance, at least 32 Mi,
 // plus the waves' own chunks; 2^18 triangles).  Takes effect at the next frame.
 extern "C" int zr_set_limits(zr_ctx* c, uint32_t record_chunks, uint32_t slow_triangles)
@@ -744,11 +760,11 @@ static int finalize_scene(zr_ctx* c)
         // triangle-binned camera pass: triangle records (32 B + a 4-byte tile id) live in chunks of ZR_TPOOL_CHUNK; every wave of k_geom's
         // fixed grid starts in two chunks of its own (drawn / deferred records) and takes further ones from the pool (a pool that runs dry
         // is reported like a bin overflow); k_index moves the drawn ones into a second array in tile order.  Sized from the scene:
-        // 8 records per meshlet-instance, at least 32 Mi (3 x 8192 x 256 on top are the waves' own chunks: drawn, deferred, round 2) - 68 bytes
+        // 8 records per meshlet-instance, at least 32 Mi (8192 x 256 on top are the waves' own chunks) - 68 bytes
         // apiece, 2.6 GB of 288 reserved, touched as far as a frame needs.
         free_tri_bins(c);
         c->tb.n_waves = 8192; c->tb.slow_cap = 1u << 18;
-        const uint64_t n_rec = std::min<uint64_t>(std::max<uint64_t>(32ull << 20, 8ull * c->n_work) + 3ull * c->tb.n_waves * ZR_TPOOL_CHUNK, 0x3FFFFFFFull);
+        const uint64_t n_rec = std::min<uint64_t>(std::max<uint64_t>(32ull << 20, 8ull * c->n_work) + 1ull * c->tb.n_waves * ZR_TPOOL_CHUNK, 0x3FFFFFFFull);
         c->tb.n_chunks = (uint32_t)(n_rec / ZR_TPOOL_CHUNK);
         if (c->limit_record_chunks) c->tb.n_chunks = c->limit_record_chunks;      // zr_set_limits (a host sizing the pool; the overflow tests)
         if (c->limit_slow_triangles) c->tb.slow_cap = std::max(2u, c->limit_slow_triangles);
@@ -762,8 +778,6 @@ static int finalize_scene(zr_ctx* c)
         HIPCHK(c, dev_alloc(&c->tb.chunk_fill, c->tb.n_chunks));
         HIPCHK(c, hipMemset(c->tb.chunk_fill, 0, (size_t)c->tb.n_chunks * 4));
         HIPCHK(c, dev_alloc(&c->tb.wave_culled, c->tb.n_waves));
-        HIPCHK(c, dev_alloc(&c->tb.wave_direct, c->tb.n_waves));
-        HIPCHK(c, dev_alloc(&c->tb.wave_retest, 2ull * c->tb.n_waves));
         HIPCHK(c, dev_alloc(&c->tb.slow, 4ull * c->tb.slow_cap));
         c->chunk_capacity = std::max<uint32_t>(c->chunk_capacity, c->tb.sorted_cap / ZR_TCHUNK + 2u * std::max(c->n_tiles, c->sn_tiles) + 1u);
         for (auto& sc : c->sc) { dev_free(sc.chunk_tab); HIPCHK(c, dev_alloc(&sc.chunk_tab, c->chunk_capacity)); }
@@ -774,7 +788,6 @@ static int finalize_scene(zr_ctx* c)
     c->any_images = false;
     for (const ZrObject& d : tab) for (int t = 0; t < 7; ++t) if (d.tex[t].data) c->any_images = true;
     c->vis_history = false;         // work item numbering changed: last frame's visibility says nothing about this scene
-    c->hiz_valid = false;
     c->scene_dirty = false;
     return ZR_OK;
 }
@@ -1095,18 +1108,16 @@ static void tri_select(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hip
 {
     zr_launch_select(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->tb, c->d_stats, slot, s);
 }
-// Round 1 (or the only round): records -> tile order -> tile raster.  Round 2: the few triangles the pyramid lets through are rasterised
-// where they are found (k_geom<true>), then round 1's deferred triangles are looked at again (k_retest).  One k_tile_slow after the
-// last round draws the clipped / long triangles of both.
+// One round of the triangle-binned camera pass: triangles -> records (k_geom), records -> tile order (k_index), tile raster (k_tile).  One
+// k_tile_slow after the last round draws the clipped / long triangles of both.
 static void tri_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s, bool last)
 {
     const zr_ctx::Scratch& sc = c->sc[1];
     if (P.n_work == 0) return;          // nothing to draw: the pass is its clear
     zr_launch_geom(P, Z, c->tb, sc.tile_count, c->d_stats, slot, c->d_vis, s);
-    if (slot == 2 && c->predict_now) zr_launch_retest(P, Z, c->tb, c->d_stats, c->d_vis, s);      // round 1's deferred triangles
     zr_launch_index(c->tb, c->n_tiles, sc.tile_count, sc.tile_cursor, sc.chunk_tab, c->chunk_capacity, c->d_stats, slot, s);
     zr_launch_tile(P, sc.chunk_tab, c->tb, sc.tile_count, sc.tile_cursor, c->n_tiles, c->d_stats, slot, c->d_vis, c->raster_blocks, s);
-    if (last) zr_launch_tile_slow_camera(P, c->tb, c->d_owned, c->n_owned, c->d_stats, slot, c->d_vis, slot == 2 && c->predict_now, s);
+    if (last) zr_launch_tile_slow_camera(P, c->tb, c->d_owned, c->n_owned, c->d_stats, slot, c->d_vis, s);
 }
 static void raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s)
 {
@@ -1221,15 +1232,6 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
     zr_launch_cull_box(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, s, c->tb.sel, c->last_two_round ? Z.vis_prev : nullptr);
     if (hiz_on && P.use_worklist) HIPCHK(c, hipMemsetAsync(c->d_visflag[c->vis_cur], 0, c->n_work, s));     // else k_cull clears them
     const bool two = c->last_two_round;
-    // round 1 may consult LAST frame's pyramid (still in the arrays) to put off triangles that were hidden then; k_retest settles them
-    // against this frame's.  Only a guess is needed (any subset may be drawn first), so a stale pyramid costs time, never pixels.
-    // The pyramid is a picture of the screen: it is only a good guess while the camera stands still (a camera turning 2 degrees per frame
-    // had round 1 put off a third of what was visible: 4 860 -> 3 560 Mpixel/s), so the guess is used when this frame's transform is bit
-    // for bit last frame's.
-    const bool same_view = memcmp(P.PVM, c->last_pvm, sizeof P.PVM) == 0;
-    memcpy(c->last_pvm, P.PVM, sizeof P.PVM);
-    c->predict_now = tri_bins && two && c->hiz_valid && same_view && !(c->cfg.flags & ZR_FLAG_NO_PREDICT);
-    Z.predict = c->predict_now ? 1u : 0u;
     auto bin = [&](int slot) { if (!tri_bins) bin_and_raster(c, P, Z, slot, c->n_tiles, s); else if (slot == 2) tri_select(c, P, Z, slot, s); };
     auto rast = [&](int slot) { if (tri_bins) tri_raster(c, P, Z, slot, s, slot == 2 || !two); else raster(c, P, Z, slot, s); };
     if (c->last_two_round) {
@@ -1239,8 +1241,7 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
         rast(1);
         if (ev) HIPCHK(c, hipEventRecord(ev[4], s));
         zr_launch_hiz_build(c->d_vis, c->W, c->H, Z, s);
-        c->hiz_valid = true;
-        Z.phase = 2; Z.predict = 0u;
+        Z.phase = 2;
         bin(2);
         if (ev) HIPCHK(c, hipEventRecord(ev[5], s));
         rast(2);
@@ -1259,8 +1260,7 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
     if (ev) HIPCHK(c, hipEventRecord(ev[6], s));
     zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_lut, c->d_unorm_lut, Z.vis_now, c->d_stats, s);
     if (ev) HIPCHK(c, hipEventRecord(ev[7], s));
-    if (hiz_on) { c->vis_history = true; c->vis_cur ^= 1; } else { c->vis_history = false; c->hiz_valid = false; }
-    if (!two) c->hiz_valid = false;        // a one-round frame builds no pyramid: what the arrays hold is two frames old or older
+    if (hiz_on) { c->vis_history = true; c->vis_cur ^= 1; } else c->vis_history = false;
     HIPCHK(c, hipGetLastError());
     return ZR_OK;
 }
@@ -1564,7 +1564,6 @@ extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out)
     }
     out->survivors[1] += c->h_stats.survivors[2]; out->bin_entries[1] += c->h_stats.bin_entries[2];    // both rounds of the camera pass
     out->hiz_culled = c->h_stats.hiz_culled; out->round1_survivors = c->last_two_round ? c->h_stats.survivors[1] : 0;
-    out->deferred_triangles = c->h_stats.n_deferred; out->deferred_drawn = c->h_stats.n_retest_kept; out->direct_triangles = c->h_stats.bin_entries[2];
     out->covered_pixels = c->h_stats.covered; out->covered_shadow_texels = c->h_stats.covered_shadow; out->overflow = c->h_stats.overflow;
     return rc;
 }

@@ -15,12 +15,10 @@
 //                     merge touched keys into HBM (atomic min); DEFER: clipped triangles go to a list for k_tile_slow
 //   camera pass: triangle-level binning
 //   k_select          round 2: the meshlet-instances the Hi-Z pyramid does not hide -> 32-byte records
-//   k_geom<false>     round 1, wave per meshlet-instance: vertices once, exact per-triangle tests, one 32-byte record per (triangle, tile);
-//                     triangles last frame's pyramid hides are deferred to k_retest instead
+//   k_geom<HIZ>       wave per meshlet-instance: vertices once, exact per-triangle tests (round 2: + the pyramid per meshlet and per triangle),
+//                     one 32-byte record per (triangle, tile) + its tile id
 //   k_index           per-tile offsets and work units (every workgroup scans the counts itself), records MOVED into tile order
 //   k_tile / k_tile_slow   lane per record, streamed: edge set-up + walk into the tile's LDS keys; clipped triangles through raster_clipped
-//   k_geom<true>      round 2: as round 1 + this frame's pyramid per meshlet and per triangle; survivors rasterised directly (atomicMin)
-//   k_retest          round 1's deferred triangles against this frame's pyramid, survivors rasterised directly
 //   k_hiz_build       max-depth pyramid of the key buffer after round 1 (two-pass occlusion culling of the camera pass)
 //   k_resolve_gbuffer BaseScene.frag per pixel from the key buffer; SoA GBuffer planes, coalesced row stores; marks the
 //                     meshlet-instances that own a pixel (next frame's round 1)
@@ -1672,22 +1670,18 @@ __global__ __launch_bounds__(256) void k_select(ZrPass P, const ZrObject* __rest
 // 64 px - that reaches the tile has its vertices within [-16384, 24576] sub-pixel units of it) with their depth bits, and the primitive id:
 //   plane A: (X0 | Y0 << 16, z0, X1 | Y1 << 16, z1)      plane B: (X2 | Y2 << 16, z2, prim, 0)
 // plus the tile id in a separate dword stream (k_index reads 4 bytes per record, not the record, to find where it goes).  Records live
-// in chunks of ZR_TPOOL_CHUNK, structure-of-arrays inside a chunk (every store and load of a wave is one contiguous run).
-// Two kinds of chunks: DRAWN records go through k_index / k_tile now; DEFERRED ones (round 1 predicted them hidden, see k_geom) wait for
-// k_retest.  chunk_fill[c] = records | kind << 31.
-#define ZR_CHUNK_DEFERRED 0x80000000u
-#define ZR_CHUNK_ROUND2   0x40000000u       // drawn records of round 2 (k_index / k_tile run once per round)
-#define ZR_CHUNK_COUNT(cf) ((cf) & 0x3FFFFFFFu)
+// in chunks of ZR_TPOOL_CHUNK, structure-of-arrays inside a chunk (every store and load of a wave is one contiguous run); chunk_fill[c] =
+// records in chunk c.  Both rounds of a frame use the chunks from 0: round 1's records have been moved and rasterised by then.
 __device__ __forceinline__ uint32_t pack_xy(int X, int Y) { return ((uint32_t)X & 0xFFFFu) | ((uint32_t)Y << 16); }
 struct RecWriter {                 // wave-uniform state of one record stream of a wave
     uint32_t cur, fill;            // the chunk being filled (>= n_chunks: the pool ran dry) and its fill
 };
 // room for `n` more records (wave-uniform): closes the chunk and takes one from the pool when it would overflow; false: pool dry
-__device__ __forceinline__ bool rec_reserve(RecWriter& W, uint32_t n, uint32_t kind, uint32_t lane, const ZrTriBins& B, ZrDevStats* __restrict__ stats, int slot)
+__device__ __forceinline__ bool rec_reserve(RecWriter& W, uint32_t n, uint32_t lane, const ZrTriBins& B, ZrDevStats* __restrict__ stats, int slot)
 {
     if (W.cur < B.n_chunks && W.fill + n > ZR_TPOOL_CHUNK) {
         uint32_t nx_c = 0;
-        if (lane == 0) { B.chunk_fill[W.cur] = W.fill | kind; nx_c = 3u * B.n_waves + atomicAdd(&stats->pool_next[1], 1u); }      // (one pool for both rounds)
+        if (lane == 0) { B.chunk_fill[W.cur] = W.fill; nx_c = B.n_waves + atomicAdd(&stats->pool_next[slot], 1u); }
         W.cur = min((uint32_t)__builtin_amdgcn_readfirstlane((int)nx_c), B.n_chunks);
         W.fill = 0;
     }
@@ -1712,81 +1706,6 @@ __device__ __forceinline__ RecTri rec_load(const uint4 qa, const uint4 qb)
     return t;
 }
 
-// Up to 64 small triangles (every edge under 64 px; lane l holds triangle l, `draw` says whether it is to be drawn) straight into the
-// frame's key buffer, FLATTENED: the pixels of all their clipped boxes form one sequence, and the wave takes 64 of them per step, whatever
-// triangle they belong to (owner found by a search over the running sum of the box areas; the owner's set-up travels by ds_bpermute).
-// Every lane is busy on every step and the guarding reads of the key buffer are 64 independent loads per step - a lane-per-triangle walk
-// waits for one such read per pixel, and unguarded atomics (most of these fragments lose: the triangles that reach this path are the ones a
-// conservative pyramid test could not reject) run at ~16 G/s when scattered like this.
-// Same integers and floats as raster_sub<GBUFFER, SMALL> on absolute coordinates: an edge value is E(origin) + steps * increment (exact
-// integer arithmetic either way, all below 2^31: the box is clipped to the target and the edges are under 2^14), the depth is the same
-// fma chain from the same operands.  Only for the FEW triangles of round 2 / k_retest: device-scope atomics are slow.
-__device__ __forceinline__ void raster_flat(const ZrPass& P, const SV& v0, const SV& v1, const SV& v2, uint32_t prim, bool draw, uint32_t lane,
-                                            unsigned long long* __restrict__ vis64)
-{
-    // ---- per-triangle set-up, in the owner's lane
-    int x0 = 0, y0 = 0, bw = 0, area = 0, E0 = 0, E1 = 0, E2 = 0, sx0 = 0, sx1 = 0, sx2 = 0, sy0 = 0, sy1 = 0, sy2 = 0;
-    float gx = 0.0f, gy = 0.0f, zlo = 0.0f, zhi = 0.0f;
-    if (draw) {
-        const int dX1 = v1.X - v0.X, dY1 = v1.Y - v0.Y, dX2 = v2.X - v0.X, dY2 = v2.Y - v0.Y;
-        const int A = dX1 * dY2 - dX2 * dY1;
-        x0 = max((imin3(v0.X, v1.X, v2.X) - 128 + 255) >> 8, 0); const int x1 = min((imax3(v0.X, v1.X, v2.X) - 128) >> 8, (int)P.W - 1);
-        y0 = max((imin3(v0.Y, v1.Y, v2.Y) - 128 + 255) >> 8, 0); const int y1 = min((imax3(v0.Y, v1.Y, v2.Y) - 128) >> 8, (int)P.H - 1);
-        if (A < 0 && x0 <= x1 && y0 <= y1) {              // (A >= 0: degenerate or back-facing, ZE:5113-5123)
-            bw = x1 - x0 + 1; area = bw * (y1 - y0 + 1);
-            const int ex0 = -(v2.X - v1.X), ey0 = -(v2.Y - v1.Y), ex1 = -(v0.X - v2.X), ey1 = -(v0.Y - v2.Y), ex2 = -(v1.X - v0.X), ey2 = -(v1.Y - v0.Y);
-            const int Px0 = x0 * 256 + 128, Py0 = y0 * 256 + 128;
-            const int tl0 = ((ey0 < 0) || (ey0 == 0 && ex0 > 0)) ? 0 : 1, tl1 = ((ey1 < 0) || (ey1 == 0 && ex1 > 0)) ? 0 : 1;
-            const int tl2 = ((ey2 < 0) || (ey2 == 0 && ex2 > 0)) ? 0 : 1;
-            E0 = ex0 * (Py0 - v1.Y) - ey0 * (Px0 - v1.X) - tl0;
-            E1 = ex1 * (Py0 - v2.Y) - ey1 * (Px0 - v2.X) - tl1;
-            E2 = ex2 * (Py0 - v0.Y) - ey2 * (Px0 - v0.X) - tl2;
-            sx0 = -ey0 * 256; sx1 = -ey1 * 256; sx2 = -ey2 * 256; sy0 = ex0 * 256; sy1 = ex1 * 256; sy2 = ex2 * 256;
-            const float invA = 1.0f / (float)A;
-            const float a1 = (float)(v2.Y - v0.Y) * invA, b1 = (float)(v0.X - v2.X) * invA;
-            const float a2 = (float)(v0.Y - v1.Y) * invA, b2 = (float)(v1.X - v0.X) * invA;
-            const float dz1 = v1.z - v0.z, dz2 = v2.z - v0.z;
-            gx = __builtin_fmaf(a2, dz2, a1 * dz1); gy = __builtin_fmaf(b2, dz2, b1 * dz1);
-            zlo = __builtin_fminf(__builtin_fminf(v0.z, v1.z), v2.z); zhi = __builtin_fmaxf(__builtin_fmaxf(v0.z, v1.z), v2.z);
-        }
-    }
-    // ---- running sum of the box areas over the lanes (inclusive), total in every lane
-    int incl = area;
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
-    const int total = __shfl(incl, 63);
-    for (int f0 = 0; f0 < total; f0 += 64) {
-        const int f = f0 + (int)lane;
-        // owner = the first lane whose inclusive sum exceeds f (lanes with an empty box never own anything)
-        int lo = 0, hi = 63;
-#pragma unroll
-        for (int it = 0; it < 6; ++it) { const int mid = (lo + hi) >> 1; if (__shfl(incl, mid) > f) hi = mid; else lo = mid + 1; }
-        const int o = lo;
-        const int o_incl = __shfl(incl, o), o_area = __shfl(area, o), o_bw = __shfl(bw, o);
-        const int o_x0 = __shfl(x0, o), o_y0 = __shfl(y0, o);
-        const int oE0 = __shfl(E0, o), oE1 = __shfl(E1, o), oE2 = __shfl(E2, o);
-        const int osx0 = __shfl(sx0, o), osx1 = __shfl(sx1, o), osx2 = __shfl(sx2, o), osy0 = __shfl(sy0, o), osy1 = __shfl(sy1, o), osy2 = __shfl(sy2, o);
-        const int oX = __shfl(v0.X, o), oY = __shfl(v0.Y, o);
-        const float oz = __shfl(v0.z, o), ogx = __shfl(gx, o), ogy = __shfl(gy, o), ozlo = __shfl(zlo, o), ozhi = __shfl(zhi, o);
-        const uint32_t oprim = (uint32_t)__shfl((int)prim, o);
-        if (f >= total) continue;
-        const int local = f - (o_incl - o_area);           // index inside the owner's box, row-major
-        const int ry = local / o_bw, rx = local - ry * o_bw;
-        const int x = o_x0 + rx, y = o_y0 + ry;
-        const int e0 = oE0 + osx0 * rx + osy0 * ry, e1 = oE1 + osx1 * rx + osy1 * ry, e2 = oE2 + osx2 * rx + osy2 * ry;
-        if ((e0 | e1 | e2) < 0) continue;
-        if (P.tile_world > 1u && tile_owner((uint32_t)x / TILE, (uint32_t)y / TILE, P.tile_world) != P.tile_rank) continue;
-        const float fx = (float)(x * 256 + 128 - oX), fy = (float)(y * 256 + 128 - oY);
-        float z = __builtin_fmaf(ogy, fy, __builtin_fmaf(ogx, fx, oz));
-        z = __builtin_fminf(__builtin_fmaxf(z, ozlo), ozhi);
-        z = z + 0.0f;
-        if (z >= 0.0f && z < 1.0f) {
-            const unsigned long long k = (unsigned long long)zr_f2u(z) << 32 | oprim;
-            unsigned long long* q = vis64 + ((size_t)y * P.W + (size_t)x);
-            if (k < *q) atomicMin(q, k);
-        }
-    }
-}
-
 // Max depth already in the key buffer (per the pyramid Z) over the pixel blocks a snapped box touches: 4 x 4 blocks for a box under 16
 // pixels, else 8 x 8 (blocks of other ranks' tiles hold 0).  A triangle whose least vertex depth lies behind it cannot win a pixel.
 __device__ __forceinline__ float pyramid_max(const ZrHiz& Z, int x0, int y0, int x1, int y1)
@@ -1803,15 +1722,11 @@ __device__ __forceinline__ float pyramid_max(const ZrHiz& Z, int x0, int y0, int
 }
 
 // One wave per selected meshlet-instance: vertices -> LDS, then a lane per triangle.
-// ROUND 1 (HIZ = false) turns triangles into records, one per (triangle, owned tile), in the wave's own chunks (wave k starts in chunk
-// k and takes further ones from a pool: one atomic per ZR_TPOOL_CHUNK records; a round is ONE launch whatever the scene's size).  With
-// Z.predict (a pyramid of the PREVIOUS frame exists) a triangle that pyramid hides is not drawn now but DEFERRED - one record in the
-// wave's deferred chunks (wave k: chunk n_waves + k) - and k_retest looks at it again once this frame's pyramid stands.  Any guess is
-// allowed here: round 1 only has to put good occluders down, the depth test and k_retest decide the pixels.  With a still camera the
-// guess is as good as round 2's own test, so round 1 draws little more than what ends up visible - at triangle, not meshlet granularity.
-// ROUND 2 (HIZ = true): a meshlet whose snapped vertex box lies behind this frame's pyramid is dropped after the vertex phase, every
-// triangle is tested once more by itself, and the few that remain are rasterised straight into the key buffer (raster_direct): no
-// records, no binning chain behind this launch.
+// Triangles that pass the exact tests (facing, a pixel centre of the target inside the snapped box) become records, one per (triangle,
+// owned tile), in the wave's own chunks (wave k starts in chunk k and takes further ones from a pool: one atomic per ZR_TPOOL_CHUNK
+// records; a round is ONE launch whatever the scene's size).
+// ROUND 2 (HIZ = true): a meshlet whose snapped vertex box lies behind this frame's pyramid is dropped after the vertex phase, and every
+// triangle is tested once more by itself against the 4 x 4-pixel level (the meshlet's blocks stay in LDS for that).
 template <bool HIZ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, uint32_t* __restrict__ tile_count,
@@ -1823,11 +1738,11 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
     const uint32_t n = stats->n_sel[slot];
     const unsigned long long lt = (1ull << lane) - 1ull;
     const uint32_t wave_id = blockIdx.x * 4u + wv, n_waves = gridDim.x * 4u;
-    const bool pyramid = HIZ || Z.predict != 0u;          // a pyramid is consulted: this frame's (round 2) or last frame's (round 1's guess)
+    constexpr bool pyramid = HIZ;
     if (HIZ && wave_id == 0u && lane == 0u) stats->survivors[slot] = n;      // (k_tile_slow takes the meshlets dropped behind the pyramid off)
-    RecWriter Wd, Wq;                                    // drawn / deferred streams (round 2 draws into a chunk range of its own)
-    Wd.cur = (HIZ ? 2u * n_waves : 0u) + wave_id; Wd.fill = 0; Wq.cur = n_waves + wave_id; Wq.fill = 0;
-    uint32_t culled = 0, n_direct = 0;
+    RecWriter Wd;                                        // the wave's record stream
+    Wd.cur = wave_id; Wd.fill = 0;
+    uint32_t culled = 0;
     for (uint32_t i = wave_id; i < n; i += n_waves) {
         const uint4* __restrict__ rec = (const uint4*)(sel + i);
         const uint4 e0 = rec[0], e1 = rec[1];
@@ -1948,18 +1863,7 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
                     } else { stats->overflow = 1u; stats->overflow_sticky = 1u; }
                 }
             }
-            if (HIZ) n_direct += (uint32_t)__popcll(__ballot(alive && !hidden));
-            // ---- round 1, deferred: one record per triangle, filed under the first tile of its box
-            const unsigned long long mq = HIZ ? 0ull : __ballot(alive && hidden);
-            if (mq && rec_reserve(Wq, (uint32_t)__popcll(mq), ZR_CHUNK_DEFERRED, lane, B, stats, slot)) {
-                if (alive && hidden) {
-                    const uint32_t tile = (uint32_t)(y0 / TILE) * P.tiles_x + (uint32_t)(x0 / TILE);
-                    rec_store(B, Wq.cur * ZR_TPOOL_CHUNK + Wq.fill + (uint32_t)__popcll(mq & lt), r0, r1, r2, prim, tile, x0 / TILE, y0 / TILE);
-                }
-                Wq.fill += (uint32_t)__popcll(mq);
-            }
-            // ---- drawn (round 1: what last frame's pyramid does not hide; round 2: what this frame's does not): one record per
-            // (triangle, owned tile); ranks within a tile are handed out by k_index
+            // ---- one record per (triangle, owned tile); ranks within a tile are handed out by k_index
             const bool draw = alive && !hidden;
             const int tx0 = x0 / TILE, ty0 = y0 / TILE;
             const int nx = draw ? x1 / TILE - tx0 + 1 : 0, ny = draw ? y1 / TILE - ty0 + 1 : 0, ntile = nx * ny;
@@ -1976,7 +1880,7 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
                 }
                 const unsigned long long me = __ballot(emit);
                 if (!me) continue;
-                if (!rec_reserve(Wd, (uint32_t)__popcll(me), HIZ ? ZR_CHUNK_ROUND2 : 0u, lane, B, stats, slot)) continue;
+                if (!rec_reserve(Wd, (uint32_t)__popcll(me), lane, B, stats, slot)) continue;
                 // count per tile: one add per (wave, tile), all of a step's in one instruction, and nobody waits for them
                 unsigned long long pend = me;
                 uint32_t cnt = 0;
@@ -1994,10 +1898,8 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
         }
     }
     if (lane == 0) {
-        if (Wd.cur < B.n_chunks) B.chunk_fill[Wd.cur] = Wd.fill | (HIZ ? ZR_CHUNK_ROUND2 : 0u);
-        if (!HIZ && Wq.cur < B.n_chunks) B.chunk_fill[Wq.cur] = Wq.fill | ZR_CHUNK_DEFERRED;
+        if (Wd.cur < B.n_chunks) B.chunk_fill[Wd.cur] = Wd.fill;
         B.wave_culled[wave_id] = HIZ ? culled : 0u;
-        B.wave_direct[wave_id] = n_direct;
     }
 }
 
@@ -2049,14 +1951,10 @@ __global__ __launch_bounds__(256) void k_index(ZrTriBins B, ZrDevStats* __restri
         }
         __syncthreads();
     }
-    const uint32_t used = max(3u * B.n_waves, min(3u * B.n_waves + stats->pool_next[1], B.n_chunks));
+    const uint32_t used = min(B.n_waves + stats->pool_next[slot], B.n_chunks);
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const uint32_t my_kind = slot == 2 ? ZR_CHUNK_ROUND2 : 0u, own0 = slot == 2 ? 2u * B.n_waves : 0u;
-    for (uint32_t w = blockIdx.x * 4u + wv; w < B.n_waves + (used - 3u * B.n_waves); w += gridDim.x * 4u) {
-        const uint32_t ch = w < B.n_waves ? own0 + w : 3u * B.n_waves + (w - B.n_waves);      // the round's own chunks, then the pool
-        const uint32_t cf = B.chunk_fill[ch];
-        if ((cf & (ZR_CHUNK_DEFERRED | ZR_CHUNK_ROUND2)) != my_kind) continue;
-        const uint32_t n = ZR_CHUNK_COUNT(cf), r0 = ch * ZR_TPOOL_CHUNK;
+    for (uint32_t ch = blockIdx.x * 4u + wv; ch < used; ch += gridDim.x * 4u) {
+        const uint32_t n = B.chunk_fill[ch], r0 = ch * ZR_TPOOL_CHUNK;
         for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
             const uint32_t j = j0 + lane, i = r0 + j;
             const bool have = j < n;
@@ -2129,53 +2027,13 @@ __global__ __launch_bounds__(256) void k_tile(ZrPass P, const uint4* __restrict_
     }
 }
 
-// Round 1's deferred triangles against THIS frame's pyramid (exactly round 2's per-triangle test: a lower bound of the fragments' depth
-// against a max of depths already in the key buffer, so nothing that could win a pixel is dropped); what the pyramid lets through after
-// all is rasterised straight into the key buffer (raster_flat).  With a still camera nearly everything deferred stays hidden: the kernel
-// streams 36 bytes per record and a few pyramid texels.  One wave per deferred chunk (a wave of round 1 leaves ~80 records in its own):
-// the kernel is bound by the latency of its dependent loads, so it wants many short waves.
-__global__ __launch_bounds__(256) void k_retest(ZrPass P, ZrHiz Z, ZrTriBins B, ZrDevStats* __restrict__ stats, unsigned long long* __restrict__ vis64)
-{
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t used = max(3u * B.n_waves, min(3u * B.n_waves + stats->pool_next[1], B.n_chunks));
-    uint32_t kept = 0, seen = 0;
-    for (uint32_t w = blockIdx.x * 4u + wv; w < B.n_waves + (used - 3u * B.n_waves); w += gridDim.x * 4u) {
-        const uint32_t ch = w < B.n_waves ? B.n_waves + w : 3u * B.n_waves + (w - B.n_waves);      // the waves' deferred chunks, then the pool
-        const uint32_t cf = B.chunk_fill[ch];
-        if (!(cf & ZR_CHUNK_DEFERRED)) continue;
-        const uint32_t n = ZR_CHUNK_COUNT(cf), r0 = ch * ZR_TPOOL_CHUNK;
-        for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
-            const uint32_t j = j0 + lane, i = r0 + j;
-            bool draw = false;
-            RecTri t; t.a.X = t.a.Y = t.b.X = t.b.Y = t.c.X = t.c.Y = 0; t.a.z = t.b.z = t.c.z = 0.0f; t.a.rw = t.b.rw = t.c.rw = 0.0f; t.prim = 0u;
-            if (j < n) {
-                const uint32_t tile = B.rtile[i];
-                t = rec_load(B.recA[i], B.recB[i]);
-                const int ox = (int)(tile % P.tiles_x) * (TILE * 256), oy = (int)(tile / P.tiles_x) * (TILE * 256);
-                t.a.X += ox; t.a.Y += oy; t.b.X += ox; t.b.Y += oy; t.c.X += ox; t.c.Y += oy;
-                ++seen;
-                const int x0 = max((imin3(t.a.X, t.b.X, t.c.X) - 128 + 255) >> 8, 0), x1 = min((imax3(t.a.X, t.b.X, t.c.X) - 128) >> 8, (int)P.W - 1);
-                const int y0 = max((imin3(t.a.Y, t.b.Y, t.c.Y) - 128 + 255) >> 8, 0), y1 = min((imax3(t.a.Y, t.b.Y, t.c.Y) - 128) >> 8, (int)P.H - 1);
-                const float tz = __builtin_fminf(__builtin_fminf(t.a.z, t.b.z), t.c.z);
-                draw = !(tz > pyramid_max(Z, x0, y0, x1, y1));
-                if (draw) ++kept;
-            }
-            if (__ballot(draw)) raster_flat(P, t.a, t.b, t.c, t.prim, draw, lane, vis64);      // the whole wave, pixel by pixel
-        }
-    }
-    // (per-wave counts, summed by k_tile_slow: 8 192 atomics on one address would queue up for ~10 ns apiece and hold the kernel's end)
-    kept = (uint32_t)wave_sum((int)kept); seen = (uint32_t)wave_sum((int)seen);
-    if (lane == 0) { const uint32_t w_ = blockIdx.x * 4u + wv; B.wave_retest[2u * w_] = seen; B.wave_retest[2u * w_ + 1u] = kept; }
-}
-
 // The slow triangles of the round (they need the clipper, or have an edge of 64 px or more): every owned tile tries every one of
 // them through raster_clipped.  One workgroup per owned tile; returns at once when the round has none (the usual case).
 template <int MODE, bool BY_TILE>
 __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __restrict__ owned_tiles, const uint4* __restrict__ slow,
                                                    uint32_t slow_cap, ZrDevStats* __restrict__ stats, int slot,
                                                    unsigned long long* __restrict__ vis64, uint32_t* __restrict__ shadow_bits,
-                                                   const uint32_t* __restrict__ wave_culled, const uint32_t* __restrict__ wave_direct,
-                                                   const uint32_t* __restrict__ wave_retest, uint32_t n_waves)
+                                                   const uint32_t* __restrict__ wave_culled, uint32_t n_waves)
 {
     __shared__ unsigned long long keys64[MODE == ZR_MODE_GBUFFER ? TILE_PIX : 1];
     __shared__ uint32_t keys32[MODE == ZR_MODE_SHADOW ? TILE_PIX : 1];
@@ -2184,20 +2042,12 @@ __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __r
     const uint32_t half = BY_TILE ? slow_cap : slow_cap / 2u;
     const uint32_t n_a = min(stats->n_slow[BY_TILE ? slot : 1], half), n_b = (!BY_TILE && slot == 2) ? min(stats->n_slow[2], half) : 0u;
     if (!BY_TILE && slot == 2 && wave_culled && blockIdx.x * 256u < n_waves) {
-        // round 2 has no binning chain behind it any more: its books are closed here (meshlets k_geom dropped behind the pyramid, triangles
-        // it handed to k_retest, what k_retest saw and kept) - a slice of the per-wave counts per workgroup
+        // the meshlets round 2's k_geom dropped behind the pyramid: a slice of the per-wave counts per workgroup (one atomic per wave of
+        // THAT kernel on one address would queue up for ~10 ns apiece and hold its end)
         const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-        uint32_t nc = 0, nd = 0, ns = 0, nk = 0;
-        if (i < n_waves) {
-            nc = wave_culled[i]; nd = wave_direct[i];
-            if (wave_retest) { ns = wave_retest[2u * i]; nk = wave_retest[2u * i + 1u]; }
-        }
-        nc = (uint32_t)wave_sum((int)nc); nd = (uint32_t)wave_sum((int)nd); ns = (uint32_t)wave_sum((int)ns); nk = (uint32_t)wave_sum((int)nk);
-        if ((threadIdx.x & 63u) == 0u) {
-            if (nc) { atomicAdd(&stats->hiz_culled, nc); atomicSub(&stats->survivors[2], nc); }
-            if (ns) atomicAdd(&stats->n_deferred, ns);
-            if (nk) atomicAdd(&stats->n_retest_kept, nk);
-        }
+        uint32_t nc = i < n_waves ? wave_culled[i] : 0u;
+        nc = (uint32_t)wave_sum((int)nc);
+        if ((threadIdx.x & 63u) == 0u && nc) { atomicAdd(&stats->hiz_culled, nc); atomicSub(&stats->survivors[2], nc); }
     }
     if (n_a + n_b == 0u) return;
     const uint32_t tid = threadIdx.x, tile = owned_tiles[blockIdx.x];
@@ -2889,7 +2739,7 @@ void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4*
     if (slow) {    // shadow pass: clipped triangles go through a list + k_tile_slow
         hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false, true>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u, slow, slow_cap);
         if (n_tiles) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_SHADOW, true>), dim3(n_tiles), dim3(256), 0, s, P, tiles, slow, slow_cap, stats, slot, (unsigned long long*)nullptr, shadow_bits,
-                                        (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u);
+                                        (const uint32_t*)nullptr, 0u);
     } else
         hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u, (uint4*)nullptr, 0u);
 }
@@ -2915,15 +2765,11 @@ void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B,
 {
     hipLaunchKernelGGL(k_tile<ZR_MODE_GBUFFER>, dim3(n_blocks), dim3(256), 0, s, P, chunk_tab, B, tile_count, tile_cursor, n_tiles, stats, slot, vis64);
 }
-void zr_launch_retest(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats, unsigned long long* vis64, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_retest, dim3(B.n_waves / 4u), dim3(256), 0, s, P, Z, B, stats, vis64);
-}
 void zr_launch_tile_slow_camera(const ZrPass& P, const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned, ZrDevStats* stats, int slot,
-                                unsigned long long* vis64, bool retested, hipStream_t s)
+                                unsigned long long* vis64, hipStream_t s)
 {
     if (n_owned) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_GBUFFER, false>), dim3(n_owned), dim3(256), 0, s, P, owned_tiles, B.slow, B.slow_cap, stats, slot, vis64,
-                                    (uint32_t*)nullptr, B.wave_culled, B.wave_direct, retested ? B.wave_retest : (const uint32_t*)nullptr, B.n_waves);
+                                    (uint32_t*)nullptr, B.wave_culled, B.n_waves);
 }
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, const float* unorm_lut, uint8_t* vis_now,

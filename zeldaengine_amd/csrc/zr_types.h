@@ -121,7 +121,6 @@ struct ZrDevStats {
     uint32_t n_sel[3];               // triangle-binned camera pass: meshlet-instances selected for a round (slots as above)
     uint32_t n_slow[3];              //   triangles of the round that need the clipper / the 64-bit walk
     uint32_t pool_next[3], pool_used[3];   // record chunks taken from the pool: running (k_geom) / final
-    uint32_t n_deferred, n_retest_kept;    // round 1's deferred triangles / those this frame's pyramid let through after all (k_retest)
     uint32_t overflow_sticky;        // LAST member: not cleared at frame begin; set with `overflow`, cleared by zr_finish when it reports it
 };
 
@@ -136,7 +135,6 @@ struct ZrHiz {
     const uint8_t* vis_prev;         // per meshlet-instance: owned a pixel of the previous frame
     uint8_t*  vis_now;               // marked by the resolve
     uint32_t  phase;                 // 0: no Hi-Z (one round); 1: round 1 = last frame's visible set; 2: round 2 = the rest, Hi-Z tested
-    uint32_t  predict;               // round 1: the arrays still hold LAST frame's pyramid: triangles it hides are deferred to k_retest
     uint32_t  tiles_x, tile_rank, tile_world;   // pyramid texels over another rank's tiles read 0 ("hidden"): nothing is drawn there
 };
 
@@ -177,18 +175,16 @@ void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint4* chunk_tab,
                     uint32_t chunk_cap, uint32_t n, uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s,
                     uint32_t chunk = ZR_CHUNK);
-// triangle-binned camera pass: round 1 k_geom -> k_index -> k_tile; round 2 k_select -> k_geom (direct) + k_retest
+// triangle-binned camera pass, per round: [k_select ->] k_geom -> k_index -> k_tile
 struct ZrTriBins {
     ZrBinEntry* sel;                 // meshlet-instances of this round, as self-contained 32-byte records
     // 32-byte triangle records (see zr_kernels.hip, "triangle records"), in chunks of ZR_TPOOL_CHUNK, structure-of-arrays inside a chunk:
     uint4*    recA; uint4* recB;     //   (X0|Y0, z0, X1|Y1, z1)  (X2|Y2, z2, prim, 0), tile-relative int16 coordinates
     uint32_t* rtile;                 //   the record's tile
-    uint32_t  n_chunks;              //   chunk k < n_waves: where wave k of k_geom starts its DRAWN records; n_waves + k: its DEFERRED ones;
-    uint32_t* chunk_fill;            //   the rest is the pool.  chunk_fill[c] = records | kind << 31
+    uint32_t  n_chunks;              //   chunk k < n_waves: where wave k of k_geom starts; the rest is the pool
+    uint32_t* chunk_fill;            //   records in each chunk
     uint32_t  n_waves;               // waves of the k_geom grid
     uint32_t* wave_culled;           // per wave: meshlets it dropped behind the Hi-Z pyramid (round 2)
-    uint32_t* wave_direct;           // per wave: triangles it rasterised directly (round 2)
-    uint32_t* wave_retest;           // per wave of k_retest: deferred triangles seen, drawn after all
     uint4*    srtA; uint4* srtB;     // the drawn records moved into tile order by k_index: k_tile streams them
     uint32_t  sorted_cap;
     uint4*    slow; uint32_t slow_cap;      // 4 x uint4 per slow triangle: three clip-space vertices, (prim, 0, 0, 0)
@@ -209,9 +205,8 @@ void zr_launch_index(const ZrTriBins& B, uint32_t n_tiles, const uint32_t* tile_
                      ZrDevStats* stats, int slot, hipStream_t s);
 void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B, uint32_t* tile_count, uint32_t* tile_cursor, uint32_t n_tiles,
                     ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s);
-void zr_launch_retest(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats, unsigned long long* vis64, hipStream_t s);
 void zr_launch_tile_slow_camera(const ZrPass& P, const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned, ZrDevStats* stats, int slot,
-                                unsigned long long* vis64, bool retested, hipStream_t s);
+                                unsigned long long* vis64, hipStream_t s);
 void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, const ZrHiz& Z, ZrDevStats* stats,
                         int slot, hipStream_t s, ZrBinEntry* sel = nullptr, const uint8_t* vis_prev = nullptr);      // sel: round 1's list (camera)
 void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,

@@ -417,8 +417,7 @@ class Renderer:
         self._chk(self.L.zr_get_stats(self.h, C.byref(s)))
         return {"work_items": list(s.work_items), "survivors": list(s.survivors), "bin_entries": list(s.bin_entries),
                 "covered_pixels": int(s.covered_pixels), "covered_shadow_texels": int(s.covered_shadow_texels), "overflow": int(s.overflow),
-                "hiz_culled": int(s.hiz_culled), "round1_survivors": int(s.round1_survivors),
-                "deferred_triangles": int(s.deferred_triangles), "deferred_drawn": int(s.deferred_drawn), "direct_triangles": int(s.direct_triangles)}
+                "hiz_culled": int(s.hiz_culled), "round1_survivors": int(s.round1_survivors)}
 
     # ---- read-back
     def color(self):
