@@ -32,7 +32,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-VALU_PEAK_PER_S = 256 * 4 * 2.4e9 / 4.0     # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
+# Vector-ALU issue peak: a SIMD-32 issues a wave64 instruction over 2 cycles (MI355X_MICROARCH.md: 157.3 TFLOP/s FP32 vector = 32 lanes per
+# clock per SIMD), 1 024 SIMDs at 2.4 GHz.  What plain loops of independent instructions actually reach on this chip is measured by
+# tools/valu_calib (profiles/<tag>_valu_calib.json): one wave alone issues one instruction per ~8 cycles, two per SIMD reach 4, eight
+# ~2.7 (0.9 T wave-instructions/s for v_mul_f32 / v_add_u32, 0.6-0.7 T for a three-source v_fma_f32) - both are quoted.
+VALU_PEAK_PER_S = 256 * 4 * 2.4e9 / 2.0
 PROFILE_INDEX = os.path.join(ROOT, "profiles", "current.json")     # written by tools/make_profile_summary.py
 
 # the kernels of each timed pass (the cull / hiz passes are groups of launch-bound kernels).  A camera round of the triangle-binned
@@ -84,6 +88,15 @@ def load_profile(workload):
     if prof.get("workload") != workload:
         return None
     prof["_file"] = "profiles/" + idx["pmc"]
+    try:        # the measured issue rates of this chip (tools/valu_calib), collected with the profile
+        cal = json.load(open(os.path.join(ROOT, "profiles", idx["valu_calib"])))
+        plain = [r for r in cal["rows"] if r["op"].startswith(("v_fma_f32 (", "v_mul_f32", "v_add_u32"))]
+        best = max(plain, key=lambda r: r["ginst_per_s"])
+        prof["_calib"] = {"file": "profiles/" + idx["valu_calib"], "best_per_s": best["ginst_per_s"] * 1e9, "best_op": best["op"],
+                          "best_waves_per_simd": best["waves_per_simd"],
+                          "one_wave_cycles_per_inst": min(r["cyc_per_inst_wave"] for r in plain if r["waves_per_simd"] == 1)}
+    except Exception:      # noqa: BLE001
+        prof["_calib"] = None
     return prof
 
 
@@ -275,6 +288,12 @@ def main():
         def kernel_row(p, ms):
             row = {"pass": p, "kernels": list(KERNEL_OF_PASS[p]), "ms": round(ms[p], 4), "algorithmic_bytes": int(alg[p]),
                    "achieved_gbs": round(alg[p] / (ms[p] * 1e-3) / 1e9, 2) if ms[p] > 0 else None, "traffic": pass_traffic(p)}
+            # what bounds each kernel, from the SQ counters of the committed profile (tools/make_profile_summary.py: share of a wave's life
+            # with a vector instruction in execution / parked on memory or a barrier / ready but not issued; mean resident waves per SIMD)
+            iss = {k: ptraffic[k]["issue"] for k in KERNEL_OF_PASS[p] if k in ptraffic and "issue" in ptraffic[k]}
+            if iss:
+                row["issue"] = {k: {f: v.get(f) for f in ("valu_active_frac", "wait_mem_frac", "wait_issue_frac", "waves_per_simd", "valu_simd_busy",
+                                                          "valu_cycles_per_inst_simd")} for k, v in iss.items()}
             return row
 
         def gb_pass(ms):
@@ -304,7 +323,14 @@ def main():
             mn = prof["valu_insts_per_frame"] / VALU_PEAK_PER_S * 1e3
             valu = {"valu_wave_insts_per_frame": int(prof["valu_insts_per_frame"]), "peak_per_s": VALU_PEAK_PER_S, "min_ms": round(mn, 4),
                     "frame_ms": round(ms_per_step, 4), "frac": round(mn / ms_per_step, 4), "source": prof["_file"],
-                    "note": "sum of SQ_INSTS_VALU over the frame's kernels x 4 cycles / (1024 SIMDs x 2.4 GHz): what bounds the frame"}
+                    "note": "sum of SQ_INSTS_VALU over the frame's kernels x 2 cycles / (1024 SIMDs x 2.4 GHz), the datasheet issue rate"}
+            cal = prof.get("_calib")
+            if cal:
+                mm = prof["valu_insts_per_frame"] / cal["best_per_s"] * 1e3
+                valu["measured"] = {"peak_per_s": cal["best_per_s"], "op": cal["best_op"], "waves_per_simd": cal["best_waves_per_simd"],
+                                    "one_wave_cycles_per_inst": cal["one_wave_cycles_per_inst"], "min_ms": round(mm, 4),
+                                    "frac": round(mm / ms_per_step, 4), "source": cal["file"],
+                                    "note": "against the best rate tools/valu_calib reached on this chip with independent instructions"}
         frame_hbm = None
         if prof and prof.get("hbm_bytes_per_frame"):
             g = prof["hbm_bytes_per_frame"] / (ms_per_step * 1e-3) / 1e9

@@ -157,3 +157,124 @@ def test_rotation_matrix_convention_against_the_oracle(oracle_lib):
         L.zo_kat_rotmat(e.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
         mine = ie.make_rot_matrix(e.astype(np.float64))
         assert np.allclose(out.reshape(3, 3).T, mine, atol=2e-6)      # the oracle stores mat3(rotMat) column-major
+
+
+# ---------------------------------------------------------------------------------------------------------------- raster rules
+# The oracle's coverage, facing, depth test and depth bias against tests/independent_raster.py (exact integers / fractions, written from
+# the rules).  Vertices are given on the 1/256-pixel grid through identity matrices (w = 1), so the oracle's transform and snap are exact
+# and both sides see the same integers: what is compared is the RULE, not the arithmetic that feeds it.
+
+def _raster_case(oracle_lib, tris_px, zs, W=32, H=32):
+    """tris_px: per triangle three (x, y) in pixels, multiples of 1/256; zs: three depths each.  -> (oracle, sub-pixel triangles)"""
+    import independent_raster as ir
+    o = oracle_lib.Oracle(W, H, W)                      # shadow map of the same size: the shadow pass sees the same triangles
+    verts = np.zeros(3 * len(tris_px), dtype=abi.XkVertex)
+    k = 0
+    for tri, z in zip(tris_px, zs):
+        for (x, y), zz in zip(tri, z):
+            verts[k]["Position"] = (x / (W / 2.0) - 1.0, y / (H / 2.0) - 1.0, zz)     # ndc = clip (w = 1): exact in float32
+            verts[k]["Normal"] = (0.0, 0.0, 1.0); verts[k]["Color"] = (1.0, 1.0, 1.0)
+            k += 1
+    o.object_add(o.mesh_create(verts, np.arange(len(verts), dtype=np.uint32)))
+    d, p, sp = _lights(1, 1)
+    o.update_uniforms(abi.make_camera(), d, p, sp, 0.0, 0.0, 0.0)
+    cam, sh, view = o.get_frame()
+    ident = np.eye(4, dtype=np.float32).reshape(16)
+    for m in (cam, sh):
+        m["Model"] = ident; m["View"] = ident; m["Proj"] = ident
+    o.set_frame(cam, sh, view)
+    o.render(0, 3)                                       # shadow + deferred-scene passes
+    sub = [[(int(round(x * ir.SUB)), int(round(y * ir.SUB))) for x, y in tri] for tri in tris_px]
+    for tri_px, tri in zip(tris_px, sub):
+        assert all(abs(x * ir.SUB - X) < 1e-9 and abs(y * ir.SUB - Y) < 1e-9 for (x, y), (X, Y) in zip(tri_px, tri)), "vertices must sit on the grid"
+    return o, sub
+
+
+def _check_raster(oracle_lib, tris_px, zs, W=32, H=32, min_ambiguous_free=0.98):
+    import independent_raster as ir
+    o, sub = _raster_case(oracle_lib, tris_px, zs, W, H)
+    zs32 = [[float(np.float32(v)) for v in z] for z in zs]
+    # ---- deferred-scene pass: who owns each pixel, and at what depth
+    win, dep, amb = ir.render(sub, zs32, W, H, shadow=False)
+    vis, depth = o.visibility(), o.gbuffer(0)
+    checked = 0
+    for y in range(H):
+        for x in range(W):
+            if amb[y][x]:
+                continue
+            checked += 1
+            want = 0xFFFFFFFF if win[y][x] is None else win[y][x]
+            assert int(vis[y, x]) == want, "pixel (%d, %d): oracle %d, rules %s" % (x, y, int(vis[y, x]), win[y][x])
+            if win[y][x] is not None:
+                assert abs(float(depth[y, x]) - float(dep[y][x])) <= 3e-7, (x, y, float(depth[y, x]), float(dep[y][x]))
+    assert checked >= min_ambiguous_free * W * H
+    # ---- shadow pass: cull NONE, LESS_OR_EQUAL, biased depth
+    _, sdep, _ = ir.render(sub, zs32, W, H, shadow=True)
+    sm = o.shadowmap()
+    for y in range(H):
+        for x in range(W):
+            want = 1.0 if sdep[y][x] is None else float(sdep[y][x])
+            assert abs(float(sm[y, x]) - want) <= 6e-7, "shadow texel (%d, %d): oracle %.9g, rules %.9g" % (x, y, float(sm[y, x]), want)
+    return vis
+
+
+def test_top_left_rule_on_shared_and_centre_crossing_edges(oracle_lib):
+    """Edges that run exactly through pixel centres: a quad cut along a diagonal through the centres, its outer edges ON the centres of
+    rows / columns (top and left ones count, bottom and right ones do not), a fan around a vertex that sits on a centre (exactly one
+    triangle may own that pixel), both windings (the back-facing twin is culled in the deferred-scene pass, drawn in the shadow pass)."""
+    c = 0.5
+    quad = [[(4 + c, 4 + c), (4 + c, 12 + c), (12 + c, 12 + c)], [(4 + c, 4 + c), (12 + c, 12 + c), (12 + c, 4 + c)]]
+    fan_centre = (22 + c, 9 + c)
+    ring = [(26.0, 9.5), (25.0, 13.0), (22.5, 14.0), (19.0, 12.0), (18.0, 9.5), (19.5, 5.0), (22.5, 4.0), (25.5, 5.5)]
+    fan = [[fan_centre, ring[(i + 1) % 8], ring[i]] for i in range(8)]
+    back = [[(6.0, 20.0), (14.0, 20.5), (8.0, 28.0)]]              # the other winding: culled (BACK) - but a shadow caster
+    front = [[(18.0, 20.0), (22.0, 28.0), (28.5, 20.5)]]
+    tris = quad + fan + back + front
+    zs = [[0.5, 0.5, 0.5]] * 2 + [[0.25, 0.5, 0.5]] * 8 + [[0.3, 0.4, 0.6]] + [[0.7, 0.2, 0.4]]
+    vis = _check_raster(oracle_lib, tris, zs)
+    import independent_raster as ir
+    assert ir.front_facing([(int(x * 256), int(y * 256)) for x, y in quad[0]]) and not ir.front_facing([(int(x * 256), int(y * 256)) for x, y in back[0]])
+    # the quad: its top row and left column of centres are in, the bottom row and right column are out; 8 x 8 pixels, each owned once
+    assert (vis[4:12, 4:12] <= 1).all() and (vis[12, 4:13] == 0xFFFFFFFF).all() and (vis[4:13, 12] == 0xFFFFFFFF).all()
+    assert ((vis[4:12, 4:12] == 0).sum(), (vis[4:12, 4:12] == 1).sum()) in ((36, 28), (28, 36))
+    assert vis[9, 22] in range(2, 10)                              # the fan's hub pixel has exactly one owner
+
+
+def _on_grid(tris):
+    return [[(round(x * 256) / 256.0, round(y * 256) / 256.0) for x, y in t] for t in tris]
+
+
+def test_slivers_degenerates_and_subpixel_triangles(oracle_lib):
+    tris = _on_grid([[(3.0, 3.25), (29.0, 3.5), (3.0, 3.75)],               # a sliver thinner than a pixel, crossing a row of centres
+            [(3.0, 8.0), (29.0, 8.6), (3.0, 8.2)],                 # ... and one that threads between two rows
+            [(5.0, 12.0), (9.0, 16.0), (13.0, 20.0)],              # zero area (collinear)
+            [(20.0, 12.0), (20.0, 12.0), (24.0, 16.0)],            # zero area (repeated vertex)
+            [(10.6, 24.6), (10.9, 25.4), (11.4, 24.7)],            # lies between the centres: no fragment
+            [(20.5, 24.5), (20.5, 25.5), (21.5, 25.5)],            # vertices ON three centres
+            [(26.0, 22.0), (26.25, 30.0), (26.75, 22.0)]])         # a vertical sliver
+    zs = [[0.5, 0.6, 0.5], [0.1, 0.2, 0.3], [0.5, 0.5, 0.5], [0.5, 0.5, 0.5], [0.4, 0.4, 0.4], [0.3, 0.35, 0.4], [0.9, 0.95, 0.9]]
+    _check_raster(oracle_lib, tris, zs)
+
+
+def test_depth_order_ties_and_clip_against_exact_arithmetic(oracle_lib):
+    """Overlapping triangles: nearer wins whatever the draw order, the first drawn keeps a pixel on equal depth (LESS), fragments beyond
+    z = 1 are clipped per fragment (the plane leaves the depth range inside the triangle), z = 1 never beats the clear."""
+    big = lambda z: [[(2.0, 2.0), (2.0, 30.0), (30.0, 30.0)], z]
+    cases = [big([0.6, 0.6, 0.6]), big([0.4, 0.4, 0.4]), big([0.4, 0.4, 0.4]), big([0.5, 0.2, 0.8]),
+             [[(4.0, 2.0), (30.0, 28.0), (30.0, 2.0)], [0.25, 0.5, 1.25]],           # leaves the depth range inside the triangle (far side:
+                                                                                      # clipped per fragment; the near side goes through
+                                                                                      # the oracle's polygon clipper, whose re-snapped
+                                                                                      # intersections are its own stated choice)
+             [[(16.0, 4.0), (20.0, 12.0), (24.0, 4.0)], [1.0, 1.0, 1.0]]]            # at the clear depth: never visible
+    _check_raster(oracle_lib, [t for t, _ in cases], [z for _, z in cases], min_ambiguous_free=0.9)
+
+
+def test_random_triangles_on_the_subpixel_grid(oracle_lib):
+    rng = np.random.default_rng(17)
+    tris, zs = [], []
+    for _ in range(160):
+        cx, cy = rng.uniform(2, 30, 2)
+        pts = [(float(np.round((cx + rng.uniform(-6, 6)) * 256) / 256), float(np.round((cy + rng.uniform(-6, 6)) * 256) / 256)) for _ in range(3)]
+        tris.append(pts)
+        zs.append([float(np.float32(v)) for v in rng.uniform(0.05, 0.95, 3)])
+    _check_raster(oracle_lib, tris, zs, min_ambiguous_free=0.97)

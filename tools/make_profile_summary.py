@@ -166,7 +166,10 @@ summary = {"tag": tag, "workload": bench["config"]["workload"], "bench_value_und
                      "--steps 20 --warmup 5 --no-cpu-baseline --no-extras`; bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 FETCH_SIZE correction); "
                      "issue fractions: tools/make_profile_summary.py docstring"}
 json.dump(summary, open(os.path.join(ROOT, "profiles", tag + "_pmc.json"), "w"), indent=1)
-json.dump({"pmc": tag + "_pmc.json", "kernel_stats": tag + "_kernel_stats.csv"}, open(os.path.join(ROOT, "profiles", "current.json"), "w"), indent=1)
+cur = {"pmc": tag + "_pmc.json", "kernel_stats": tag + "_kernel_stats.csv"}
+if os.path.exists(os.path.join(ROOT, "profiles", tag + "_valu_calib.json")):
+    cur["valu_calib"] = tag + "_valu_calib.json"
+json.dump(cur, open(os.path.join(ROOT, "profiles", "current.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "kernels"}, indent=1))
 for k, v in out.items():
     i = v.get("issue", {})

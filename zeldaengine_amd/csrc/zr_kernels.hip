@@ -2103,13 +2103,26 @@ __global__ __launch_bounds__(256) void k_resolve_gbuffer(ZrPass P, const ZrObjec
     if (tid == 0) covered_s = 0;
     __syncthreads();
     uint32_t ncov = 0;
-    // row-major within the tile -> 128 B (256 B for GBufferD / keys) contiguous row segments per wave
-    for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
+    // row-major within the tile -> 128 B (256 B for GBufferD / keys) contiguous row segments per wave.  The thread's four keys are fetched
+    // (and reset) together: four independent loads in flight instead of one at the head of each pixel's chain of dependent loads.
+    unsigned long long keys[TILE_PIX / 256];
+#pragma unroll
+    for (uint32_t q = 0; q < TILE_PIX / 256u; ++q) {
+        const uint32_t i = tid + q * 256u;
+        const int px = tx0 + (int)(i & (TILE - 1)), py = ty0 + (int)(i / TILE);
+        keys[q] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
+        if (px < (int)P.W && py < (int)P.H) {
+            const size_t p = (size_t)py * P.W + (size_t)px;
+            keys[q] = vis64[p];
+            vis64[p] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
+        }
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < TILE_PIX / 256u; ++q) {
+        const uint32_t i = tid + q * 256u;
         const int px = tx0 + (int)(i & (TILE - 1)), py = ty0 + (int)(i / TILE);
         if (px >= (int)P.W || py >= (int)P.H) continue;
-        const size_t p = (size_t)py * P.W + (size_t)px;
-        const unsigned long long k = vis64[p];
-        vis64[p] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
+        const unsigned long long k = keys[q];
         ncov += resolve_pixel<IMAGES>(P, objs, (uint32_t)k, zr_u2f((uint32_t)(k >> 32)), px, py, G, dlut, vis_now) ? 1u : 0u;
     }
     if (ncov) atomicAdd(&covered_s, ncov);
