@@ -281,3 +281,31 @@ def test_record_pool_chunks_beyond_the_first(oracle_lib, gpu_engine):
     _identical(o, g, "60 000 instances, one round")
     assert st["covered_pixels"] == o.covered_pixels()
     g.close()
+
+
+def test_big_scene_shadow_path_with_a_moving_light(oracle_lib, gpu_engine):
+    """Scenes with the instance-level pre-pass (>= 65 536 instances: whole-instance frustum / "no texel centre" rejects, compacted work
+    list with one reservation per 4 096 instances) against the oracle, with the light moving every frame: 70 000 low-poly spheres lie
+    many deep under a 256^2 shadow map."""
+    W, H, SD = 320, 200, 256
+    mesh = scenes.uv_sphere(8, 4, 0.5)
+    inst = scenes.generate_instances(70000, 0.5, 9.0, 0.15, 0.5, seed=9)
+    o = oracle_lib.Oracle(W, H, SD)
+    g = gpu_engine.Renderer(W, H, SD)
+    for r in (o, g):
+        r.set_cubemap(scenes.synthetic_cubemap(8))
+        r.object_add(r.mesh_create(*scenes.grid_plane(24.0, 4, 0.0)))
+        r.object_add(r.mesh_create(*mesh), None, inst)
+    d, p, s = _lights()
+    cam = abi.make_camera((7.0, 6.0, 5.0), (0.0, 0.0, 0.3))
+    for i, lpos in enumerate([(20.0, 0.0, 20.0), (20.0, 0.0, 20.0), (16.0, 9.0, 18.0), (-3.0, 19.0, 9.0)]):
+        d[0]["Position"][:3] = lpos; d[0]["Direction"][:3] = lpos
+        for r in (o, g):
+            r.update_uniforms(cam, d, p, s, 0.0, 0.01 * i, 1.0)
+        o.render(0)
+        g.render(); g.finish()
+        assert np.array_equal(o.shadowmap().view(np.uint32), g.shadowmap().view(np.uint32)), "shadow map, frame %d" % i
+        _identical(o, g, "frame %d" % i)
+        st = g.stats()
+        assert st["overflow"] == 0 and st["survivors"][0] > 0 and st["work_items"][0] == 70001
+    g.close()

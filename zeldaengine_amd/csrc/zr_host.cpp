@@ -1108,23 +1108,26 @@ static void tri_select(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hip
 {
     zr_launch_select(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->tb, c->d_stats, slot, s);
 }
-// One round of the triangle-binned camera pass: triangles -> records (k_geom), records -> tile order (k_index), tile raster (k_tile).  One
+// One round of the triangle-binned camera pass: triangles -> records (k_geom), offsets (k_scan_tri), records -> tile order (k_index), tile
+// raster (k_tile).  One
 // k_tile_slow after the last round draws the clipped / long triangles of both.
 static void tri_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s, bool last)
 {
     const zr_ctx::Scratch& sc = c->sc[1];
     if (P.n_work == 0) return;          // nothing to draw: the pass is its clear
     zr_launch_geom(P, Z, c->tb, sc.tile_count, c->d_stats, slot, c->d_vis, s);
-    zr_launch_index(c->tb, c->n_tiles, sc.tile_count, sc.tile_cursor, sc.chunk_tab, c->chunk_capacity, c->d_stats, slot, s);
+    zr_launch_scan_tri(sc.tile_count, sc.tile_offset, sc.chunk_tab, c->chunk_capacity, c->n_tiles, c->tb, c->d_stats, slot, s);
+    zr_launch_index(c->tb, sc.tile_offset, sc.tile_cursor, c->d_stats, slot, s);
     zr_launch_tile(P, sc.chunk_tab, c->tb, sc.tile_count, sc.tile_cursor, c->n_tiles, c->d_stats, slot, c->d_vis, c->raster_blocks, s);
     if (last) zr_launch_tile_slow_camera(P, c->tb, c->d_owned, c->n_owned, c->d_stats, slot, c->d_vis, s);
 }
 static void raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s)
 {
-    const zr_ctx::Scratch& sc = c->sc[slot ? 1 : 0];
-    const bool defer = slot == 0 && c->env_shadow_defer && c->d_slow0 != nullptr;
+    const bool shadow = slot == 0;
+    const zr_ctx::Scratch& sc = c->sc[shadow ? 0 : 1];
+    const bool defer = shadow && c->env_shadow_defer && c->d_slow0 != nullptr;
     zr_launch_raster_chunks(P, c->d_objs, sc.chunk_tab, sc.bins, c->d_stats, slot, c->d_vis,
-                            (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), slot == 0 ? c->shadow_blocks : c->raster_blocks, Z, s,
+                            (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), shadow ? c->shadow_blocks : c->raster_blocks, Z, s,
                             defer ? c->d_slow0 : nullptr, c->slow0_cap, c->d_sowned, c->sn_tiles);
 }
 

@@ -17,7 +17,7 @@
 //   k_select          round 2: the meshlet-instances the Hi-Z pyramid does not hide -> 32-byte records
 //   k_geom<HIZ>       wave per meshlet-instance: vertices once, exact per-triangle tests (round 2: + the pyramid per meshlet and per triangle),
 //                     one 32-byte record per (triangle, tile) + its tile id
-//   k_index           per-tile offsets and work units (every workgroup scans the counts itself), records MOVED into tile order
+//   k_scan_tri / k_index   per-tile offsets and work units; records MOVED into tile order
 //   k_tile / k_tile_slow   lane per record, streamed: edge set-up + walk into the tile's LDS keys; clipped triangles through raster_clipped
 //   k_hiz_build       max-depth pyramid of the key buffer after round 1 (two-pass occlusion culling of the camera pass)
 //   k_resolve_gbuffer BaseScene.frag per pixel from the key buffer; SoA GBuffer planes, coalesced row stores; marks the
@@ -264,47 +264,76 @@ __device__ __forceinline__ bool sphere_reaches_owned_tile(const ZrPass& P, zf3 c
 // Level 1 of the cull hierarchy: one lane per instance, whole-mesh bounding sphere against the frustum (same inflated
 // bounds as the meshlet test, so it is conservative).  The meshlet-instances of the surviving instances are appended to
 // work[]; one atomic per wave reserves the range.  Also applies the shadow-pass filters (skydome, instance partition).
+#define ZR_CI_THREADS 1024u
+#define ZR_CI_PER 4u                        // instances per thread: one reservation per 4 096 instances
+// instance g (global ordinal) against the pass's instance-level tests; nm / wbase: its meshlet-instances, co / radius: its bounding sphere
+// after the instance transform (object space of PVM)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_cull_instances(ZrPass P, const ZrObject* __restrict__ objs, uint32_t* __restrict__ work,
-                                                        ZrDevStats* __restrict__ stats, int slot)
+__device__ __forceinline__ bool instance_test(const ZrPass& P, const ZrObject* __restrict__ objs, uint32_t g, uint32_t& nm, uint32_t& wbase, zf3& co, float& radius)
 {
-    const uint32_t g = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
-    uint32_t nm = 0, wbase = 0;
-    if (g < P.n_inst_total) {
-        const ZrObject* __restrict__ O = objs + find_object_inst(objs, (int)P.n_objects, g);
-        const uint32_t inst_i = g - O->inst_base;
-        bool vis = true;
-        // the skydome is not a shadow caster (ZE:4709-4720); with N GPUs each draws every N-th instance into its own copy of
-        // the shadow map and the copies are min-reduced (depth test LESS_OR_EQUAL is a min, so the split is exact)
-        if (MODE == ZR_MODE_SHADOW && ((O->flags & ZR_OBJ_SKY) || inst_i % P.inst_world != P.inst_rank)) vis = false;
-        if (vis && (P.frustum_ok | P.rect_cull | P.sphere_ok)) {
-            const ZrInstance I = O->inst[inst_i];
-            const bool instanced = O->instanced != 0;
-            const zf3 co = vs_position(zr3(O->mesh_center[0], O->mesh_center[1], O->mesh_center[2]), I, instanced);
-            const zf4 cw4 = zr_mat4_point(P.M, co);
-            float rw = O->mesh_radius * (instanced ? __builtin_fabsf(I.s) : 1.0f) * P.m_scale;
-            rw = __builtin_fmaf(rw, 1.001f, 1e-5f * (__builtin_fabsf(cw4.x) + __builtin_fabsf(cw4.y) + __builtin_fabsf(cw4.z) + 1.0f));
-            for (int k = 0; k < 6 && P.frustum_ok; ++k) {
-                const float d = __builtin_fmaf(P.planes[k][0], cw4.x, __builtin_fmaf(P.planes[k][1], cw4.y,
-                                __builtin_fmaf(P.planes[k][2], cw4.z, P.planes[k][3])));
-                if (d < -rw) vis = false;
-            }
-            if (vis && MODE == ZR_MODE_GBUFFER && P.rect_cull &&
-                !sphere_reaches_owned_tile(P, co, O->mesh_radius * (instanced ? __builtin_fabsf(I.s) : 1.0f))) vis = false;
-            // a whole instance between the pixel (texel) centres: a million instances under a 1024^2 shadow map are mostly that
-            if (vis && P.sphere_ok && P.frustum_ok && sphere_holds_no_centre(P, co, O->mesh_radius * (instanced ? __builtin_fabsf(I.s) : 1.0f))) vis = false;
+    const ZrObject* __restrict__ O = objs + find_object_inst(objs, (int)P.n_objects, g);
+    const uint32_t inst_i = g - O->inst_base;
+    bool vis = true;
+    co = zr3(0.0f, 0.0f, 0.0f); radius = 0.0f;
+    // the skydome is not a shadow caster (ZE:4709-4720); with N GPUs each draws every N-th instance into its own copy of
+    // the shadow map and the copies are min-reduced (depth test LESS_OR_EQUAL is a min, so the split is exact)
+    if (MODE == ZR_MODE_SHADOW && ((O->flags & ZR_OBJ_SKY) || inst_i % P.inst_world != P.inst_rank)) vis = false;
+    if (vis && (P.frustum_ok | P.rect_cull | P.sphere_ok)) {
+        const ZrInstance I = O->inst[inst_i];
+        const bool instanced = O->instanced != 0;
+        co = vs_position(zr3(O->mesh_center[0], O->mesh_center[1], O->mesh_center[2]), I, instanced);
+        radius = O->mesh_radius * (instanced ? __builtin_fabsf(I.s) : 1.0f);
+        const zf4 cw4 = zr_mat4_point(P.M, co);
+        float rw = radius * P.m_scale;
+        rw = __builtin_fmaf(rw, 1.001f, 1e-5f * (__builtin_fabsf(cw4.x) + __builtin_fabsf(cw4.y) + __builtin_fabsf(cw4.z) + 1.0f));
+        for (int k = 0; k < 6 && P.frustum_ok; ++k) {
+            const float d = __builtin_fmaf(P.planes[k][0], cw4.x, __builtin_fmaf(P.planes[k][1], cw4.y,
+                            __builtin_fmaf(P.planes[k][2], cw4.z, P.planes[k][3])));
+            if (d < -rw) vis = false;
         }
-        if (vis) { nm = O->n_meshlets; wbase = O->work_base + inst_i * nm; }
+        if (vis && MODE == ZR_MODE_GBUFFER && P.rect_cull && !sphere_reaches_owned_tile(P, co, radius)) vis = false;
+        // a whole instance between the pixel (texel) centres: a million instances under a 1024^2 shadow map are mostly that
+        if (vis && P.sphere_ok && P.frustum_ok && sphere_holds_no_centre(P, co, radius)) vis = false;
     }
-    // wave-aggregated reservation
-    uint32_t incl = nm;
+    nm = O->n_meshlets; wbase = O->work_base + inst_i * nm;
+    return vis;
+}
+// workgroup-wide (ZR_CI_THREADS) exclusive scan of per-thread counts + ONE global reservation on *counter; returns this thread's offset.
+// (A returning atomic per wave on one address: 15 600 of them at a million instances queued up for 0.7 ms.)
+__device__ __forceinline__ uint32_t block_reserve(uint32_t mine, uint32_t* __restrict__ counter, uint32_t* wsum, uint32_t* base_s)
+{
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t incl = mine;
     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, o); if ((int)lane >= o) incl += v; }
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-    uint32_t base = 0;
-    if (lane == 63 && total) base = atomicAdd(&stats->n_vis_work[slot], total);
-    base = (uint32_t)__shfl((int)base, 63);
-    const uint32_t off = base + incl - nm;
-    for (uint32_t m = 0; m < nm; ++m) work[off + m] = wbase + m;
+    __syncthreads();                                      // (wsum / base_s may still be read from a previous call)
+    if (lane == 63u) wsum[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t i = 0; i < ZR_CI_THREADS / 64u; ++i) { const uint32_t t = wsum[i]; wsum[i] = tot; tot += t; }
+        *base_s = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    return *base_s + wsum[wv] + incl - mine;
+}
+template <int MODE>
+__global__ __launch_bounds__(ZR_CI_THREADS) void k_cull_instances(ZrPass P, const ZrObject* __restrict__ objs, uint32_t* __restrict__ work,
+                                                                  ZrDevStats* __restrict__ stats, int slot)
+{
+    __shared__ uint32_t wsum[ZR_CI_THREADS / 64u], base_s;
+    uint32_t nm[ZR_CI_PER], wbase[ZR_CI_PER], mine = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < ZR_CI_PER; ++j) {
+        const uint32_t g = (blockIdx.x * ZR_CI_PER + j) * ZR_CI_THREADS + threadIdx.x;
+        nm[j] = 0; wbase[j] = 0;
+        zf3 co; float radius;
+        if (g < P.n_inst_total && !instance_test<MODE>(P, objs, g, nm[j], wbase[j], co, radius)) nm[j] = 0;
+        if (g >= P.n_inst_total) nm[j] = 0;
+        mine += nm[j];
+    }
+    uint32_t off = block_reserve(mine, &stats->n_vis_work[slot], wsum, &base_s);
+#pragma unroll
+    for (uint32_t j = 0; j < ZR_CI_PER; ++j) { for (uint32_t m = 0; m < nm[j]; ++m) work[off + m] = wbase[j] + m; off += nm[j]; }
 }
 
 // Level 2, in two stages inside one wavefront that owns ZR_CULL_GROUP consecutive work items (every rejection is exact or conservative:
@@ -1903,54 +1932,57 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
     }
 }
 
-// Every DRAWN record -> its place in its tile's stretch of the sorted record array, and the record itself is MOVED there, so that k_tile
-// streams its work unit instead of gathering it.  First every workgroup scans the per-tile counts into offsets for itself (LDS, the
-// counts sit in L2; the separate one-workgroup scan launch of round 2 cost 8 us of pure latency on the camera pipeline's critical path);
-// workgroup 0 also lays out k_tile's work units and the round's statistics.  Then a cursor per tile is advanced once per (wave, distinct
-// tile) - the 64 records of a wave come meshlet by meshlet, so they name a handful of tiles - because atomics on one address run at
-// about 10 ns apiece on this part and there are half a million records: the lanes first sort themselves into tile groups (scalar work,
-// no memory), then every group's first lane issues its add in ONE instruction.  One wave per record chunk.
-__global__ __launch_bounds__(256) void k_index(ZrTriBins B, ZrDevStats* __restrict__ stats, int slot, uint32_t n_tiles,
-                                               const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_cursor,
-                                               uint4* __restrict__ chunk_tab, uint32_t chunk_cap, uint32_t unit)
+// Exclusive scan of the per-tile record counts into tile_offset and k_tile's work units of <= `unit` records of ONE tile (the counters
+// and cursors of the tiles sit ZR_TSTRIDE words apart: atomics on one cache line queue up behind each other, and neighbouring tiles are
+// hit together); books the round.  ONE workgroup: every workgroup of k_index scanning the counts for itself was tried (a launch less on
+// the camera pipeline's critical path) and is as fast at 1080p but four times slower at 3840 x 2160 (8 160 tiles per scan, 32 KB of LDS
+// per workgroup: k_index 1.1 ms instead of 0.3).
+__global__ __launch_bounds__(1024) void k_scan_tri(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
+                                                   uint4* __restrict__ chunk_tab, uint32_t chunk_cap, uint32_t n_tiles, uint32_t sorted_cap,
+                                                   ZrDevStats* __restrict__ stats, int slot, uint32_t unit)
 {
-    extern __shared__ uint32_t toff[];                     // the tiles' counts, then the exclusive offsets of their stretches
-    __shared__ uint32_t wtot[4], cwtot[4];
+    __shared__ uint32_t wtot[16], cwtot[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    {
-        for (uint32_t i = tid; i < n_tiles; i += 256u) toff[i] = tile_count[i * ZR_TSTRIDE];      // coalesced (16-byte stride), from L2
-        __syncthreads();
-        const uint32_t per = (n_tiles + 255u) / 256u;
-        const uint32_t b = min(n_tiles, tid * per), e = min(n_tiles, b + per);
-        uint32_t s = 0, cs = 0;
-        for (uint32_t i = b; i < e; ++i) { const uint32_t t = toff[i]; s += t; cs += (t + unit - 1u) / unit; }
-        uint32_t incl = s, cincl = cs;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t v = (uint32_t)__shfl_up((int)incl, o), cv = (uint32_t)__shfl_up((int)cincl, o);
-            if ((int)lane >= o) { incl += v; cincl += cv; }
-        }
-        if (lane == 63u) { wtot[wv] = incl; cwtot[wv] = cincl; }
-        __syncthreads();
-        uint32_t wpre = 0, cwpre = 0, tot = 0, ctot = 0;
-        for (uint32_t i = 0; i < 4u; ++i) { if (i < wv) { wpre += wtot[i]; cwpre += cwtot[i]; } tot += wtot[i]; ctot += cwtot[i]; }
-        uint32_t run = wpre + incl - s, crun = cwpre + cincl - cs;
-        for (uint32_t i = b; i < e; ++i) {
-            const uint32_t t = toff[i], nu = (t + unit - 1u) / unit;
-            toff[i] = run;                 // (this thread's own stretch of the array: nobody else reads it before the barrier)
-            if (blockIdx.x == 0)          // k_tile's work units: (tile, first record, end) - one load there, not a search
-                for (uint32_t k = 0; k < nu; ++k)
-                    if (crun + k < chunk_cap) chunk_tab[crun + k] = make_uint4(i, run + k * unit, run + min(t, (k + 1u) * unit), 0u);
-            run += t; crun += nu;
-        }
-        if (blockIdx.x == 0 && tid == 0) {
-            stats->bin_entries[slot] = tot;               // drawn triangle records of the round
-            stats->n_chunks[slot] = min(ctot, chunk_cap);
-            stats->chunk_counter[slot] = 0;
-            stats->survivors[slot] = stats->n_sel[slot];
-            if (ctot > chunk_cap || tot > B.sorted_cap) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
-        }
-        __syncthreads();
+    const uint32_t per = (n_tiles + 1023u) / 1024u;
+    const uint32_t b = min(n_tiles, tid * per), e = min(n_tiles, b + per);
+    uint32_t s = 0, cs = 0;
+    for (uint32_t i = b; i < e; ++i) { const uint32_t t = tile_count[i * ZR_TSTRIDE]; s += t; cs += (t + unit - 1u) / unit; }
+    // scan: inside the wave by shuffles, across the 16 waves through LDS - one barrier (this kernel is one workgroup on the critical path)
+    uint32_t incl = s, cincl = cs;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, o), cv = (uint32_t)__shfl_up((int)cincl, o);
+        if ((int)lane >= o) { incl += v; cincl += cv; }
     }
+    if (lane == 63u) { wtot[wv] = incl; cwtot[wv] = cincl; }
+    __syncthreads();
+    uint32_t wpre = 0, cwpre = 0, tot = 0, ctot = 0;
+    for (uint32_t i = 0; i < 16u; ++i) { if (i < wv) { wpre += wtot[i]; cwpre += cwtot[i]; } tot += wtot[i]; ctot += cwtot[i]; }
+    uint32_t run = wpre + incl - s, crun = cwpre + cincl - cs;
+    for (uint32_t i = b; i < e; ++i) {
+        const uint32_t t = tile_count[i * ZR_TSTRIDE], nu = (t + unit - 1u) / unit;
+        tile_offset[i] = run;
+        for (uint32_t k = 0; k < nu; ++k)          // k_tile's work units: (tile, first record, end) - one load there, not a search
+            if (crun + k < chunk_cap) chunk_tab[crun + k] = make_uint4(i, run + k * unit, run + min(t, (k + 1u) * unit), 0u);
+        run += t; crun += nu;
+    }
+    if (tid == 0) {
+        stats->bin_entries[slot] = tot;               // triangle records of the round
+        stats->n_chunks[slot] = min(ctot, chunk_cap);
+        stats->chunk_counter[slot] = 0;
+        stats->survivors[slot] = stats->n_sel[slot];
+        if (ctot > chunk_cap || tot > sorted_cap) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
+    }
+}
+
+// Every record -> its place in its tile's stretch of the sorted record array, and the record itself is MOVED there, so that k_tile
+// streams its work unit instead of gathering it.  A cursor per tile is advanced once per (wave, distinct tile) - the 64 records of a wave
+// come meshlet by meshlet, so they name a handful of tiles - because atomics on one address run at about 10 ns apiece on this part and
+// there are half a million records: the lanes first sort themselves into tile groups (scalar work, no memory), then every group's first
+// lane issues its add in ONE instruction.  One wave per record chunk.
+__global__ __launch_bounds__(256) void k_index(ZrTriBins B, const ZrDevStats* __restrict__ stats, int slot,
+                                               const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t used = min(B.n_waves + stats->pool_next[slot], B.n_chunks);
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (uint32_t ch = blockIdx.x * 4u + wv; ch < used; ch += gridDim.x * 4u) {
@@ -1961,7 +1993,7 @@ __global__ __launch_bounds__(256) void k_index(ZrTriBins B, ZrDevStats* __restri
             const uint32_t tile = have ? B.rtile[i] : 0u;
             uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
             if (have) { qa = B.recA[i]; qb = B.recB[i]; }
-            const uint32_t off = have ? toff[tile] : 0u;
+            const uint32_t off = have ? tile_offset[tile] : 0u;
             uint32_t rank = 0, cnt = 0;
             int first = (int)lane;
             unsigned long long pend = __ballot(have);
@@ -2659,18 +2691,18 @@ void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint3
                     int slot, uint32_t n_waves, hipStream_t s)
 {
     if (P.n_work == 0) return;
-    const dim3 gi((P.n_inst_total + 255) / 256), b(256);
+    const dim3 gi((P.n_inst_total + ZR_CI_THREADS * ZR_CI_PER - 1u) / (ZR_CI_THREADS * ZR_CI_PER)), bi(ZR_CI_THREADS), b(256);
     // one wave per ZR_CULL_GROUP work items; with the work list the count is only known on the device: a fixed grid strides over it
     const uint32_t all = (uint32_t)(((uint64_t)P.n_work + 4u * ZR_CULL_GROUP - 1) / (4u * ZR_CULL_GROUP));
     const uint32_t blocks = P.use_worklist ? std::min<uint32_t>(all, std::max<uint32_t>(1u, n_waves / 4u)) : all;
     if (P.mode == ZR_MODE_GBUFFER) {
         if (P.use_worklist) {
-            hipLaunchKernelGGL(k_cull_instances<ZR_MODE_GBUFFER>, gi, b, 0, s, P, objs, work, stats, slot);
+            hipLaunchKernelGGL(k_cull_instances<ZR_MODE_GBUFFER>, gi, bi, 0, s, P, objs, work, stats, slot);
             hipLaunchKernelGGL((k_cull<ZR_MODE_GBUFFER, true>), dim3(blocks), b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot);
         } else hipLaunchKernelGGL((k_cull<ZR_MODE_GBUFFER, false>), dim3(blocks), b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot);
     } else {
         if (P.use_worklist) {
-            hipLaunchKernelGGL(k_cull_instances<ZR_MODE_SHADOW>, gi, b, 0, s, P, objs, work, stats, slot);
+            hipLaunchKernelGGL(k_cull_instances<ZR_MODE_SHADOW>, gi, bi, 0, s, P, objs, work, stats, slot);
             hipLaunchKernelGGL((k_cull<ZR_MODE_SHADOW, true>), dim3(blocks), b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot);
         } else hipLaunchKernelGGL((k_cull<ZR_MODE_SHADOW, false>), dim3(blocks), b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot);
     }
@@ -2680,16 +2712,16 @@ void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, u
                         int slot, hipStream_t s, ZrBinEntry* sel, const uint8_t* vis_prev)
 {
     if (P.n_work == 0) return;
-    const dim3 gi((P.n_inst_total + 255) / 256), b(256);
+    const dim3 gi((P.n_inst_total + ZR_CI_THREADS * ZR_CI_PER - 1u) / (ZR_CI_THREADS * ZR_CI_PER)), bi(ZR_CI_THREADS), b(256);
     const dim3 g(std::min<uint32_t>((P.n_work + 255u) / 256u, 8192u));
     if (P.mode == ZR_MODE_GBUFFER) {
         if (P.use_worklist) {
-            hipLaunchKernelGGL(k_cull_instances<ZR_MODE_GBUFFER>, gi, b, 0, s, P, objs, work, stats, slot);
+            hipLaunchKernelGGL(k_cull_instances<ZR_MODE_GBUFFER>, gi, bi, 0, s, P, objs, work, stats, slot);
             hipLaunchKernelGGL((k_cull_box<ZR_MODE_GBUFFER, true>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot, sel, vis_prev);
         } else hipLaunchKernelGGL((k_cull_box<ZR_MODE_GBUFFER, false>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot, sel, vis_prev);
     } else {
         if (P.use_worklist) {
-            hipLaunchKernelGGL(k_cull_instances<ZR_MODE_SHADOW>, gi, b, 0, s, P, objs, work, stats, slot);
+            hipLaunchKernelGGL(k_cull_instances<ZR_MODE_SHADOW>, gi, bi, 0, s, P, objs, work, stats, slot);
             hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, true>), g, b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot, (ZrBinEntry*)nullptr, (const uint8_t*)nullptr);
         } else hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, false>), g, b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot, (ZrBinEntry*)nullptr, (const uint8_t*)nullptr);
     }
@@ -2768,10 +2800,14 @@ void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, uint32_
     if (Z.phase == 2u) hipLaunchKernelGGL(k_geom<true>, g, b, 0, s, P, B.sel, Z, B, tile_count, stats, slot, vis64);
     else hipLaunchKernelGGL(k_geom<false>, g, b, 0, s, P, B.sel, Z, B, tile_count, stats, slot, vis64);
 }
-void zr_launch_index(const ZrTriBins& B, uint32_t n_tiles, const uint32_t* tile_count, uint32_t* tile_cursor, uint4* chunk_tab, uint32_t chunk_cap,
-                     ZrDevStats* stats, int slot, hipStream_t s)
+void zr_launch_scan_tri(const uint32_t* tile_count, uint32_t* tile_offset, uint4* chunk_tab, uint32_t chunk_cap, uint32_t n_tiles, const ZrTriBins& B,
+                        ZrDevStats* stats, int slot, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_index, dim3(B.n_waves / 4u), dim3(256), n_tiles * sizeof(uint32_t), s, B, stats, slot, n_tiles, tile_count, tile_cursor, chunk_tab, chunk_cap, ZR_TCHUNK);
+    hipLaunchKernelGGL(k_scan_tri, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, chunk_tab, chunk_cap, n_tiles, B.sorted_cap, stats, slot, ZR_TCHUNK);
+}
+void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* tile_cursor, const ZrDevStats* stats, int slot, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_index, dim3(B.n_waves / 4u), dim3(256), 0, s, B, stats, slot, tile_offset, tile_cursor);
 }
 void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B, uint32_t* tile_count, uint32_t* tile_cursor, uint32_t n_tiles,
                     ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s)

@@ -175,7 +175,7 @@ void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint4* chunk_tab,
                     uint32_t chunk_cap, uint32_t n, uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s,
                     uint32_t chunk = ZR_CHUNK);
-// triangle-binned camera pass, per round: [k_select ->] k_geom -> k_index -> k_tile
+// triangle-binned camera pass, per round: [k_select ->] k_geom -> k_scan_tri -> k_index -> k_tile
 struct ZrTriBins {
     ZrBinEntry* sel;                 // meshlet-instances of this round, as self-contained 32-byte records
     // 32-byte triangle records (see zr_kernels.hip, "triangle records"), in chunks of ZR_TPOOL_CHUNK, structure-of-arrays inside a chunk:
@@ -201,8 +201,9 @@ struct ZrTriBins {
 void zr_launch_select(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats,
                       int slot, hipStream_t s);
 void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, uint32_t* tile_count, ZrDevStats* stats, int slot, unsigned long long* vis64, hipStream_t s);
-void zr_launch_index(const ZrTriBins& B, uint32_t n_tiles, const uint32_t* tile_count, uint32_t* tile_cursor, uint4* chunk_tab, uint32_t chunk_cap,
-                     ZrDevStats* stats, int slot, hipStream_t s);
+void zr_launch_scan_tri(const uint32_t* tile_count, uint32_t* tile_offset, uint4* chunk_tab, uint32_t chunk_cap, uint32_t n_tiles, const ZrTriBins& B,
+                        ZrDevStats* stats, int slot, hipStream_t s);
+void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* tile_cursor, const ZrDevStats* stats, int slot, hipStream_t s);
 void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B, uint32_t* tile_count, uint32_t* tile_cursor, uint32_t n_tiles,
                     ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s);
 void zr_launch_tile_slow_camera(const ZrPass& P, const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned, ZrDevStats* stats, int slot,
