@@ -115,9 +115,11 @@ def main():
                     help="3: the metric's workload (default); 4: 1M instances at 3840x2160; 5: config 4 with 256 point lights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the moving-camera / textured / one-stream extra loops")
-    ap.add_argument("--split-shadow", action="store_true",
-                    help="N > 1: every rank rasterises 1/N of the shadow casters and the maps are MIN all-reduced (a second collective); "
-                         "default: every rank renders the whole 1024^2 map and the all-gather of the composite is the only collective")
+    ap.add_argument("--replicated-shadow", action="store_true",
+                    help="N > 1: every rank renders the whole 1024^2 shadow map and the all-gather of the composite is the only collective. "
+                         "Default for N > 1: every rank rasterises 1/N of the casters and the maps are MIN all-reduced (4 MiB; the shadow "
+                         "lane is otherwise the part of the frame that does not shrink with N: profiles/r03_*_scaling_projection.json)")
+    ap.add_argument("--split-shadow", action="store_true", help="(the default for N > 1; kept so that older command lines still parse)")
     ap.add_argument("--python-dist", action="store_true", help="N > 1: torch.distributed frame loop (dist.py) instead of the library's native RCCL host")
     ap.add_argument("--timing-interval", type=int, default=0,
                     help="per-kernel hipEvents are recorded on every n-th timed frame (each record is a ~6 us stream bubble); "
@@ -164,6 +166,7 @@ def main():
         if world > 1:
             dist.all_reduce(torch.zeros(1, dtype=torch.int32))      # a CPU tensor: gloo
 
+    args.split_shadow = world > 1 and not args.replicated_shadow
     n_point = 256 if args.config == 5 else 16
     if args.config == 3:
         cfg = scenes.config3(args.instances, cube_dim=args.cube_dim)
@@ -397,8 +400,8 @@ def cpu_baseline(n_inst, cube_dim):
     t0 = time.perf_counter()
     o.render()
     dt = time.perf_counter() - t0
-    # the same frame again with the oracle's per-pixel stages (GBuffer resolve, lighting) on an OpenMP team of all host cores; the
-    # rasteriser stays serial (it resolves the depth test in draw order).  Informative extra, same pixels.
+    # the same frame again on an OpenMP team of all host cores: the per-pixel stages (GBuffer resolve, lighting) by rows, the
+    # rasteriser by contiguous slices of the draw sequence into per-thread targets merged in draw order.  Same pixels.
     n_all = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     n_all = max(1, min(n_all, 16))               # a one-GPU box shares its host: 16 cores are this job's
     o.set_threads(n_all)
@@ -410,7 +413,7 @@ def cpu_baseline(n_inst, cube_dim):
             "sample": "1 frame of config 3 with %d of its 10000 instances at 1920x1080 (same lights, shadow map, PCF); "
                       "scalar C oracle, %.2f s" % (n_inst, dt),
             "value_all_cores": round(cfg["width"] * cfg["height"] / dt_all / 1e6, 4), "cores_all": n_all,
-            "note_all_cores": "per-pixel stages on an OpenMP team, serial rasteriser; %.2f s" % dt_all}
+            "note_all_cores": "rasteriser (draw slices, merged in draw order) and per-pixel stages on an OpenMP team; %.2f s" % dt_all}
 
 
 if __name__ == "__main__":

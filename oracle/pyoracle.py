@@ -71,6 +71,10 @@ def lib():
         L.zo_kat_sincos.argtypes = [C.c_float, C.c_void_p]
         L.zo_kat_rotmat.argtypes = [C.c_void_p, C.c_void_p]
         L.zo_kat_aniso.argtypes = [C.c_float] * 4 + [C.c_int, C.c_void_p]
+        L.zo_kat_tex_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.zo_kat_tex_mip.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+        L.zo_kat_cube_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        L.zo_kat_cube_mip.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         _lib = L
     return _lib
 
@@ -179,6 +183,41 @@ class Oracle:
 
     def visibility(self):
         return self._view(self.L.zo_visibility(self.h), np.uint32, (self.H, self.W))
+
+    # sampler KATs (tests/independent_sampler.py)
+    def tex_sample(self, image, srgb, uv, duv):
+        """texture(sampler2D, uv) of an (h, w, 4) uint8 image with the screen-space derivatives duv = (dudx, dvdx, dudy, dvdy)"""
+        im = np.ascontiguousarray(image, np.uint8)
+        a = np.asarray(uv, np.float32); d = np.asarray(duv, np.float32); out = np.zeros(4, np.float32)
+        lib().zo_kat_tex_sample(self.h, _ptr(im), im.shape[1], im.shape[0], int(srgb), _ptr(a), _ptr(d), _ptr(out))
+        return out
+
+    def tex_mips(self, image, srgb):
+        im = np.ascontiguousarray(image, np.uint8)
+        h, w = im.shape[:2]
+        out, level = [], 0
+        while True:
+            lw, lh = max(1, w >> level), max(1, h >> level)
+            buf = np.zeros((lh, lw, 4), np.uint8)
+            n = lib().zo_kat_tex_mip(self.h, _ptr(im), w, h, int(srgb), level, _ptr(buf))
+            out.append(buf); level += 1
+            if level >= n:
+                return out
+
+    def cube_sample(self, direction, lod):
+        d = np.asarray(direction, np.float32); out = np.zeros(3, np.float32)
+        lib().zo_kat_cube_sample(self.h, _ptr(d), float(lod), _ptr(out))
+        return out
+
+    def cube_mips(self, dim):
+        out, level = [], 0
+        while (dim >> level) >= 1:
+            d = dim >> level
+            buf = np.zeros((6, d, d, 4), np.uint8)
+            if lib().zo_kat_cube_mip(self.h, level, _ptr(buf)) != d:
+                break
+            out.append(buf); level += 1
+        return out
 
     def set_threads(self, n):
         """OpenMP team for the per-pixel stages (resolve, lighting): the all-cores CPU baseline.  Results do not change."""

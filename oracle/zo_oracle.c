@@ -17,6 +17,7 @@
 #include "zo_oracle.h"
 #include "zo_math.h"
 
+#include <omp.h>
 #include <stdlib.h>
 #include <stdio.h>
 
@@ -637,16 +638,19 @@ static void zo_raster_tri(const zo_target* T, const zo_v4 c[3], uint32_t prim)
     for (int i = 1; i + 1 < n; ++i) { v[0] = pv[0]; v[1] = pv[i]; v[2] = pv[i + 1]; zo_raster_sub(T, v, prim); }
 }
 
-/* one pass over every draw in reference order */
-static void zo_raster_scene(zo_ctx* c, const zo_target* T, const float* PVM)
+/* draws [g0, g1) of the flattened (object in reference order, instance) sequence */
+static void zo_raster_range(zo_ctx* c, const zo_target* T, const float* PVM, uint64_t g0, uint64_t g1)
 {
-    zo_finalize_order(c);
-    for (int k = 0; k < c->n_objects; ++k) {
+    uint64_t base = 0;
+    for (int k = 0; k < c->n_objects && base < g1; ++k) {
         const zo_object* o = &c->objects[c->order[k]];
         const zo_mesh* m = &c->meshes[o->mesh];
+        uint64_t lo = g0 > base ? g0 - base : 0, hi = g1 - base < o->n_inst ? g1 - base : o->n_inst;
+        base += o->n_inst;
+        if (lo >= hi) continue;
         uint32_t ntri = m->ni / 3;
         zo_v4* clip = (zo_v4*)malloc(sizeof(zo_v4) * m->nv);
-        for (uint32_t i = 0; i < o->n_inst; ++i) {
+        for (uint32_t i = (uint32_t)lo; i < (uint32_t)hi; ++i) {
             zo_xform x; zo_xform_make(o, i, &x);
             for (uint32_t vi = 0; vi < m->nv; ++vi)
                 clip[vi] = zo_mat4_point(PVM, zo_vs_position(&m->v[vi], &x, o->instanced));
@@ -657,6 +661,41 @@ static void zo_raster_scene(zo_ctx* c, const zo_target* T, const float* PVM)
         }
         free(clip);
     }
+}
+
+/* one pass over every draw in reference order.  With zo_set_threads(n > 1) (the all-cores CPU baseline) thread t rasterises the t-th
+ * contiguous slice of the draw sequence into a target of its own and the targets are merged in thread order with the pass's own
+ * depth test, which gives the serial result: LESS keeps the earlier draw on equal depth, LESS_OR_EQUAL of depths alone is a min. */
+static void zo_raster_scene(zo_ctx* c, const zo_target* T, const float* PVM)
+{
+    zo_finalize_order(c);
+    uint64_t total = 0;
+    for (int k = 0; k < c->n_objects; ++k) total += c->objects[k].n_inst;
+    int nt = c->threads;
+    if ((uint64_t)nt > total) nt = (int)total;
+    if (nt <= 1) { zo_raster_range(c, T, PVM, 0, total); return; }
+    size_t n = (size_t)T->W * T->H;
+    float* depth = (float*)malloc(sizeof(float) * n * (size_t)nt);
+    uint32_t* vis = T->vis ? (uint32_t*)malloc(sizeof(uint32_t) * n * (size_t)nt) : NULL;
+#pragma omp parallel num_threads(nt)
+    {
+        int t = omp_get_thread_num(), tn = omp_get_num_threads();
+        zo_target P = *T;
+        P.depth = depth + n * (size_t)t; memcpy(P.depth, T->depth, sizeof(float) * n);
+        if (vis) { P.vis = vis + n * (size_t)t; memcpy(P.vis, T->vis, sizeof(uint32_t) * n); }
+        if (t < tn) zo_raster_range(c, &P, PVM, total * (uint64_t)t / (uint64_t)tn, total * (uint64_t)(t + 1) / (uint64_t)tn);
+#pragma omp barrier
+#pragma omp for schedule(static)
+        for (long long p = 0; p < (long long)n; ++p) {
+            float z = T->depth[p]; uint32_t v = vis ? T->vis[p] : 0u;
+            for (int q = 0; q < tn; ++q) {
+                float zq = depth[n * (size_t)q + (size_t)p];
+                if (zq < z) { z = zq; if (vis) v = vis[n * (size_t)q + (size_t)p]; }
+            }
+            T->depth[p] = z; if (vis) T->vis[p] = v;
+        }
+    }
+    free(depth); free(vis);
 }
 
 static void zo_pvm(const XkUniformBufferMVP* u, float* PVM)   /* proj * view * model, left to right */
@@ -1367,3 +1406,43 @@ float zo_kat_log2(float x) { return zo_log2f(x); }
 float zo_kat_pow(float x, float y) { return zo_powf(x, y); }
 uint16_t zo_kat_f32_to_f16(float x) { return zo_f32_to_f16(x); }
 void  zo_kat_rotmat(const float e[3], float out9[9]) { zo_make_rot(e, out9); }
+
+/* sampler KATs (tests/independent_sampler.py restates the Vulkan rules in float64 and is compared with these) */
+int zo_kat_tex_sample(zo_ctx* c, const uint8_t* rgba8, uint32_t w, uint32_t h, int srgb, const float uv[2], const float duv[4], float out[4])
+{
+    zo_tex tx; memset(&tx, 0, sizeof tx);
+    zo_image im; memset(&im, 0, sizeof im);
+    im.rgba8 = rgba8; im.width = w; im.height = h;
+    zo_tex_from_image(c, &tx, &im, srgb);
+    zo_tex_sample(c, &tx, srgb, uv[0], uv[1], duv[0], duv[1], duv[2], duv[3], out);     /* duv = dudx, dvdx, dudy, dvdy */
+    int levels = tx.levels;
+    zo_tex_free(&tx);
+    return levels;
+}
+int zo_kat_tex_mip(zo_ctx* c, const uint8_t* rgba8, uint32_t w, uint32_t h, int srgb, int level, uint8_t* out)   /* returns the level count */
+{
+    zo_tex tx; memset(&tx, 0, sizeof tx);
+    zo_image im; memset(&im, 0, sizeof im);
+    im.rgba8 = rgba8; im.width = w; im.height = h;
+    zo_tex_from_image(c, &tx, &im, srgb);
+    int levels = tx.levels;
+    if (level >= 0 && level < levels) {
+        uint32_t lw = w >> level, lh = h >> level; if (!lw) lw = 1; if (!lh) lh = 1;
+        memcpy(out, tx.mip[level], (size_t)lw * lh * 4);
+    }
+    zo_tex_free(&tx);
+    return levels;
+}
+int zo_kat_cube_sample(zo_ctx* c, const float dir[3], float lod, float out[3])            /* the context's cubemap (zo_set_cubemap) */
+{
+    zo_v3 r = zo_cube_sample(c, zo_v3make(dir[0], dir[1], dir[2]), lod);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+    return c->cube_levels;
+}
+int zo_kat_cube_mip(zo_ctx* c, int level, uint8_t* out)                                   /* 6 faces of the level, RGBA8; returns its edge */
+{
+    if (level < 0 || level >= c->cube_levels) return 0;
+    uint32_t d = c->cube_dim >> level; if (!d) d = 1;
+    memcpy(out, c->cube[level], (size_t)d * d * 4 * 6);
+    return (int)d;
+}

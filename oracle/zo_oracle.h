@@ -67,6 +67,11 @@ float zo_kat_pow(float x, float y);
 uint16_t zo_kat_f32_to_f16(float x);
 void  zo_kat_rotmat(const float euler[3], float out9[9]);
 void  zo_kat_aniso(float ax, float ay, float bx, float by, int levels, float out[3]);   /* N, lambda, x-major */
+/* the samplers themselves (material textures: mips by LINEAR blits, REPEAT, trilinear, anisotropic; cubemap: textureLod) */
+int   zo_kat_tex_sample(zo_ctx*, const uint8_t* rgba8, uint32_t w, uint32_t h, int srgb, const float uv[2], const float duv[4], float out[4]);
+int   zo_kat_tex_mip(zo_ctx*, const uint8_t* rgba8, uint32_t w, uint32_t h, int srgb, int level, uint8_t* out);
+int   zo_kat_cube_sample(zo_ctx*, const float dir[3], float lod, float out[3]);
+int   zo_kat_cube_mip(zo_ctx*, int level, uint8_t* out);
 
 #ifdef __cplusplus
 }

@@ -278,3 +278,96 @@ def test_random_triangles_on_the_subpixel_grid(oracle_lib):
         tris.append(pts)
         zs.append([float(np.float32(v)) for v in rng.uniform(0.05, 0.95, 3)])
     _check_raster(oracle_lib, tris, zs, min_ambiguous_free=0.97)
+
+
+# ---------------------------------------------------------------- the samplers against a float64 restatement of the Vulkan rules
+import independent_sampler as isamp
+
+
+def _noise_image(w, h, seed, smooth=False):
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    if smooth:                                               # large flat-ish areas as well as noise
+        yy, xx = np.mgrid[0:h, 0:w]
+        img[..., 0] = (xx * 255 // max(1, w - 1)).astype(np.uint8)
+        img[..., 1] = (yy * 255 // max(1, h - 1)).astype(np.uint8)
+    return img
+
+
+@pytest.mark.parametrize("w,h,srgb", [(64, 64, 0), (64, 64, 1), (48, 20, 1), (33, 7, 0), (1, 16, 1), (5, 5, 0)])
+def test_mip_chains_are_linear_blits_in_linear_light(oracle_lib, w, h, srgb):
+    """RHIGenerateMipmaps (ZE:6348-6433): floor(log2(max(w, h))) + 1 levels (ZE:6887), each the LINEAR blit of the one before
+    (sRGB formats are filtered in linear light).  Every 8-bit code of the oracle's chain is the rounding of the float64 value."""
+    o = oracle_lib.Oracle(8, 8, 8)
+    img = _noise_image(w, h, seed=w * 131 + h + srgb, smooth=True)
+    chain = o.tex_mips(img, srgb)
+    assert len(chain) == int(math.floor(math.log2(max(w, h)))) + 1
+    assert np.array_equal(chain[0], img)
+    for l in range(1, len(chain)):
+        assert chain[l].shape[:2] == (max(1, h >> l), max(1, w >> l))
+        real = isamp.blit_half_real(chain[l - 1], srgb)
+        err = np.abs(chain[l].astype(np.float64) - real)
+        assert err.max() <= 0.5 + 2e-3, (l, err.max())       # the rounding of the real value (float32 noise only at exact ties)
+    o.close()
+
+
+@pytest.mark.parametrize("srgb", [0, 1])
+def test_material_sampler_against_float64(oracle_lib, srgb):
+    """texture(sampler2D, uv) with derivatives: footprint -> tap count / LOD / major axis, REPEAT addressing, trilinear taps averaged.
+    600 random samples over magnified, minified, 2:1 .. beyond-16:1 footprints and coordinates outside [0, 1]."""
+    o = oracle_lib.Oracle(8, 8, 8)
+    rng = np.random.default_rng(77 + srgb)
+    img = _noise_image(64, 32, seed=5 + srgb)
+    chain = o.tex_mips(img, srgb)
+    checked, taps_seen = 0, set()
+    for k in range(600):
+        uv = rng.uniform(-2.0, 3.0, 2)
+        scale = 2.0 ** rng.uniform(-9.0, -1.0)                 # footprint from 1/8 texel to half the image
+        ang = rng.uniform(0, 2 * math.pi)
+        ratio = rng.choice([1.0, 1.37, 2.4, 5.5, 11.3, 15.6, 40.0])
+        major = np.array([math.cos(ang), math.sin(ang)]) * scale
+        minor = np.array([-math.sin(ang), math.cos(ang)]) * scale / ratio
+        duv = (major[0], major[1], minor[0], minor[1]) if k % 2 else (minor[0], minor[1], major[0], major[1])
+        if k % 10 == 0:                                        # an exactly isotropic footprint of t texels: one trilinear tap
+            t = np.float32(2.0 ** rng.uniform(-3.0, 5.0))
+            duv = (t / 64, 0.0, 0.0, t / 32)
+        duv32 = np.asarray(duv, np.float32); uv32 = np.asarray(uv, np.float32)
+        want, n, lam, margin = isamp.sample_2d(chain, srgb, uv32.astype(np.float64), duv32.astype(np.float64))
+        if margin < 1e-3:
+            continue                                           # Pmax / Pmin on an integer: N or N + 1 taps are both right
+        got = o.tex_sample(img, srgb, uv32, duv32)
+        assert np.allclose(got, want, atol=3e-5, rtol=0), (k, n, lam, got, want)
+        checked += 1; taps_seen.add(n)
+    assert checked > 550 and {1, 2, 3, 6, 12, 16} <= taps_seen
+    # exact cases: the centre of a texel at magnification is that texel; one whole-image footprint is the last level's only texel
+    px = o.tex_sample(img, srgb, ((10 + 0.5) / 64, (7 + 0.5) / 32), (0, 0, 0, 0))
+    assert np.allclose(px, isamp.decode(img, srgb)[7, 10], atol=1e-6)
+    far = o.tex_sample(img, srgb, (0.3, 0.8), (4.0, 0, 0, 4.0))
+    assert np.allclose(far, isamp.decode(chain[-1], srgb)[0, 0], atol=1e-6)
+    o.close()
+
+
+def test_cubemap_chain_and_textureLod_against_float64(oracle_lib):
+    """textureLod(samplerCube, R, lod): face selection table (ties: z over y over x), bilinear inside the face, linear between
+    levels; the chain is a 2x2 box in linear light.  Faces carry noise, so a wrong face, a flipped axis or a wrong level shows."""
+    dim = 32
+    rng = np.random.default_rng(3)
+    faces = [rng.integers(0, 256, (dim, dim, 4), dtype=np.uint8) for _ in range(6)]
+    o = oracle_lib.Oracle(8, 8, 8)
+    o.set_cubemap(faces)
+    chain = o.cube_mips(dim)
+    assert len(chain) == 6 and np.array_equal(chain[0], np.stack(faces))
+    for l in range(1, len(chain)):
+        rgb, alpha = isamp.cube_half_real(chain[l - 1])
+        assert np.abs(chain[l][..., :3].astype(np.float64) - rgb).max() <= 0.5 + 2e-3
+        assert np.abs(chain[l][..., 3].astype(np.float64) - alpha).max() <= 0.5
+    dirs = list(rng.normal(size=(400, 3)))
+    dirs += [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1),          # face centres
+             (1, 1, 0.3), (1, 0.2, 1), (0.1, 1, 1), (1, 1, 1), (-1, 1, -1), (2, -2, 0.5)]  # ties between major axes
+    for k, r in enumerate(dirs):
+        r32 = np.asarray(r, np.float32)
+        for lod in (0.0, 0.37, 1.0, 2.5, 4.99, 5.0, 7.0, -1.0):
+            got = o.cube_sample(r32, lod)
+            want = isamp.sample_cube(chain, r32.astype(np.float64), np.float32(lod))
+            assert np.allclose(got, want, atol=3e-5, rtol=0), (k, r, lod, got, want)
+    o.close()

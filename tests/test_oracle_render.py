@@ -85,6 +85,35 @@ def test_depth_less_keeps_first_on_ties_and_nearest_otherwise(oracle_lib):
     assert d.min() == np.float32(0.25) and d.max() == np.float32(1.0)
 
 
+def test_threaded_rasteriser_is_the_serial_one(oracle_lib):
+    """zo_set_threads(n): the draw sequence is cut into n contiguous slices rasterised into per-thread targets and merged in draw
+    order with the pass's depth test (bench.py's all-cores CPU baseline).  Instances that coincide exactly (equal depth everywhere)
+    must still go to the earlier draw; shadow map, visibility and colour are those of the serial pass."""
+    from zeldaengine_amd import scenes as sc
+    W, H = 160, 96
+    inst = sc.generate_instances(40, 0.5, 4.0, 0.4, 1.0, seed=3)
+    inst = np.concatenate([inst, inst[:25], inst[10:30]])            # coinciding instances in different slices
+    mesh = sc.uv_sphere(12, 6, 0.5)
+
+    def frame(threads):
+        o = oracle_lib.Oracle(W, H, 64)
+        o.set_cubemap(sc.synthetic_cubemap(4))
+        o.object_add(o.mesh_create(*sc.grid_plane(12.0, 2, 0.0)))
+        o.object_add(o.mesh_create(*mesh), None, inst)
+        o.update_uniforms(abi.make_camera((5.0, 4.0, 3.0), (0.0, 0.0, 0.2)), *sc.lights_from_world(sc.sample_world()), 0.0, 0.0, 1.0)
+        o.set_threads(threads)
+        o.render()
+        out = (o.visibility().copy(), o.shadowmap().view(np.uint32).copy(), o.color().copy())
+        o.close()
+        return out
+    ref = frame(1)
+    assert (ref[0] != 0xFFFFFFFF).sum() > W * H // 4
+    for n in (2, 3, 7, 200):                                          # 200 > the 86 draws: one draw per thread at most
+        got = frame(n)
+        for a, b, what in zip(ref, got, ("visibility", "shadow map", "colour")):
+            assert np.array_equal(a, b), (n, what)
+
+
 def test_depth_clip_discards_outside_zero_one(oracle_lib):
     far = ((2, 2, 1.5), (2, 30, 1.5), (30, 30, 1.5))
     assert _render(oracle_lib, [far]).covered_pixels() == 0
