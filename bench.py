@@ -126,6 +126,8 @@ def main():
                          "0 = steps // 12 clamped to 5..8 (a short run still leaves four frames in five undisturbed)")
     ap.add_argument("--cube-dim", type=int, default=1024, help="cubemap face edge (the engine's is 1024: 11 mips)")
     ap.add_argument("--flags", type=int, default=0, help="experiments: extra zr_config flags (e.g. 8 = ZR_FLAG_NO_HIZ)")
+    ap.add_argument("--textured", action="store_true", help="profiling: config 3 with seven sampled 512^2 material images in the main loop "
+                                                             "(the default line reports this variant as value_textured)")
     ap.add_argument("--serial", action="store_true", help="profiling: the whole frame on ONE stream (ZR_FLAG_SERIAL_PASSES), every kernel alone on the GPU")
     args = ap.parse_args()
 
@@ -169,7 +171,7 @@ def main():
     args.split_shadow = world > 1 and not args.replicated_shadow
     n_point = 256 if args.config == 5 else 16
     if args.config == 3:
-        cfg = scenes.config3(args.instances, cube_dim=args.cube_dim)
+        cfg = scenes.config3(args.instances, cube_dim=args.cube_dim, textured=args.textured)
     else:
         cfg = scenes.config4(args.instances if args.instances != 10000 else 1000000, n_point, cube_dim=args.cube_dim)
     W, H = cfg["width"], cfg["height"]
@@ -281,6 +283,8 @@ def main():
             owned_px += (min(W, x0 + 32) - x0) * (min(H, y0 + 32) - y0)
         alg = algorithmic_bytes(stats, mesh, n_inst, owned_px)
         workload = workload_name(args.config, n_inst, stats["work_items"][1], W, H, len(cfg["point"]), args.cube_dim)
+        if args.textured:
+            workload += " [seven sampled 512^2 material images]"
         prof = load_profile(workload) if world == 1 else None
         ptraffic = (prof or {}).get("kernels", {})
 

@@ -390,6 +390,44 @@ def test_textured_materials_trilinear_repeat_srgb(oracle_lib, gpu_engine):
     _identical(o, g, "textured")
 
 
+def test_materials_whose_images_share_a_size_are_sampled_packed(oracle_lib, gpu_engine):
+    """The usual material: every image slot of one size.  The library interleaves such slots into one 16-byte texel per mip texel
+    (ZrObject::packed) and the resolve reads a tap's texels of all seven slots with one load each; constant slots of such a material
+    stay constants (the oracle does not filter them: (c + c + c) / 3 is not c).  Three materials - all seven slots sampled,
+    three sampled + four constant (one of them a constant IMAGE), one image only - over a tiled ground seen at a grazing angle
+    (every tap count) and instanced spheres (minification), with a skydome image beside them."""
+    rng = np.random.default_rng(21)
+
+    def noise(w, h, lo=0, hi=256):
+        img = rng.integers(lo, hi, size=(h, w, 4), dtype=np.uint8); img[..., 3] = 255
+        return img
+    full = [noise(64, 32) for _ in range(7)]
+    full[3] = noise(64, 32, 96, 160); full[3][..., 2] = 255                 # a plausible normal map
+    full[6][..., 0] = 255                                                   # mask r = 1: lit
+    some = [noise(16, 16), None, noise(16, 16, 40, 255), None, np.full((16, 16, 4), 200, np.uint8), None, None]
+    some[6] = noise(16, 16); some[6][..., 0] = 255
+    one = [None, None, noise(40, 24, 30, 255), None, None, None, None]
+
+    def build(r):
+        r.set_cubemap(scenes.synthetic_cubemap(16))
+        r.set_skydome(*scenes.sky_dome(), scenes.synthetic_sky_image())
+        keep = []
+        mats = []
+        for spec in (full, some, one):
+            m, k = abi.make_material(spec); mats.append(m); keep.append(k)
+        r._keepalive = keep
+        v, idx = scenes.grid_plane(26.0, 6, 0.0)                # (inside the dome: corners at 18.4 of its radius 20.48)
+        v = v.copy(); v["TexCoord"] *= 7.0
+        r.object_add(r.mesh_create(v, idx), mats[0])
+        r.object_add(r.mesh_create(*scenes.uv_sphere()), mats[1], scenes.generate_instances(80, 1.0, 7.0, 0.3, 1.1, seed=4))
+        r.object_add(r.mesh_create(*scenes.uv_sphere(12, 6, 0.5)), mats[0], scenes.generate_instances(40, 1.0, 9.0, 0.5, 1.4, seed=5))
+        r.object_add(r.mesh_create(*scenes.box((0.9, 0.9, 0.9), (0, 0, 0.9))), mats[2])
+    cam = abi.make_camera((0.0, -9.0, 0.8), (0.0, 6.0, 0.4), fov=55.0, znear=0.05, zfar=120.0)
+    o, g = _both(oracle_lib, gpu_engine, 400, 240, 256, build, _std_frame(cam))
+    assert len(np.unique(o.gbuffer(4))) > 500 and len(np.unique(o.gbuffer(1))) > 100
+    _identical(o, g, "packed materials")
+
+
 def test_anisotropic_filtering_at_grazing_angles(oracle_lib, gpu_engine):
     """Samplers have anisotropy on at the device maximum (ZE:6540): a striped ground plane seen almost edge-on gives footprints
     from 1:1 near the camera to beyond 16:1 at the horizon, i.e. every tap count of the scheme."""

@@ -35,8 +35,9 @@ struct ZrSceneObject {
     std::vector<XkInstanceData> inst;    // host copy (zr_object_get_instances)
     ZrInstance* d_inst = nullptr;
     uint32_t texel[7]; float bc_linear[3];
-    uint8_t* d_tex[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-    uint32_t tex_w[7] = { 0 }, tex_h[7] = { 0 }, tex_levels[7] = { 0 };
+    uint8_t* d_tex[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // [7]: the packed material (ZrObject::packed)
+    uint32_t tex_w[8] = { 0 }, tex_h[8] = { 0 }, tex_levels[8] = { 0 };
+    bool mixed_sizes = false;            // image slots of different sizes: no packed form
 };
 
 // XkWorld (ZE:1025-1291) as parsed from JSON
@@ -120,7 +121,7 @@ struct zr_ctx {
     bool shadow_cleared[2] = { false, false };      // d_shadow_b[i] already holds depth 1.0 (cleared by the previous lighting pass)
     unsigned long long* d_vis = nullptr; uint32_t raster_blocks = 2048, shadow_blocks = 2048; bool env_shadow_box = true, env_shadow_defer = true;
     uint4* d_slow0 = nullptr; uint32_t slow0_cap = 1u << 18;      // shadow pass: triangles for the clipper (k_tile_slow)
-    uint32_t work_capacity = 0, bin_capacity = 0; bool any_images = false;
+    uint32_t work_capacity = 0, bin_capacity = 0; bool any_images = false, mixed_images = false;
     uint32_t limit_record_chunks = 0, limit_slow_triangles = 0;      // zr_set_limits (0 = defaults)
     // two-pass Hi-Z occlusion culling of the camera pass: per work item pixel bbox + least depth (written by the cull),
     // visibility of the previous / current frame (one byte per meshlet-instance, marked by the resolve), the pyramid

@@ -572,14 +572,36 @@ int zr_object_add_internal(zr_ctx* c, uint32_t mesh_id, const ZrMaterialHost& ma
     if (n_inst) o.inst.assign(inst, inst + n_inst);
     HIPCHK(c, hipSetDevice(c->device));
     auto cleanup = [&]() { dev_free(o.d_inst); for (auto& t : o.d_tex) dev_free(t); };
+    std::vector<uint8_t> chains[7];
+    int lead = -1;                                          // first slot that holds an image
     for (int t = 0; t < 7; ++t) {
         if (mat.image[t].empty()) continue;
-        std::vector<uint8_t> chain; uint32_t levels = 1;
+        std::vector<uint8_t>& chain = chains[t]; uint32_t levels = 1;
         build_mip_chain(c, mat.image[t], mat.w[t], mat.h[t], t == 0, &chain, &levels);
         hipError_t e = dev_alloc_image(&o.d_tex[t], chain.size());
         if (e == hipSuccess) e = hipMemcpy(o.d_tex[t], chain.data(), chain.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) { cleanup(); return zr_fail(c, ZR_ERR_DEVICE, hipGetErrorString(e)); }
         o.tex_w[t] = mat.w[t]; o.tex_h[t] = mat.h[t]; o.tex_levels[t] = levels;
+        if (lead < 0) lead = t;
+        else if (mat.w[t] != mat.w[lead] || mat.h[t] != mat.h[lead]) o.mixed_sizes = true;
+    }
+    if (lead >= 0 && !o.mixed_sizes) {
+        // The packed material: per texel of the (common) mip chain the 13 channels BaseScene.frag reads, 16 B (ZR_PK_*); constant slots
+        // put their constant there (the resolve takes those from the draw record, not from here).
+        static const struct { int slot, ch, n; } kPack[7] = { {0, ZR_PK_BC, 3}, {1, ZR_PK_ME, 1}, {2, ZR_PK_RO, 1}, {3, ZR_PK_NO, 3}, {4, ZR_PK_AO, 1}, {5, ZR_PK_EM, 3}, {6, ZR_PK_MS, 1} };
+        const size_t n_texels = chains[lead].size() / 4;
+        std::vector<uint8_t> pk(n_texels * 16, 0);
+        for (const auto& k : kPack) {
+            const bool image = !chains[k.slot].empty();
+            const uint8_t* src = image ? chains[k.slot].data() : nullptr;
+            for (size_t i = 0; i < n_texels; ++i)
+                for (int ch = 0; ch < k.n; ++ch)
+                    pk[i * 16 + (size_t)k.ch + (size_t)ch] = image ? src[i * 4 + (size_t)ch] : (uint8_t)(mat.texel[k.slot] >> (8 * ch));
+        }
+        hipError_t e = dev_alloc_image(&o.d_tex[7], pk.size());
+        if (e == hipSuccess) e = hipMemcpy(o.d_tex[7], pk.data(), pk.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { cleanup(); return zr_fail(c, ZR_ERR_DEVICE, hipGetErrorString(e)); }
+        o.tex_w[7] = mat.w[lead]; o.tex_h[7] = mat.h[lead]; o.tex_levels[7] = o.tex_levels[lead];
     }
     { hipError_t e = dev_alloc(&o.d_inst, o.n_inst); if (e != hipSuccess) { cleanup(); return zr_fail(c, ZR_ERR_DEVICE, hipGetErrorString(e)); } }
     XkInstanceData* d_raw = nullptr;
@@ -722,6 +744,7 @@ static int finalize_scene(zr_ctx* c)
                 d.texc[t][ch] = (t == 0 && ch < 3) ? c->lut[v8] : (float)v8 / 255.0f;
             }
         for (int t = 0; t < 7; ++t) { d.tex[t].data = o.d_tex[t]; d.tex[t].w = o.tex_w[t]; d.tex[t].h = o.tex_h[t]; d.tex[t].levels = o.tex_levels[t]; d.tex[t]._pad = 0; }
+        d.packed.data = o.d_tex[7]; d.packed.w = o.tex_w[7]; d.packed.h = o.tex_h[7]; d.packed.levels = o.tex_levels[7]; d.packed._pad = 0;
         memcpy(d.mesh_center, m.center, sizeof d.mesh_center); d.mesh_radius = m.radius;
         // BaseScene.frag on constant slots, once per draw instead of once per pixel (the kernels' own arithmetic: zr_math.h)
         for (int t = 0; t < 7; ++t) if (!o.d_tex[t]) d.const_slots |= 1u << t;
@@ -785,8 +808,9 @@ static int finalize_scene(zr_ctx* c)
         HIPCHK(c, dev_alloc(&c->d_visflag[0], cap_w)); HIPCHK(c, dev_alloc(&c->d_visflag[1], cap_w));
         c->work_capacity = cap_w;              // every buffer is there
     }
-    c->any_images = false;
+    c->any_images = c->mixed_images = false;
     for (const ZrObject& d : tab) for (int t = 0; t < 7; ++t) if (d.tex[t].data) c->any_images = true;
+    for (const auto& o : c->objects) if (o.mixed_sizes) c->mixed_images = true;      // (the skydome's one image is sampled by itself)
     c->vis_history = false;         // work item numbering changed: last frame's visibility says nothing about this scene
     c->scene_dirty = false;
     return ZR_OK;
@@ -1033,7 +1057,7 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
     P->tiles_x = mode == ZR_MODE_SHADOW ? c->stiles_x : c->tiles_x; P->tiles_y = mode == ZR_MODE_SHADOW ? c->stiles_y : c->tiles_y;
     P->tile_rank = mode == ZR_MODE_SHADOW ? 0 : c->cfg.tile_rank; P->tile_world = mode == ZR_MODE_SHADOW ? 1 : c->cfg.tile_world;
     P->inst_rank = mode == ZR_MODE_SHADOW ? c->shadow_rank : 0; P->inst_world = mode == ZR_MODE_SHADOW ? c->shadow_world : 1;
-    P->images = c->any_images ? 1u : 0u;
+    P->images = !c->any_images ? 0u : c->mixed_images ? 2u : 1u;     // 1: every material with images has the packed form
     P->n_objects = c->n_objs; P->n_work = c->n_work; P->n_inst_total = c->n_inst_total; P->bin_capacity = c->bin_capacity;
     // the instance-level pre-pass pays for itself on big scenes; small ones go straight to one wave per meshlet-instance
     P->use_worklist = c->n_inst_total >= 65536u ? 1u : 0u;

@@ -1254,21 +1254,153 @@ __device__ __forceinline__ zf4 tex_sample_image(const ZrTex& T, bool srgb, const
     const TexFootprint F = tex_footprint(T, dudx, dvdx, dudy, dvdy);
     return tex_sample_footprint(T, F, srgb, lut, u, v);
 }
-// the same, reusing (or replacing) the caller's footprint when the image has the size it was formed for
-template <bool IMAGES>
-__device__ __forceinline__ zf4 tex_sample_shared(const ZrTex& T, const float* __restrict__ constant, bool srgb, const float* __restrict__ lut,
-                                                 float u, float v, float dudx, float dvdx, float dudy, float dvdy, TexFootprint& F)
+// A material's seven slots (BaseScene.frag:30-36) at once.  Everything about a tap but the texels themselves - footprint, the two
+// mip levels, the four texel addresses and the two weights per level - depends on the image's SIZE only, and a material's images are
+// usually of one size: the slots of one size are sampled as a group, tap by tap, with that part formed once per tap instead of once
+// per tap and slot (it was more than half of the sampled resolve's instructions).  Per slot the arithmetic and its order are
+// those of tex_sample_footprint (acc = 0 + t1 + t2 ..., / N; a single tap's 0 + t is t: no filtered texel is -0).
+struct TexGeo { uint32_t o00, o10, o01, o11; float a, b; };       // byte offsets of the four texels from the image's base
+__device__ __forceinline__ TexGeo tex_geo(uint32_t W0, uint32_t H0, int level, float u, float v)
 {
-    if (!IMAGES || T.data == nullptr) {      // constant slot: decoded once on the host
-        zf4 r; r.x = constant[0]; r.y = constant[1]; r.z = constant[2]; r.w = constant[3];
-        return r;
+    uint32_t off = 0;
+    uint32_t w = W0 >> level, h = H0 >> level;
+    if (w != 0u && h != 0u && (W0 & (W0 - 1u)) == 0u && (H0 & (H0 - 1u)) == 0u) {
+        const uint32_t sz = W0 * H0;                      // as in tex_bilinear
+        off = ((sz - (sz >> (2 * level))) / 3u) * 16u;
+    } else
+        for (int l = 0; l < level; ++l) { uint32_t lw = W0 >> l, lh = H0 >> l; if (!lw) lw = 1; if (!lh) lh = 1; off += lw * lh * 4u; }
+    if (!w) w = 1; if (!h) h = 1;
+    const float ur = u - __builtin_floorf(u), vr = v - __builtin_floorf(v);
+    const float x = __builtin_fmaf(ur, (float)w, -0.5f), y = __builtin_fmaf(vr, (float)h, -0.5f);
+    const float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
+    int x0 = tex_idx_clamp(fx + 1.0f, (int)w) - 1, y0 = tex_idx_clamp(fy + 1.0f, (int)h) - 1;
+    int x1 = x0 + 1; if (x1 >= (int)w) x1 = 0; if (x0 < 0) x0 = (int)w - 1;
+    int y1 = y0 + 1; if (y1 >= (int)h) y1 = 0; if (y0 < 0) y0 = (int)h - 1;
+    TexGeo g;
+    g.a = x - fx; g.b = y - fy;
+    const uint32_t r0 = off + (uint32_t)y0 * w * 4u, r1 = off + (uint32_t)y1 * w * 4u;
+    g.o00 = r0 + (uint32_t)x0 * 4u; g.o10 = r0 + (uint32_t)x1 * 4u; g.o01 = r1 + (uint32_t)x0 * 4u; g.o11 = r1 + (uint32_t)x1 * 4u;
+    return g;
+}
+__device__ __forceinline__ zf4 tex_decode4(uint32_t t, bool srgb, const float* __restrict__ lut)
+{
+    zf4 r;
+    r.x = tex_decode(t & 255u, srgb, lut); r.y = tex_decode((t >> 8) & 255u, srgb, lut);
+    r.z = tex_decode((t >> 16) & 255u, srgb, lut); r.w = tex_decode(t >> 24, false, lut);
+    return r;
+}
+__device__ __forceinline__ zf4 tex_bilinear_geo(const uint8_t* __restrict__ base, const TexGeo& g, bool srgb, const float* __restrict__ lut)
+{
+    const uint32_t u00 = *(const uint32_t*)(base + g.o00), u10 = *(const uint32_t*)(base + g.o10);
+    const uint32_t u01 = *(const uint32_t*)(base + g.o01), u11 = *(const uint32_t*)(base + g.o11);
+    const zf4 t00 = tex_decode4(u00, srgb, lut), t10 = tex_decode4(u10, srgb, lut), t01 = tex_decode4(u01, srgb, lut), t11 = tex_decode4(u11, srgb, lut);
+    const float a = g.a, b = g.b;
+    zf4 r;
+    { const float top = __builtin_fmaf(a, t10.x - t00.x, t00.x), bot = __builtin_fmaf(a, t11.x - t01.x, t01.x); r.x = __builtin_fmaf(b, bot - top, top); }
+    { const float top = __builtin_fmaf(a, t10.y - t00.y, t00.y), bot = __builtin_fmaf(a, t11.y - t01.y, t01.y); r.y = __builtin_fmaf(b, bot - top, top); }
+    { const float top = __builtin_fmaf(a, t10.z - t00.z, t00.z), bot = __builtin_fmaf(a, t11.z - t01.z, t01.z); r.z = __builtin_fmaf(b, bot - top, top); }
+    { const float top = __builtin_fmaf(a, t10.w - t00.w, t00.w), bot = __builtin_fmaf(a, t11.w - t01.w, t01.w); r.w = __builtin_fmaf(b, bot - top, top); }
+    return r;
+}
+// The packed material (ZrObject::packed, 16 B per texel = the 13 channels BaseScene.frag reads): one 16-byte load per texel instead of
+// seven 4-byte ones.  The sampled resolve is bound by the vector cache's line rate (a wave's 64 lanes scatter over the image), so the
+// number of loads is what counts: 8 per tap instead of 56.  Per channel the arithmetic and its order are tex_sample_footprint's.
+__device__ __forceinline__ float pk_decode(const uint4& t, int byte, const float* __restrict__ lut)
+{
+    const uint32_t w = byte < 4 ? t.x : byte < 8 ? t.y : byte < 12 ? t.z : t.w;
+    const uint32_t v = (w >> (8 * (byte & 3))) & 255u;
+    return lut[(byte < 3 ? 0u : 256u) + v];               // bytes 0..2: base colour rgb, sRGB; the rest UNORM
+}
+__device__ __forceinline__ void tex_sample_packed(const ZrTex& T, const float* __restrict__ lut, float u, float v,
+                                                  float dudx, float dvdx, float dudy, float dvdy, float (&out)[ZR_PK_CHANNELS])
+{
+    const TexFootprint F = tex_footprint(T, dudx, dvdx, dudy, dvdy);
+    const float fl = __builtin_floorf(F.lambda);
+    const int l0 = (int)fl, l1 = min(l0 + 1, (int)F.levels - 1);
+    const float f = F.lambda - fl;
+    const int N = F.N;
+    float acc[ZR_PK_CHANNELS];
+#pragma unroll
+    for (int k = 0; k < ZR_PK_CHANNELS; ++k) acc[k] = 0.0f;
+    const uint8_t* __restrict__ base = T.data;
+    for (int i = 1; i <= N; ++i) {
+        float uu = u, vv = v;
+        if (N > 1) {
+            const float off = (float)i / (float)(N + 1) - 0.5f;
+            uu = __builtin_fmaf(F.du, off, u); vv = __builtin_fmaf(F.dv, off, v);
+        }
+        const TexGeo g0 = tex_geo(F.w, F.h, l0, uu, vv), g1 = tex_geo(F.w, F.h, l1, uu, vv);     // offsets for 4-byte texels: x 4 here
+        const uint4 a00 = *(const uint4*)(base + (size_t)g0.o00 * 4u), a10 = *(const uint4*)(base + (size_t)g0.o10 * 4u);
+        const uint4 a01 = *(const uint4*)(base + (size_t)g0.o01 * 4u), a11 = *(const uint4*)(base + (size_t)g0.o11 * 4u);
+        const uint4 b00 = *(const uint4*)(base + (size_t)g1.o00 * 4u), b10 = *(const uint4*)(base + (size_t)g1.o10 * 4u);
+        const uint4 b01 = *(const uint4*)(base + (size_t)g1.o01 * 4u), b11 = *(const uint4*)(base + (size_t)g1.o11 * 4u);
+#pragma unroll
+        for (int k = 0; k < ZR_PK_CHANNELS; ++k) {
+            const float s00 = pk_decode(a00, k, lut), s10 = pk_decode(a10, k, lut), s01 = pk_decode(a01, k, lut), s11 = pk_decode(a11, k, lut);
+            const float t00 = pk_decode(b00, k, lut), t10 = pk_decode(b10, k, lut), t01 = pk_decode(b01, k, lut), t11 = pk_decode(b11, k, lut);
+            const float top0 = __builtin_fmaf(g0.a, s10 - s00, s00), bot0 = __builtin_fmaf(g0.a, s11 - s01, s01);
+            const float c0 = __builtin_fmaf(g0.b, bot0 - top0, top0);
+            const float top1 = __builtin_fmaf(g1.a, t10 - t00, t00), bot1 = __builtin_fmaf(g1.a, t11 - t01, t01);
+            const float c1 = __builtin_fmaf(g1.b, bot1 - top1, top1);
+            acc[k] += __builtin_fmaf(f, c1 - c0, c0);
+        }
     }
-    if (F.w != T.w || F.h != T.h || F.levels != T.levels) F = tex_footprint(T, dudx, dvdx, dudy, dvdy);
-    return tex_sample_footprint(T, F, srgb, lut, u, v);
+#pragma unroll
+    for (int k = 0; k < ZR_PK_CHANNELS; ++k) out[k] = N > 1 ? acc[k] / (float)N : acc[k];
+}
+#define ZR_MATERIAL_SLOTS 7
+__device__ __forceinline__ void tex_sample_material(const ZrObject* __restrict__ O, const float* __restrict__ lut, float u, float v,
+                                                    float dudx, float dvdx, float dudy, float dvdy, zf4 (&out)[ZR_MATERIAL_SLOTS])
+{
+    uint32_t todo = 0;                                    // slots that hold an image and are not sampled yet
+#pragma unroll
+    for (int s = 0; s < ZR_MATERIAL_SLOTS; ++s) {
+        if (O->tex[s].data != nullptr) todo |= 1u << s;
+        else { out[s].x = O->texc[s][0]; out[s].y = O->texc[s][1]; out[s].z = O->texc[s][2]; out[s].w = O->texc[s][3]; }   // constant slot: decoded once on the host
+    }
+    while (todo) {                                        // one turn per image size among the slots (one, as a rule)
+        const int lead = __builtin_ctz(todo);
+        const ZrTex& TL = O->tex[lead];
+        const TexFootprint F = tex_footprint(TL, dudx, dvdx, dudy, dvdy);
+        uint32_t grp = 0;
+#pragma unroll
+        for (int s = 0; s < ZR_MATERIAL_SLOTS; ++s)
+            if ((todo >> s & 1u) && O->tex[s].w == F.w && O->tex[s].h == F.h && O->tex[s].levels == F.levels) grp |= 1u << s;
+        todo &= ~grp;
+        const float fl = __builtin_floorf(F.lambda);
+        const int l0 = (int)fl, l1 = min(l0 + 1, (int)F.levels - 1);
+        const float f = F.lambda - fl;
+        const int N = F.N;
+        zf4 acc[ZR_MATERIAL_SLOTS];
+#pragma unroll
+        for (int s = 0; s < ZR_MATERIAL_SLOTS; ++s) acc[s].x = acc[s].y = acc[s].z = acc[s].w = 0.0f;
+        for (int i = 1; i <= N; ++i) {
+            float uu = u, vv = v;
+            if (N > 1) {
+                const float off = (float)i / (float)(N + 1) - 0.5f;
+                uu = __builtin_fmaf(F.du, off, u); vv = __builtin_fmaf(F.dv, off, v);
+            }
+            const TexGeo g0 = tex_geo(F.w, F.h, l0, uu, vv), g1 = tex_geo(F.w, F.h, l1, uu, vv);
+#pragma unroll
+            for (int s = 0; s < ZR_MATERIAL_SLOTS; ++s) {
+                if (!(grp >> s & 1u)) continue;
+                const uint8_t* __restrict__ base = O->tex[s].data;
+                const zf4 c0 = tex_bilinear_geo(base, g0, s == 0, lut), c1 = tex_bilinear_geo(base, g1, s == 0, lut);
+                acc[s].x += __builtin_fmaf(f, c1.x - c0.x, c0.x); acc[s].y += __builtin_fmaf(f, c1.y - c0.y, c0.y);
+                acc[s].z += __builtin_fmaf(f, c1.z - c0.z, c0.z); acc[s].w += __builtin_fmaf(f, c1.w - c0.w, c0.w);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < ZR_MATERIAL_SLOTS; ++s) {
+            if (!(grp >> s & 1u)) continue;
+            if (N > 1) { acc[s].x = acc[s].x / (float)N; acc[s].y = acc[s].y / (float)N; acc[s].z = acc[s].z / (float)N; acc[s].w = acc[s].w / (float)N; }
+            out[s] = acc[s];
+        }
+    }
 }
 // IMAGES = false: the caller knows that no slot of the scene holds an image (every material constant, the common synthetic
 // case): the filter is not even instantiated, which keeps eight inlined copies of it out of the kernel's registers.
-template <bool IMAGES>
+template <int IMAGES>
 __device__ __forceinline__ zf4 tex_sample(const ZrTex& T, const float* __restrict__ constant, bool srgb, const float* __restrict__ lut,
                                           float u, float v, float dudx, float dvdx, float dudy, float dvdy)
 {
@@ -1304,7 +1436,7 @@ __device__ __forceinline__ zf3 model_point(const ZrPass& P, zf3 p)
 
 // BaseScene.frag:26-48 for the pixel (px, py) whose winning primitive is `prim`
 // returns true when the pixel holds scene geometry (not empty, not sky)
-template <bool IMAGES>
+template <int IMAGES>
 __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* __restrict__ objs, uint32_t prim, float depth,
                                               int px, int py, const GBufferPtrs& G, const float* __restrict__ lut,
                                               uint8_t* __restrict__ vis_now)
@@ -1377,15 +1509,28 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
         w_sc = O->c_scene_color; w_gB = O->c_gB; w_gC = O->c_gC;
         ts = zr3(O->ts_const[0], O->ts_const[1], O->ts_const[2]);
     } else {
-        TexFootprint F;
-        F.w = F.h = F.levels = 0u; F.N = 1; F.lambda = 0.0f; F.du = F.dv = 0.0f;      // formed by the first slot that holds an image
-        const zf4 tb = tex_sample_shared<IMAGES>(O->tex[0], O->texc[0], true, lut, u0, v0, s1, t1, s2, t2, F);
-        const zf4 tme = tex_sample_shared<IMAGES>(O->tex[1], O->texc[1], false, lut, u0, v0, s1, t1, s2, t2, F);
-        const zf4 tro = tex_sample_shared<IMAGES>(O->tex[2], O->texc[2], false, lut, u0, v0, s1, t1, s2, t2, F);
-        const zf4 tno = tex_sample_shared<IMAGES>(O->tex[3], O->texc[3], false, lut, u0, v0, s1, t1, s2, t2, F);
-        const zf4 tao = tex_sample_shared<IMAGES>(O->tex[4], O->texc[4], false, lut, u0, v0, s1, t1, s2, t2, F);
-        const zf4 tem = tex_sample_shared<IMAGES>(O->tex[5], O->texc[5], false, lut, u0, v0, s1, t1, s2, t2, F);
-        const zf4 tms = tex_sample_shared<IMAGES>(O->tex[6], O->texc[6], false, lut, u0, v0, s1, t1, s2, t2, F);
+        zf4 tb, tme, tro, tno, tao, tem, tms;
+        if (IMAGES == 1) {                                 // every material of the scene that has images has them packed
+            tb.x = O->texc[0][0]; tb.y = O->texc[0][1]; tb.z = O->texc[0][2]; tme.x = O->texc[1][0]; tro.x = O->texc[2][0];
+            tno.x = O->texc[3][0]; tno.y = O->texc[3][1]; tno.z = O->texc[3][2]; tao.x = O->texc[4][0];
+            tem.x = O->texc[5][0]; tem.y = O->texc[5][1]; tem.z = O->texc[5][2]; tms.x = O->texc[6][0];
+            if (O->packed.data != nullptr) {
+                float pk[ZR_PK_CHANNELS];
+                tex_sample_packed(O->packed, lut, u0, v0, s1, t1, s2, t2, pk);
+                const uint32_t cs = O->const_slots;         // a constant slot stays the constant (the oracle does not filter it)
+                if (!(cs & 1u)) { tb.x = pk[ZR_PK_BC]; tb.y = pk[ZR_PK_BC + 1]; tb.z = pk[ZR_PK_BC + 2]; }
+                if (!(cs & 2u)) tme.x = pk[ZR_PK_ME];
+                if (!(cs & 4u)) tro.x = pk[ZR_PK_RO];
+                if (!(cs & 8u)) { tno.x = pk[ZR_PK_NO]; tno.y = pk[ZR_PK_NO + 1]; tno.z = pk[ZR_PK_NO + 2]; }
+                if (!(cs & 16u)) tao.x = pk[ZR_PK_AO];
+                if (!(cs & 32u)) { tem.x = pk[ZR_PK_EM]; tem.y = pk[ZR_PK_EM + 1]; tem.z = pk[ZR_PK_EM + 2]; }
+                if (!(cs & 64u)) tms.x = pk[ZR_PK_MS];
+            }
+        } else {
+            zf4 ms[ZR_MATERIAL_SLOTS];
+            tex_sample_material(O, lut, u0, v0, s1, t1, s2, t2, ms);
+            tb = ms[0]; tme = ms[1]; tro = ms[2]; tno = ms[3]; tao = ms[4]; tem = ms[5]; tms = ms[6];
+        }
         const float Rough = __builtin_fmaxf(0.01f, tro.x);
         w_sc = zr_unorm(tem.x, 255.0f) | zr_unorm(tem.y, 255.0f) << 8 | zr_unorm(tem.z, 255.0f) << 16 | zr_unorm(tms.x, 255.0f) << 24;
         w_gB = zr_unorm(tme.x, 255.0f) | zr_unorm(1.0f, 255.0f) << 8 | zr_unorm(Rough, 255.0f) << 16 | 255u << 24;
@@ -2118,7 +2263,7 @@ __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __r
 }
 
 // BaseScene.frag for every pixel of the owned tiles, from the frame's key buffer; resets the keys for the next frame.
-template <bool IMAGES>
+template <int IMAGES>      // 0: no material images in the scene; 1: every material with images has the packed form; 2: per-slot sampling
 __global__ __launch_bounds__(256) void k_resolve_gbuffer(ZrPass P, const ZrObject* __restrict__ objs,
                                                          const uint32_t* __restrict__ owned_tiles,
                                                          unsigned long long* __restrict__ vis64, GBufferPtrs G,
@@ -2353,7 +2498,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 else if (BACKGROUND && L.bg_enabled && 1.0f <= G.depth[p]) {
                     const float u = ((float)px + 0.5f) / (float)L.W, v = ((float)py + 0.5f) / (float)L.H;
                     const float one4[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
-                    const zf4 bgc = tex_sample<true>(L.bg, one4, true, tl, u, v, 1.0f / (float)L.W, 0.0f, 0.0f, 1.0f / (float)L.H);
+                    const zf4 bgc = tex_sample<2>(L.bg, one4, true, tl, u, v, 1.0f / (float)L.W, 0.0f, 0.0f, 1.0f / (float)L.H);
                     rgba = zr_unorm(zr_pow(bgc.x, 0.4545f), 255.0f) | zr_unorm(zr_pow(bgc.y, 0.4545f), 255.0f) << 8 |
                            zr_unorm(zr_pow(bgc.z, 0.4545f), 255.0f) << 16 | 255u << 24;
                 }
@@ -2825,8 +2970,9 @@ void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint
                                ZrDevStats* stats, hipStream_t s)
 {
     if (n_owned == 0) return;
-    if (P.images) hipLaunchKernelGGL(k_resolve_gbuffer<true>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats);
-    else hipLaunchKernelGGL(k_resolve_gbuffer<false>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats);
+    if (P.images == 1u) hipLaunchKernelGGL(k_resolve_gbuffer<1>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats);
+    else if (P.images) hipLaunchKernelGGL(k_resolve_gbuffer<2>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats);
+    else hipLaunchKernelGGL(k_resolve_gbuffer<0>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats);
 }
 void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, hipStream_t s)
 {

@@ -53,6 +53,8 @@ struct ZrObject {
     uint32_t prim_base;              // first primitive id of this draw
     uint32_t inst_base;              // instances in earlier draws (global instance ordinal of instance 0)
     ZrTex    tex[7];                 // sampled material slots (data == nullptr: the slot is the constant `texel`)
+    ZrTex    packed;                 // the image slots of ONE size interleaved, 16 B per texel (see ZR_PK_*): what BaseScene.frag reads of
+                                     // a texel of all seven slots comes with one load.  nullptr: no image, or images of different sizes
     uint32_t texel[7];               // constant material: RGBA8 per PBR slot (bc, m, r, n, ao, ev, ms)
     float    bc_linear[3];           // sRGB-decoded base colour (slot 0 is R8G8B8A8_SRGB, ZE:5878)
     float    texc[7][4];             // the constant texels decoded on the host (slot 0 rgb through the sRGB table, the rest c / 255)
@@ -64,6 +66,17 @@ struct ZrObject {
     float    ts_const[3];            // normalize(2 * normalize(texNormal) - 1) when slot 3 is constant (ComputeNormal, SH/Common.glsl:125-126)
     uint32_t c_scene_color, c_gB, c_gC;   // the packed SceneColor / GBufferB / GBufferC words when their slots (5,6 / 1,2 / 0,4) are constant
 };
+
+// byte of a packed material texel that holds a channel BaseScene.frag uses (:30-48): base colour rgb, metallic r, roughness r, normal rgb,
+// ambient occlusion r, emissive rgb, mask r; bytes 13..15 are zero
+#define ZR_PK_BC 0
+#define ZR_PK_ME 3
+#define ZR_PK_RO 4
+#define ZR_PK_NO 5
+#define ZR_PK_AO 8
+#define ZR_PK_EM 9
+#define ZR_PK_MS 12
+#define ZR_PK_CHANNELS 13
 
 // One (tile, meshlet-instance) entry of a bin list, self-contained: the rasteriser starts every load of a meshlet from
 // this record alone (one dependent round trip instead of bins -> draw table -> meshlet -> vertices).
