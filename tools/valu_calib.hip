@@ -22,9 +22,10 @@
 
 #define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum Op { OP_FMA, OP_FMA_1V, OP_MUL_F32, OP_ADD_U32, OP_MUL_LO, OP_MAD_U64, OP_RCP, OP_SQRT_HW, OP_DIV, OP_SQRT, OP_FMA_DEP, OP_CNDMASK, OP_CVT_I2F, OP_LDS_MIN64, OP_COUNT };
+enum Op { OP_FMA, OP_FMA_1V, OP_MUL_F32, OP_ADD_U32, OP_MUL_LO, OP_MAD_U64, OP_RCP, OP_SQRT_HW, OP_DIV, OP_SQRT, OP_FMA_DEP, OP_CNDMASK, OP_CVT_I2F, OP_LDS_MIN64, OP_PK_FMA, OP_PK_MUL, OP_COUNT };
 static const char* kOpName[OP_COUNT] = { "v_fma_f32 (3 VGPR sources)", "v_fma_f32 (1 VGPR source)", "v_mul_f32", "v_add_u32", "v_mul_lo_u32", "v_mad_u64_u32", "v_rcp_f32", "v_sqrt_f32", "ieee_div_f32",
-                                         "ieee_sqrt_f32", "v_fma_f32_dependent", "v_cndmask_b32", "v_cvt_f32_i32", "ds_min_u64" };
+                                         "ieee_sqrt_f32", "v_fma_f32_dependent", "v_cndmask_b32", "v_cvt_f32_i32", "ds_min_u64",
+                                         "v_pk_fma_f32 (two fp32 lanes per instruction)", "v_pk_mul_f32 (two fp32 lanes per instruction)" };
 
 #define UNROLL 8
 
@@ -33,9 +34,12 @@ __global__ __launch_bounds__(256) void k_calib(float* __restrict__ out, unsigned
                                               int iters, float seed)
 {
     __shared__ unsigned long long keys[1024];
-    float a[UNROLL]; unsigned u[UNROLL]; unsigned long long w[UNROLL];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    float a[UNROLL]; unsigned u[UNROLL]; unsigned long long w[UNROLL]; f2 p[UNROLL];
     const float b = 1.0000001f + seed, c = 1e-9f;
     for (int i = 0; i < UNROLL; ++i) { a[i] = 1.0f + 0.001f * (float)(threadIdx.x + i); u[i] = threadIdx.x * 2654435761u + (unsigned)i; w[i] = u[i]; }
+    for (int i = 0; i < UNROLL; ++i) { p[i].x = a[i]; p[i].y = a[i] + 0.5f; }
+    const f2 pb = { b, b }, pc = { c, c };
     if (OP == OP_LDS_MIN64) { for (int i = threadIdx.x; i < 1024; i += 256) keys[i] = ~0ull; __syncthreads(); }
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int it = 0; it < iters; ++it) {
@@ -52,6 +56,8 @@ __global__ __launch_bounds__(256) void k_calib(float* __restrict__ out, unsigned
             else if (OP == OP_SQRT_HW) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i]));
             else if (OP == OP_CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[i]) : "v"(u[(i + 1) % UNROLL]) : );
             else if (OP == OP_CVT_I2F) asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(a[i]) : "v"(u[i]));
+            else if (OP == OP_PK_FMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pb), "v"(pc));
+            else if (OP == OP_PK_MUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pb));
             else if (OP == OP_DIV) { a[i] = b / a[i]; asm volatile("" : "+v"(a[i])); }
             else if (OP == OP_SQRT) { a[i] = __builtin_sqrtf(a[i]) + 1.0f; asm volatile("" : "+v"(a[i])); }
             else if (OP == OP_LDS_MIN64) { u[i] = u[i] * 1664525u + 1013904223u; atomicMin(&keys[u[i] >> 22], (unsigned long long)u[i] << 32 | (unsigned)i); }
@@ -59,7 +65,7 @@ __global__ __launch_bounds__(256) void k_calib(float* __restrict__ out, unsigned
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.0f; unsigned su = 0;
-    for (int i = 0; i < UNROLL; ++i) { s += a[i]; su += u[i] + (unsigned)w[i]; }
+    for (int i = 0; i < UNROLL; ++i) { s += a[i] + p[i].x + p[i].y; su += u[i] + (unsigned)w[i]; }
     if (OP == OP_LDS_MIN64) { __syncthreads(); su += (unsigned)keys[threadIdx.x]; }
     out[blockIdx.x * 256 + threadIdx.x] = s + (float)su;
     if ((threadIdx.x & 63) == 0) {
@@ -134,6 +140,8 @@ int main()
     run_all<OP_DIV>(n_cu, d_out, d_cyc, d_rt, js, first);
     run_all<OP_SQRT>(n_cu, d_out, d_cyc, d_rt, js, first);
     run_all<OP_LDS_MIN64>(n_cu, d_out, d_cyc, d_rt, js, first);
+    run_all<OP_PK_FMA>(n_cu, d_out, d_cyc, d_rt, js, first);
+    run_all<OP_PK_MUL>(n_cu, d_out, d_cyc, d_rt, js, first);
     printf("{\"device\": \"%s\", \"compute_units\": %d, \"simds\": %d, \"clock_mhz_max\": %d, \"unroll\": %d,\n \"what\": \"cyc_per_inst_simd = shader cycles a SIMD spends per wave64 "
            "instruction (per division / square root for the ieee_* rows, per 64-lane ds_min_u64 on random keys of a 1024-key tile for the last row)\",\n \"rows\": [%s\n]}\n",
            prop.gcnArchName, n_cu, n_cu * 4, prop.clockRate / 1000, UNROLL, js.c_str());

@@ -125,7 +125,10 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     if (ok) ok &= hipMemcpy(c->d_lut, c->lut, sizeof c->lut, hipMemcpyHostToDevice) == hipSuccess;
     {
         std::vector<float> ul(1280);
-        for (int i = 0; i < 256; ++i) ul[(size_t)i] = (float)i / 255.0f;
+        for (int i = 0; i < 256; ++i) {
+            ul[(size_t)i] = (float)i / 255.0f;
+            ok &= fmaf((float)i, ZR_UNORM8_HI, (float)i * ZR_UNORM8_LO) == ul[(size_t)i];        // the packed sampler's division-free decode
+        }
         for (int i = 0; i < 1024; ++i) ul[256 + (size_t)i] = (float)i / 1023.0f;
         ok &= dev_alloc(&c->d_unorm_lut, ul.size()) == hipSuccess;
         if (ok) ok &= hipMemcpy(c->d_unorm_lut, ul.data(), ul.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
@@ -1591,7 +1594,8 @@ extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out)
     }
     out->survivors[1] += c->h_stats.survivors[2]; out->bin_entries[1] += c->h_stats.bin_entries[2];    // both rounds of the camera pass
     out->hiz_culled = c->h_stats.hiz_culled; out->round1_survivors = c->last_two_round ? c->h_stats.survivors[1] : 0;
-    out->covered_pixels = c->h_stats.covered; out->covered_shadow_texels = c->h_stats.covered_shadow; out->overflow = c->h_stats.overflow;
+    out->covered_pixels = 0; for (uint32_t v : c->h_stats.covered_part) out->covered_pixels += v;
+    out->covered_shadow_texels = c->h_stats.covered_shadow; out->overflow = c->h_stats.overflow;
     return rc;
 }
 

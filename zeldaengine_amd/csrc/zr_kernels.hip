@@ -1305,11 +1305,22 @@ __device__ __forceinline__ zf4 tex_bilinear_geo(const uint8_t* __restrict__ base
 // The packed material (ZrObject::packed, 16 B per texel = the 13 channels BaseScene.frag reads): one 16-byte load per texel instead of
 // seven 4-byte ones.  The sampled resolve is bound by the vector cache's line rate (a wave's 64 lanes scatter over the image), so the
 // number of loads is what counts: 8 per tap instead of 56.  Per channel the arithmetic and its order are tex_sample_footprint's.
-__device__ __forceinline__ float pk_decode(const uint4& t, int byte, const float* __restrict__ lut)
+typedef float zr_f2 __attribute__((ext_vector_type(2)));
+// channel pair (2 j, 2 j + 1) of a packed texel, decoded.  Two channels ride in one register pair from here on: gfx950 issues
+// v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 (two IEEE fp32 operations per lane) at the cost of one scalar-float instruction when
+// few waves share a SIMD (tools/valu_calib), and the 13 channels of a tap are independent of each other.
+__device__ __forceinline__ zr_f2 pk_decode2(const uint4& t, int j, const float* __restrict__ lut)
 {
-    const uint32_t w = byte < 4 ? t.x : byte < 8 ? t.y : byte < 12 ? t.z : t.w;
-    const uint32_t v = (w >> (8 * (byte & 3))) & 255u;
-    return lut[(byte < 3 ? 0u : 256u) + v];               // bytes 0..2: base colour rgb, sRGB; the rest UNORM
+    const uint32_t w = j < 2 ? t.x : j < 4 ? t.y : j < 6 ? t.z : t.w;
+    const uint32_t v0 = (w >> (16 * (j & 1))) & 255u, v1 = (w >> (16 * (j & 1) + 8)) & 255u;
+    // UNORM: the IEEE quotient c / 255 of an integer c in 0..255 is fma(c, k_hi, c * k_lo) with k_hi + k_lo = 1 / 255 to 48 bits (all 256
+    // values: zr_create checks them against the table) - no division, and no LDS read whose 64 random addresses collide in the banks
+    zr_f2 c; c.x = (float)v0; c.y = (float)v1;
+    const zr_f2 hi = { ZR_UNORM8_HI, ZR_UNORM8_HI }, lo = { ZR_UNORM8_LO, ZR_UNORM8_LO };
+    zr_f2 r = __builtin_elementwise_fma(c, hi, c * lo);
+    if (j == 0) { r.x = lut[v0]; r.y = lut[v1]; }          // bytes 0..2: base colour rgb, through the sRGB table
+    if (j == 1) r.x = lut[v0];
+    return r;
 }
 __device__ __forceinline__ void tex_sample_packed(const ZrTex& T, const float* __restrict__ lut, float u, float v,
                                                   float dudx, float dvdx, float dudy, float dvdy, float (&out)[ZR_PK_CHANNELS])
@@ -1318,10 +1329,12 @@ __device__ __forceinline__ void tex_sample_packed(const ZrTex& T, const float* _
     const float fl = __builtin_floorf(F.lambda);
     const int l0 = (int)fl, l1 = min(l0 + 1, (int)F.levels - 1);
     const float f = F.lambda - fl;
+    const zr_f2 f2 = { f, f };
     const int N = F.N;
-    float acc[ZR_PK_CHANNELS];
+    constexpr int PAIRS = (ZR_PK_CHANNELS + 1) / 2;
+    zr_f2 acc[PAIRS];
 #pragma unroll
-    for (int k = 0; k < ZR_PK_CHANNELS; ++k) acc[k] = 0.0f;
+    for (int j = 0; j < PAIRS; ++j) acc[j] = (zr_f2){ 0.0f, 0.0f };
     const uint8_t* __restrict__ base = T.data;
     for (int i = 1; i <= N; ++i) {
         float uu = u, vv = v;
@@ -1334,19 +1347,23 @@ __device__ __forceinline__ void tex_sample_packed(const ZrTex& T, const float* _
         const uint4 a01 = *(const uint4*)(base + (size_t)g0.o01 * 4u), a11 = *(const uint4*)(base + (size_t)g0.o11 * 4u);
         const uint4 b00 = *(const uint4*)(base + (size_t)g1.o00 * 4u), b10 = *(const uint4*)(base + (size_t)g1.o10 * 4u);
         const uint4 b01 = *(const uint4*)(base + (size_t)g1.o01 * 4u), b11 = *(const uint4*)(base + (size_t)g1.o11 * 4u);
+        const zr_f2 a0 = { g0.a, g0.a }, b0 = { g0.b, g0.b }, a1 = { g1.a, g1.a }, b1 = { g1.b, g1.b };
 #pragma unroll
-        for (int k = 0; k < ZR_PK_CHANNELS; ++k) {
-            const float s00 = pk_decode(a00, k, lut), s10 = pk_decode(a10, k, lut), s01 = pk_decode(a01, k, lut), s11 = pk_decode(a11, k, lut);
-            const float t00 = pk_decode(b00, k, lut), t10 = pk_decode(b10, k, lut), t01 = pk_decode(b01, k, lut), t11 = pk_decode(b11, k, lut);
-            const float top0 = __builtin_fmaf(g0.a, s10 - s00, s00), bot0 = __builtin_fmaf(g0.a, s11 - s01, s01);
-            const float c0 = __builtin_fmaf(g0.b, bot0 - top0, top0);
-            const float top1 = __builtin_fmaf(g1.a, t10 - t00, t00), bot1 = __builtin_fmaf(g1.a, t11 - t01, t01);
-            const float c1 = __builtin_fmaf(g1.b, bot1 - top1, top1);
-            acc[k] += __builtin_fmaf(f, c1 - c0, c0);
+        for (int j = 0; j < PAIRS; ++j) {                  // per channel: tex_bilinear's and tex_trilinear's expressions, in their order
+            const zr_f2 s00 = pk_decode2(a00, j, lut), s10 = pk_decode2(a10, j, lut), s01 = pk_decode2(a01, j, lut), s11 = pk_decode2(a11, j, lut);
+            const zr_f2 t00 = pk_decode2(b00, j, lut), t10 = pk_decode2(b10, j, lut), t01 = pk_decode2(b01, j, lut), t11 = pk_decode2(b11, j, lut);
+            const zr_f2 top0 = __builtin_elementwise_fma(a0, s10 - s00, s00), bot0 = __builtin_elementwise_fma(a0, s11 - s01, s01);
+            const zr_f2 c0 = __builtin_elementwise_fma(b0, bot0 - top0, top0);
+            const zr_f2 top1 = __builtin_elementwise_fma(a1, t10 - t00, t00), bot1 = __builtin_elementwise_fma(a1, t11 - t01, t01);
+            const zr_f2 c1 = __builtin_elementwise_fma(b1, bot1 - top1, top1);
+            acc[j] = acc[j] + __builtin_elementwise_fma(f2, c1 - c0, c0);
         }
     }
 #pragma unroll
-    for (int k = 0; k < ZR_PK_CHANNELS; ++k) out[k] = N > 1 ? acc[k] / (float)N : acc[k];
+    for (int k = 0; k < ZR_PK_CHANNELS; ++k) {
+        const float a = (k & 1) ? acc[k / 2].y : acc[k / 2].x;
+        out[k] = N > 1 ? a / (float)N : a;
+    }
 }
 #define ZR_MATERIAL_SLOTS 7
 __device__ __forceinline__ void tex_sample_material(const ZrObject* __restrict__ O, const float* __restrict__ lut, float u, float v,
@@ -2263,21 +2280,30 @@ __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __r
 }
 
 // BaseScene.frag for every pixel of the owned tiles, from the frame's key buffer; resets the keys for the next frame.
-template <int IMAGES>      // 0: no material images in the scene; 1: every material with images has the packed form; 2: per-slot sampling
-__global__ __launch_bounds__(256) void k_resolve_gbuffer(ZrPass P, const ZrObject* __restrict__ objs,
-                                                         const uint32_t* __restrict__ owned_tiles,
-                                                         unsigned long long* __restrict__ vis64, GBufferPtrs G,
-                                                         const float* __restrict__ srgb_lut, const float* __restrict__ unorm_lut,
-                                                         uint8_t* __restrict__ vis_now, ZrDevStats* __restrict__ stats)
+// IMAGES 0: no material images in the scene; 1: every material with images has the packed form; 2: per-slot sampling.
+// TB = threads per workgroup.  A tile is 256 threads x 4 pixels either way; without images that is one workgroup.  The sampled variants
+// run as four independent single-wave workgroups per tile: their waves differ a lot in length (tap counts 1..16 at silhouettes) and
+// hold 177+ registers, so a four-wave workgroup that waits for one slot on EVERY SIMD and retires with its slowest wave left the
+// SIMDs at 1.46 resident waves of the 2 that fit.
+#ifndef ZR_RESOLVE_IMG_WAVES
+#define ZR_RESOLVE_IMG_WAVES 3
+#endif
+template <int IMAGES, int TB>
+__global__ __launch_bounds__(TB, TB == 64 ? ZR_RESOLVE_IMG_WAVES : 1) void k_resolve_gbuffer(ZrPass P, const ZrObject* __restrict__ objs,
+                                                        const uint32_t* __restrict__ owned_tiles,
+                                                        unsigned long long* __restrict__ vis64, GBufferPtrs G,
+                                                        const float* __restrict__ srgb_lut, const float* __restrict__ unorm_lut,
+                                                        uint8_t* __restrict__ vis_now, ZrDevStats* __restrict__ stats)
 {
     __shared__ uint32_t covered_s;
     __shared__ float tlut[IMAGES ? 512 : 1];       // texel decode tables of the sampler (see tex_decode)
-    const uint32_t tid = threadIdx.x;
-    if (IMAGES) { tlut[tid] = srgb_lut[tid]; tlut[256u + tid] = unorm_lut[tid]; }      // (256 threads; the barrier below orders it)
+    constexpr uint32_t PARTS = 256u / (uint32_t)TB;
+    const uint32_t tid = threadIdx.x + (blockIdx.x % PARTS) * (uint32_t)TB;             // the thread's place among the tile's 256
+    if (IMAGES) for (uint32_t i = threadIdx.x; i < 256u; i += (uint32_t)TB) { tlut[i] = srgb_lut[i]; tlut[256u + i] = unorm_lut[i]; }   // (the barrier below orders it)
     const float* __restrict__ dlut = IMAGES ? tlut : srgb_lut;
-    const uint32_t tile = owned_tiles[blockIdx.x];
+    const uint32_t tile = owned_tiles[blockIdx.x / PARTS];
     const int tx0 = (int)(tile % P.tiles_x) * TILE, ty0 = (int)(tile / P.tiles_x) * TILE;
-    if (tid == 0) covered_s = 0;
+    if (threadIdx.x == 0) covered_s = 0;
     __syncthreads();
     uint32_t ncov = 0;
     // row-major within the tile -> 128 B (256 B for GBufferD / keys) contiguous row segments per wave.  The thread's four keys are fetched
@@ -2304,7 +2330,8 @@ __global__ __launch_bounds__(256) void k_resolve_gbuffer(ZrPass P, const ZrObjec
     }
     if (ncov) atomicAdd(&covered_s, ncov);
     __syncthreads();
-    if (tid == 0 && covered_s) atomicAdd(&stats->covered, covered_s);
+    // (one add per workgroup; spread over 32 words - 32 000 single-wave workgroups on ONE address would queue for 10 ns apiece)
+    if (threadIdx.x == 0 && covered_s) atomicAdd(&stats->covered_part[blockIdx.x & 31u], covered_s);
 }
 
 // statistics only (not part of the frame): shadow-map texels with depth < 1
@@ -2970,9 +2997,9 @@ void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint
                                ZrDevStats* stats, hipStream_t s)
 {
     if (n_owned == 0) return;
-    if (P.images == 1u) hipLaunchKernelGGL(k_resolve_gbuffer<1>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats);
-    else if (P.images) hipLaunchKernelGGL(k_resolve_gbuffer<2>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats);
-    else hipLaunchKernelGGL(k_resolve_gbuffer<0>, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats);
+    if (P.images == 1u) hipLaunchKernelGGL((k_resolve_gbuffer<1, 64>), dim3(n_owned * 4u), dim3(64), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats);
+    else if (P.images) hipLaunchKernelGGL((k_resolve_gbuffer<2, 64>), dim3(n_owned * 4u), dim3(64), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats);
+    else hipLaunchKernelGGL((k_resolve_gbuffer<0, 256>), dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats);
 }
 void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, hipStream_t s)
 {

@@ -15,6 +15,11 @@
 
 #define ZR_HD __host__ __device__ __forceinline__
 
+// c / 255.0f for an integer c in 0..255 without a division: fma(c, ZR_UNORM8_HI, c * ZR_UNORM8_LO) is the correctly rounded quotient
+// for all 256 values (k_hi = fl(1 / 255), k_lo = fl(1 / 255 - k_hi); checked exhaustively in exact arithmetic and again by zr_create)
+#define ZR_UNORM8_HI 0x1.010102p-8f
+#define ZR_UNORM8_LO -0x1.fdfdfep-33f
+
 struct zf3 { float x, y, z; };
 struct zf4 { float x, y, z, w; };
 

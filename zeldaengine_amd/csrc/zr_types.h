@@ -124,7 +124,7 @@ struct ZrPass {
 struct ZrDevStats {
     uint32_t survivors[3];           // slots: 0 shadow pass, 1 camera pass (round 1), 2 camera pass round 2 (after Hi-Z)
     uint32_t bin_entries[3];
-    uint32_t covered;
+    uint32_t covered_part[32];       // covered pixels, in 32 partial sums (the resolve adds to word blockIdx & 31)
     uint32_t covered_shadow;
     uint32_t overflow;
     uint32_t n_chunks[3];
