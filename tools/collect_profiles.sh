@@ -22,6 +22,6 @@ fi
 cd $R && python tools/make_profile_summary.py $tag $O/stats $O/bench_under_rocprof.json $O/fetch $O/write $O/sqa $O/sqb > $O/summary.txt || { tail -5 $O/summary.txt; exit 1; }
 [ -d $O/calib ] && python tools/make_profile_summary.py --calib $tag $O/calib >> $O/summary.txt
 grep "^{" $O/bench_under_rocprof.json > profiles/${tag}_bench_under_rocprof.json
-cp profiles/${tag}_kernel_stats.csv profiles/${tag}_pmc.json profiles/current.json profiles/${tag}_bench_under_rocprof.json $O/
+cp profiles/${tag}_*.csv profiles/${tag}_*.json profiles/current.json $O/      # (gpurun merges gpurun_out/ back, not profiles/)
 rm -rf $O/stats $O/fetch $O/write $O/sqa $O/sqb $O/calib
 head -80 $O/summary.txt
