@@ -2430,10 +2430,16 @@ __device__ __forceinline__ float shadow_tap(const float* __restrict__ S, int SD,
 }
 
 // BaseLighting.frag:147-254 for every pixel of the owned tiles (the full-screen quad of ZE:3531-3540)
-template <bool LIGHT_LIST, bool BACKGROUND>
+#ifndef ZR_LIGHT_TB
+#define ZR_LIGHT_TB 256
+#endif
+// TB threads per workgroup, 256 / TB workgroups per tile (each thread keeps its four pixels of the tile either way).  Measured: with
+// single-wave workgroups the pass itself is 5 % shorter (waves retire one by one), but its waves then fill every gap of the machine and
+// the shadow rasteriser beside it goes 131 -> 167 us: 4 690 against 4 820 Mpixel/s for the frame.  One workgroup per tile stays.
+template <bool LIGHT_LIST, bool BACKGROUND, int TB>
 // (compiled for exactly 4 waves per SIMD: left to itself the allocator takes 127 VGPRs, told so it makes do with 97 - the same four
 // waves, but 120 registers per SIMD left for the other lane's kernels; 5 or 6 waves (95 / 80 VGPRs) are faster alone, not beside)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lighting(ZrLightParams L, const XkView* __restrict__ view,
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lighting(ZrLightParams L, const XkView* __restrict__ view,
                                                   const uint32_t* __restrict__ owned_tiles, GBufferPtrs G,
                                                   const float* __restrict__ shadowmap, CubeDesc C,
                                                   const float* __restrict__ srgb_lut, const float* __restrict__ unorm_lut,
@@ -2443,14 +2449,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __shared__ float tl[512];            // [0, 256) sRGB decode (24 cubemap fetches per pixel), [256, 512) c / 255: tex_decode's layout
     __shared__ float u10[1024];
     float* const slut = tl; float* const u8 = tl + 256;
-    for (uint32_t i = threadIdx.x; i < 256u; i += 256u) { u8[i] = unorm_lut[i]; slut[i] = srgb_lut[i]; }
-    for (uint32_t i = threadIdx.x; i < 1024u; i += 256u) u10[i] = unorm_lut[256u + i];
+    constexpr uint32_t PARTS = 256u / (uint32_t)TB, WAVES = (uint32_t)TB / 64u;
+    const uint32_t tid = threadIdx.x + (blockIdx.x % PARTS) * (uint32_t)TB;      // the thread's place among the tile's 256
+    const uint32_t tile_slot = blockIdx.x / PARTS;
+    for (uint32_t i = threadIdx.x; i < 256u; i += (uint32_t)TB) { u8[i] = unorm_lut[i]; slut[i] = srgb_lut[i]; }
+    for (uint32_t i = threadIdx.x; i < 1024u; i += (uint32_t)TB) u10[i] = unorm_lut[256u + i];
     __syncthreads();
     if (L.clear_next) {      // the clear of the next frame's shadow pass (depth 1.0, ZE:3248), a slice per workgroup: saves a launch
         const uint32_t per = (L.clear_n + gridDim.x - 1u) / gridDim.x, b = blockIdx.x * per;
-        for (uint32_t i = threadIdx.x; i < per && b + i < L.clear_n; i += 256u) L.clear_next[b + i] = 0x3F800000u;
+        for (uint32_t i = threadIdx.x; i < per && b + i < L.clear_n; i += (uint32_t)TB) L.clear_next[b + i] = 0x3F800000u;
     }
-    const uint32_t tile = owned_tiles[blockIdx.x];
+    const uint32_t tile = owned_tiles[tile_slot];
     const int tx0 = (int)(tile % L.tiles_x) * TILE, ty0 = (int)(tile / L.tiles_x) * TILE;
     const zf3 cam = zr3(view->CameraInfo[0], view->CameraInfo[1], view->CameraInfo[2]);
     const uint32_t nDir = (uint32_t)view->LightsCount[0], nPoint = (uint32_t)view->LightsCount[1];
@@ -2461,13 +2470,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // positions would be skipped by every pixel's own exact test below (|lp - P| >= the box distance per axis, and the squared
     // sums are monotonic), so it is dropped for the whole tile.  The list is a bitmask, walked in ascending order: the
     // accumulation order over lights is unchanged.  Pixels with Mask = 0 do not count: their colour is (...) * 0 -> stored 0.
-    __shared__ float bbp[LIGHT_LIST ? 4 : 1][6];
+    __shared__ float bbp[LIGHT_LIST ? WAVES : 1][6];
     __shared__ uint32_t lmask[LIGHT_LIST ? XK_MAX_POINT_LIGHTS_NUM / 32 : 1];
     constexpr bool use_mask = LIGHT_LIST;
     if constexpr (LIGHT_LIST) {
         float lo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, hi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
         bool odd = false;                    // a non-finite position: keep every light
-        for (uint32_t i = threadIdx.x; i < TILE_PIX; i += 256u) {
+        for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
             const int px = tx0 + (int)(i & (TILE - 1)), py = ty0 + (int)(i / TILE);
             if (px >= (int)L.W || py >= (int)L.H) continue;
             const size_t p = (size_t)py * L.W + (size_t)px;
@@ -2486,14 +2495,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             o[0] = wodd ? -__builtin_inff() : lo[0]; o[1] = wodd ? -__builtin_inff() : lo[1]; o[2] = wodd ? -__builtin_inff() : lo[2];
             o[3] = wodd ? __builtin_inff() : hi[0]; o[4] = wodd ? __builtin_inff() : hi[1]; o[5] = wodd ? __builtin_inff() : hi[2];
         }
-        for (uint32_t i = threadIdx.x; i < XK_MAX_POINT_LIGHTS_NUM / 32; i += 256u) lmask[i] = 0u;
+        for (uint32_t i = threadIdx.x; i < XK_MAX_POINT_LIGHTS_NUM / 32; i += (uint32_t)TB) lmask[i] = 0u;
         __syncthreads();
         float blo[3], bhi[3];
         for (int a = 0; a < 3; ++a) {
-            blo[a] = __builtin_fminf(__builtin_fminf(bbp[0][a], bbp[1][a]), __builtin_fminf(bbp[2][a], bbp[3][a]));
-            bhi[a] = __builtin_fmaxf(__builtin_fmaxf(bbp[0][3 + a], bbp[1][3 + a]), __builtin_fmaxf(bbp[2][3 + a], bbp[3][3 + a]));
+            blo[a] = bbp[0][a]; bhi[a] = bbp[0][3 + a];
+            for (uint32_t w = 1; w < WAVES; ++w) { blo[a] = __builtin_fminf(blo[a], bbp[w][a]); bhi[a] = __builtin_fmaxf(bhi[a], bbp[w][3 + a]); }
         }
-        for (uint32_t li = threadIdx.x; li < nPoint; li += 256u) {
+        for (uint32_t li = threadIdx.x; li < nPoint; li += (uint32_t)TB) {
             const XkLight* __restrict__ Lt = &view->PointLights[li];
             const bool lfinite = __builtin_fabsf(Lt->Color[0]) <= 3.402823466e38f && __builtin_fabsf(Lt->Color[1]) <= 3.402823466e38f &&
                                  __builtin_fabsf(Lt->Color[2]) <= 3.402823466e38f && __builtin_fabsf(Lt->Color[3]) <= 3.402823466e38f;
@@ -2511,7 +2520,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         __syncthreads();
     }
 
-    for (uint32_t i = threadIdx.x; i < TILE_PIX; i += 256u) {
+    for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
         const int px = tx0 + (int)(i & (TILE - 1)), py = ty0 + (int)(i / TILE);
         if (px >= (int)L.W || py >= (int)L.H) continue;
         const size_t p = (size_t)py * L.W + (size_t)px;
@@ -2530,7 +2539,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                            zr_unorm(zr_pow(bgc.z, 0.4545f), 255.0f) << 16 | 255u << 24;
                 }
             }
-            if (L.packed_out) out[(size_t)blockIdx.x * TILE_PIX + i] = rgba;
+            if (L.packed_out) out[(size_t)tile_slot * TILE_PIX + i] = rgba;
             else out[p] = rgba;
         };
         // A pixel nothing was drawn to holds the clear values of every target (ZE:3427-3433), so the shader computes the same
@@ -3011,7 +3020,7 @@ void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32
 {
     if (n_owned == 0) return;
     // with several point lights each tile first builds its light list (L.light_list: decided on the host from the light count)
-#define ZR_LAUNCH_LIGHTING(LL, BG) hipLaunchKernelGGL((k_lighting<LL, BG>), dim3(n_owned), dim3(256), 0, s, L, view, owned_tiles, G, shadowmap, C, lut, unorm_lut, out)
+#define ZR_LAUNCH_LIGHTING(LL, BG) hipLaunchKernelGGL((k_lighting<LL, BG, ZR_LIGHT_TB>), dim3(n_owned * (256u / ZR_LIGHT_TB)), dim3(ZR_LIGHT_TB), 0, s, L, view, owned_tiles, G, shadowmap, C, lut, unorm_lut, out)
     if (L.light_list) { if (L.bg_enabled) ZR_LAUNCH_LIGHTING(true, true); else ZR_LAUNCH_LIGHTING(true, false); }
     else { if (L.bg_enabled) ZR_LAUNCH_LIGHTING(false, true); else ZR_LAUNCH_LIGHTING(false, false); }
 #undef ZR_LAUNCH_LIGHTING
