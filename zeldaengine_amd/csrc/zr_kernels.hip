@@ -2288,7 +2288,9 @@ __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __r
 #ifndef ZR_RESOLVE_IMG_WAVES
 #define ZR_RESOLVE_IMG_WAVES 3
 #endif
-template <int IMAGES, int TB>
+// PPT = pixels per thread, 4 or 1 (1: four times the workgroups, a quarter of the work each - when a rank of a multi-GPU job owns so few
+// tiles that they would not fill the machine once, zr_launch_resolve_gbuffer).
+template <int IMAGES, int TB, int PPT>
 __global__ __launch_bounds__(TB, TB == 64 ? ZR_RESOLVE_IMG_WAVES : 1) void k_resolve_gbuffer(ZrPass P, const ZrObject* __restrict__ objs,
                                                         const uint32_t* __restrict__ owned_tiles,
                                                         unsigned long long* __restrict__ vis64, GBufferPtrs G,
@@ -2297,8 +2299,8 @@ __global__ __launch_bounds__(TB, TB == 64 ? ZR_RESOLVE_IMG_WAVES : 1) void k_res
 {
     __shared__ uint32_t covered_s;
     __shared__ float tlut[IMAGES ? 512 : 1];       // texel decode tables of the sampler (see tex_decode)
-    constexpr uint32_t PARTS = 256u / (uint32_t)TB;
-    const uint32_t tid = threadIdx.x + (blockIdx.x % PARTS) * (uint32_t)TB;             // the thread's place among the tile's 256
+    constexpr uint32_t T = TILE_PIX / (uint32_t)PPT, PARTS = T / (uint32_t)TB;          // threads / workgroups per tile
+    const uint32_t tid = threadIdx.x + (blockIdx.x % PARTS) * (uint32_t)TB;             // the thread's place among the tile's T
     if (IMAGES) for (uint32_t i = threadIdx.x; i < 256u; i += (uint32_t)TB) { tlut[i] = srgb_lut[i]; tlut[256u + i] = unorm_lut[i]; }   // (the barrier below orders it)
     const float* __restrict__ dlut = IMAGES ? tlut : srgb_lut;
     const uint32_t tile = owned_tiles[blockIdx.x / PARTS];
@@ -2308,10 +2310,10 @@ __global__ __launch_bounds__(TB, TB == 64 ? ZR_RESOLVE_IMG_WAVES : 1) void k_res
     uint32_t ncov = 0;
     // row-major within the tile -> 128 B (256 B for GBufferD / keys) contiguous row segments per wave.  The thread's four keys are fetched
     // (and reset) together: four independent loads in flight instead of one at the head of each pixel's chain of dependent loads.
-    unsigned long long keys[TILE_PIX / 256];
+    unsigned long long keys[PPT];
 #pragma unroll
-    for (uint32_t q = 0; q < TILE_PIX / 256u; ++q) {
-        const uint32_t i = tid + q * 256u;
+    for (uint32_t q = 0; q < (uint32_t)PPT; ++q) {
+        const uint32_t i = tid + q * T;
         const int px = tx0 + (int)(i & (TILE - 1)), py = ty0 + (int)(i / TILE);
         keys[q] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
         if (px < (int)P.W && py < (int)P.H) {
@@ -2321,8 +2323,8 @@ __global__ __launch_bounds__(TB, TB == 64 ? ZR_RESOLVE_IMG_WAVES : 1) void k_res
         }
     }
 #pragma unroll
-    for (uint32_t q = 0; q < TILE_PIX / 256u; ++q) {
-        const uint32_t i = tid + q * 256u;
+    for (uint32_t q = 0; q < (uint32_t)PPT; ++q) {
+        const uint32_t i = tid + q * T;
         const int px = tx0 + (int)(i & (TILE - 1)), py = ty0 + (int)(i / TILE);
         if (px >= (int)P.W || py >= (int)P.H) continue;
         const unsigned long long k = keys[q];
@@ -2430,13 +2432,27 @@ __device__ __forceinline__ float shadow_tap(const float* __restrict__ S, int SD,
 }
 
 // BaseLighting.frag:147-254 for every pixel of the owned tiles (the full-screen quad of ZE:3531-3540)
+// Shape of the per-pixel kernels' grids (A/B'd on the whole two-lane frame, not on the kernel alone: what counts is what the pass
+// leaves to the other lane while it runs).  Pixels per thread 1 instead of 4: + 3.5 % (the pass itself takes LONGER beside the camera
+// lane, 123 -> 187 us, and the camera lane's short kernels stop starving: hiz 80 -> 40 us); 512-thread workgroups for the lighting
+// pass: + 1 % more (128 threads: - 8 %, 1 024: - 2 %; single-wave workgroups at 4 pixels per thread: - 3 %).  One pixel per thread
+// is also what a rank of a multi-GPU job needs, whose few tiles would otherwise fill a quarter of the machine.
 #ifndef ZR_LIGHT_TB
-#define ZR_LIGHT_TB 256
+#define ZR_LIGHT_TB 512
 #endif
-// TB threads per workgroup, 256 / TB workgroups per tile (each thread keeps its four pixels of the tile either way).  Measured: with
-// single-wave workgroups the pass itself is 5 % shorter (waves retire one by one), but its waves then fill every gap of the machine and
-// the shadow rasteriser beside it goes 131 -> 167 us: 4 690 against 4 820 Mpixel/s for the frame.  One workgroup per tile stays.
-template <bool LIGHT_LIST, bool BACKGROUND, int TB>
+#ifndef ZR_FINE_RESOLVE
+#define ZR_FINE_RESOLVE 1000000u     // owned tiles up to which the resolve takes ZR_FINE_PPT pixels per thread (A/B: 0 = never)
+#endif
+#ifndef ZR_FINE_LIGHT
+#define ZR_FINE_LIGHT 1000000u
+#endif
+#ifndef ZR_FINE_PPT
+#define ZR_FINE_PPT 1
+#endif
+#ifndef ZR_RESOLVE_TB
+#define ZR_RESOLVE_TB 256
+#endif
+template <bool LIGHT_LIST, bool BACKGROUND, int TB, int PPT>      // PPT: pixels per thread, 4 or 1 (as in k_resolve_gbuffer)
 // (compiled for exactly 4 waves per SIMD: left to itself the allocator takes 127 VGPRs, told so it makes do with 97 - the same four
 // waves, but 120 registers per SIMD left for the other lane's kernels; 5 or 6 waves (95 / 80 VGPRs) are faster alone, not beside)
 __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lighting(ZrLightParams L, const XkView* __restrict__ view,
@@ -2449,8 +2465,8 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     __shared__ float tl[512];            // [0, 256) sRGB decode (24 cubemap fetches per pixel), [256, 512) c / 255: tex_decode's layout
     __shared__ float u10[1024];
     float* const slut = tl; float* const u8 = tl + 256;
-    constexpr uint32_t PARTS = 256u / (uint32_t)TB, WAVES = (uint32_t)TB / 64u;
-    const uint32_t tid = threadIdx.x + (blockIdx.x % PARTS) * (uint32_t)TB;      // the thread's place among the tile's 256
+    constexpr uint32_t T = TILE_PIX / (uint32_t)PPT, PARTS = T / (uint32_t)TB, WAVES = (uint32_t)TB / 64u;
+    const uint32_t tid = threadIdx.x + (blockIdx.x % PARTS) * (uint32_t)TB;      // the thread's place among the tile's T
     const uint32_t tile_slot = blockIdx.x / PARTS;
     for (uint32_t i = threadIdx.x; i < 256u; i += (uint32_t)TB) { u8[i] = unorm_lut[i]; slut[i] = srgb_lut[i]; }
     for (uint32_t i = threadIdx.x; i < 1024u; i += (uint32_t)TB) u10[i] = unorm_lut[256u + i];
@@ -2476,7 +2492,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if constexpr (LIGHT_LIST) {
         float lo[3] = { __builtin_inff(), __builtin_inff(), __builtin_inff() }, hi[3] = { -__builtin_inff(), -__builtin_inff(), -__builtin_inff() };
         bool odd = false;                    // a non-finite position: keep every light
-        for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
+        for (uint32_t i = tid; i < TILE_PIX; i += T) {
             const int px = tx0 + (int)(i & (TILE - 1)), py = ty0 + (int)(i / TILE);
             if (px >= (int)L.W || py >= (int)L.H) continue;
             const size_t p = (size_t)py * L.W + (size_t)px;
@@ -2520,7 +2536,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         __syncthreads();
     }
 
-    for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
+    for (uint32_t i = tid; i < TILE_PIX; i += T) {
         const int px = tx0 + (int)(i & (TILE - 1)), py = ty0 + (int)(i / TILE);
         if (px >= (int)L.W || py >= (int)L.H) continue;
         const size_t p = (size_t)py * L.W + (size_t)px;
@@ -3006,9 +3022,13 @@ void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint
                                ZrDevStats* stats, hipStream_t s)
 {
     if (n_owned == 0) return;
-    if (P.images == 1u) hipLaunchKernelGGL((k_resolve_gbuffer<1, 64>), dim3(n_owned * 4u), dim3(64), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats);
-    else if (P.images) hipLaunchKernelGGL((k_resolve_gbuffer<2, 64>), dim3(n_owned * 4u), dim3(64), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats);
-    else hipLaunchKernelGGL((k_resolve_gbuffer<0, 256>), dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats);
+    // few owned tiles (a rank of a multi-GPU job): one pixel per thread, so that the tiles fill the machine instead of a quarter of it
+    const bool fine = n_owned <= ZR_FINE_RESOLVE;
+#define ZR_LAUNCH_RESOLVE(IM, TB, PPT) hipLaunchKernelGGL((k_resolve_gbuffer<IM, TB, PPT>), dim3(n_owned * (TILE_PIX / (PPT) / (TB))), dim3(TB), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats)
+    if (P.images == 1u) { if (fine) ZR_LAUNCH_RESOLVE(1, 64, 1); else ZR_LAUNCH_RESOLVE(1, 64, 4); }
+    else if (P.images) { if (fine) ZR_LAUNCH_RESOLVE(2, 64, 1); else ZR_LAUNCH_RESOLVE(2, 64, 4); }
+    else { if (fine) ZR_LAUNCH_RESOLVE(0, ZR_RESOLVE_TB, ZR_FINE_PPT); else ZR_LAUNCH_RESOLVE(0, 256, 4); }
+#undef ZR_LAUNCH_RESOLVE
 }
 void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, hipStream_t s)
 {
@@ -3020,9 +3040,12 @@ void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32
 {
     if (n_owned == 0) return;
     // with several point lights each tile first builds its light list (L.light_list: decided on the host from the light count)
-#define ZR_LAUNCH_LIGHTING(LL, BG) hipLaunchKernelGGL((k_lighting<LL, BG, ZR_LIGHT_TB>), dim3(n_owned * (256u / ZR_LIGHT_TB)), dim3(ZR_LIGHT_TB), 0, s, L, view, owned_tiles, G, shadowmap, C, lut, unorm_lut, out)
+#define ZR_LAUNCH_LIGHTING2(LL, BG, PPT) hipLaunchKernelGGL((k_lighting<LL, BG, ZR_LIGHT_TB, PPT>), dim3(n_owned * (TILE_PIX / (PPT) / ZR_LIGHT_TB)), dim3(ZR_LIGHT_TB), 0, s, L, view, owned_tiles, G, shadowmap, C, lut, unorm_lut, out)
+#define ZR_LAUNCH_LIGHTING(LL, BG) do { if (n_owned <= ZR_FINE_LIGHT) ZR_LAUNCH_LIGHTING2(LL, BG, ZR_FINE_PPT); else ZR_LAUNCH_LIGHTING2(LL, BG, 4); } while (0)
+    // (few tiles - a rank of a multi-GPU job: one pixel per thread, see zr_launch_resolve_gbuffer)
     if (L.light_list) { if (L.bg_enabled) ZR_LAUNCH_LIGHTING(true, true); else ZR_LAUNCH_LIGHTING(true, false); }
     else { if (L.bg_enabled) ZR_LAUNCH_LIGHTING(false, true); else ZR_LAUNCH_LIGHTING(false, false); }
+#undef ZR_LAUNCH_LIGHTING2
 #undef ZR_LAUNCH_LIGHTING
 }
 void zr_launch_gbuffer_vis(const ZrLightParams& L, const XkView* view, const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C,
