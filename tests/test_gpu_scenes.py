@@ -416,7 +416,7 @@ def test_materials_whose_images_share_a_size_are_sampled_packed(oracle_lib, gpu_
         for spec in (full, some, one):
             m, k = abi.make_material(spec); mats.append(m); keep.append(k)
         r._keepalive = keep
-        v, idx = scenes.grid_plane(26.0, 6, 0.0)                # (inside the dome: corners at 18.4 of its radius 20.48)
+        v, idx = scenes.grid_plane(40.0, 6, 0.0)                # (its corners lie outside the dome, radius 20.48)
         v = v.copy(); v["TexCoord"] *= 7.0
         r.object_add(r.mesh_create(v, idx), mats[0])
         r.object_add(r.mesh_create(*scenes.uv_sphere()), mats[1], scenes.generate_instances(80, 1.0, 7.0, 0.3, 1.1, seed=4))
@@ -426,6 +426,25 @@ def test_materials_whose_images_share_a_size_are_sampled_packed(oracle_lib, gpu_
     o, g = _both(oracle_lib, gpu_engine, 400, 240, 256, build, _std_frame(cam))
     assert len(np.unique(o.gbuffer(4))) > 500 and len(np.unique(o.gbuffer(1))) > 100
     _identical(o, g, "packed materials")
+
+
+def test_geometry_behind_the_skydome_keeps_its_gbuffer(oracle_lib, gpu_engine):
+    """The skydome is drawn after the lighting quad, depth-tested, colour only (ZE:3681-3691): scene geometry that lies OUTSIDE the dome
+    (radius 20.48) is hidden by it in the image but stays in every GBuffer attachment, and is lit like any other pixel before the dome
+    covers it.  The library resolves the dome in a key plane of its own for that (k_sky_tiles)."""
+    def build(r):
+        r.set_cubemap(scenes.synthetic_cubemap(16))
+        r.set_skydome(*scenes.sky_dome(), scenes.synthetic_sky_image())
+        r.object_add(r.mesh_create(*scenes.grid_plane(90.0, 6, 0.0)))                     # corners 64 units out: far beyond the dome
+        r.object_add(r.mesh_create(*scenes.uv_sphere()), None, scenes.generate_instances(120, 2.0, 40.0, 0.5, 2.0, seed=8))   # inside and outside
+    cam = abi.make_camera((0.0, -12.0, 2.0), (0.0, 30.0, 1.0), fov=60.0, znear=0.1, zfar=200.0)
+    o, g = _both(oracle_lib, gpu_engine, 400, 240, 256, build, _std_frame(cam))
+    depth = o.gbuffer(0)
+    dome = (o.color() != 0).any(axis=2) & (depth < 1.0)
+    assert (depth < 1.0).sum() > 400 * 240 // 3                   # the plane fills the lower half, dome pixels above AND over its far part
+    _identical(o, g, "geometry behind the dome")
+    g.render(); g.finish()                                        # and again with the visibility history of the first frame
+    _identical(o, g, "geometry behind the dome, second frame")
 
 
 def test_anisotropic_filtering_at_grazing_angles(oracle_lib, gpu_engine):

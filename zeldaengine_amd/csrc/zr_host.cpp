@@ -234,6 +234,7 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     c->shadow_blocks = c->raster_blocks;
     if (ok) ok &= dev_alloc(&c->d_slow0, 4ull * c->slow0_cap) == hipSuccess;
 #ifdef ZR_DIAG
+    if (const char* e = getenv("ZR_RASTER_BLOCKS")) c->raster_blocks = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("ZR_SHADOW_BLOCKS")) c->shadow_blocks = (uint32_t)std::max(1, atoi(e));
 #endif
     {   // Hi-Z pyramid: level l = max depth per (8 << l)^2 pixel block
@@ -299,7 +300,7 @@ extern "C" void zr_destroy(zr_ctx* c)
         dev_free(G.depth); dev_free(G.scene_color); dev_free(G.gA); dev_free(G.gB); dev_free(G.gC); dev_free(G.gD); dev_free(G.overlay);
         dev_free(c->d_shadow_b[b]); dev_free(c->d_view_b[b]); dev_free(c->d_empty_b[b]);
     }
-    dev_free(c->d_color); dev_free(c->d_stats); dev_free(c->d_lut); dev_free(c->d_unorm_lut);
+    dev_free(c->d_color); dev_free(c->d_stats); dev_free(c->d_lut); dev_free(c->d_unorm_lut); dev_free(c->d_sky_keys);
     dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles); dev_free(c->d_tile_map);
     for (auto& sc : c->sc) {
         dev_free(sc.tile_count); dev_free(sc.tile_offset); dev_free(sc.tile_cursor); dev_free(sc.chunk_offset);
@@ -762,11 +763,16 @@ static int finalize_scene(zr_ctx* c)
     for (int pass = 0; pass < 2; ++pass)                 // non-instanced draws, then instanced draws (ZE:3445-3476)
         for (auto& o : c->objects)
             if ((int)o.instanced == pass) emit(o, c->meshes[o.mesh], 0u);
-    if (sky) emit(c->sky_obj, c->sky_mesh, ZR_OBJ_SKY);   // drawn last, after the lighting quad (ZE:3681-3691)
+    // The skydome is the table's last record but no work item of the shadow or the deferred-scene pass: it is drawn after the lighting
+    // quad (ZE:3681-3691), depth-tested against the scene and colour only - k_sky_tiles + the resolve.
+    const uint64_t scene_work = work, scene_inst = inst_total;
+    if (sky) emit(c->sky_obj, c->sky_mesh, ZR_OBJ_SKY);
     if (work >= 0xFFFFFFFFull || prim >= 0xFFFFFFFFull) return zr_fail(c, ZR_ERR_OVERFLOW, "scene exceeds 2^32 meshlet-instances or primitives");
     dev_free(c->d_objs);
     HIPCHK(c, upload(&c->d_objs, tab));
-    c->n_objs = (uint32_t)tab.size(); c->n_work = (uint32_t)work; c->n_inst_total = (uint32_t)inst_total;
+    c->n_objs = (uint32_t)tab.size(); c->n_work = (uint32_t)scene_work; c->n_inst_total = (uint32_t)scene_inst;
+    c->sky_object = sky ? (uint32_t)tab.size() - 1u : 0u;
+    if (sky && !c->d_sky_keys) HIPCHK(c, dev_alloc(&c->d_sky_keys, (size_t)c->W * c->H));
     if (c->n_work > c->work_capacity) {
         for (auto& sc : c->sc) { dev_free(sc.rects); dev_free(sc.bins); dev_free(sc.work); dev_free(sc.chunk_tab); }
         dev_free(c->d_pxrect); dev_free(c->d_zmin); dev_free(c->d_visflag[0]); dev_free(c->d_visflag[1]);
@@ -1286,6 +1292,8 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
         const bool sky = c->sky_set && c->sky_enabled;
         P.write_overlay = (sky || c->overlay_dirty[par]) ? 1u : 0u;
         c->overlay_dirty[par] = sky;
+        P.sky_keys = nullptr; P.sky_object = c->sky_object;
+        if (sky && c->d_sky_keys) { zr_launch_sky_tiles(P, c->d_objs, c->d_owned, c->n_owned, c->d_sky_keys, s); P.sky_keys = c->d_sky_keys; }
     }
     if (ev) HIPCHK(c, hipEventRecord(ev[6], s));
     zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_lut, c->d_unorm_lut, Z.vis_now, c->d_stats, s);

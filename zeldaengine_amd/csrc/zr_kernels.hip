@@ -1509,10 +1509,9 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
     const zf3 pos_dx = (P0 - Ph) * sx, pos_dy = (P0 - Pv) * sy;
     const float s1 = (u0 - uh) * sx, t1 = (v0 - vh) * sx, s2 = (u0 - uv_) * sy, t2 = (v0 - vv) * sy;
 
-    if (O->flags & ZR_OBJ_SKY) {    // Skydome.frag: texture(skydomeSampler, uv).rgb, gamma; the GBuffer keeps its clear values
+    if (O->flags & ZR_OBJ_SKY) {    // Skydome.frag: texture(skydomeSampler, uv).rgb, gamma - colour only, into the overlay plane: the pass
+        // is drawn after the lighting quad (ZE:3681-3691) and no GBuffer attachment is written by it
         const zf4 sk = tex_sample<IMAGES>(O->tex[0], O->texc[0], true, lut, u0, v0, s1, t1, s2, t2);
-        G.depth[p] = 1.0f; G.scene_color[p] = 0xFF000000u; G.gA[p] = 0u; G.gB[p] = 0xFF000000u; G.gC[p] = 0xFF000000u;
-        G.gD[p] = make_uint2(0u, 0x3C000000u);
         G.overlay[p] = zr_unorm(zr_pow(sk.x, 0.4545f), 255.0f) | zr_unorm(zr_pow(sk.y, 0.4545f), 255.0f) << 8 |
                        zr_unorm(zr_pow(sk.z, 0.4545f), 255.0f) << 16 | 255u << 24;
         return false;
@@ -2279,6 +2278,38 @@ __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __r
     }
 }
 
+// The skydome pass's visibility (ZE:3681-3691, SH/Skydome.vert): the dome's triangles against each other, LESS in draw order, into a key
+// plane of their own (depth bits << 32 | triangle).  Workgroup per owned tile; every thread takes its share of the dome's few hundred
+// triangles through the general path (classification, clipper, 64-bit walk: the dome surrounds the eye, most of its triangles cross
+// the guard band), clipped to the tile; the tile's keys are stored whole, so the plane needs no clear.
+__global__ __launch_bounds__(256) void k_sky_tiles(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ owned_tiles,
+                                                   unsigned long long* __restrict__ sky64)
+{
+    __shared__ unsigned long long keys64[TILE_PIX];
+    const uint32_t tid = threadIdx.x, tile = owned_tiles[blockIdx.x];
+    for (uint32_t i = tid; i < TILE_PIX; i += 256u) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
+    __syncthreads();
+    const ZrObject* __restrict__ O = objs + P.sky_object;
+    const int tpx0 = (int)(tile % P.tiles_x) * TILE, tpy0 = (int)(tile / P.tiles_x) * TILE;
+    TileCtx T;
+    T.px0 = 0; T.py0 = 0; T.W = (int)P.W - tpx0; T.H = (int)P.H - tpy0;
+    const ZrInstance I = O->inst[0];
+    for (uint32_t t = tid; t < O->n_tris; t += 256u) {
+        zf4 c[3];
+        for (int k = 0; k < 3; ++k) {
+            const float4 q0 = *(const float4*)(O->rverts + O->indices[3u * t + (uint32_t)k]);
+            c[k] = zr_mat4_point(P.PVM, vs_position(zr3(q0.x, q0.y, q0.z), I, false));
+        }
+        if (classify(vertex_flags(c[0]), vertex_flags(c[1]), vertex_flags(c[2])) == 0) continue;
+        raster_clipped<ZR_MODE_GBUFFER>(c[0], c[1], c[2], t, T, P.hw, P.hh, tpx0 * 256, tpy0 * 256, keys64, (uint32_t*)nullptr);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
+        const int px = tpx0 + (int)(i & (TILE - 1)), py = tpy0 + (int)(i / TILE);
+        if (px < (int)P.W && py < (int)P.H) sky64[(size_t)py * P.W + (size_t)px] = keys64[i];
+    }
+}
+
 // BaseScene.frag for every pixel of the owned tiles, from the frame's key buffer; resets the keys for the next frame.
 // IMAGES 0: no material images in the scene; 1: every material with images has the packed form; 2: per-slot sampling.
 // TB = threads per workgroup.  A tile is 256 threads x 4 pixels either way; without images that is one workgroup.  The sampled variants
@@ -2329,6 +2360,14 @@ __global__ __launch_bounds__(TB, TB == 64 ? ZR_RESOLVE_IMG_WAVES : 1) void k_res
         if (px >= (int)P.W || py >= (int)P.H) continue;
         const unsigned long long k = keys[q];
         ncov += resolve_pixel<IMAGES>(P, objs, (uint32_t)k, zr_u2f((uint32_t)(k >> 32)), px, py, G, dlut, vis_now) ? 1u : 0u;
+        if (IMAGES != 0 && P.sky_keys != nullptr) {
+            // The skydome (ZE:3681-3691: drawn last, depth test LESS against the scene's depth, colour only).  Its triangles were
+            // resolved among themselves into a key plane of their own; the dome shows where that depth is less than the scene's.
+            // (The scene pixel above cleared the overlay word; the GBuffer keeps what the scene pass wrote, hidden or not.)
+            const unsigned long long ks = P.sky_keys[(size_t)py * P.W + (size_t)px];
+            if ((uint32_t)ks != ZR_EMPTY_PRIM && zr_u2f((uint32_t)(ks >> 32)) < zr_u2f((uint32_t)(k >> 32)))
+                resolve_pixel<IMAGES>(P, objs, objs[P.sky_object].prim_base + (uint32_t)ks, zr_u2f((uint32_t)(ks >> 32)), px, py, G, dlut, nullptr);
+        }
     }
     if (ncov) atomicAdd(&covered_s, ncov);
     __syncthreads();
@@ -3029,6 +3068,10 @@ void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint
     else if (P.images) { if (fine) ZR_LAUNCH_RESOLVE(2, 64, 1); else ZR_LAUNCH_RESOLVE(2, 64, 4); }
     else { if (fine) ZR_LAUNCH_RESOLVE(0, ZR_RESOLVE_TB, ZR_FINE_PPT); else ZR_LAUNCH_RESOLVE(0, 256, 4); }
 #undef ZR_LAUNCH_RESOLVE
+}
+void zr_launch_sky_tiles(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned, unsigned long long* sky64, hipStream_t s)
+{
+    if (n_owned) hipLaunchKernelGGL(k_sky_tiles, dim3(n_owned), dim3(256), 0, s, P, objs, owned_tiles, sky64);
 }
 void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, hipStream_t s)
 {

@@ -118,6 +118,8 @@ struct ZrPass {
     float    pz_a, pz_b;             //   ndc depth of a point d in front of the eye = pz_a + pz_b / d
     uint32_t m_identity;             // M is bit for bit the identity: M * vec4(p, 1) == p + 0.0f for finite p
     uint32_t write_overlay;          // the resolve must write the overlay plane (a skydome is drawn, or stale sky pixels must go)
+    const unsigned long long* sky_keys;   // the skydome's own key plane (k_sky_tiles) or nullptr: a dome pixel shows where its depth is LESS
+    uint32_t sky_object;             //   than the scene's; index of the dome's record in the draw table
 };
 
 // Frame statistics block in device memory (one per pass slot: [shadow, camera]).
@@ -235,6 +237,7 @@ void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4*
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, const float* unorm_lut, uint8_t* vis_now,
                                ZrDevStats* stats, hipStream_t s);
+void zr_launch_sky_tiles(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned, unsigned long long* sky64, hipStream_t s);
 void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, hipStream_t s);
 void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32_t* owned_tiles, uint32_t n_owned,
                         const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C, const float* lut, const float* unorm_lut,
