@@ -112,3 +112,31 @@ def render(tris, zs, W, H, shadow=False):
                 if passes:
                     win[py][px] = i; dep[py][px] = zf
     return win, dep, amb
+
+
+# ---------------------------------------------------------------------------------------------------------------- clipping
+def covers_clip_space(tri_clip, X, Y):
+    """Exact coverage of the NDC point (X, Y) by a triangle given in CLIP space (x, y, z, w as Fractions), for triangles that may cross
+    the eye plane (w <= 0 at some vertices) - the case a rasteriser needs its clipper for.  A point of the triangle is a convex
+    combination sum(mu_k v_k); it projects onto (X, Y) iff sum(mu_k (x_k, y_k, w_k)) = t (X, Y, 1) with t = w > 0, i.e. iff the solution
+    lambda = mu / t of M lambda = (X, Y, 1), M = columns (x_k, y_k, w_k), has no negative component (2D homogeneous rasterisation; no
+    division by any w_k, so nothing special happens at w = 0).  Returns None when not covered or degenerate, else (ndc depth, lambdas):
+    the NDC depth of that point is sum(mu_k z_k) / t = sum(lambda_k z_k)."""
+    (x0, y0, z0, w0), (x1, y1, z1, w1), (x2, y2, z2, w2) = tri_clip
+    det = x0 * (y1 * w2 - y2 * w1) - x1 * (y0 * w2 - y2 * w0) + x2 * (y0 * w1 - y1 * w0)
+    if det == 0:
+        return None
+    # Cramer's rule for M lambda = (X, Y, 1)
+    l0 = (X * (y1 * w2 - y2 * w1) - x1 * (Y * w2 - y2) + x2 * (Y * w1 - y1)) / det
+    l1 = (x0 * (Y * w2 - y2) - X * (y0 * w2 - y2 * w0) + x2 * (y0 - Y * w0)) / det
+    l2 = (x0 * (y1 - Y * w1) - x1 * (y0 - Y * w0) + X * (y0 * w1 - y1 * w0)) / det
+    if l0 < 0 or l1 < 0 or l2 < 0:
+        return None
+    return l0 * z0 + l1 * z1 + l2 * z2, (l0, l1, l2)
+
+
+def orientation_clip_space(tri_clip):
+    """sign of det(columns (x, y, w)): the orientation of the triangle's visible part on the screen (+1: positive signed area in NDC)."""
+    (x0, y0, _, w0), (x1, y1, _, w1), (x2, y2, _, w2) = tri_clip
+    det = x0 * (y1 * w2 - y2 * w1) - x1 * (y0 * w2 - y2 * w0) + x2 * (y0 * w1 - y1 * w0)
+    return (det > 0) - (det < 0)

@@ -371,3 +371,75 @@ def test_cubemap_chain_and_textureLod_against_float64(oracle_lib):
             want = isamp.sample_cube(chain, r32.astype(np.float64), np.float32(lod))
             assert np.allclose(got, want, atol=3e-5, rtol=0), (k, r, lod, got, want)
     o.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------- the clipper
+def test_near_plane_and_guard_band_clipping_against_exact_homogeneous_coverage(oracle_lib):
+    """Triangles that cross the eye plane, the near plane and the guard band, through a perspective whose arithmetic is exact in float32
+    (dyadic entries: clip = (x, y, -1.5 z - 1.5, -z), near 1, far 3).  What the oracle's clipper + re-projection + snap draws is compared
+    with the exact coverage of the UNCLIPPED triangle in homogeneous coordinates (tests/independent_raster.covers_clip_space) cut at
+    0 <= depth <= 1, on every pixel whose centre is not within 6/256 px of an edge or of a clip boundary (the clipper's new vertices are
+    snapped like any other, which moves its edges by up to a sub-pixel step): owner, and depth to within what it varies over those 6/256 px.  Both windings: one is drawn, the
+    other culled."""
+    import independent_raster as ir
+    from fractions import Fraction as Fr
+    W = H = 48
+    P = np.zeros((4, 4), np.float32)
+    P[0, 0] = 1.0; P[1, 1] = 1.0; P[2, 2] = -1.5; P[2, 3] = -1.5; P[3, 2] = -1.0      # row-major here; stored column-major below
+    cases = [   # object-space triangles (x, y, z), dyadic; z < 0 is in front of the eye
+        [(-0.5, -0.75, -2.5), (0.75, -0.5, -1.25), (0.25, 2.0, 0.5)],       # one vertex behind the eye
+        [(-2.0, -0.25, 0.25), (1.5, -0.5, 0.75), (0.0, 0.75, -2.0)],        # two vertices behind the eye
+        [(-0.75, -0.5, -0.5), (0.5, -0.75, -0.75), (0.25, 0.5, -1.5)],      # between eye and near plane: crosses z = 0 only
+        [(-40.0, -1.0, -1.5), (30.0, -0.75, -1.75), (0.5, 35.0, -2.0)],     # far outside the guard band on three sides
+        [(-0.5, -0.5, -2.5), (0.5, -0.5, -3.5), (0.0, 0.75, -4.0)],         # crosses the far plane: per-fragment depth clip
+    ]
+    delta = Fr(6, 256)
+    for ci, tri in enumerate(cases):
+        for flip in (False, True):
+            t3 = [tri[0], tri[2], tri[1]] if flip else tri
+            o = oracle_lib.Oracle(W, H, 8)
+            verts = np.zeros(3, dtype=abi.XkVertex)
+            for k, p in enumerate(t3):
+                verts[k]["Position"] = p; verts[k]["Normal"] = (0.0, 0.0, 1.0); verts[k]["Color"] = (1.0, 1.0, 1.0)
+            o.object_add(o.mesh_create(verts, np.arange(3, dtype=np.uint32)))
+            d, pl, sp = _lights(1, 1)
+            o.update_uniforms(abi.make_camera(), d, pl, sp, 0.0, 0.0, 0.0)
+            cam, sh, view = o.get_frame()
+            ident = np.eye(4, dtype=np.float32).reshape(16)
+            for m in (cam, sh):
+                m["Model"] = ident; m["View"] = ident
+            cam["Proj"] = P.T.reshape(16)                   # column-major storage
+            o.set_frame(cam, sh, view)
+            o.render(0, 2)
+            vis, depth = o.visibility(), o.gbuffer(0)
+            clip = [(Fr(x), Fr(y), Fr(-3, 2) * Fr(z) - Fr(3, 2), -Fr(z)) for x, y, z in t3]
+            # facing of the visible part: the rule of independent_raster.front_facing (front = negative signed area, y down) on det's sign
+            front = ir.orientation_clip_space(clip) < 0
+            decisive = drawn = 0
+            for py in range(H):
+                for px in range(W):
+                    probes = []
+                    for dx, dy in ((-delta, -delta), (delta, -delta), (-delta, delta), (delta, delta), (0, 0)):
+                        X = (Fr(2 * px + 1, 2) + dx) / Fr(W, 2) - 1
+                        Y = (Fr(2 * py + 1, 2) + dy) / Fr(H, 2) - 1
+                        c = ir.covers_clip_space(clip, X, Y)
+                        probes.append(None if c is None or not (0 <= c[0] <= 1) else c[0])
+                    inside = [q is not None for q in probes]
+                    if any(inside) != all(inside):
+                        continue                                              # near an edge, the near plane or the far plane
+                    if all(inside) and any(abs(q) < Fr(1, 2000) or abs(1 - q) < Fr(1, 2000) for q in probes):
+                        continue
+                    decisive += 1
+                    want = all(inside) and front
+                    got = int(vis[py, px]) != 0xFFFFFFFF
+                    assert got == want, "case %d%s pixel (%d, %d): oracle %s, exact %s" % (ci, " flipped" if flip else "", px, py, got, want)
+                    if want:
+                        drawn += 1
+                        # (the clipper's vertices are snapped to 1/256 px: near the near plane the depth changes fast across a pixel, so the
+                        # tolerance is what the depth does over the probe square, 12/256 px wide)
+                        tol = 2e-4 + float(max(probes) - min(probes))
+                        assert abs(float(depth[py, px]) - float(probes[4])) < tol, (ci, px, py, float(depth[py, px]), float(probes[4]), tol)
+            assert decisive > W * H * 0.8
+            if front:
+                assert drawn > 5, (ci, flip, drawn)
+            o.close()

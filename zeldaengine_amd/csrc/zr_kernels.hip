@@ -20,6 +20,7 @@
 //   k_scan_tri / k_index   per-tile offsets and work units; records MOVED into tile order
 //   k_tile / k_tile_slow   lane per record, streamed: edge set-up + walk into the tile's LDS keys; clipped triangles through raster_clipped
 //   k_hiz_build       max-depth pyramid of the key buffer after round 1 (two-pass occlusion culling of the camera pass)
+//   k_sky_tiles       the skydome's triangles into a key plane of their own (drawn after lighting, depth-tested, colour only)
 //   k_resolve_gbuffer BaseScene.frag per pixel from the key buffer; SoA GBuffer planes, coalesced row stores; marks the
 //                     meshlet-instances that own a pixel (next frame's round 1)
 //   k_lighting        BaseLighting.frag per pixel (PCF 5x5, per-tile light list, ambient, cubemap IBL, gamma, debug views)
