@@ -20,7 +20,14 @@ t = time.perf_counter()
 for i in range(60): step(10 + i)
 g.finish()
 dt = (time.perf_counter() - t) / 60
-print("world %d rank %d config %d%s: %.4f ms/frame wall" % (world, rank, config, " serial" if serial else "", dt * 1e3))
+import numpy as np
+per = np.asarray(g.frame_periods(59))
+host = []
+for i in range(40):
+    t0 = time.perf_counter(); step(70 + i); host.append(time.perf_counter() - t0)
+g.finish()
+print("world %d rank %d config %d%s: %.4f ms/frame wall, GPU period median %.4f ms, host call median %.1f us (blocks when two frames are in flight)"
+      % (world, rank, config, " serial" if serial else "", dt * 1e3, float(np.median(per)), float(np.median(host)) * 1e6))
 g.set_timing_interval(4)
 for i in range(40): step(70 + i)
 g.finish()

@@ -794,7 +794,8 @@ __global__ __launch_bounds__(1024) void k_bin_count(ZrPass P, const uint32_t* __
 __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
                                                uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ chunk_offset,
                                                uint4* __restrict__ chunk_tab, uint32_t chunk_cap,
-                                               uint32_t n, uint32_t capacity, ZrDevStats* __restrict__ stats, int slot, uint32_t chunk)
+                                               uint32_t n, uint32_t capacity, ZrDevStats* __restrict__ stats, int slot, uint32_t chunk,
+                                               uint32_t units_wanted)
 {
     __shared__ uint32_t part[1024];
     __shared__ uint32_t cpart[1024];
@@ -802,13 +803,26 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
     const uint32_t per = (n + 1023u) / 1024u;
     const uint32_t b = tid * per, e = min(n, b + per);
     uint32_t s = 0, cs = 0;
-    for (uint32_t i = b; i < e; ++i) { const uint32_t c = tile_count[i]; s += c; cs += (c + chunk - 1u) / chunk; }
-    part[tid] = s; cpart[tid] = cs;
+    for (uint32_t i = b; i < e; ++i) s += tile_count[i];
+    part[tid] = s;
     __syncthreads();
     for (uint32_t off = 1; off < 1024; off <<= 1) {
-        const uint32_t v = (tid >= off) ? part[tid - off] : 0u, cv = (tid >= off) ? cpart[tid - off] : 0u;
+        const uint32_t v = (tid >= off) ? part[tid - off] : 0u;
         __syncthreads();
-        part[tid] += v; cpart[tid] += cv;
+        part[tid] += v;
+        __syncthreads();
+    }
+    // The size of a work unit follows the pass: `chunk` entries when there is plenty of work, fewer (down to 8) when the whole pass
+    // would otherwise be fewer units than the rasteriser's persistent grid can take at once (`units_wanted`) - a rank of a multi-GPU
+    // job that draws an eighth of the shadow casters has some 20 entries per tile, one unit per tile, and half its workgroups idle.
+    if (units_wanted) chunk = min(chunk, max(8u, (part[1023] + units_wanted - 1u) / units_wanted));
+    for (uint32_t i = b; i < e; ++i) cs += (tile_count[i] + chunk - 1u) / chunk;
+    cpart[tid] = cs;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const uint32_t cv = (tid >= off) ? cpart[tid - off] : 0u;
+        __syncthreads();
+        cpart[tid] += cv;
         __syncthreads();
     }
     uint32_t run = part[tid] - s, crun = cpart[tid] - cs;
@@ -2976,9 +2990,9 @@ void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H
 }
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint4* chunk_tab,
                     uint32_t chunk_cap, uint32_t n, uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s,
-                    uint32_t chunk)
+                    uint32_t units_wanted, uint32_t chunk)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, chunk_offset, chunk_tab, chunk_cap, n, capacity, stats, slot, chunk);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, chunk_offset, chunk_tab, chunk_cap, n, capacity, stats, slot, chunk, units_wanted);
 }
 void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
                         uint32_t* tile_cursor, ZrBinEntry* bins, const ZrHiz& Z, ZrDevStats* stats, int slot, hipStream_t s)
