@@ -81,6 +81,20 @@ def build_headless(force=False):
     return HEADLESS_OUT
 
 
+CALIB_SRC = os.path.join(os.path.dirname(HERE), "tools", "valu_calib.hip")
+CALIB_OUT = os.path.join(os.path.dirname(HERE), "tools", "valu_calib")
+
+
+def build_valu_calib(force=False):
+    """tools/valu_calib: a stand-alone HIP program (no library, no torch) that measures what a SIMD issues."""
+    if not force and os.path.exists(CALIB_OUT) and os.path.getmtime(CALIB_OUT) >= os.path.getmtime(CALIB_SRC):
+        return CALIB_OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-o", CALIB_OUT, CALIB_SRC])
+    return CALIB_OUT
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_headless(force="--force" in sys.argv))
+    print(build_valu_calib(force="--force" in sys.argv))
