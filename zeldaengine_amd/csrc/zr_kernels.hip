@@ -2334,8 +2334,7 @@ __global__ __launch_bounds__(256) void k_sky_tiles(ZrPass P, const ZrObject* __r
 #ifndef ZR_RESOLVE_IMG_WAVES
 #define ZR_RESOLVE_IMG_WAVES 3
 #endif
-// PPT = pixels per thread, 4 or 1 (1: four times the workgroups, a quarter of the work each - when a rank of a multi-GPU job owns so few
-// tiles that they would not fill the machine once, zr_launch_resolve_gbuffer).
+// PPT = pixels per thread (ZR_PIXELS_PER_THREAD; the note above k_lighting says why it is 1).
 template <int IMAGES, int TB, int PPT>
 __global__ __launch_bounds__(TB, TB == 64 ? ZR_RESOLVE_IMG_WAVES : 1) void k_resolve_gbuffer(ZrPass P, const ZrObject* __restrict__ objs,
                                                         const uint32_t* __restrict__ owned_tiles,
@@ -2494,15 +2493,10 @@ __device__ __forceinline__ float shadow_tap(const float* __restrict__ S, int SD,
 #ifndef ZR_LIGHT_TB
 #define ZR_LIGHT_TB 512
 #endif
-#ifndef ZR_FINE_RESOLVE
-#define ZR_FINE_RESOLVE 1000000u     // owned tiles up to which the resolve takes ZR_FINE_PPT pixels per thread (A/B: 0 = never)
+#ifndef ZR_PIXELS_PER_THREAD
+#define ZR_PIXELS_PER_THREAD 1       // of k_resolve_gbuffer and k_lighting: 1, 2 or 4 (a tile is 1 024 pixels; workgroups per tile follow)
 #endif
-#ifndef ZR_FINE_LIGHT
-#define ZR_FINE_LIGHT 1000000u
-#endif
-#ifndef ZR_FINE_PPT
-#define ZR_FINE_PPT 1
-#endif
+static_assert(TILE_PIX / ZR_PIXELS_PER_THREAD >= ZR_LIGHT_TB && TILE_PIX / ZR_PIXELS_PER_THREAD >= 256, "a tile's threads must fill at least one workgroup");
 #ifndef ZR_RESOLVE_TB
 #define ZR_RESOLVE_TB 256
 #endif
@@ -3076,12 +3070,11 @@ void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint
                                ZrDevStats* stats, hipStream_t s)
 {
     if (n_owned == 0) return;
-    // few owned tiles (a rank of a multi-GPU job): one pixel per thread, so that the tiles fill the machine instead of a quarter of it
-    const bool fine = n_owned <= ZR_FINE_RESOLVE;
+    // one pixel per thread (ZR_PIXELS_PER_THREAD): see the note above k_lighting
 #define ZR_LAUNCH_RESOLVE(IM, TB, PPT) hipLaunchKernelGGL((k_resolve_gbuffer<IM, TB, PPT>), dim3(n_owned * (TILE_PIX / (PPT) / (TB))), dim3(TB), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats)
-    if (P.images == 1u) { if (fine) ZR_LAUNCH_RESOLVE(1, 64, 1); else ZR_LAUNCH_RESOLVE(1, 64, 4); }
-    else if (P.images) { if (fine) ZR_LAUNCH_RESOLVE(2, 64, 1); else ZR_LAUNCH_RESOLVE(2, 64, 4); }
-    else { if (fine) ZR_LAUNCH_RESOLVE(0, ZR_RESOLVE_TB, ZR_FINE_PPT); else ZR_LAUNCH_RESOLVE(0, 256, 4); }
+    if (P.images == 1u) ZR_LAUNCH_RESOLVE(1, 64, ZR_PIXELS_PER_THREAD);
+    else if (P.images) ZR_LAUNCH_RESOLVE(2, 64, ZR_PIXELS_PER_THREAD);
+    else ZR_LAUNCH_RESOLVE(0, ZR_RESOLVE_TB, ZR_PIXELS_PER_THREAD);
 #undef ZR_LAUNCH_RESOLVE
 }
 void zr_launch_sky_tiles(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned, unsigned long long* sky64, hipStream_t s)
@@ -3098,12 +3091,9 @@ void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32
 {
     if (n_owned == 0) return;
     // with several point lights each tile first builds its light list (L.light_list: decided on the host from the light count)
-#define ZR_LAUNCH_LIGHTING2(LL, BG, PPT) hipLaunchKernelGGL((k_lighting<LL, BG, ZR_LIGHT_TB, PPT>), dim3(n_owned * (TILE_PIX / (PPT) / ZR_LIGHT_TB)), dim3(ZR_LIGHT_TB), 0, s, L, view, owned_tiles, G, shadowmap, C, lut, unorm_lut, out)
-#define ZR_LAUNCH_LIGHTING(LL, BG) do { if (n_owned <= ZR_FINE_LIGHT) ZR_LAUNCH_LIGHTING2(LL, BG, ZR_FINE_PPT); else ZR_LAUNCH_LIGHTING2(LL, BG, 4); } while (0)
-    // (few tiles - a rank of a multi-GPU job: one pixel per thread, see zr_launch_resolve_gbuffer)
+#define ZR_LAUNCH_LIGHTING(LL, BG) hipLaunchKernelGGL((k_lighting<LL, BG, ZR_LIGHT_TB, ZR_PIXELS_PER_THREAD>), dim3(n_owned * (TILE_PIX / ZR_PIXELS_PER_THREAD / ZR_LIGHT_TB)), dim3(ZR_LIGHT_TB), 0, s, L, view, owned_tiles, G, shadowmap, C, lut, unorm_lut, out)
     if (L.light_list) { if (L.bg_enabled) ZR_LAUNCH_LIGHTING(true, true); else ZR_LAUNCH_LIGHTING(true, false); }
     else { if (L.bg_enabled) ZR_LAUNCH_LIGHTING(false, true); else ZR_LAUNCH_LIGHTING(false, false); }
-#undef ZR_LAUNCH_LIGHTING2
 #undef ZR_LAUNCH_LIGHTING
 }
 void zr_launch_gbuffer_vis(const ZrLightParams& L, const XkView* view, const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C,
