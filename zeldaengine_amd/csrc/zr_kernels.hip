@@ -1821,12 +1821,13 @@ void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* _
 
 // ------------------------------------------------------------------------------------------------ triangle-binned camera pass
 //
-// The meshlet-binned rasteriser above re-transforms a meshlet's vertices and re-tests all of its triangles in every tile the
-// meshlet touches (2.5 on average in the camera pass) and walks the survivors in whatever mix of sizes the queue hands a wave.
+// A meshlet-binned rasteriser re-transforms a meshlet's vertices and re-tests all of its triangles in every tile the meshlet touches
+// (2.5 on average in the camera pass) and walks the survivors in whatever mix of sizes the queue hands a wave.
 // Here a meshlet is processed ONCE: k_geom transforms its vertices, applies the exact per-triangle tests (facing, degenerate, no
-// pixel centre, Hi-Z in round 2) and emits one 48-byte record per (triangle, owned tile); k_scan lays the records' ranks out per
-// tile, k_index turns (tile, rank) into a gather list, and k_tile's lanes do nothing but edge setup + walk on live triangles.
-// Same arithmetic, same keys: the frame is bit for bit the one the meshlet-binned path produces.
+// pixel centre, Hi-Z in round 2) and emits one 32-byte record per (triangle, owned tile) - vertices relative to the tile, three depths,
+// the primitive id - plus its tile id; k_scan_tri lays the tiles' ranges out, k_index MOVES the records into tile order, and k_tile's
+// lanes stream them and do nothing but edge setup + walk on live triangles.  Same arithmetic, same keys as the meshlet-binned path
+// (kept in -DZR_DIAG builds for A/B): the frame is the same bit for bit.
 
 // Which meshlet-instances does this round draw?  (The split of the two-pass occlusion culling, as k_bin_count makes it.)
 // Compacted per workgroup: one global atomic per 1024 work items (atomics on one address run at ~10 ns apiece on this part).
