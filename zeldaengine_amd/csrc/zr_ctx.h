@@ -111,7 +111,6 @@ struct zr_ctx {
     // camera pipeline - a chain of short kernels - is then starved by two heavy neighbours instead of one.
     hipStream_t shadow_s = nullptr, light_s = nullptr; bool in_render = false, three_lanes = false, lanes3_now = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cam = nullptr;
-    uint32_t units_wanted_mul = 1;       // the shadow rasteriser's work units shrink until there are this many per persistent workgroup (k_scan)
     unsigned long long* d_sky_keys = nullptr; uint32_t sky_object = 0;      // the skydome's key plane (k_sky_tiles) and its draw record
     // End of every frame's lighting pass, one (timing-enabled) event per frame in a ring: the next-but-one frame waits for it before
     // it reuses the double-buffered copies, and consecutive ones give the per-frame GPU period (zr_get_frame_periods) for free.

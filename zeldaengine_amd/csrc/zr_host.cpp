@@ -235,7 +235,6 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     if (ok) ok &= dev_alloc(&c->d_slow0, 4ull * c->slow0_cap) == hipSuccess;
 #ifdef ZR_DIAG
     if (const char* e = getenv("ZR_RASTER_BLOCKS")) c->raster_blocks = (uint32_t)std::max(1, atoi(e));
-    if (const char* e = getenv("ZR_UNITS_WANTED_MUL")) c->units_wanted_mul = (uint32_t)std::max(0, atoi(e));
     if (const char* e = getenv("ZR_SHADOW_BLOCKS")) c->shadow_blocks = (uint32_t)std::max(1, atoi(e));
 #endif
     {   // Hi-Z pyramid: level l = max depth per (8 << l)^2 pixel block
@@ -1132,8 +1131,7 @@ static void bin_and_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot,
 {
     const zr_ctx::Scratch& sc = c->sc[slot ? 1 : 0];
     zr_launch_bin_count(P, sc.work, sc.rects, sc.tile_count, Z, c->d_stats, slot, s);
-    zr_launch_scan(sc.tile_count, sc.tile_offset, sc.tile_cursor, sc.chunk_offset, sc.chunk_tab, c->chunk_capacity, n_tiles, c->bin_capacity, c->d_stats, slot, s,
-                   c->units_wanted_mul * (slot == 0 ? c->shadow_blocks : c->raster_blocks));
+    zr_launch_scan(sc.tile_count, sc.tile_offset, sc.tile_cursor, sc.chunk_offset, sc.chunk_tab, c->chunk_capacity, n_tiles, c->bin_capacity, c->d_stats, slot, s);
     zr_launch_bin_fill(P, c->d_objs, sc.work, sc.rects, sc.tile_offset, sc.tile_cursor, sc.bins, Z, c->d_stats, slot, s);
 }
 // One round of the triangle-binned camera pass: which meshlet-instances (k_select: timed with the cull), then their triangles as

@@ -813,8 +813,7 @@ __global__ __launch_bounds__(1024) void k_bin_count(ZrPass P, const uint32_t* __
 __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
                                                uint32_t* __restrict__ tile_cursor, uint32_t* __restrict__ chunk_offset,
                                                uint4* __restrict__ chunk_tab, uint32_t chunk_cap,
-                                               uint32_t n, uint32_t capacity, ZrDevStats* __restrict__ stats, int slot, uint32_t chunk,
-                                               uint32_t units_wanted)
+                                               uint32_t n, uint32_t capacity, ZrDevStats* __restrict__ stats, int slot, uint32_t chunk)
 {
     __shared__ uint32_t part[1024];
     __shared__ uint32_t cpart[1024];
@@ -831,10 +830,6 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
         part[tid] += v;
         __syncthreads();
     }
-    // The size of a work unit follows the pass: `chunk` entries when there is plenty of work, fewer (down to 8) when the whole pass
-    // would otherwise be fewer units than the rasteriser's persistent grid can take at once (`units_wanted`) - a rank of a multi-GPU
-    // job that draws an eighth of the shadow casters has some 20 entries per tile, one unit per tile, and half its workgroups idle.
-    if (units_wanted) chunk = min(chunk, max(8u, (part[1023] + units_wanted - 1u) / units_wanted));
     for (uint32_t i = b; i < e; ++i) cs += (tile_count[i] + chunk - 1u) / chunk;
     cpart[tid] = cs;
     __syncthreads();
@@ -3004,9 +2999,9 @@ void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H
 }
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint4* chunk_tab,
                     uint32_t chunk_cap, uint32_t n, uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s,
-                    uint32_t units_wanted, uint32_t chunk)
+                    uint32_t chunk)
 {
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, chunk_offset, chunk_tab, chunk_cap, n, capacity, stats, slot, chunk, units_wanted);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, chunk_offset, chunk_tab, chunk_cap, n, capacity, stats, slot, chunk);
 }
 void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
                         uint32_t* tile_cursor, ZrBinEntry* bins, const ZrHiz& Z, ZrDevStats* stats, int slot, hipStream_t s)

@@ -189,7 +189,7 @@ void zr_launch_bin_count(const ZrPass& P, const uint32_t* work, uint32_t* rects,
 void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H, const ZrHiz& Z, hipStream_t s);
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint4* chunk_tab,
                     uint32_t chunk_cap, uint32_t n, uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s,
-                    uint32_t units_wanted = 0, uint32_t chunk = ZR_CHUNK);
+                    uint32_t chunk = ZR_CHUNK);
 // triangle-binned camera pass, per round: [k_select ->] k_geom -> k_scan_tri -> k_index -> k_tile
 struct ZrTriBins {
     ZrBinEntry* sel;                 // meshlet-instances of this round, as self-contained 32-byte records
