@@ -1,0 +1,139 @@
+"""GPU parity over RANDOM combinations of the path's features (every target bit for bit against the CPU oracle, as everywhere).
+
+The named tests exercise features one or two at a time; here a seeded generator draws small scenes that mix them: instanced and
+non-instanced draws of several meshes, constant / packed / mixed-size sampled materials, skydome and background on or off, 0-2 directional
+and 0-40 point lights, cameras inside and outside the dome looking along and across the ground (near-plane clipping, guard band,
+anisotropic footprints), odd target and shadow-map sizes (partial tiles, shadow windows cut by the map's edge), debug views, culls
+switched off, one stream or two lanes, and two frames in a row with a moved camera (visibility history, stale Hi-Z).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from parity_util import compare_all
+from zeldaengine_amd import abi, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _image(rng, w, h, kind):
+    if kind == 0:
+        img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    else:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.zeros((h, w, 4), np.uint8)
+        img[..., 0] = (xx * 255 // max(1, w - 1)); img[..., 1] = (yy * 255 // max(1, h - 1))
+        img[..., 2] = (((xx // 3) + (yy // 2)) & 1) * 200 + 30
+    img[..., 3] = 255
+    return img
+
+
+def _material(rng):
+    """None (engine defaults), constants as images, one image size for all image slots (the packed form), or mixed sizes"""
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        return None
+    sizes = [(int(rng.choice([4, 16, 24, 64])), int(rng.choice([4, 8, 32, 48])))]
+    if kind == 3:
+        sizes.append((int(rng.choice([5, 32])), int(rng.choice([3, 16]))))
+    imgs = []
+    for slot in range(7):
+        r = rng.random()
+        if r < 0.3:
+            imgs.append(None)
+        elif r < 0.45 or kind == 1:
+            imgs.append(np.tile(rng.integers(0, 256, 4, dtype=np.uint8), (4, 4, 1)))       # a constant image
+        else:
+            w, h = sizes[int(rng.integers(0, len(sizes)))]
+            img = _image(rng, w, h, int(rng.integers(0, 2)))
+            if slot == 6:
+                img[..., 0] = 255                                                        # mask r = 1: lit
+            if slot == 3:
+                img[..., :2] = (img[..., :2] // 4 + 96); img[..., 2] = 255               # a plausible normal map
+            imgs.append(img)
+    return imgs
+
+
+def _scene(seed):
+    rng = np.random.default_rng(seed)
+    W, H = int(rng.choice([160, 200, 257, 320])), int(rng.choice([96, 120, 131, 200]))
+    SD = int(rng.choice([64, 100, 128, 256]))
+    meshes = [scenes.uv_sphere(), scenes.uv_sphere(12, 6, 0.5), scenes.box((0.6, 0.4, 0.5), (0.0, 0.0, 0.5)), scenes.grid_plane(float(rng.choice([12.0, 30.0, 70.0])), int(rng.integers(2, 7)), 0.0)]
+    draws = []
+    n_draws = int(rng.integers(2, 6))
+    for k in range(n_draws):
+        mi = 3 if k == 0 else int(rng.integers(0, 3))
+        mat = _material(rng)
+        inst = None
+        if mi != 3 and rng.random() < 0.7:
+            inst = scenes.generate_instances(int(rng.integers(1, 120)), float(rng.uniform(0.2, 2.0)), float(rng.uniform(3.0, 30.0)), 0.2, float(rng.uniform(0.4, 2.0)), seed=int(rng.integers(1, 1 << 30)))
+        uvscale = float(rng.choice([1.0, 3.0, 9.0]))
+        draws.append((mi, mat, inst, uvscale))
+    sky = rng.random() < 0.5
+    bg = rng.random() < 0.3
+    w = scenes.sample_world()
+    d, _, s = scenes.lights_from_world(w)
+    w["PointLights"] = scenes.sample_point_lights(int(rng.choice([0, 1, 3, 8, 16, 40])))
+    _, p, _ = scenes.lights_from_world(w)
+    if rng.random() < 0.2:
+        d = d[:0]
+    ang = rng.uniform(0, 2 * math.pi)
+    rad = float(rng.choice([3.0, 8.0, 25.0]))
+    eye = (rad * math.cos(ang), rad * math.sin(ang), float(rng.choice([0.3, 1.5, 6.0])))
+    look = (float(rng.uniform(-2, 2)), float(rng.uniform(-2, 2)), float(rng.uniform(0.0, 1.0)))
+    cam = dict(position=eye, lookat=look, fov=float(rng.choice([35.0, 45.0, 70.0])), znear=float(rng.choice([0.05, 0.1, 0.5])), zfar=float(rng.choice([20.0, 45.0, 200.0])))
+    flags = int(rng.choice([0, 0, 0, abi.FLAG_NO_HIZ, abi.FLAG_NO_FRUSTUM_CULL | abi.FLAG_NO_CONE_CULL, abi.FLAG_SERIAL_PASSES]))
+    view = int(rng.choice([0, 0, 0, 0, 1, 2, 3, 4, 5, 7, 8, 9]))
+    return dict(W=W, H=H, SD=SD, meshes=meshes, draws=draws, sky=sky, bg=bg, lights=(d, p, s), cam=cam, flags=flags, view=view,
+                roll=(float(rng.uniform(0, 1)), float(rng.uniform(0, 1))))
+
+
+def _build(r, sc):
+    r.set_cubemap(scenes.synthetic_cubemap(16))
+    keep = []
+    ids = {}
+    for mi, mat, inst, uvscale in sc["draws"]:
+        key = (mi, uvscale)
+        if key not in ids:
+            v, idx = sc["meshes"][mi]
+            v = v.copy(); v["TexCoord"] *= uvscale
+            ids[key] = r.mesh_create(v, idx)
+        m = None
+        if mat is not None:
+            m, k = abi.make_material(mat); keep.append(k)
+        r.object_add(ids[key], m, inst)
+    if sc["sky"]:
+        r.set_skydome(*scenes.sky_dome(), scenes.synthetic_sky_image(64, 32))
+    if sc["bg"]:
+        r.set_background(scenes.synthetic_sky_image(48, 40)[:, ::-1].copy())
+    r._keepalive = keep
+
+
+N_SEEDS = int(os.environ.get("ZR_FUZZ_SEEDS", "40"))      # (a longer hunt: ZR_FUZZ_SEEDS=2000 pytest tests/test_gpu_fuzz.py -m gpu)
+
+
+@pytest.mark.parametrize("seed", list(range(N_SEEDS)))
+def test_random_scene_matches_the_oracle(oracle_lib, gpu_engine, seed):
+    sc = _scene(1000 + seed)
+    o = oracle_lib.Oracle(sc["W"], sc["H"], sc["SD"])
+    g = gpu_engine.Renderer(sc["W"], sc["H"], sc["SD"], flags=sc["flags"])
+    for r in (o, g):
+        _build(r, sc)
+    d, p, s = sc["lights"]
+    cam = dict(sc["cam"])
+    for frame in range(2):
+        if frame == 1:                                   # the camera moves: the second frame runs on the first one's visibility history
+            e = cam["position"]
+            cam["position"] = (e[0] * 0.9 - 0.3 * e[1], e[1] * 0.9 + 0.3 * e[0], e[2] + 0.2)
+        for r in (o, g):
+            r.update_uniforms(abi.make_camera(**cam), d, p, s, sc["roll"][0], sc["roll"][1] + 0.05 * frame, 1.0 + frame)
+        o.render(sc["view"])
+        g.render(sc["view"]); g.finish()
+        diff = {k: v for k, v in compare_all(o, g).items() if v}
+        assert not diff, "seed %d frame %d (flags %d, view %d, %dx%d, shadow %d): %r" % (seed, frame, sc["flags"], sc["view"], sc["W"], sc["H"], sc["SD"], diff)
+    st = g.stats()
+    assert st["overflow"] == 0
+    g.close()
+    o.close()

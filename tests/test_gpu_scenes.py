@@ -239,6 +239,47 @@ def test_empty_scene_and_scene_reuse(oracle_lib, gpu_engine):
     _identical(o, g, "after scene_clear")
 
 
+def test_triangles_with_one_long_edge(oracle_lib, gpu_engine):
+    """A triangle whose two edges at its FIRST vertex are under 64 pixels while the third is twice that is not a "small" triangle: the
+    small-triangle forms keep tile-relative 16-bit coordinates and 32-bit edge products.  (Found by tests/test_gpu_fuzz.py: only
+    the first vertex's edges were looked at, and such a triangle lost its part in the leftmost tile it touches.)  Pixel-space
+    triangles through identity matrices, in both passes - shadow map of the target's size - and every rotation of the vertex order."""
+    W, H = 192, 96
+    base = [((70.3, 20.2, 0.40), (9.1, 30.7, 0.50), (131.6, 33.4, 0.45)),        # 62 / 63 px from vertex 0, 123 px between the others
+            ((100.5, 60.1, 0.30), (40.2, 75.6, 0.35), (161.9, 70.3, 0.30)),
+            ((20.0, 50.0, 0.60), (20.7, 90.9, 0.62), (80.2, 8.4, 0.58))]         # the long edge mostly vertical
+    tris = []
+    for t in base:
+        for rot in range(3):
+            tris.append(tuple(t[(k + rot) % 3] for k in range(3)))
+            tris.append(tuple(t[(rot - k) % 3] for k in range(3)))              # the other winding: back face in the camera pass, drawn in the shadow pass
+    verts = np.zeros(3 * len(tris), dtype=abi.XkVertex)
+    for k, tri in enumerate(tris):
+        for j, (x, y, z) in enumerate(tri):
+            dz = 0.001 * (k // 6)                                                 # the copies of one triangle do not tie in depth
+            verts[3 * k + j]["Position"] = (x / (W / 2.0) - 1.0, y / (H / 2.0) - 1.0, z + dz)
+            verts[3 * k + j]["Normal"] = (0.0, 0.0, 1.0); verts[3 * k + j]["Color"] = (1.0, 1.0, 1.0)
+
+    def build(r):
+        r.set_cubemap(scenes.synthetic_cubemap(8))
+        r.object_add(r.mesh_create(verts, np.arange(len(verts), dtype=np.uint32)))
+
+    def frame(r):
+        _std_frame()(r)
+        cam, sh, view = r.get_frame()
+        ident = np.eye(4, dtype=np.float32).reshape(16)
+        for m in (cam, sh):
+            m["Model"] = ident; m["View"] = ident; m["Proj"] = ident
+        r.set_frame(cam, sh, view)
+    o = oracle_lib.Oracle(W, H, 192)
+    g = gpu_engine.Renderer(W, H, 192)
+    for r in (o, g):
+        build(r); frame(r)
+    o.render(); g.render(); g.finish()
+    assert (o.gbuffer(0) < 1.0).sum() > 1500 and (o.shadowmap() < 1.0).sum() > 1500
+    _identical(o, g, "one long edge")
+
+
 def test_many_lights_config5_style(oracle_lib, gpu_engine):
     """256 point lights (config 5's count): the zero-radiance skip in k_lighting must stay exact."""
     o, g = _both(oracle_lib, gpu_engine, 160, 96, 128, _mixed_scene, _std_frame(n_point=256))

@@ -992,6 +992,13 @@ __device__ __forceinline__ void shade_key(int x, int y, float fy, const SV& v0, 
 // (raster_clipped, a call), which holds the general form - so the loop's register budget carries no 64-bit edge state.  Both forms
 // produce the same integers.
 #define ZR_SMALL_EDGE (1 << 14)
+// every component of every EDGE below ZR_SMALL_EDGE  <=>  the snapped box is narrower than that on both axes (the widest edge
+// component along an axis IS the box's extent along it).  All three edges: a triangle whose two edges at vertex 0 are short can still
+// have a long third one (found by tests/test_gpu_fuzz.py: such a triangle overflowed the tile-relative 16-bit coordinates).
+__device__ __forceinline__ bool tri_is_small(int x0, int y0, int x1, int y1, int x2, int y2)
+{
+    return imax3(x0, x1, x2) - imin3(x0, x1, x2) < ZR_SMALL_EDGE && imax3(y0, y1, y2) - imin3(y0, y1, y2) < ZR_SMALL_EDGE;
+}
 template <int MODE, bool SMALL>
 __device__ __forceinline__ void raster_sub(const SV& v0, const SV& v1, const SV& v2, uint32_t prim, const TileCtx& T,
                                            unsigned long long* __restrict__ keys64, uint32_t* __restrict__ keys32)
@@ -1735,7 +1742,7 @@ void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* _
                     int cls = flagged ? classify((uint32_t)r0.w, (uint32_t)r1.w, (uint32_t)r2.w) : 1;
                     // a triangle with an edge of 64 pixels or more goes the clipper's way too: that route holds the 64-bit walk
                     // (it leaves a triangle that needs no clipping as it is, so the pixels are the same)
-                    if (cls == 1 && max(max(abs(r1.x - r0.x), abs(r1.y - r0.y)), max(abs(r2.x - r0.x), abs(r2.y - r0.y))) >= ZR_SMALL_EDGE) cls = 2;
+                    if (cls == 1 && !tri_is_small(r0.x, r0.y, r1.x, r1.y, r2.x, r2.y)) cls = 2;
                     if (cls == 1) {
                         const float tz = HIZ ? __builtin_fminf(__builtin_fminf(zr_u2f((uint32_t)r0.z), zr_u2f((uint32_t)r1.z)), zr_u2f((uint32_t)r2.z)) : 0.0f;
                         alive = tri_prefilter<MODE, HIZ>(r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, T, tz, hz);
@@ -2041,7 +2048,7 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
                 i0 = tri_w[round].x & 255u; i1 = (tri_w[round].x >> 8) & 255u; i2 = (tri_w[round].x >> 16) & 255u;
                 r0 = vstage[wv][i0]; r1 = vstage[wv][i1]; r2 = vstage[wv][i2];
                 int cls = flagged ? classify((uint32_t)r0.w, (uint32_t)r1.w, (uint32_t)r2.w) : 1;
-                if (cls == 1 && max(max(abs(r1.x - r0.x), abs(r1.y - r0.y)), max(abs(r2.x - r0.x), abs(r2.y - r0.y))) >= ZR_SMALL_EDGE) cls = 2;
+                if (cls == 1 && !tri_is_small(r0.x, r0.y, r1.x, r1.y, r2.x, r2.y)) cls = 2;
                 if (cls == 2) is_slow = true;
                 else if (cls == 1) {
                     // the tests of tri_prefilter / raster_sub that do not depend on the tile: facing + degenerate (edges below 2^14:
