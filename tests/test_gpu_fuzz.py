@@ -3,8 +3,10 @@
 The named tests exercise features one or two at a time; here a seeded generator draws small scenes that mix them: instanced and
 non-instanced draws of several meshes, constant / packed / mixed-size sampled materials, skydome and background on or off, 0-2 directional
 and 0-40 point lights, cameras inside and outside the dome looking along and across the ground (near-plane clipping, guard band,
-anisotropic footprints), odd target and shadow-map sizes (partial tiles, shadow windows cut by the map's edge), debug views, culls
-switched off, one stream or two lanes, and two frames in a row with a moved camera (visibility history, stale Hi-Z).
+anisotropic footprints), the sun anywhere (grazing shadow projections), odd target and shadow-map sizes (partial tiles, shadow windows
+cut by the map's edge), debug views, culls switched off, one stream or two lanes, and two frames in a row with a moved camera
+(visibility history, stale Hi-Z); now and then 70 000 instances (the instance pre-pass), a model matrix that is sheared or mirrored, a
+vertex that is NaN or infinite, instances of scale 0 / negative / denormal.
 """
 import math
 import os
@@ -74,6 +76,11 @@ def _scene(seed):
     sky = rng.random() < 0.5
     bg = rng.random() < 0.3
     w = scenes.sample_world()
+    if rng.random() < 0.6:                               # the sun somewhere else: another shadow projection, grazing ones included
+        a, el = rng.uniform(0, 2 * math.pi), float(rng.choice([0.15, 0.6, 1.2, 1.5]))
+        dist = float(rng.choice([8.0, 28.0, 60.0]))
+        pos = [dist * math.cos(a) * math.cos(el), dist * math.sin(a) * math.cos(el), dist * math.sin(el)]
+        w["DirectionalLights"][0]["Position"] = pos; w["DirectionalLights"][0]["Direction"] = pos
     d, _, s = scenes.lights_from_world(w)
     w["PointLights"] = scenes.sample_point_lights(int(rng.choice([0, 1, 3, 8, 16, 40])))
     _, p, _ = scenes.lights_from_world(w)
@@ -86,24 +93,45 @@ def _scene(seed):
     cam = dict(position=eye, lookat=look, fov=float(rng.choice([35.0, 45.0, 70.0])), znear=float(rng.choice([0.05, 0.1, 0.5])), zfar=float(rng.choice([20.0, 45.0, 200.0])))
     flags = int(rng.choice([0, 0, 0, abi.FLAG_NO_HIZ, abi.FLAG_NO_FRUSTUM_CULL | abi.FLAG_NO_CONE_CULL, abi.FLAG_SERIAL_PASSES]))
     view = int(rng.choice([0, 0, 0, 0, 1, 2, 3, 4, 5, 7, 8, 9]))
+    # rarer ingredients
+    extra = {}
+    r = rng.random()
+    if r < 0.08:          # the instance-level pre-pass and its work lists: >= 65 536 instances of a 12-triangle box
+        extra["many"] = scenes.generate_instances(66000 + int(rng.integers(0, 9000)), 0.5, float(rng.choice([6.0, 14.0])), 0.02, 0.12, seed=int(rng.integers(1, 1 << 30)))
+    elif r < 0.16:        # a model matrix that is not rigid (cone and sphere tests must switch themselves off), or mirrored
+        m = np.eye(4, dtype=np.float32)
+        m[:3, :3] = np.diag(rng.choice([0.5, 1.0, 2.5, -1.0], 3)).astype(np.float32)
+        m[0, 1] = np.float32(rng.choice([0.0, 0.4]))
+        extra["model"] = m
+    elif r < 0.22:        # a vertex that is not a number / not finite: its triangles are dropped, nothing else is
+        extra["bad_vertex"] = (int(rng.integers(0, 3)), float(rng.choice([np.nan, np.inf, -np.inf, 3.0e38])))
+    elif r < 0.28:        # instances with zero and negative scale among the others
+        extra["odd_scale"] = True
     return dict(W=W, H=H, SD=SD, meshes=meshes, draws=draws, sky=sky, bg=bg, lights=(d, p, s), cam=cam, flags=flags, view=view,
-                roll=(float(rng.uniform(0, 1)), float(rng.uniform(0, 1))))
+                roll=(float(rng.uniform(0, 1)), float(rng.uniform(0, 1))), extra=extra)
 
 
 def _build(r, sc):
     r.set_cubemap(scenes.synthetic_cubemap(16))
     keep = []
     ids = {}
-    for mi, mat, inst, uvscale in sc["draws"]:
+    extra = sc.get("extra", {})
+    for di, (mi, mat, inst, uvscale) in enumerate(sc["draws"]):
         key = (mi, uvscale)
         if key not in ids:
             v, idx = sc["meshes"][mi]
             v = v.copy(); v["TexCoord"] *= uvscale
+            if "bad_vertex" in extra and mi == extra["bad_vertex"][0]:
+                v["Position"][len(v) // 2][1] = extra["bad_vertex"][1]
             ids[key] = r.mesh_create(v, idx)
         m = None
         if mat is not None:
             m, k = abi.make_material(mat); keep.append(k)
+        if inst is not None and extra.get("odd_scale") and len(inst) > 3:
+            inst = inst.copy(); inst["InstancePScale"][0] = 0.0; inst["InstancePScale"][1] = -0.7; inst["InstancePScale"][2] = 1e-30
         r.object_add(ids[key], m, inst)
+    if "many" in extra:
+        r.object_add(r.mesh_create(*scenes.box((0.5, 0.5, 0.5), (0.0, 0.0, 0.5))), None, extra["many"])
     if sc["sky"]:
         r.set_skydome(*scenes.sky_dome(), scenes.synthetic_sky_image(64, 32))
     if sc["bg"]:
@@ -111,12 +139,13 @@ def _build(r, sc):
     r._keepalive = keep
 
 
-N_SEEDS = int(os.environ.get("ZR_FUZZ_SEEDS", "40"))      # (a longer hunt: ZR_FUZZ_SEEDS=2000 pytest tests/test_gpu_fuzz.py -m gpu)
+N_SEEDS = int(os.environ.get("ZR_FUZZ_SEEDS", "48"))      # (a longer hunt: ZR_FUZZ_SEEDS=2000 [ZR_FUZZ_BASE=5000] pytest tests/test_gpu_fuzz.py -m gpu)
+BASE = int(os.environ.get("ZR_FUZZ_BASE", "1000"))
 
 
 @pytest.mark.parametrize("seed", list(range(N_SEEDS)))
 def test_random_scene_matches_the_oracle(oracle_lib, gpu_engine, seed):
-    sc = _scene(1000 + seed)
+    sc = _scene(BASE + seed)
     o = oracle_lib.Oracle(sc["W"], sc["H"], sc["SD"])
     g = gpu_engine.Renderer(sc["W"], sc["H"], sc["SD"], flags=sc["flags"])
     for r in (o, g):
@@ -129,6 +158,11 @@ def test_random_scene_matches_the_oracle(oracle_lib, gpu_engine, seed):
             cam["position"] = (e[0] * 0.9 - 0.3 * e[1], e[1] * 0.9 + 0.3 * e[0], e[2] + 0.2)
         for r in (o, g):
             r.update_uniforms(abi.make_camera(**cam), d, p, s, sc["roll"][0], sc["roll"][1] + 0.05 * frame, 1.0 + frame)
+            if "model" in sc.get("extra", {}):           # raw frame: the engine's view / projection with another model matrix, both passes
+                cm, sh, view = r.get_frame()
+                for u in (cm, sh):
+                    u["Model"] = (np.asarray(u["Model"], np.float32).reshape(4, 4).T @ sc["extra"]["model"]).T.reshape(16)
+                r.set_frame(cm, sh, view)
         o.render(sc["view"])
         g.render(sc["view"]); g.finish()
         diff = {k: v for k, v in compare_all(o, g).items() if v}

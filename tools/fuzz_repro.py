@@ -7,7 +7,7 @@ from oracle import pyoracle
 from zeldaengine_amd import abi, engine
 seed = int(sys.argv[1])
 flags = int(sys.argv[2]) if len(sys.argv) > 2 else None
-sc = t._scene(1000 + seed)
+sc = t._scene(t.BASE + seed)
 if flags is not None: sc["flags"] = flags
 print({k: sc[k] for k in ("W", "H", "SD", "sky", "bg", "cam", "flags", "view")}, [(d[0], d[1] is not None, None if d[2] is None else len(d[2]), d[3]) for d in sc["draws"]])
 o = pyoracle.Oracle(sc["W"], sc["H"], sc["SD"]); g = engine.Renderer(sc["W"], sc["H"], sc["SD"], flags=sc["flags"])
