@@ -171,3 +171,41 @@ def test_random_scene_matches_the_oracle(oracle_lib, gpu_engine, seed):
     assert st["overflow"] == 0
     g.close()
     o.close()
+
+
+@pytest.mark.parametrize("seed", list(range(max(8, N_SEEDS // 4))))
+def test_random_scene_over_a_tile_partition(oracle_lib, gpu_engine, seed):
+    """The same random scenes as N rank contexts (2..8 ranks: super-tile ownership, owned-region reject, per-rank visibility history): every
+    rank's packed tiles are the oracle's pixels of the tiles it owns, on two frames."""
+    from zeldaengine_amd import dist as zdist
+    sc = _scene(BASE + 100000 + seed)
+    if sc["view"] == 9:
+        sc["view"] = 0
+    world = int(np.random.default_rng(seed).choice([2, 3, 4, 8]))
+    o = oracle_lib.Oracle(sc["W"], sc["H"], sc["SD"])
+    ranks = [gpu_engine.Renderer(sc["W"], sc["H"], sc["SD"], flags=sc["flags"], tile_rank=r, tile_world=world) for r in range(world)]
+    for r in [o] + ranks:
+        _build(r, sc)
+    d, p, s = sc["lights"]
+    cam = dict(sc["cam"])
+    for frame in range(2):
+        if frame == 1:
+            e = cam["position"]
+            cam["position"] = (e[0] * 0.9 - 0.3 * e[1], e[1] * 0.9 + 0.3 * e[0], e[2] + 0.2)
+        for r in [o] + ranks:
+            r.update_uniforms(abi.make_camera(**cam), d, p, s, sc["roll"][0], sc["roll"][1] + 0.05 * frame, 1.0 + frame)
+            if "model" in sc.get("extra", {}):
+                cm, sh, view = r.get_frame()
+                for u in (cm, sh):
+                    u["Model"] = (np.asarray(u["Model"], np.float32).reshape(4, 4).T @ sc["extra"]["model"]).T.reshape(16)
+                r.set_frame(cm, sh, view)
+        o.render(sc["view"])
+        want = o.color()
+        for rk, g in enumerate(ranks):
+            g.render(sc["view"])
+            assert np.array_equal(g.read_tiles(), zdist.pack_tiles(want, rk, world)), \
+                "seed %d frame %d rank %d of %d (flags %d, view %d, %dx%d)" % (seed, frame, rk, world, sc["flags"], sc["view"], sc["W"], sc["H"])
+            assert g.stats()["overflow"] == 0
+    for g in ranks:
+        g.close()
+    o.close()
