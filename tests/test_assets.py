@@ -171,3 +171,93 @@ def _write_adam7_rgb(path, rgb):
     with open(path, "wb") as f:
         f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
     return path
+
+
+def _png_fix_crcs(data):
+    """recompute every chunk's CRC after a mutation, so that the damage reaches the decoder instead of dying at the checksum"""
+    import struct
+    import zlib
+    out, pos = bytearray(data[:8]), 8
+    while pos + 12 <= len(data):
+        n = struct.unpack(">I", data[pos:pos + 4])[0]
+        if pos + 12 + n > len(data):
+            break
+        t, d = data[pos + 4:pos + 8], data[pos + 8:pos + 8 + n]
+        out += data[pos:pos + 8] + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+        pos += 12 + n
+    return bytes(out + data[pos:])
+
+
+N_MUT = int(os.environ.get("ZR_MUTATIONS", "150"))
+
+
+def test_mutated_png_and_obj_files_are_errors_not_crashes(tmp_path):
+    """The loaders read files a livelink world names: a damaged or hostile file must come back as an error code (or as some image /
+    mesh), never as a crash or an out-of-bounds access (run under a host AddressSanitizer build with ZR_MUTATIONS=5000 when the loaders
+    change).  Mutations: byte flips, truncations, length / dimension fields blown up, chunks duplicated; CRCs repaired half the time."""
+    import struct
+    from PIL import Image
+    rng = np.random.default_rng(99)
+    seeds = []
+    for mode in ("RGBA", "RGB", "L", "LA", "P", "1"):
+        im = Image.fromarray(rng.integers(0, 256, size=(19, 31, 4), dtype=np.uint8), "RGBA")
+        im = im.convert("RGB").quantize(16) if mode == "P" else im.convert(mode)
+        p = str(tmp_path / ("s_%s.png" % mode)); im.save(p)
+        seeds.append(open(p, "rb").read())
+    seeds.append(open(_write_adam7_rgb(str(tmp_path / "s_a7.png"), rng.integers(0, 256, size=(13, 17, 3), dtype=np.uint8)), "rb").read())
+    ok = bad = 0
+    for k in range(N_MUT):
+        data = bytearray(seeds[k % len(seeds)])
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 6))):
+                data[int(rng.integers(8, len(data)))] ^= int(rng.integers(1, 256))
+        elif kind == 1:
+            data = data[:int(rng.integers(0, len(data)))]
+        elif kind == 2:                                            # IHDR fields: width, height, depth, colour type, interlace
+            off = 16 + int(rng.integers(0, 13))
+            data[off] = int(rng.choice([0, 1, 3, 7, 16, 64, 255]))
+        elif kind == 3:                                            # a chunk length blown up
+            pos = 8
+            lens = []
+            while pos + 12 <= len(data):
+                lens.append(pos); pos += 12 + struct.unpack(">I", data[pos:pos + 4])[0]
+            at = lens[int(rng.integers(0, len(lens)))]
+            data[at:at + 4] = struct.pack(">I", int(rng.choice([0, 1, 0x7FFFFFFF, 0xFFFFFFFF, 100000])))
+        else:                                                      # IDAT duplicated / IEND moved
+            i = bytes(data).find(b"IDAT")
+            if i > 4:
+                n = struct.unpack(">I", data[i - 4:i])[0]
+                data = data[:i + 8 + n] + data[i - 4:i + 8 + n] + data[i + 8 + n:]
+        blob = bytes(data)
+        if k % 2 and len(blob) > 8:
+            blob = _png_fix_crcs(blob)
+        p = str(tmp_path / "m.png")
+        open(p, "wb").write(blob)
+        try:
+            img = engine.load_png_rgba8(p)
+            assert img.ndim == 3 and img.shape[2] == 4 and 0 < img.shape[0] <= 16384 and 0 < img.shape[1] <= 16384
+            ok += 1
+        except engine.ZeldaRenderError:
+            bad += 1
+    assert bad > N_MUT // 4 and ok + bad == N_MUT
+    # OBJ: numbers replaced by junk, indices out of range / negative / huge, lines cut
+    obj = (OBJ * 3).split("\\n")
+    for k in range(N_MUT):
+        lines = list(obj)
+        for _ in range(int(rng.integers(1, 5))):
+            i = int(rng.integers(0, len(lines)))
+            toks = lines[i].split(" ")
+            if len(toks) > 1:
+                j = int(rng.integers(1, len(toks)))
+                toks[j] = str(rng.choice(["", "nan", "1e999", "-0", "999999999999", "-7", "1/", "//", "1/2/3/4", "0/0/0", "4294967297/1/1", "x", "1e-400"]))
+                lines[i] = " ".join(toks)
+            if rng.random() < 0.2:
+                lines[i] = lines[i][:int(rng.integers(0, len(lines[i]) + 1))]
+        p = str(tmp_path / "m.obj")
+        open(p, "w").write("\\n".join(lines))
+        try:
+            v, idx = engine.load_obj(p)
+            assert len(idx) % 3 == 0 and (len(idx) == 0 or int(idx.max()) < len(v))
+        except engine.ZeldaRenderError:
+            pass
