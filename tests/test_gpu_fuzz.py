@@ -209,3 +209,30 @@ def test_random_scene_over_a_tile_partition(oracle_lib, gpu_engine, seed):
     for g in ranks:
         g.close()
     o.close()
+
+
+@pytest.mark.parametrize("seed,size", [(3, (1600, 900)), (11, (1920, 1080)), (17, (2048, 857))])
+def test_random_scene_at_full_size(oracle_lib, gpu_engine, seed, size):
+    """A few of the random scenes at target sizes of thousands of tiles (the small ones above are 15 to 70): the oracle's rasteriser and
+    per-pixel stages on all cores."""
+    sc = _scene(BASE + 500000 + seed)
+    sc["W"], sc["H"], sc["SD"] = size[0], size[1], 1024
+    o = oracle_lib.Oracle(sc["W"], sc["H"], sc["SD"])
+    o.set_threads(16)
+    g = gpu_engine.Renderer(sc["W"], sc["H"], sc["SD"], flags=sc["flags"])
+    for r in (o, g):
+        _build(r, sc)
+    d, p, s = sc["lights"]
+    cam = dict(sc["cam"])
+    for frame in range(2):
+        if frame == 1:
+            e = cam["position"]
+            cam["position"] = (e[0] * 0.9 - 0.3 * e[1], e[1] * 0.9 + 0.3 * e[0], e[2] + 0.2)
+        for r in (o, g):
+            r.update_uniforms(abi.make_camera(**cam), d, p, s, sc["roll"][0], sc["roll"][1] + 0.05 * frame, 1.0 + frame)
+        o.render(sc["view"])
+        g.render(sc["view"]); g.finish()
+        diff = {k: v for k, v in compare_all(o, g).items() if v}
+        assert not diff, "seed %d frame %d at %dx%d: %r" % (seed, frame, sc["W"], sc["H"], diff)
+    g.close()
+    o.close()
