@@ -236,3 +236,31 @@ def test_random_scene_at_full_size(oracle_lib, gpu_engine, seed, size):
         assert not diff, "seed %d frame %d at %dx%d: %r" % (seed, frame, sc["W"], sc["H"], diff)
     g.close()
     o.close()
+
+
+@pytest.mark.parametrize("abs_seed,size,sd", [(900030, (1000, 1000), 2048), (900126, (1000, 1000), 2048), (900156, (1280, 720), 2048)])
+def test_big_casters_under_a_large_shadow_map(oracle_lib, gpu_engine, abs_seed, size, sd):
+    """Scenes a hunt with the generator above at large sizes found: a ground plane that crosses the light's near plane is listed for every
+    tile of the shadow map (its box cannot be projected) and its triangles - 64 texels and more across - go the clipper's way; under a
+    2048^2 map that is 4 096 lists, each of which used to hand every such triangle on, whether it reached the tile or not, until
+    the list of handed-on triangles (2^18) overflowed: ZR_ERR_OVERFLOW for scenes that are nothing special.  Now a list hands a big
+    triangle on only if its snapped box reaches the list's window, and the list grows with the map."""
+    sc = _scene(abs_seed)
+    sc["W"], sc["H"], sc["SD"] = size[0], size[1], sd
+    o = oracle_lib.Oracle(sc["W"], sc["H"], sc["SD"]); o.set_threads(16)
+    g = gpu_engine.Renderer(sc["W"], sc["H"], sc["SD"], flags=sc["flags"])
+    for r in (o, g):
+        _build(r, sc)
+    d, p, s = sc["lights"]
+    for r in (o, g):
+        r.update_uniforms(abi.make_camera(**sc["cam"]), d, p, s, sc["roll"][0], sc["roll"][1], 1.0)
+        if "model" in sc.get("extra", {}):
+            cm, sh, view = r.get_frame()
+            for u in (cm, sh):
+                u["Model"] = (np.asarray(u["Model"], np.float32).reshape(4, 4).T @ sc["extra"]["model"]).T.reshape(16)
+            r.set_frame(cm, sh, view)
+    o.render(sc["view"])
+    g.render(sc["view"]); g.finish()                       # (ZR_ERR_OVERFLOW would raise here)
+    diff = {k: v for k, v in compare_all(o, g).items() if v}
+    assert not diff and g.stats()["overflow"] == 0, (abs_seed, diff)
+    g.close(); o.close()

@@ -232,6 +232,7 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     if (ok) { zr_launch_fill64(c->d_vis, (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM, n, c->stream); ok &= hipStreamSynchronize(c->stream) == hipSuccess; }
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->raster_blocks = (uint32_t)prop.multiProcessorCount * 8u; }
     c->shadow_blocks = c->raster_blocks;
+    c->slow0_cap = std::max<uint32_t>(c->slow0_cap, 128u * c->sn_tiles);      // (a clipped triangle is listed once per tile of its meshlet)
     if (ok) ok &= dev_alloc(&c->d_slow0, 4ull * c->slow0_cap) == hipSuccess;
 #ifdef ZR_DIAG
     if (const char* e = getenv("ZR_RASTER_BLOCKS")) c->raster_blocks = (uint32_t)std::max(1, atoi(e));

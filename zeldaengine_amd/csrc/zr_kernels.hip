@@ -1741,8 +1741,10 @@ void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* _
                     r0 = vstage[wv][i0]; r1 = vstage[wv][i1]; r2 = vstage[wv][i2];
                     int cls = flagged ? classify((uint32_t)r0.w, (uint32_t)r1.w, (uint32_t)r2.w) : 1;
                     // a triangle with an edge of 64 pixels or more goes the clipper's way too: that route holds the 64-bit walk
-                    // (it leaves a triangle that needs no clipping as it is, so the pixels are the same)
-                    if (cls == 1 && !tri_is_small(r0.x, r0.y, r1.x, r1.y, r2.x, r2.y)) cls = 2;
+                    // (it leaves a triangle that needs no clipping as it is, so the pixels are the same) - but only for the windows its
+                    // snapped box reaches: a ground triangle under a 2048^2 map is met in thousands of tiles' lists and touches a few
+                    if (cls == 1 && !tri_is_small(r0.x, r0.y, r1.x, r1.y, r2.x, r2.y))
+                        cls = tri_prefilter<MODE, false>(r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, T) ? 2 : 0;
                     if (cls == 1) {
                         const float tz = HIZ ? __builtin_fminf(__builtin_fminf(zr_u2f((uint32_t)r0.z), zr_u2f((uint32_t)r1.z)), zr_u2f((uint32_t)r2.z)) : 0.0f;
                         alive = tri_prefilter<MODE, HIZ>(r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, T, tz, hz);
