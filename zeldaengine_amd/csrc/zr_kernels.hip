@@ -2050,7 +2050,14 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
                 i0 = tri_w[round].x & 255u; i1 = (tri_w[round].x >> 8) & 255u; i2 = (tri_w[round].x >> 16) & 255u;
                 r0 = vstage[wv][i0]; r1 = vstage[wv][i1]; r2 = vstage[wv][i2];
                 int cls = flagged ? classify((uint32_t)r0.w, (uint32_t)r1.w, (uint32_t)r2.w) : 1;
-                if (cls == 1 && !tri_is_small(r0.x, r0.y, r1.x, r1.y, r2.x, r2.y)) cls = 2;
+                if (cls == 1 && !tri_is_small(r0.x, r0.y, r1.x, r1.y, r2.x, r2.y)) {
+                    // a big triangle goes to the list every owned tile tries - unless it faces away or its snapped box holds no pixel
+                    // centre of the target (raster_sub's own first tests, in 64 bits here: big coordinates)
+                    const long long A = (long long)(r1.x - r0.x) * (r2.y - r0.y) - (long long)(r2.x - r0.x) * (r1.y - r0.y);
+                    const int bx0 = max((imin3(r0.x, r1.x, r2.x) - 128 + 255) >> 8, 0), bx1 = min((imax3(r0.x, r1.x, r2.x) - 128) >> 8, (int)P.W - 1);
+                    const int by0 = max((imin3(r0.y, r1.y, r2.y) - 128 + 255) >> 8, 0), by1 = min((imax3(r0.y, r1.y, r2.y) - 128) >> 8, (int)P.H - 1);
+                    cls = (A < 0 && bx0 <= bx1 && by0 <= by1) ? 2 : 0;
+                }
                 if (cls == 2) is_slow = true;
                 else if (cls == 1) {
                     // the tests of tri_prefilter / raster_sub that do not depend on the tile: facing + degenerate (edges below 2^14:
