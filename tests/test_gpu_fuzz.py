@@ -107,6 +107,9 @@ def _scene(seed):
         extra["bad_vertex"] = (int(rng.integers(0, 3)), float(rng.choice([np.nan, np.inf, -np.inf, 3.0e38])))
     elif r < 0.28:        # instances with zero and negative scale among the others
         extra["odd_scale"] = True
+    elif r < 0.36:        # a projection that is not the engine's: off-centre, un-flipped, stretched (both passes' own matrices are touched:
+        #                   the sphere / cone / owned-region tests must notice that their assumptions do not hold)
+        extra["proj"] = (float(rng.choice([0.0, 0.15, -0.4])), float(rng.choice([0.0, -0.2, 0.3])), float(rng.choice([1.0, -1.0])), float(rng.choice([1.0, 0.6, 1.7])))
     return dict(W=W, H=H, SD=SD, meshes=meshes, draws=draws, sky=sky, bg=bg, lights=(d, p, s), cam=cam, flags=flags, view=view,
                 roll=(float(rng.uniform(0, 1)), float(rng.uniform(0, 1))), extra=extra)
 
@@ -139,6 +142,25 @@ def _build(r, sc):
     r._keepalive = keep
 
 
+def _raw_frame(r, sc):
+    """zr_set_frame with the engine's matrices altered: another model matrix and / or another projection, both passes"""
+    extra = sc.get("extra", {})
+    if "model" not in extra and "proj" not in extra:
+        return
+    cm, sh, view = r.get_frame()
+    for u in (cm, sh):
+        if "model" in extra:
+            u["Model"] = (np.asarray(u["Model"], np.float32).reshape(4, 4).T @ extra["model"]).T.reshape(16)
+        if "proj" in extra:
+            ox, oy, fy, sx = extra["proj"]
+            P = np.asarray(u["Proj"], np.float32).reshape(4, 4).T.copy()
+            P[0, 2] += np.float32(ox); P[1, 2] += np.float32(oy)          # off-centre frustum
+            P[1, :] *= np.float32(fy)                                     # un-flipped y: handedness reverses
+            P[0, 0] *= np.float32(sx)                                     # stretched
+            u["Proj"] = P.T.reshape(16)
+    r.set_frame(cm, sh, view)
+
+
 N_SEEDS = int(os.environ.get("ZR_FUZZ_SEEDS", "48"))      # (a longer hunt: ZR_FUZZ_SEEDS=2000 [ZR_FUZZ_BASE=5000] pytest tests/test_gpu_fuzz.py -m gpu)
 BASE = int(os.environ.get("ZR_FUZZ_BASE", "1000"))
 
@@ -158,11 +180,7 @@ def test_random_scene_matches_the_oracle(oracle_lib, gpu_engine, seed):
             cam["position"] = (e[0] * 0.9 - 0.3 * e[1], e[1] * 0.9 + 0.3 * e[0], e[2] + 0.2)
         for r in (o, g):
             r.update_uniforms(abi.make_camera(**cam), d, p, s, sc["roll"][0], sc["roll"][1] + 0.05 * frame, 1.0 + frame)
-            if "model" in sc.get("extra", {}):           # raw frame: the engine's view / projection with another model matrix, both passes
-                cm, sh, view = r.get_frame()
-                for u in (cm, sh):
-                    u["Model"] = (np.asarray(u["Model"], np.float32).reshape(4, 4).T @ sc["extra"]["model"]).T.reshape(16)
-                r.set_frame(cm, sh, view)
+            _raw_frame(r, sc)
         o.render(sc["view"])
         g.render(sc["view"]); g.finish()
         diff = {k: v for k, v in compare_all(o, g).items() if v}
@@ -194,11 +212,7 @@ def test_random_scene_over_a_tile_partition(oracle_lib, gpu_engine, seed):
             cam["position"] = (e[0] * 0.9 - 0.3 * e[1], e[1] * 0.9 + 0.3 * e[0], e[2] + 0.2)
         for r in [o] + ranks:
             r.update_uniforms(abi.make_camera(**cam), d, p, s, sc["roll"][0], sc["roll"][1] + 0.05 * frame, 1.0 + frame)
-            if "model" in sc.get("extra", {}):
-                cm, sh, view = r.get_frame()
-                for u in (cm, sh):
-                    u["Model"] = (np.asarray(u["Model"], np.float32).reshape(4, 4).T @ sc["extra"]["model"]).T.reshape(16)
-                r.set_frame(cm, sh, view)
+            _raw_frame(r, sc)
         o.render(sc["view"])
         want = o.color()
         for rk, g in enumerate(ranks):
@@ -254,11 +268,7 @@ def test_big_casters_under_a_large_shadow_map(oracle_lib, gpu_engine, abs_seed, 
     d, p, s = sc["lights"]
     for r in (o, g):
         r.update_uniforms(abi.make_camera(**sc["cam"]), d, p, s, sc["roll"][0], sc["roll"][1], 1.0)
-        if "model" in sc.get("extra", {}):
-            cm, sh, view = r.get_frame()
-            for u in (cm, sh):
-                u["Model"] = (np.asarray(u["Model"], np.float32).reshape(4, 4).T @ sc["extra"]["model"]).T.reshape(16)
-            r.set_frame(cm, sh, view)
+        _raw_frame(r, sc)
     o.render(sc["view"])
     g.render(sc["view"]); g.finish()                       # (ZR_ERR_OVERFLOW would raise here)
     diff = {k: v for k, v in compare_all(o, g).items() if v}

@@ -15,7 +15,7 @@ for seed in range(lo, hi):
     g = engine.Renderer(sc["W"], sc["H"], sc["SD"], flags=sc["flags"])
     t._build(g, sc)
     d, p, s = sc["lights"]
-    g.update_uniforms(abi.make_camera(**sc["cam"]), d, p, s, sc["roll"][0], sc["roll"][1], 1.0)
+    g.update_uniforms(abi.make_camera(**sc["cam"]), d, p, s, sc["roll"][0], sc["roll"][1], 1.0); t._raw_frame(g, sc)
     try:
         g.render(sc["view"]); g.finish()
     except engine.ZeldaRenderError as e:
@@ -25,7 +25,7 @@ for seed in range(lo, hi):
         g.close(); continue
     o = pyoracle.Oracle(sc["W"], sc["H"], sc["SD"]); o.set_threads(16)
     t._build(o, sc)
-    o.update_uniforms(abi.make_camera(**sc["cam"]), d, p, s, sc["roll"][0], sc["roll"][1], 1.0)
+    o.update_uniforms(abi.make_camera(**sc["cam"]), d, p, s, sc["roll"][0], sc["roll"][1], 1.0); t._raw_frame(o, sc)
     o.render(sc["view"])
     diff = {k: v for k, v in compare_all(o, g).items() if v}
     if diff:

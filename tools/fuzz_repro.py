@@ -13,7 +13,8 @@ print({k: sc[k] for k in ("W", "H", "SD", "sky", "bg", "cam", "flags", "view")},
 o = pyoracle.Oracle(sc["W"], sc["H"], sc["SD"]); g = engine.Renderer(sc["W"], sc["H"], sc["SD"], flags=sc["flags"])
 for r in (o, g): t._build(r, sc)
 d, p, s = sc["lights"]
-for r in (o, g): r.update_uniforms(abi.make_camera(**sc["cam"]), d, p, s, sc["roll"][0], sc["roll"][1], 1.0)
+for r in (o, g):
+    r.update_uniforms(abi.make_camera(**sc["cam"]), d, p, s, sc["roll"][0], sc["roll"][1], 1.0); t._raw_frame(r, sc)
 o.render(sc["view"]); g.render(sc["view"]); g.finish()
 do, dg = o.gbuffer(0), g.gbuffer(0)
 bad = np.argwhere(do.view(np.uint32) != dg.view(np.uint32))
