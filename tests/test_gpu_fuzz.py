@@ -274,3 +274,71 @@ def test_big_casters_under_a_large_shadow_map(oracle_lib, gpu_engine, abs_seed, 
     diff = {k: v for k, v in compare_all(o, g).items() if v}
     assert not diff and g.stats()["overflow"] == 0, (abs_seed, diff)
     g.close(); o.close()
+
+
+def _random_meshlets(rng, oracle_lib, v, idx, scattered):
+    """A valid meshlet partition of (v, idx) that no clusteriser would make: triangles in random order (scattered: every meshlet a
+    random handful from all over the mesh - wide cones, huge spheres) or in runs of random length, cut at 64 vertices / 124 triangles;
+    bounds and cones from the ORACLE's meshopt_computeMeshletBounds restatement (zo_meshlet_bounds), not from the library's."""
+    import ctypes as C
+    tris = idx.reshape(-1, 3)
+    order = rng.permutation(len(tris)) if scattered else np.arange(len(tris))
+    ml, mv, mt, flat_order = [], [], [], []
+    i = 0
+    while i < len(order):
+        want = int(rng.integers(1, 125))
+        local, lt = {}, []
+        while i < len(order) and len(lt) < want:
+            t = tris[order[i]]
+            new = [x for x in dict.fromkeys(int(a) for a in t) if x not in local]
+            if len(local) + len(new) > 64:
+                break
+            for x in new:
+                local[x] = len(local)
+            lt.append([local[int(a)] for a in t]); flat_order.append(int(order[i])); i += 1
+        rec = np.zeros((), dtype=abi.XkMeshlet)
+        rec["VertexOffset"] = len(mv); rec["VertexCount"] = len(local); rec["TriangleOffset"] = len(mt); rec["TriangleCount"] = len(lt)
+        verts = np.asarray(list(local.keys()), np.uint32); tb = np.asarray(lt, np.uint8).reshape(-1)
+        out = np.zeros((), dtype=abi.XkMeshlet)
+        assert oracle_lib.lib().zo_meshlet_bounds(v.ctypes.data_as(C.c_void_p), verts.ctypes.data_as(C.c_void_p), tb.ctypes.data_as(C.c_void_p), len(lt), out.ctypes.data_as(C.c_void_p)) == 0
+        for f in ("BoundsCenter", "BoundsRadius", "ConeApex", "ConeAxis", "ConeCutoff"):
+            rec[f] = out[f]
+        ml.append(rec); mv += list(verts); mt += list(tb)
+        while len(mt) % 4:
+            mt.append(0)                                  # (the container pads a meshlet's triangle bytes to four)
+    return np.asarray(ml, dtype=abi.XkMeshlet), np.asarray(mv, np.uint32), np.asarray(mt, np.uint8), np.asarray(flat_order)
+
+
+@pytest.mark.parametrize("seed", list(range(max(6, N_SEEDS // 4))))
+def test_random_meshlet_partitions_from_the_caller(oracle_lib, gpu_engine, seed):
+    """zr_mesh_set_meshlets with partitions a clusteriser would never produce, bounds and cones computed by the oracle's independent
+    restatement of meshopt's formulas: every cull (frustum, cone, box, Hi-Z, owned region) must stay invisible whatever the meshlets
+    look like.  The oracle draws the flattened index buffer of the same partition (ZE:4733-4756)."""
+    rng = np.random.default_rng(40000 + seed)
+    sc = _scene(BASE + 300000 + seed)
+    sc["extra"] = {}
+    o = oracle_lib.Oracle(sc["W"], sc["H"], sc["SD"])
+    g = gpu_engine.Renderer(sc["W"], sc["H"], sc["SD"], flags=sc["flags"] & ~3)        # the culls stay ON here
+    for r in (o, g):
+        r.set_cubemap(scenes.synthetic_cubemap(16))
+    for di, (mi, mat, inst, uvscale) in enumerate(sc["draws"]):
+        v, idx = sc["meshes"][mi]
+        ml, mv, mt, order = _random_meshlets(rng, oracle_lib, v, idx, scattered=bool(rng.integers(0, 2)))
+        flat = idx.reshape(-1, 3)[order].reshape(-1)
+        o.object_add(o.mesh_create(v, flat), None, inst)
+        m = g.mesh_create(v, idx)
+        g.mesh_set_meshlets(m, ml, mv, mt)
+        g.object_add(m, None, inst)
+    d, p, s = sc["lights"]
+    cam = dict(sc["cam"])
+    for frame in range(2):
+        if frame == 1:
+            e = cam["position"]
+            cam["position"] = (e[0] * 0.9 - 0.3 * e[1], e[1] * 0.9 + 0.3 * e[0], e[2] + 0.2)
+        for r in (o, g):
+            r.update_uniforms(abi.make_camera(**cam), d, p, s, sc["roll"][0], sc["roll"][1] + 0.05 * frame, 1.0 + frame)
+        o.render(sc["view"])
+        g.render(sc["view"]); g.finish()
+        diff = {k: v_ for k, v_ in compare_all(o, g).items() if v_}
+        assert not diff, "seed %d frame %d: %r" % (seed, frame, diff)
+    g.close(); o.close()
