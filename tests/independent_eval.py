@@ -233,10 +233,12 @@ def bxdf(diffuse_color, roughness, LoH, NoV, NoL, NoH):
     return diffuse_color * (1.0 - F)[..., None] * Fd[..., None] + Fr[..., None]
 
 
-def lighting(gb, shadow_map, view, cube_face_colors, W, H):
+def lighting(gb, shadow_map, view, cube_face_colors, W, H, pcf_eps=0.0):
     """BaseLighting.frag:147-227 + case 0 of the switch for every pixel of the W x H quad.
 
     gb: dict scene_color / a / b / c (float RGBA as texture() returns them) and d (fp16 values), each (H, W, 4); view: XkView record
+    pcf_eps: added to the reference depth of the 25 shadow comparisons - the shader's one discontinuity: a caller that wants to know
+    which pixels sit on it evaluates with +-eps and looks at the spread
     -> (H, W, 3) float colour before the UNORM store
     """
     PI = 3.14159265359
@@ -266,7 +268,7 @@ def lighting(gb, shadow_map, view, cube_face_colors, W, H):
                 f = np.ones(P.shape[:-1])
                 inside = (sc[..., 2] > -1.0) & (sc[..., 2] < 1.0)
                 dist = texture_linear_clamp(shadow_map.astype(F64), sc[..., 0] + dx * x, sc[..., 1] + dx * y)
-                f = np.where(inside & (sc[..., 3] > 0.0) & (dist < sc[..., 2]), 0.1, f)
+                f = np.where(inside & (sc[..., 3] > 0.0) & (dist < sc[..., 2] + pcf_eps), 0.1, f)
                 total += f
         shadow = total / 25.0
 

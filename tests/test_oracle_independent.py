@@ -93,7 +93,35 @@ def scene_rolled_and_clipped():
     return s, abi.make_camera((3.0, -4.0, 1.2), (0.0, 0.0, 0.6), fov=60.0), _lights(1, 16), 0.35
 
 
+def scene_random(seed):
+    """seeded mixtures: 2-5 draws of plane / box / sphere with random constant materials (metallic, rough, emissive, masked, odd normal
+    texels), with and without instances, 0-1 directional and 0-24 point lights, the camera anywhere around, the stage rolled"""
+    import math
+    rng = np.random.default_rng(7000 + seed)
+    s = Scene()
+
+    def texels():
+        if rng.random() < 0.3:
+            return None
+        t = [tuple(int(x) for x in rng.integers(0, 256, 3)) + (255,) for _ in range(7)]
+        t[3] = (int(rng.integers(100, 156)), int(rng.integers(100, 156)), int(rng.integers(200, 256)), 255)      # a plausible normal texel
+        t[6] = (int(rng.choice([255, 255, 255, 0, 128])), 0, 0, 255)                                              # the lighting mask
+        return t
+    s.add(scenes.grid_plane(float(rng.choice([10.0, 24.0, 60.0])), int(rng.integers(2, 5)), 0.0), texels())
+    for _ in range(int(rng.integers(1, 5))):
+        kind = int(rng.integers(0, 3))
+        mesh = [scenes.uv_sphere(12, 6, 0.6), scenes.uv_sphere(16, 8, 0.9), scenes.box((0.7, 0.5, 0.6), (0.0, 0.0, 0.6))][kind]
+        inst = scenes.generate_instances(int(rng.integers(2, 20)), 0.8, float(rng.uniform(3.0, 9.0)), 0.4, 1.3, seed=int(rng.integers(1, 1 << 30))) if rng.random() < 0.7 else None
+        s.add(mesh, texels(), inst)
+    a, rad = rng.uniform(0, 2 * math.pi), float(rng.choice([3.5, 6.0, 11.0]))
+    cam = abi.make_camera((rad * math.cos(a), rad * math.sin(a), float(rng.choice([0.6, 2.0, 5.0]))), (float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), 0.4),
+                          fov=float(rng.choice([40.0, 55.0, 70.0])))
+    return s, cam, _lights(int(rng.integers(0, 2)), int(rng.choice([0, 1, 3, 8, 24]))), float(rng.uniform(0.0, 1.0))
+
+
 SCENES = {"mixed": scene_mixed, "single_sphere_no_sun": scene_single_sphere_no_sun, "rolled_and_clipped": scene_rolled_and_clipped}
+for _k in range(10):
+    SCENES["random_%02d" % _k] = (lambda k: (lambda: scene_random(k)))(_k)
 
 
 def _within_one(a, b):
@@ -110,7 +138,7 @@ def test_oracle_agrees_with_an_independent_float64_evaluation(oracle_lib, name):
     o.render(0)
     mvp, _sh, view = o.get_frame()
     prim = o.visibility()
-    assert (prim != 0xFFFFFFFF).sum() > 0.2 * W * H
+    assert (prim != 0xFFFFFFFF).sum() > (0.2 * W * H if not name.startswith("random") else 1500)
 
     # ---- BaseScene.frag: the five colour targets of every covered pixel, recomputed from the scene description
     mine = ie.base_scene(scene.draws(), mvp, prim, W, H)
@@ -140,6 +168,15 @@ def test_oracle_agrees_with_an_independent_float64_evaluation(oracle_lib, name):
     want_rgb = ie.unorm(lit, 8)
     have = o.color().astype(np.int64)
     ok = _within_one(have[..., :3], want_rgb)
+    # The shader's one discontinuity is the PCF comparison `dist < z`: where a tap's filtered depth and the reference depth agree to a few
+    # float32 ulps, float32 and float64 may decide differently and the pixel jumps by a tap's worth of light.  Such pixels are found by
+    # evaluating with the reference depth moved by +-4e-7 (a few ulps of a depth near 1) and accepted when the oracle's colour lies within
+    # what that spans.
+    lo_hi = [ie.unorm(ie.lighting(gb, o.shadowmap(), view, FACES, W, H, pcf_eps=e), 8) for e in (-4e-7, 4e-7)]
+    lo, hi = np.minimum(np.minimum(lo_hi[0], lo_hi[1]), want_rgb) - 1, np.maximum(np.maximum(lo_hi[0], lo_hi[1]), want_rgb) + 1
+    on_edge = (lo_hi[0] != lo_hi[1]).any(axis=-1)
+    ok = ok | (on_edge & np.all((have[..., :3] >= lo) & (have[..., :3] <= hi), axis=-1))
+    assert on_edge.mean() < 0.1
     assert (have[..., 3] == 255).all()
     assert ok.mean() >= 0.999, "lit colour: only %.4f of the pixels within one LSB (worst %d)" % (ok.mean(), np.abs(have[..., :3] - want_rgb).max())
     assert len(np.unique(have.reshape(-1, 4), axis=0)) > 200        # a real picture: lights, shadow, reflection all vary
