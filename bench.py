@@ -115,11 +115,13 @@ def main():
                     help="3: the metric's workload (default); 4: 1M instances at 3840x2160; 5: config 4 with 256 point lights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the moving-camera / textured / one-stream extra loops")
+    ap.add_argument("--split-shadow", action="store_true",
+                    help="N > 1: every rank rasterises 1/N of the casters and the maps are MIN all-reduced (4 MiB, on the shadow -> lighting "
+                         "dependency of every frame).  NOT the default: no N > 1 run on hardware has compared the two modes yet "
+                         "(profiles/r04_scaling_projection.json is a one-GPU projection), and the north star names one collective")
     ap.add_argument("--replicated-shadow", action="store_true",
-                    help="N > 1: every rank renders the whole 1024^2 shadow map and the all-gather of the composite is the only collective. "
-                         "Default for N > 1: every rank rasterises 1/N of the casters and the maps are MIN all-reduced (4 MiB; the shadow "
-                         "lane is otherwise the part of the frame that does not shrink with N: profiles/r03_*_scaling_projection.json)")
-    ap.add_argument("--split-shadow", action="store_true", help="(the default for N > 1; kept so that older command lines still parse)")
+                    help="(the default for N > 1, kept so that older command lines still parse) every rank renders the whole 1024^2 shadow "
+                         "map; the all-gather of the composite is the only collective")
     ap.add_argument("--python-dist", action="store_true", help="N > 1: torch.distributed frame loop (dist.py) instead of the library's native RCCL host")
     ap.add_argument("--timing-interval", type=int, default=0,
                     help="per-kernel hipEvents are recorded on every n-th timed frame (each record is a ~6 us stream bubble); "
@@ -168,7 +170,7 @@ def main():
         if world > 1:
             dist.all_reduce(torch.zeros(1, dtype=torch.int32))      # a CPU tensor: gloo
 
-    args.split_shadow = world > 1 and not args.replicated_shadow
+    args.split_shadow = world > 1 and args.split_shadow and not args.replicated_shadow
     n_point = 256 if args.config == 5 else 16
     if args.config == 3:
         cfg = scenes.config3(args.instances, cube_dim=args.cube_dim, textured=args.textured)

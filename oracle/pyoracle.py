@@ -57,9 +57,11 @@ def lib():
             ("zo_kat_D_GGX", 2, C.c_float), ("zo_kat_V_SmithGGXCorrelated", 3, C.c_float),
             ("zo_kat_F_Schlick", 3, C.c_float), ("zo_kat_Fr_DisneyDiffuse", 4, C.c_float),
             ("zo_kat_ReflectionMip", 2, C.c_float), ("zo_kat_exp2", 1, C.c_float), ("zo_kat_log2", 1, C.c_float),
-            ("zo_kat_pow", 2, C.c_float)]:
+            ("zo_kat_pow", 2, C.c_float), ("zo_kat_rsqrt", 1, C.c_float)]:
             getattr(L, n).restype = res
             getattr(L, n).argtypes = [C.c_float] * args
+        L.zo_kat_rsqrt_worst.restype = C.c_double
+        L.zo_kat_rsqrt_worst.argtypes = [C.c_uint32] * 3
         L.zo_kat_srgb8_to_linear.restype = C.c_float
         L.zo_kat_srgb8_to_linear.argtypes = [C.c_uint32]
         L.zo_kat_f32_to_f16.restype = C.c_uint16

@@ -11,7 +11,9 @@
  *
  * GLSL leaves the precision of sin/cos/pow/exp2/log2 and the evaluation order of
  * fp expressions to the implementation.  The oracle fixes ONE evaluation: every
- * expression below is written op by op (explicit fmaf, IEEE / and sqrtf) and is
+ * expression below is written op by op (explicit fmaf, IEEE / and sqrtf, inversesqrt
+ * as the fixed fma sequence zo_rsqrt; a vector / scalar is one IEEE reciprocal and
+ * multiplies; x / PI and x / 25 are multiplications by the rounded reciprocal) and is
  * compiled with -ffp-contract=off, so results are reproducible bit for bit.  The
  * transcendental functions are small polynomial kernels (Cody-Waite reduction +
  * Cephes-style minimax coefficients) instead of libm, for the same reason.
@@ -119,8 +121,25 @@ static inline zo_v3 zo_cross(zo_v3 a, zo_v3 b)
     return zo_v3make(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
 static inline float zo_length(zo_v3 a) { return sqrtf(zo_dot(a, a)); }
-/* normalize(v) = v * inversesqrt(dot(v,v)); inversesqrt = 1/sqrt (IEEE), so |v| = 0 -> NaN as on GPUs. */
-static inline zo_v3 zo_normalize(zo_v3 a) { return zo_scale(a, 1.0f / sqrtf(zo_dot(a, a))); }
+/* inversesqrt(x) of the shader stages.  GLSL allows 2 ulp and leaves x <= 0 undefined; the evaluation fixed here (and, op for op,
+ * in csrc/zr_math.h: zr_rsqrt): integer seed, one third-order step y (1 + e/2 + 3 e^2/8) with e = 1 - x y^2, one residual step
+ * y + (y/2) e.  Error < 1.2 ulp over every normal float (tests/test_oracle_kat.py).  NaN -> NaN, +inf -> 0; zero, denormals
+ * (flushed, as GLSL allows) and negatives -> +inf, so normalize(0) is NaN as with 1 / sqrt. */
+static inline float zo_rsqrt(float x)
+{
+    float y = zo_u2f(0x5F3759DFu - (zo_f2u(x) >> 1));
+    float t = x * y, e = fmaf(-t, y, 1.0f);
+    y = fmaf(y, e * fmaf(0.375f, e, 0.5f), y);
+    t = x * y; e = fmaf(-t, y, 1.0f);
+    y = fmaf(y * 0.5f, e, y);
+    float sp = (x == INFINITY) ? 0.0f : INFINITY;
+    return ((x >= 1.17549435e-38f && x < INFINITY) || x != x) ? y : sp;
+}
+/* normalize(v) = v * inversesqrt(dot(v,v)) in shader code */
+static inline zo_v3 zo_normalize(zo_v3 a) { return zo_scale(a, zo_rsqrt(zo_dot(a, a))); }
+/* glm::normalize on the host (lookAt): v * (1 / sqrt(dot)), IEEE - the engine's own x86 arithmetic, not a shader's */
+static inline zo_v3 zo_normalize_ieee(zo_v3 a) { return zo_scale(a, 1.0f / sqrtf(zo_dot(a, a))); }
+#define ZO_INV_PI 0.318309886f     /* x / PI (Common.glsl) is evaluated as x * fl(1 / 3.14159265359) */
 
 /* column-major mat4 (glm): m[c*4+r] */
 static inline void zo_mat4_mul(const float* A, const float* B, float* C) /* C = A*B; C may not alias */

@@ -297,7 +297,8 @@ static zo_v3 zo_cube_sample(const zo_ctx* c, zo_v3 R, float lod)
     if (az >= ax && az >= ay) { ma = az; if (R.z >= 0.0f) { face = 4; sc = R.x; tc = -R.y; } else { face = 5; sc = -R.x; tc = -R.y; } }
     else if (ay >= ax)        { ma = ay; if (R.y >= 0.0f) { face = 2; sc = R.x; tc = R.z; }  else { face = 3; sc = R.x; tc = -R.z; } }
     else                      { ma = ax; if (R.x >= 0.0f) { face = 0; sc = -R.z; tc = -R.y; } else { face = 1; sc = R.z; tc = -R.y; } }
-    float s = fmaf(sc / ma, 0.5f, 0.5f), t = fmaf(tc / ma, 0.5f, 0.5f);
+    float rma = 1.0f / ma;
+    float s = fmaf(sc * rma, 0.5f, 0.5f), t = fmaf(tc * rma, 0.5f, 0.5f);
     float maxl = (float)(c->cube_levels - 1);
     float l = fminf(fmaxf(lod, 0.0f), maxl);
     float fl = floorf(l);
@@ -324,8 +325,8 @@ static void zo_perspective(float fovy, float aspect, float zn, float zf, float* 
 
 static void zo_lookat(zo_v3 eye, zo_v3 center, zo_v3 up, float* m)                /* glm::lookAtRH */
 {
-    zo_v3 f = zo_normalize(zo_sub(center, eye));
-    zo_v3 s = zo_normalize(zo_cross(f, up));
+    zo_v3 f = zo_normalize_ieee(zo_sub(center, eye));       /* glm on the host */
+    zo_v3 s = zo_normalize_ieee(zo_cross(f, up));
     zo_v3 u = zo_cross(s, f);
     m[0] = s.x; m[4] = s.y; m[8] = s.z;
     m[1] = u.x; m[5] = u.y; m[9] = u.z;
@@ -826,9 +827,10 @@ static void zo_tex_sample(const zo_ctx* c, const zo_tex* t, int srgb, float u, f
 static zo_v3 zo_compute_normal(zo_v3 pos_dx, zo_v3 pos_dy, float s1, float t1, float s2, float t2, zo_v3 fragN, zo_v3 texN)
 {
     float det = fmaf(s1, t2, -(s2 * t1));
-    zo_v3 T = zo_v3make(fmaf(t2, pos_dx.x, -(t1 * pos_dy.x)) / det,
-                        fmaf(t2, pos_dx.y, -(t1 * pos_dy.y)) / det,
-                        fmaf(t2, pos_dx.z, -(t1 * pos_dy.z)) / det);
+    float rdet = 1.0f / det;                                /* vec3 / scalar: one reciprocal, three multiplies */
+    zo_v3 T = zo_v3make(fmaf(t2, pos_dx.x, -(t1 * pos_dy.x)) * rdet,
+                        fmaf(t2, pos_dx.y, -(t1 * pos_dy.y)) * rdet,
+                        fmaf(t2, pos_dx.z, -(t1 * pos_dy.z)) * rdet);
     zo_v3 N = zo_normalize(fragN);
     T = zo_normalize(zo_sub(T, zo_scale(N, zo_dot(N, T))));
     zo_v3 B = zo_normalize(zo_cross(N, T));
@@ -1037,11 +1039,12 @@ static void zo_gbuffer_sample(const zo_ctx* c, float u, float v, zo_gtexel* out)
 static float zo_pcf(const zo_ctx* c, const float* SB, zo_v3 P, float dxy)
 {
     zo_v4 s4 = zo_mat4_point(SB, P);
-    float sx = s4.x / s4.w, sy = s4.y / s4.w, sz = s4.z / s4.w, sw = s4.w / s4.w;
+    float rsw = 1.0f / s4.w;                                /* shadowCoord / shadowCoord.w */
+    float sx = s4.x * rsw, sy = s4.y * rsw, sz = s4.z * rsw, sw = s4.w * rsw;
     float sum = 0.0f;
     for (int x = -2; x <= 2; ++x) for (int y = -2; y <= 2; ++y)               /* ComputePCF r=2, :323-342 */
         sum += zo_shadow_tap(c, sx, sy, sz, sw, dxy * (float)x, dxy * (float)y);
-    return sum / 25.0f;
+    return sum * 0.04f;                                     /* ShadowFactor / Count */
 }
 
 static zo_v3 zo_gbuffer_vis(const zo_ctx* c, uint32_t px, uint32_t py, zo_v3 FinalColor, const float* SB, zo_v3 cam, float dxy)
@@ -1130,8 +1133,10 @@ static void zo_lighting(zo_ctx* c, uint32_t debug_view)
             int isdir = i < nDir;
             const XkLight* Lt = isdir ? &V->DirectionalLights[i] : &V->PointLights[i - nDir];
             zo_v3 lp = zo_v3make(Lt->Position[0], Lt->Position[1], Lt->Position[2]);
-            zo_v3 L = isdir ? zo_normalize(zo_v3make(Lt->Direction[0], Lt->Direction[1], Lt->Direction[2]))
-                            : zo_normalize(zo_sub(lp, P));
+            /* point light: distance() and normalize() of light_pos - position share one inversesqrt: length = d2 * inversesqrt(d2) */
+            zo_v3 dl = zo_sub(lp, P);
+            float d2 = zo_dot(dl, dl), rd = zo_rsqrt(d2);
+            zo_v3 L = isdir ? zo_normalize(zo_v3make(Lt->Direction[0], Lt->Direction[1], Lt->Direction[2])) : zo_scale(dl, rd);
             zo_v3 Hh = zo_normalize(zo_add(Vv, L));
             float LdotH = zo_saturate(zo_dot(L, Hh)), NdotH = zo_saturate(zo_dot(N, Hh)), NdotL = zo_saturate(zo_dot(N, L));
             /* DefaultLitBxDF, Common.glsl:259-282: F0 = 0.04, F90 = saturate(50*0.04) = 1 */
@@ -1150,7 +1155,7 @@ static void zo_lighting(zo_ctx* c, uint32_t debug_view)
                 Direct = zo_v3make(fmaf(rad.x * bx.x, ShadowFactor, Direct.x), fmaf(rad.y * bx.y, ShadowFactor, Direct.y),
                                    fmaf(rad.z * bx.z, ShadowFactor, Direct.z));
             } else {
-                float dist = zo_length(zo_sub(lp, P));
+                float dist = d2 > 0.0f ? d2 * rd : 0.0f;
                 float falloff = Lt->Direction[3];
                 float att = 1.0f - zo_clampf(dist, 0.0f, falloff) / falloff;   /* remap(dist,0,falloff,0,1), :43-47 */
                 rad = zo_scale(rad, att);
@@ -1158,9 +1163,9 @@ static void zo_lighting(zo_ctx* c, uint32_t debug_view)
             }
         }
         /* (2) indirect, :210 */
-        zo_v3 Indirect = zo_v3make((((DiffuseColor.x / 3.14159265359f) * AO) * 0.3f) * ShadowFactor,
-                                   (((DiffuseColor.y / 3.14159265359f) * AO) * 0.3f) * ShadowFactor,
-                                   (((DiffuseColor.z / 3.14159265359f) * AO) * 0.3f) * ShadowFactor);
+        zo_v3 Indirect = zo_v3make((((DiffuseColor.x * ZO_INV_PI) * AO) * 0.3f) * ShadowFactor,
+                                   (((DiffuseColor.y * ZO_INV_PI) * AO) * 0.3f) * ShadowFactor,
+                                   (((DiffuseColor.z * ZO_INV_PI) * AO) * 0.3f) * ShadowFactor);
         /* (3) reflection, :213-221 */
         zo_v3 bcl = zo_v3make(zo_clampf(BaseColor.x, 0.04f, 1.0f), zo_clampf(BaseColor.y, 0.04f, 1.0f), zo_clampf(BaseColor.z, 0.04f, 1.0f));
         float dsf0 = (0.04f * 2.0f) * 0.5f;
@@ -1384,6 +1389,20 @@ int zo_meshlet_bounds(const XkVertex* v, const uint32_t* mv, const uint8_t* mt, 
 }
 
 /* ------------------------------------------------------------------ KAT exports */
+float zo_kat_rsqrt(float x) { return zo_rsqrt(x); }
+/* worst error of zo_rsqrt in ulps of the exact value over the floats with bit patterns lo, lo + step, ... < hi (normal, positive) */
+double zo_kat_rsqrt_worst(uint32_t lo, uint32_t hi, uint32_t step)
+{
+    double worst = 0.0;
+    for (uint64_t b = lo; b < hi; b += step) {
+        float x = zo_u2f((uint32_t)b);
+        double ref = 1.0 / sqrt((double)x);
+        int ex; (void)frexp(ref, &ex);
+        double err = fabs((double)zo_rsqrt(x) - ref) / ldexp(1.0, ex - 24);
+        if (err > worst) worst = err;
+    }
+    return worst;
+}
 float zo_kat_D_GGX(float a, float r) { return zo_D_GGX(a, r); }
 float zo_kat_V_SmithGGXCorrelated(float a, float b, float r) { return zo_V_SmithGGXCorrelated(a, b, r); }
 float zo_kat_F_Schlick(float f0, float f90, float u) { return zo_F_Schlick(f0, f90, u); }

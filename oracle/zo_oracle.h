@@ -50,6 +50,8 @@ void            zo_set_threads(zo_ctx*, int n); /* OpenMP threads of the per-pix
 int  zo_meshlet_bounds(const XkVertex* v, const uint32_t* mv, const uint8_t* mt, uint32_t ntri, XkMeshlet* out);
 
 /* scalar KAT entry points */
+float zo_kat_rsqrt(float x);
+double zo_kat_rsqrt_worst(uint32_t lo, uint32_t hi, uint32_t step);
 float zo_kat_D_GGX(float NdotH, float r);
 float zo_kat_V_SmithGGXCorrelated(float NdotV, float NdotL, float r);
 float zo_kat_F_Schlick(float f0, float f90, float u);

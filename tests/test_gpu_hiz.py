@@ -155,6 +155,8 @@ def test_config4_scale_culling_paths_agree(gpu_engine):
         assert np.array_equal(a[1][t].view(np.uint8), b[1][t].view(np.uint8)), "GBuffer target %d" % t
     assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
     assert a[3]["covered_pixels"] == b[3]["covered_pixels"] and a[3]["overflow"] == 0 and b[3]["overflow"] == 0
+    # (the bound was // 4 with round 2's 14-meshlet spheres: the 11 fuller meshlets of the slab x sector clusteriser have wider normal
+    # cones - frustum + cone culls remove 33 % of the meshlet-instances where they removed 41 % - so fewer fall before the rasteriser)
     assert a[3]["hiz_culled"] > 100000 and a[3]["survivors"][1] < b[3]["survivors"][1] // 3
 
 
@@ -201,6 +203,8 @@ def test_config5_full_size_culling_paths_agree(gpu_engine):
         assert np.array_equal(a[1][t].view(np.uint8), b[1][t].view(np.uint8)), "GBuffer target %d" % t
     assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
     assert a[3]["covered_pixels"] == b[3]["covered_pixels"] and a[3]["overflow"] == 0 and b[3]["overflow"] == 0
+    # (// 1.9, not // 4: same clusteriser effect as above, and with 256 lights nothing else changes what the culls see; survivors[1]
+    # counts the meshlet-instances that reach k_geom in either round - triangles the per-triangle pyramid test drops are not taken off)
     assert a[3]["round1_survivors"] > 0 and a[3]["hiz_culled"] > 100000 and a[3]["survivors"][1] < b[3]["survivors"][1] // 1.9
     assert len(np.unique(a[0].reshape(-1, 4), axis=0)) > 1000       # a lit frame, not a constant
 
@@ -264,7 +268,7 @@ def test_camera_pass_against_the_oracle_with_and_without_hiz_rounds(oracle_lib, 
 
 def test_record_pool_chunks_beyond_the_first(oracle_lib, gpu_engine):
     """With NO_HIZ every frame is one round over all frustum / cone survivors: at 60 000 instances a wave of k_geom handles ~60
-    meshlet-instances and fills its first record chunk (1 024 records) several times over, so the chunks it takes from the pool, their
+    meshlet-instances and fills its first record chunk (256 records: ZR_TPOOL_CHUNK) many times over, so the chunks it takes from the pool, their
     fill counts and k_index's walk over them are exercised.  Checked against the scalar oracle (57.6 M triangles: ~20 s of CPU)."""
     from zeldaengine_amd import engine as eng
     cfg = scenes.config3(60000, 1920, 1080)

@@ -49,6 +49,19 @@ def test_glm_matrices(L):
     assert np.allclose(M @ np.array([0, 0, 0, 1.0]), [0, 0, -math.sqrt(75), 1], atol=1e-5)   # RH: looks down -z
 
 
+def test_inversesqrt_of_the_shader_stages(L):
+    """zo_rsqrt (= csrc/zr_math.h: zr_rsqrt): the fixed fma sequence that stands for GLSL inversesqrt in normalize() / distance().
+    GLSL allows 2 ulp; the sequence stays below 1.2 ulp of the exact value over the whole range (every 997th normal float here, all
+    2^31 of them in the scratch run quoted in DESIGN.md section 4), and the special values are the IEEE ones."""
+    assert L.zo_kat_rsqrt(1.0) == 1.0 and L.zo_kat_rsqrt(4.0) == 0.5 and L.zo_kat_rsqrt(0.25) == 2.0
+    assert L.zo_kat_rsqrt(2.0) == pytest.approx(0.70710678, rel=1.5e-7) and L.zo_kat_rsqrt(3.0) == pytest.approx(0.57735027, rel=1.5e-7)
+    assert L.zo_kat_rsqrt_worst(0x00800000, 0x7F800000, 997) < 1.2
+    assert L.zo_kat_rsqrt_worst(0x3F000000, 0x40800000, 1) < 1.2            # every float of [0.5, 4): all mantissas, both exponent parities
+    inf = float("inf")
+    assert L.zo_kat_rsqrt(0.0) == inf and L.zo_kat_rsqrt(inf) == 0.0 and math.isnan(L.zo_kat_rsqrt(float("nan")))
+    assert L.zo_kat_rsqrt(1e-40) == inf and L.zo_kat_rsqrt(-1.0) == inf      # denormals are flushed; x < 0 is undefined in GLSL
+
+
 def test_sincos_accuracy(L):
     out = (C.c_float * 2)()
     rng = np.random.default_rng(0)

@@ -92,6 +92,9 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     c->device = cfg->device;
     c->W = cfg->width; c->H = cfg->height; c->SD = cfg->shadow_dim ? cfg->shadow_dim : XK_SHADOWMAP_DIM;
     if (c->SD > 255u * ZR_TILE) { delete c; return ZR_ERR_ARG; }
+#ifndef ZR_DIAG
+    if (c->cfg.flags & ZR_FLAG_MESHLET_BINS) { delete c; return ZR_ERR_UNSUPPORTED; }      // the A/B rasteriser exists in -DZR_DIAG builds only (refused before anything is allocated)
+#endif
     c->debug_view = cfg->debug_view;
     memset(&c->cam, 0, sizeof c->cam); memset(&c->shadow, 0, sizeof c->shadow); memset(&c->view, 0, sizeof c->view);
     default_lights(&c->view);
@@ -192,8 +195,6 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         if ((e = getenv("ZR_LANES"))) c->three_lanes = atoi(e) >= 3;
         if ((e = getenv("ZR_SHADOW_BOX_CULL"))) c->env_shadow_box = atoi(e) != 0;
         if ((e = getenv("ZR_SHADOW_DEFER"))) c->env_shadow_defer = atoi(e) != 0;
-#else
-        if (c->cfg.flags & ZR_FLAG_MESHLET_BINS) { delete c; return ZR_ERR_UNSUPPORTED; }      // the A/B rasteriser exists in -DZR_DIAG builds only
 #endif
     }
     ok &= hipHostMalloc((void**)&c->h_view_ring, sizeof(XkView) * zr_ctx::VIEW_RING, hipHostMallocDefault) == hipSuccess;
@@ -960,8 +961,8 @@ static void perspective_rh_zo(float fovy, float aspect, float zn, float zf, floa
 }
 static void look_at_rh(zf3 eye, zf3 center, zf3 up, float* m)
 {
-    const zf3 f = zr_normalize(center - eye);
-    const zf3 s = zr_normalize(zr_cross(f, up));
+    const zf3 f = zr_normalize_ieee(center - eye);          // (glm on the host: IEEE, not the shaders' inversesqrt)
+    const zf3 s = zr_normalize_ieee(zr_cross(f, up));
     const zf3 u = zr_cross(s, f);
     m[0] = s.x; m[4] = s.y; m[8] = s.z; m[1] = u.x; m[5] = u.y; m[9] = u.z; m[2] = -f.x; m[6] = -f.y; m[10] = -f.z;
     m[3] = 0; m[7] = 0; m[11] = 0; m[12] = -zr_dot(s, eye); m[13] = -zr_dot(u, eye); m[14] = zr_dot(f, eye); m[15] = 1.0f;

@@ -1181,10 +1181,11 @@ __device__ __forceinline__ zf3 interp3(Bary b, zf3 a0, zf3 a1, zf3 a2)
 // ComputeNormal(fragPosition, fragTexCoord, fragNormal, texNormal), SH/Common.glsl:113-127; ts = zr_tangent_space_normal(texNormal)
 __device__ __forceinline__ zf3 compute_normal(zf3 pos_dx, zf3 pos_dy, float s1, float t1, float s2, float t2, zf3 fragN, zf3 ts)
 {
-    const float det = __builtin_fmaf(s1, t2, -(s2 * t1));
-    zf3 T = zr3(__builtin_fmaf(t2, pos_dx.x, -(t1 * pos_dy.x)) / det,
-                __builtin_fmaf(t2, pos_dx.y, -(t1 * pos_dy.y)) / det,
-                __builtin_fmaf(t2, pos_dx.z, -(t1 * pos_dy.z)) / det);
+    // (vec3 / scalar: one IEEE reciprocal, three multiplies - DESIGN.md section 4)
+    const float rdet = 1.0f / __builtin_fmaf(s1, t2, -(s2 * t1));
+    zf3 T = zr3(__builtin_fmaf(t2, pos_dx.x, -(t1 * pos_dy.x)) * rdet,
+                __builtin_fmaf(t2, pos_dx.y, -(t1 * pos_dy.y)) * rdet,
+                __builtin_fmaf(t2, pos_dx.z, -(t1 * pos_dy.z)) * rdet);
     const zf3 N = zr_normalize(fragN);
     T = zr_normalize(T - N * zr_dot(N, T));
     const zf3 B = zr_normalize(zr_cross(N, T));
@@ -2192,30 +2193,46 @@ __global__ __launch_bounds__(256) void k_index(ZrTriBins B, const ZrDevStats* __
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t used = min(B.n_waves + stats->pool_next[slot], B.n_chunks);
     const unsigned long long lt = (1ull << lane) - 1ull;
+    // A chunk's four stretches of 64 records go through the dependent steps TOGETHER (tile ids -> tile offsets -> one cursor add per
+    // (stretch, tile) group -> stores): the kernel waits for memory three times per chunk, not three times per stretch (it spent 74 % of
+    // its wave-cycles waiting: round 3's counters).
+    constexpr uint32_t NB = ZR_TPOOL_CHUNK / 64u;
     for (uint32_t ch = blockIdx.x * 4u + wv; ch < used; ch += gridDim.x * 4u) {
         const uint32_t n = B.chunk_fill[ch], r0 = ch * ZR_TPOOL_CHUNK;
-        for (uint32_t j0 = 0; j0 < n; j0 += 64u) {
-            const uint32_t j = j0 + lane, i = r0 + j;
-            const bool have = j < n;
-            const uint32_t tile = have ? B.rtile[i] : 0u;
-            uint4 qa = make_uint4(0, 0, 0, 0), qb = qa;
-            if (have) { qa = B.recA[i]; qb = B.recB[i]; }
-            const uint32_t off = have ? tile_offset[tile] : 0u;
-            uint32_t rank = 0, cnt = 0;
-            int first = (int)lane;
-            unsigned long long pend = __ballot(have);
+        bool have[NB]; uint32_t tile[NB], off[NB], rank[NB], cnt[NB], b[NB]; int first[NB];
+        uint4 qa[NB], qb[NB];
+#pragma unroll
+        for (uint32_t k = 0; k < NB; ++k) {
+            const uint32_t j = k * 64u + lane;
+            have[k] = j < n;
+            tile[k] = have[k] ? B.rtile[r0 + j] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < NB; ++k) {
+            const uint32_t j = k * 64u + lane;
+            qa[k] = make_uint4(0, 0, 0, 0); qb[k] = qa[k];
+            if (have[k]) { qa[k] = B.recA[r0 + j]; qb[k] = B.recB[r0 + j]; }
+            off[k] = have[k] ? tile_offset[tile[k]] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < NB; ++k) {
+            rank[k] = 0; cnt[k] = 0; first[k] = (int)lane;
+            unsigned long long pend = __ballot(have[k]);
             while (pend) {
                 const int leader = __builtin_ctzll(pend);
-                const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
-                const unsigned long long same = __ballot(have && tile == tl) & pend;
-                if (same >> lane & 1ull) { first = leader; rank = (uint32_t)__popcll(same & lt); cnt = (uint32_t)__popcll(same); }
+                const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)tile[k], leader);
+                const unsigned long long same = __ballot(have[k] && tile[k] == tl) & pend;
+                if (same >> lane & 1ull) { first[k] = leader; rank[k] = (uint32_t)__popcll(same & lt); cnt[k] = (uint32_t)__popcll(same); }
                 pend &= ~same;
             }
-            uint32_t b = 0;
-            if (have && first == (int)lane) b = atomicAdd(&tile_cursor[tile * ZR_TSTRIDE], cnt);
-            b = (uint32_t)__shfl((int)b, first);
-            const uint32_t dst = off + b + rank;
-            if (have && dst < B.sorted_cap) { B.srtA[dst] = qa; B.srtB[dst] = qb; }
+            b[k] = 0;
+            if (have[k] && first[k] == (int)lane) b[k] = atomicAdd(&tile_cursor[tile[k] * ZR_TSTRIDE], cnt[k]);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < NB; ++k) {
+            const uint32_t bb = (uint32_t)__shfl((int)b[k], first[k]);
+            const uint32_t dst = off[k] + bb + rank[k];
+            if (have[k] && dst < B.sorted_cap) { B.srtA[dst] = qa[k]; B.srtB[dst] = qb[k]; }
         }
     }
 }
@@ -2267,9 +2284,14 @@ __global__ __launch_bounds__(256) void k_tile(ZrPass P, const uint4* __restrict_
 }
 
 // The slow triangles of the round (they need the clipper, or have an edge of 64 px or more): every owned tile tries every one of
-// them through raster_clipped.  One workgroup per owned tile; returns at once when the round has none (the usual case).
+// them through raster_clipped.  A SMALL persistent grid (ZR_SLOW_BLOCKS workgroups stride over the owned tiles): the usual round has no
+// slow triangle, and this launch sits on the camera lane's critical path - as one workgroup per owned tile (2 040 at 1080p, 8 KB of LDS
+// each) it cost 35 us beside the shadow rasteriser just to find room and return; a few dozen workgroups come and go like k_scan_tri's one.
+#ifndef ZR_SLOW_BLOCKS
+#define ZR_SLOW_BLOCKS 256u
+#endif
 template <int MODE, bool BY_TILE>
-__global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __restrict__ owned_tiles, const uint4* __restrict__ slow,
+__global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __restrict__ owned_tiles, uint32_t n_owned, const uint4* __restrict__ slow,
                                                    uint32_t slow_cap, ZrDevStats* __restrict__ stats, int slot,
                                                    unsigned long long* __restrict__ vis64, uint32_t* __restrict__ shadow_bits,
                                                    const uint32_t* __restrict__ wave_culled, uint32_t n_waves)
@@ -2280,47 +2302,51 @@ __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __r
     // (slot = 2), or round 1's alone in a one-round frame (slot = 1)
     const uint32_t half = BY_TILE ? slow_cap : slow_cap / 2u;
     const uint32_t n_a = min(stats->n_slow[BY_TILE ? slot : 1], half), n_b = (!BY_TILE && slot == 2) ? min(stats->n_slow[2], half) : 0u;
-    if (!BY_TILE && slot == 2 && wave_culled && blockIdx.x * 256u < n_waves) {
-        // the meshlets round 2's k_geom dropped behind the pyramid: a slice of the per-wave counts per workgroup (one atomic per wave of
+    if (!BY_TILE && slot == 2 && wave_culled) {
+        // the meshlets round 2's k_geom dropped behind the pyramid: the per-wave counts, strided over this grid (one atomic per wave of
         // THAT kernel on one address would queue up for ~10 ns apiece and hold its end)
-        const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-        uint32_t nc = i < n_waves ? wave_culled[i] : 0u;
+        uint32_t nc = 0;
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_waves; i += gridDim.x * 256u) nc += wave_culled[i];
         nc = (uint32_t)wave_sum((int)nc);
         if ((threadIdx.x & 63u) == 0u && nc) { atomicAdd(&stats->hiz_culled, nc); atomicSub(&stats->survivors[2], nc); }
     }
     if (n_a + n_b == 0u) return;
-    const uint32_t tid = threadIdx.x, tile = owned_tiles[blockIdx.x];
-    for (uint32_t i = tid; i < (uint32_t)SPAN_PIX(MODE); i += 256u) {
-        if (MODE == ZR_MODE_GBUFFER) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
-        else keys32[i] = 0x3F800000u;
-    }
-    __syncthreads();
-    const int tpx0 = (int)(tile % P.tiles_x) * TILE, tpy0 = (int)(tile / P.tiles_x) * TILE;
-    TileCtx T;
-    T.px0 = 0; T.py0 = 0; T.W = (int)P.W - tpx0; T.H = (int)P.H - tpy0;
-    for (uint32_t jj = tid; jj < n_a + n_b; jj += 256u) {
-        const uint32_t j = jj < n_a ? jj : half + (jj - n_a);
-        const uint4 q3 = slow[4u * j + 3u];
-        if (BY_TILE && q3.y != tile) continue;          // (the meshlet-binned rasteriser lists a triangle once per tile of its meshlet)
-        const uint4 q0 = slow[4u * j], q1 = slow[4u * j + 1u], q2 = slow[4u * j + 2u];
-        zf4 c0, c1, c2;
-        c0.x = zr_u2f(q0.x); c0.y = zr_u2f(q0.y); c0.z = zr_u2f(q0.z); c0.w = zr_u2f(q0.w);
-        c1.x = zr_u2f(q1.x); c1.y = zr_u2f(q1.y); c1.z = zr_u2f(q1.z); c1.w = zr_u2f(q1.w);
-        c2.x = zr_u2f(q2.x); c2.y = zr_u2f(q2.y); c2.z = zr_u2f(q2.z); c2.w = zr_u2f(q2.w);
-        raster_clipped<MODE>(c0, c1, c2, q3.x, T, P.hw, P.hh, tpx0 * 256, tpy0 * 256, keys64, keys32);
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < (uint32_t)SPAN_PIX(MODE); i += 256u) {
-        const int px = tpx0 + (int)(i % (uint32_t)SPAN(MODE)), py = tpy0 + (int)(i / (uint32_t)SPAN(MODE));
-        if (px >= (int)P.W || py >= (int)P.H) continue;
-        const size_t p = (size_t)py * P.W + (size_t)px;
-        if (MODE == ZR_MODE_GBUFFER) {
-            const unsigned long long k = keys64[i];
-            if ((uint32_t)k != ZR_EMPTY_PRIM && k < vis64[p]) atomicMin(&vis64[p], k);
-        } else {
-            const uint32_t k = keys32[i];
-            if (k < shadow_bits[p]) atomicMin(&shadow_bits[p], k);
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t ti = blockIdx.x; ti < n_owned; ti += gridDim.x) {
+        const uint32_t tile = owned_tiles[ti];
+        for (uint32_t i = tid; i < (uint32_t)SPAN_PIX(MODE); i += 256u) {
+            if (MODE == ZR_MODE_GBUFFER) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
+            else keys32[i] = 0x3F800000u;
         }
+        __syncthreads();
+        const int tpx0 = (int)(tile % P.tiles_x) * TILE, tpy0 = (int)(tile / P.tiles_x) * TILE;
+        TileCtx T;
+        T.px0 = 0; T.py0 = 0; T.W = (int)P.W - tpx0; T.H = (int)P.H - tpy0;
+        for (uint32_t jj = tid; jj < n_a + n_b; jj += 256u) {
+            const uint32_t j = jj < n_a ? jj : half + (jj - n_a);
+            const uint4 q3 = slow[4u * j + 3u];
+            if (BY_TILE && q3.y != tile) continue;          // (the meshlet-binned rasteriser lists a triangle once per tile of its meshlet)
+            const uint4 q0 = slow[4u * j], q1 = slow[4u * j + 1u], q2 = slow[4u * j + 2u];
+            zf4 c0, c1, c2;
+            c0.x = zr_u2f(q0.x); c0.y = zr_u2f(q0.y); c0.z = zr_u2f(q0.z); c0.w = zr_u2f(q0.w);
+            c1.x = zr_u2f(q1.x); c1.y = zr_u2f(q1.y); c1.z = zr_u2f(q1.z); c1.w = zr_u2f(q1.w);
+            c2.x = zr_u2f(q2.x); c2.y = zr_u2f(q2.y); c2.z = zr_u2f(q2.z); c2.w = zr_u2f(q2.w);
+            raster_clipped<MODE>(c0, c1, c2, q3.x, T, P.hw, P.hh, tpx0 * 256, tpy0 * 256, keys64, keys32);
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < (uint32_t)SPAN_PIX(MODE); i += 256u) {
+            const int px = tpx0 + (int)(i % (uint32_t)SPAN(MODE)), py = tpy0 + (int)(i / (uint32_t)SPAN(MODE));
+            if (px >= (int)P.W || py >= (int)P.H) continue;
+            const size_t p = (size_t)py * P.W + (size_t)px;
+            if (MODE == ZR_MODE_GBUFFER) {
+                const unsigned long long k = keys64[i];
+                if ((uint32_t)k != ZR_EMPTY_PRIM && k < vis64[p]) atomicMin(&vis64[p], k);
+            } else {
+                const uint32_t k = keys32[i];
+                if (k < shadow_bits[p]) atomicMin(&shadow_bits[p], k);
+            }
+        }
+        __syncthreads();      // the keys are cleared again for the next tile
     }
 }
 
@@ -2464,7 +2490,8 @@ __device__ __forceinline__ zf3 cube_sample(const CubeDesc& C, const float* __res
     if (az >= ax && az >= ay) { ma = az; if (R.z >= 0.0f) { face = 4; sc = R.x; tc = -R.y; } else { face = 5; sc = -R.x; tc = -R.y; } }
     else if (ay >= ax)        { ma = ay; if (R.y >= 0.0f) { face = 2; sc = R.x; tc = R.z; }  else { face = 3; sc = R.x; tc = -R.z; } }
     else                      { ma = ax; if (R.x >= 0.0f) { face = 0; sc = -R.z; tc = -R.y; } else { face = 1; sc = R.z; tc = -R.y; } }
-    const float s = __builtin_fmaf(sc / ma, 0.5f, 0.5f), t = __builtin_fmaf(tc / ma, 0.5f, 0.5f);
+    const float rma = 1.0f / ma;
+    const float s = __builtin_fmaf(sc * rma, 0.5f, 0.5f), t = __builtin_fmaf(tc * rma, 0.5f, 0.5f);
     const float l = __builtin_fminf(__builtin_fmaxf(lod, 0.0f), (float)(nlevels - 1));
     const float fl = __builtin_floorf(l);
     const int l0 = (int)fl, l1 = min(l0 + 1, nlevels - 1);
@@ -2657,7 +2684,8 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const float NdotV = zr_saturate(zr_dot(N, Vv));
 
         const zf4 s4 = zr_mat4_point(L.SB, Pw);
-        const float sx = s4.x / s4.w, sy = s4.y / s4.w, sz = s4.z / s4.w, sw = s4.w / s4.w;
+        const float rsw = 1.0f / s4.w;                 // shadowCoord / shadowCoord.w: one IEEE reciprocal, four multiplies
+        const float sx = s4.x * rsw, sy = s4.y * rsw, sz = s4.z * rsw, sw = s4.w * rsw;
         // ComputePCF r = 2 (SH/Common.glsl:323-342): 25 taps of ShadowDepthProject.  A tap's texel column / row and bilinear
         // weight depend only on its x / y offset, so they are formed once per axis (5 + 5) instead of once per tap (25 + 25);
         // every tap still evaluates fma(sx + ox, dim, -0.5) etc. with the same operands, i.e. the same bits.
@@ -2718,7 +2746,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     }
             }
         } else sum = 25.0f;      // every tap returns 1.0: 25 exact additions
-        const float ShadowFactor = sum / 25.0f;
+        const float ShadowFactor = sum * 0.04f;       // ShadowFactor / Count (25 taps)
 
         zf3 Direct = zr3(0.0f, 0.0f, 0.0f);
         const zf3 Nn = zr_normalize(N);                      // Apply*Light and refract() re-normalise N
@@ -2744,17 +2772,24 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const bool lfinite = __builtin_fabsf(Lt->Color[0]) <= 3.402823466e38f && __builtin_fabsf(Lt->Color[1]) <= 3.402823466e38f &&
                                  __builtin_fabsf(Lt->Color[2]) <= 3.402823466e38f && __builtin_fabsf(Lt->Color[3]) <= 3.402823466e38f;
             float att = 1.0f;
+            zf3 Lv;
             if (!isdir) {
                 const float falloff = Lt->Direction[3];
                 // far outside the radius (1e-6 relative margin on the squared distance covers every rounding in dist): the exact
-                // test below would give att == 0, so the square root and the quotient need not be formed
+                // test below would give att == 0, so the distance and the quotient need not be formed
                 const zf3 dl = lp - Pw;
-                if (lfinite && falloff > 0.0f && zr_dot(dl, dl) > (falloff * falloff) * 1.000001f) continue;
-                const float dist = zr_length(dl);
-                att = 1.0f - zr_clamp(dist, 0.0f, falloff) / falloff;   // remap(dist, 0, falloff, 0, 1), SH/Common.glsl:43-47
+                const float d2 = zr_dot(dl, dl);
+                if (lfinite && falloff > 0.0f && d2 > (falloff * falloff) * 1.000001f) continue;
+                // distance(light_pos, position) and normalize(light_pos - position) share ONE inversesqrt: length = d2 * inversesqrt(d2)
+                // (0 for d2 = 0; GLSL derives sqrt's precision from inversesqrt's), direction = dl * inversesqrt(d2)
+                const float rd = zr_rsqrt(d2);
+                const float dist = d2 > 0.0f ? d2 * rd : 0.0f;
+                // remap(dist, 0, falloff, 0, 1), SH/Common.glsl:43-47.  The quotient stays an IEEE division: falloff / falloff must be
+                // exactly 1 beyond the radius (the tile light lists and the skips around here rest on att == 0 there)
+                att = 1.0f - zr_clamp(dist, 0.0f, falloff) / falloff;
                 if (lfinite && att == 0.0f) continue;
-            }
-            const zf3 Lv = isdir ? zr_normalize(zr3(Lt->Direction[0], Lt->Direction[1], Lt->Direction[2])) : zr_normalize(lp - Pw);
+                Lv = dl * rd;
+            } else Lv = zr_normalize(zr3(Lt->Direction[0], Lt->Direction[1], Lt->Direction[2]));
             // ApplyDirectionalLight / ApplyPointLight (SH/Common.glsl:364-372, 399-416)
             const float ndotl = zr_clamp(zr_dot(Nn, Lv), 0.0f, 1.0f);
             if (lfinite && ndotl == 0.0f) continue;
@@ -2779,9 +2814,9 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             }
         }
         // (2) indirect, BaseLighting.frag:210
-        const zf3 Indirect = zr3((((DiffuseColor.x / 3.14159265359f) * AO) * 0.3f) * ShadowFactor,
-                                 (((DiffuseColor.y / 3.14159265359f) * AO) * 0.3f) * ShadowFactor,
-                                 (((DiffuseColor.z / 3.14159265359f) * AO) * 0.3f) * ShadowFactor);
+        const zf3 Indirect = zr3((((DiffuseColor.x * ZR_INV_PI) * AO) * 0.3f) * ShadowFactor,
+                                 (((DiffuseColor.y * ZR_INV_PI) * AO) * 0.3f) * ShadowFactor,
+                                 (((DiffuseColor.z * ZR_INV_PI) * AO) * 0.3f) * ShadowFactor);
         // (3) reflection, :213-221
         const zf3 bcl = zr3(zr_clamp(BaseColor.x, 0.04f, 1.0f), zr_clamp(BaseColor.y, 0.04f, 1.0f), zr_clamp(BaseColor.z, 0.04f, 1.0f));
         const float dsf0 = (0.04f * 2.0f) * 0.5f;
@@ -2928,12 +2963,13 @@ __global__ __launch_bounds__(256) void k_gbuffer_vis(ZrLightParams L, const XkVi
         }
         default: {
             const zf4 s4 = zr_mat4_point(L.SB, Pw);
-            const float sx = s4.x / s4.w, sy = s4.y / s4.w, sz = s4.z / s4.w, sw = s4.w / s4.w;
+            const float rsw = 1.0f / s4.w;
+            const float sx = s4.x * rsw, sy = s4.y * rsw, sz = s4.z * rsw, sw = s4.w * rsw;
             const float dxy = 1.5f * 1.0f / (float)L.SD;
             float sum = 0.0f;
             for (int xo = -2; xo <= 2; ++xo)
                 for (int yo = -2; yo <= 2; ++yo) sum += shadow_tap(shadowmap, (int)L.SD, sx, sy, sz, sw, dxy * (float)xo, dxy * (float)yo);
-            const float sf = sum / 25.0f;
+            const float sf = sum * 0.04f;
             o = zr3(sf, sf, sf);
             break;
         }
@@ -3059,8 +3095,8 @@ void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4*
     if (P.mode == ZR_MODE_GBUFFER) return;      // (not reached: the product's camera pass is triangle-binned)
     if (slow) {    // shadow pass: clipped triangles go through a list + k_tile_slow
         hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false, true>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u, slow, slow_cap);
-        if (n_tiles) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_SHADOW, true>), dim3(n_tiles), dim3(256), 0, s, P, tiles, slow, slow_cap, stats, slot, (unsigned long long*)nullptr, shadow_bits,
-                                        (const uint32_t*)nullptr, 0u);
+        if (n_tiles) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_SHADOW, true>), dim3(std::min<uint32_t>(n_tiles, ZR_SLOW_BLOCKS)), dim3(256), 0, s, P, tiles, n_tiles, slow, slow_cap, stats, slot,
+                                        (unsigned long long*)nullptr, shadow_bits, (const uint32_t*)nullptr, 0u);
     } else
         hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u, (uint4*)nullptr, 0u);
 }
@@ -3093,8 +3129,8 @@ void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B,
 void zr_launch_tile_slow_camera(const ZrPass& P, const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned, ZrDevStats* stats, int slot,
                                 unsigned long long* vis64, hipStream_t s)
 {
-    if (n_owned) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_GBUFFER, false>), dim3(n_owned), dim3(256), 0, s, P, owned_tiles, B.slow, B.slow_cap, stats, slot, vis64,
-                                    (uint32_t*)nullptr, B.wave_culled, B.n_waves);
+    if (n_owned) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_GBUFFER, false>), dim3(std::min<uint32_t>(n_owned, ZR_SLOW_BLOCKS)), dim3(256), 0, s, P, owned_tiles, n_owned, B.slow, B.slow_cap,
+                                    stats, slot, vis64, (uint32_t*)nullptr, B.wave_culled, B.n_waves);
 }
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, const float* unorm_lut, uint8_t* vis_now,

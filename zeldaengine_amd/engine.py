@@ -288,7 +288,7 @@ class Renderer:
         self._chk(self.L.zr_scene_clear(self.h))
 
     def set_limits(self, record_chunks=0, slow_triangles=0):
-        """Capacities of the triangle-record pool (chunks of 1024) and the clipped-triangle list; 0 = defaults."""
+        """Capacities of the triangle-record pool (chunks of 256 records: ZR_TPOOL_CHUNK, `zr_record_chunk_size()`) and the clipped-triangle list; 0 = defaults."""
         self._chk(self.L.zr_set_limits(self.h, record_chunks, slow_triangles))
 
     def object_count(self):
