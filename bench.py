@@ -78,14 +78,26 @@ def algorithmic_bytes(stats, mesh, n_inst, owned_px):
     }
 
 
-def load_profile(workload):
-    """The committed rocprofv3 summary (kernel stats + separate FETCH_SIZE / WRITE_SIZE / SQ passes), if it is for this workload."""
+def lib_sha16():
+    """First 16 hex digits of the SHA-256 of the renderer library this process loads: profiles/<tag>_pmc.json records the one its counters
+    were collected with, and a line whose library differs quotes no counter (a kernel change without a fresh profile would ship stale ones)."""
+    import hashlib
+    from zeldaengine_amd import engine
+    try:
+        return hashlib.sha256(open(engine.LIB_PATH, "rb").read()).hexdigest()[:16]
+    except Exception:      # noqa: BLE001
+        return None
+
+
+def load_profile(workload, sha):
+    """The committed rocprofv3 summary (kernel stats + separate FETCH_SIZE / WRITE_SIZE / SQ passes), if it is for this workload AND was
+    collected with this very build of the library."""
     try:
         idx = json.load(open(PROFILE_INDEX))
         prof = json.load(open(os.path.join(ROOT, "profiles", idx["pmc"])))
     except Exception:      # noqa: BLE001
         return None
-    if prof.get("workload") != workload:
+    if prof.get("workload") != workload or prof.get("lib_sha16") != sha:
         return None
     prof["_file"] = "profiles/" + idx["pmc"]
     try:        # the measured issue rates of this chip (tools/valu_calib), collected with the profile
@@ -222,6 +234,7 @@ def main():
         barrier()
         torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
+        timed_loop.local = el
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -229,6 +242,7 @@ def main():
         return el
 
     elapsed = timed_loop(dr, args.steps, args.warmup, uniforms_static)
+    elapsed_local = timed_loop.local
 
     # per-kernel means over the sampled frames (hipEvents on the stream each kernel runs on), per-frame GPU periods of ALL timed frames
     n_s = max(1, min(args.steps // interval, 64))
@@ -274,6 +288,17 @@ def main():
             extras["textured_note"] = "same scene with seven non-constant 512^2 material textures (trilinear + anisotropic sampling in the resolve), %d frames" % k
             dt.r.close()
 
+    rank_rows = None
+    if world > 1:
+        # every rank's own picture (wall time of its loop, GPU frame period, per-pass GPU times, survivors): the first hardware run of
+        # N > 1 must be readable without a second one
+        mine = {"rank": rank, "loop_ms_per_step": round(elapsed_local / args.steps * 1e3, 4),
+                "frame_gpu_ms_median": round(pct(periods, 0.5), 4) if periods else None,
+                "passes_ms": {k: round(v, 4) for k, v in times.items()},
+                "survivors": stats["survivors"], "covered_pixels": stats["covered_pixels"], "overflow": stats["overflow"]}
+        rows = [None] * world
+        dist.all_gather_object(rows, mine)
+        rank_rows = {"slowest": max(rows, key=lambda r: r["frame_gpu_ms_median"] or r["loop_ms_per_step"])["rank"], "per_rank": rows}
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = W * H * args.steps / elapsed / 1e6
@@ -287,7 +312,8 @@ def main():
         workload = workload_name(args.config, n_inst, stats["work_items"][1], W, H, len(cfg["point"]), args.cube_dim)
         if args.textured:
             workload += " [seven sampled 512^2 material images]"
-        prof = load_profile(workload) if world == 1 else None
+        sha = lib_sha16()
+        prof = load_profile(workload, sha) if world == 1 else None
         ptraffic = (prof or {}).get("kernels", {})
 
         def pass_traffic(p):
@@ -301,7 +327,7 @@ def main():
             # with a vector instruction in execution / parked on memory or a barrier / ready but not issued; mean resident waves per SIMD)
             iss = {k: ptraffic[k]["issue"] for k in KERNEL_OF_PASS[p] if k in ptraffic and "issue" in ptraffic[k]}
             if iss:
-                row["issue"] = {k: {f: v.get(f) for f in ("valu_active_frac", "wait_mem_frac", "wait_issue_frac", "waves_per_simd", "valu_simd_busy",
+                row["issue"] = {k: {f: v.get(f) for f in ("valu_active_frac", "wait_mem_frac", "wait_issue_frac", "waves_per_simd", "valu_simd_busy", "lanes_active_frac",
                                                           "valu_cycles_per_inst_simd")} for k, v in iss.items()}
             return row
 
@@ -318,6 +344,8 @@ def main():
             "achieved": round(gbs_gb, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs_gb / HBM_PEAK_GBS, 6),
             "traffic": int(sum(tr)) if prof and all(t is not None for t in tr) else None,
             "traffic_source": prof["_file"] if prof else None,
+            "traffic_note": None if prof else "no committed counter summary for this workload AND this build of the library (profiles/current.json; "
+                                              "tools/collect_profiles.sh makes one): counters are not quoted from another build",
             "kernel_ms": round(t_gb, 4), "algorithmic_bytes": int(b_gb),
             "algorithmic_bytes_formula": "28*W*H + 28*covered_px + mean(v*44 + t*3 + 96) * camera survivors (SURVEY 8d)",
             "timing": "HIP events on the library's camera lane, mean over %d sampled frames; the lane shares the GPU with the shadow pipeline and "
@@ -350,7 +378,7 @@ def main():
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload, "resolution": [W, H],
+            "config": {"workload": workload, "resolution": [W, H], "lib_sha16": sha,
                        "parallelism": ("screen super-tiles over %d ranks, %s, %s" % (world, "shadow casters i%%%d + MIN all-reduce" % world if args.split_shadow
                                        else "shadow map replicated (all-gather of the composite is the only collective)",
                                        "torch.distributed loop" if (args.python_dist or rehearsal) else
@@ -369,6 +397,16 @@ def main():
             "one_stream": serial,
             "stats": stats,
         }
+        # 'shaded' pixels: every pixel of the target goes through BaseLighting.frag; the ones that still hold the clear values of every GBuffer
+        # target take the shader's constant result for them (computed once per frame by the same kernel) - stated, not hidden
+        if W * H:
+            cf = stats["covered_pixels"] / float(owned_px if world > 1 else W * H)
+            line["covered_fraction"] = round(cf, 4)
+            line["value_covered_pixels"] = round(value * cf, 3) if world == 1 else None
+            line["covered_note"] = ("%d of the %d pixels hold scene geometry; the rest take the lighting shader's constant colour for a cleared GBuffer "
+                                    "(value-preserving); value_covered_pixels = covered pixels / frame time" % (stats["covered_pixels"], owned_px if world > 1 else W * H))
+        if rank_rows is not None:
+            line["ranks"] = rank_rows
         line.update(extras)
         if world == 1 and not args.no_cpu_baseline and args.config == 3:     # defined on the metric's workload only
             line["cpu_baseline"] = cpu_baseline(args.instances, args.cube_dim)

@@ -57,6 +57,8 @@ typedef struct zr_ctx zr_ctx;
 #define ZR_FLAG_MESHLET_BINS   128u /* -DZR_DIAG builds only (zr_create: ZR_ERR_UNSUPPORTED otherwise): camera pass through the meshlet-binned
                                      * rasteriser the shadow pass uses, instead of the triangle-binned one (A/B measurements) */
 #define ZR_FLAG_NO_RECT_CULL    64u /* tile_world > 1: do not reject meshlets by the rank's owned screen region before stage B (parity A/B) */
+#define ZR_FLAG_NO_LIST_REUSE  256u /* rebuild the passes' instance-level work lists every frame instead of only when camera / light matrices or the
+                                     * scene change (parity A/B; the lists are an acceleration structure, never pixels) */
 
 typedef struct zr_config {
     uint32_t width, height;   /* swapchain extent, ZE:78-79 (default 1920x1080) */

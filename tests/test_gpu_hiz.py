@@ -313,3 +313,43 @@ def test_big_scene_shadow_path_with_a_moving_light(oracle_lib, gpu_engine):
         st = g.stats()
         assert st["overflow"] == 0 and st["survivors"][0] > 0 and st["work_items"][0] == 70001
     g.close()
+
+
+@pytest.mark.gpu
+def test_work_lists_stand_only_while_camera_light_and_scene_do(oracle_lib, gpu_engine):
+    """The passes' instance-level work lists (k_cull_instances: scenes of >= 65 536 instances, and every tile-partitioned context) are
+    rebuilt only when the pass's matrices or the scene change.  70 000 instances through: two still frames (the second reuses both
+    lists), a moved camera (camera list rebuilt, shadow list kept), a still frame, a moved light (shadow list rebuilt), a changed scene
+    (both rebuilt: the work items are renumbered), a still frame - every frame against the oracle, and against a context that rebuilds
+    its lists every frame (ZR_FLAG_NO_LIST_REUSE)."""
+    W, H, SD = 320, 200, 256
+    mesh = scenes.uv_sphere(8, 4, 0.5)
+    inst = scenes.generate_instances(70000, 0.5, 9.0, 0.15, 0.5, seed=11)
+    o = oracle_lib.Oracle(W, H, SD)
+    g = gpu_engine.Renderer(W, H, SD)
+    h = gpu_engine.Renderer(W, H, SD, flags=abi.FLAG_NO_LIST_REUSE)
+    for r in (o, g, h):
+        r.set_cubemap(scenes.synthetic_cubemap(8))
+        r.object_add(r.mesh_create(*scenes.grid_plane(24.0, 4, 0.0)))
+        r.object_add(r.mesh_create(*mesh), None, inst)
+    d, p, s = _lights()
+    cams = [(7.0, 6.0, 5.0), (7.0, 6.0, 5.0), (-6.0, 7.5, 4.0), (-6.0, 7.5, 4.0), (-6.0, 7.5, 4.0), (-6.0, 7.5, 4.0), (-6.0, 7.5, 4.0)]
+    lights = [(20.0, 0.0, 20.0)] * 4 + [(14.0, 11.0, 17.0)] * 3
+    for i in range(7):
+        if i == 5:          # the scene changes under a still camera and light
+            extra = scenes.generate_instances(300, 1.0, 6.0, 0.3, 0.6, seed=12)
+            for r in (o, g, h):
+                r.object_add(r.mesh_create(*scenes.uv_sphere(12, 6, 0.5)), None, extra)
+        d[0]["Position"][:3] = lights[i]; d[0]["Direction"][:3] = lights[i]
+        cam = abi.make_camera(cams[i], (0.0, 0.0, 0.3))
+        for r in (o, g, h):
+            r.update_uniforms(cam, d, p, s, 0.0, 0.01 * i, 1.0)
+        o.render(0)
+        for r in (g, h):
+            r.render(); r.finish()
+        assert np.array_equal(o.shadowmap().view(np.uint32), g.shadowmap().view(np.uint32)), "shadow map, frame %d" % i
+        _identical(o, g, "frame %d (lists reused)" % i)
+        _identical(o, h, "frame %d (lists rebuilt)" % i)
+        sg, sh = g.stats(), h.stats()
+        assert sg["overflow"] == 0 and sg["survivors"] == sh["survivors"] and sg["covered_pixels"] == sh["covered_pixels"], (i, sg, sh)
+    g.close(); h.close()

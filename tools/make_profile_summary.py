@@ -87,6 +87,8 @@ def issue_rows(acc, dur_ns):
                 row["valu_simd_busy"] = round(g("SQ_ACTIVE_INST_VALU") / simd_quads, 4)
             if g("SQ_INSTS_VALU"):
                 row["valu_cycles_per_inst_simd"] = round(d * 1e-9 * CLOCK_HZ * SIMDS / g("SQ_INSTS_VALU"), 2)
+        if g("SQ_THREAD_CYCLES_VALU") is not None and g("SQ_ACTIVE_INST_VALU"):
+            row["lanes_active_frac"] = round(g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU")), 4)       # mean share of the 64 lanes live per vector instruction
         for c in ("SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM", "SQ_ACTIVE_INST_VMEM", "SQ_INSTS_SMEM", "SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_SCA"):
             if g(c) is not None:
                 row[c] = g(c)
@@ -159,7 +161,7 @@ fb, nf = per_frame(fetch, 2048.0)
 wb, nw = per_frame(write, 1024.0)
 vi, nv = per_frame(valu, 1.0)
 va, _ = per_frame(acc.get("SQ_ACTIVE_INST_VALU", {}), 1.0)
-summary = {"tag": tag, "workload": bench["config"]["workload"], "bench_value_under_rocprof": bench["value"],
+summary = {"tag": tag, "workload": bench["config"]["workload"], "lib_sha16": bench["config"].get("lib_sha16"), "bench_value_under_rocprof": bench["value"],
            "frames": {"fetch_pass": nf, "write_pass": nw, "sq_pass": nv},
            "hbm_bytes_per_frame": int(fb + wb), "valu_insts_per_frame": int(vi), "valu_active_quads_per_frame": int(va), "kernels": out,
            "method": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ issue set | SQ LDS / memory set in four separate passes of `python3 bench.py "

@@ -68,6 +68,7 @@ FLAG_SERIAL_PASSES = 16
 FLAG_PACKED_TILES = 32
 FLAG_NO_RECT_CULL = 64
 FLAG_MESHLET_BINS = 128
+FLAG_NO_LIST_REUSE = 256
 
 OK, ERR_ARG, ERR_DEVICE, ERR_OOM, ERR_PARSE, ERR_IO, ERR_STATE, ERR_OVERFLOW, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8
 

@@ -68,6 +68,10 @@ struct zr_ctx {
     std::vector<ZrSceneObject> objects;
     bool scene_dirty = true;
     ZrObject* d_objs = nullptr; uint32_t n_objs = 0, n_work = 0;
+    // this frame's two geometry passes (0 shadow, 1 camera), built at frame begin; the passes' work lists (k_cull_instances) are kept
+    // while the pass block and the scene stand still: list_key = the block the list on the device was built from
+    ZrPass pass[2]; bool pass_live[2] = { false, false }, list_reuse[2] = { false, false }, list_valid[2] = { false, false };
+    ZrPass list_key[2];
 
     XkUniformBufferMVP cam, shadow; XkView view; XkView* d_view = nullptr; bool frame_valid = false;
     uint32_t debug_view = 0;

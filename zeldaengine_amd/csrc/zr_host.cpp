@@ -823,6 +823,7 @@ static int finalize_scene(zr_ctx* c)
     for (const ZrObject& d : tab) for (int t = 0; t < 7; ++t) if (d.tex[t].data) c->any_images = true;
     for (const auto& o : c->objects) if (o.mixed_sizes) c->mixed_images = true;      // (the skydome's one image is sampled by itself)
     c->vis_history = false;         // work item numbering changed: last frame's visibility says nothing about this scene
+    c->list_valid[0] = c->list_valid[1] = false;      // ... and neither do the passes' work lists
     c->scene_dirty = false;
     return ZR_OK;
 }
@@ -1070,7 +1071,8 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
     P->inst_rank = mode == ZR_MODE_SHADOW ? c->shadow_rank : 0; P->inst_world = mode == ZR_MODE_SHADOW ? c->shadow_world : 1;
     P->images = !c->any_images ? 0u : c->mixed_images ? 2u : 1u;     // 1: every material with images has the packed form
     P->n_objects = c->n_objs; P->n_work = c->n_work; P->n_inst_total = c->n_inst_total; P->bin_capacity = c->bin_capacity;
-    // the instance-level pre-pass pays for itself on big scenes; small ones go straight to one wave per meshlet-instance
+    // the instance-level pre-pass pays for itself on big scenes; small ones go straight to a lane per meshlet-instance - unless this
+    // context owns a share of the tiles (below): then the pre-pass leaves a RANK-LOCAL list and the culls walk 1 / N of the scene
     P->use_worklist = c->n_inst_total >= 65536u ? 1u : 0u;
     P->debug_skip = c->env_skip;
     if (ZR_TILE == 32) {      // (both passes: the shadow pass uses it for the instance-level "no texel centre" reject)
@@ -1085,6 +1087,7 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
         P->pz_a = -pr[10]; P->pz_b = pr[14];       // z_view = -d: (p10 * -d + p14) / d
         P->sphere_ok = (centred && rigid3(u.Model) && rigid3(u.View) && finite16(P->VM)) ? 1u : 0u;
         P->rect_cull = (mode == ZR_MODE_GBUFFER && P->sphere_ok && c->cfg.tile_world > 1 && !(c->cfg.flags & ZR_FLAG_NO_RECT_CULL)) ? 1u : 0u;
+        if (P->rect_cull) P->use_worklist = 1u;
     }
     {
         static const float ident[16] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1 };
@@ -1198,6 +1201,16 @@ static int frame_begin(zr_ctx* c, hipStream_t s)
     hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
     if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
     if (c->view_dirty) { c->view_version++; c->view_dirty = false; }
+    // the frame's two geometry passes; a pass's work list on the device is rebuilt only when its block or the scene changed
+    uint32_t rebuild = 0;
+    for (int slot = 0; slot < 2; ++slot) {
+        ZrPass& P = c->pass[slot];
+        c->pass_live[slot] = build_pass(c, slot == 0 ? c->shadow : c->cam, slot == 0 ? ZR_MODE_SHADOW : ZR_MODE_GBUFFER, &P);
+        if (!c->pass_live[slot]) P.n_work = 0;      // no finite vertex: the pass is its clear
+        c->list_reuse[slot] = P.use_worklist && P.n_work != 0 && c->list_valid[slot] && memcmp(&c->list_key[slot], &P, sizeof P) == 0 &&
+                              !(c->cfg.flags & ZR_FLAG_NO_LIST_REUSE);
+        if (P.use_worklist && P.n_work != 0 && !c->list_reuse[slot]) { rebuild |= 1u << slot; c->list_key[slot] = P; c->list_valid[slot] = true; }
+    }
     const XkView* src = nullptr;
     uint32_t k = 0;
     if (c->view_uploaded[par] != c->view_version) {        // pinned ring slot: reused only after the kernel that read it last has run
@@ -1206,7 +1219,7 @@ static int frame_begin(zr_ctx* c, hipStream_t s)
         memcpy(&c->h_view_ring[k], &c->view, sizeof(XkView));
         src = &c->h_view_ring[k];
     }
-    zr_launch_frame_begin(c->d_stats, src, c->d_view, s);      // zeroes the statistics (the sticky overflow latch survives), uploads XkView
+    zr_launch_frame_begin(c->d_stats, src, c->d_view, rebuild, s);      // zeroes the statistics (the sticky overflow latch survives), uploads XkView
     if (src) { HIPCHK(c, hipEventRecord(c->view_ev[k], s)); c->view_uploaded[par] = c->view_version; }
     return ZR_OK;
 }
@@ -1215,9 +1228,7 @@ static int frame_begin(zr_ctx* c, hipStream_t s)
 static int shadow_pass(zr_ctx* c, hipStream_t s)
 {
     hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
-    ZrPass P;
-    const bool live = build_pass(c, c->shadow, ZR_MODE_SHADOW, &P);
-    if (!live) P.n_work = 0;      // no finite vertex: the pass is its clear
+    const ZrPass& P = c->pass[0];      // (built by frame_begin)
     c->last_work[0] = P.n_work;
     // clear depth 1.0 (ZE:3248): the previous frame's lighting pass already did it for the internal double-buffered map
     const int spar = (int)(c->frame_no & 1u);
@@ -1228,7 +1239,7 @@ static int shadow_pass(zr_ctx* c, hipStream_t s)
     if (!c->env_shadow_box) zr_launch_cull(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, c->raster_blocks * 4u, s);
     else
 #endif
-    zr_launch_cull_box(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, s);
+    zr_launch_cull_box(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, s, nullptr, nullptr, c->list_reuse[0]);
     bin_and_raster(c, P, Z, 0, c->sn_tiles, s);
     if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
     raster(c, P, Z, 0, s);
@@ -1242,9 +1253,7 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
 {
     hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
     if (ev) HIPCHK(c, hipEventRecord(ev[9], s));
-    ZrPass P;
-    const bool live = build_pass(c, c->cam, ZR_MODE_GBUFFER, &P);
-    if (!live) P.n_work = 0;
+    ZrPass P = c->pass[1];             // (built by frame_begin; the overlay fields are set below)
     c->last_work[1] = P.n_work;
     // Two-pass occlusion culling: round 1 draws the meshlet-instances that owned a pixel last frame, a Hi-Z pyramid of the
     // result rejects what it hides, round 2 draws the rest.  The depth test decides every pixel either way, so the frame does
@@ -1267,7 +1276,7 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
     if (!tri_bins) zr_launch_cull(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, c->raster_blocks * 4u, s);
     else
 #endif
-    zr_launch_cull_box(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, s, c->tb.sel, c->last_two_round ? Z.vis_prev : nullptr);
+    zr_launch_cull_box(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, s, c->tb.sel, c->last_two_round ? Z.vis_prev : nullptr, c->list_reuse[1]);
     if (hiz_on && P.use_worklist) HIPCHK(c, hipMemsetAsync(c->d_visflag[c->vis_cur], 0, c->n_work, s));     // else k_cull clears them
     const bool two = c->last_two_round;
     auto bin = [&](int slot) { if (!tri_bins) bin_and_raster(c, P, Z, slot, c->n_tiles, s); else if (slot == 2) tri_select(c, P, Z, slot, s); };

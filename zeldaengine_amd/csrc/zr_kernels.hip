@@ -1613,10 +1613,12 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
 // XkView from the pinned host ring slot into this frame's device copy.  (The runtime's own hipMemcpyAsync / hipMemsetAsync
 // paths cost two extra launches per frame, and the copy path stalls the host for milliseconds the first times it is used.)
 __global__ __launch_bounds__(1024) void k_frame_begin(uint32_t* __restrict__ stats, uint32_t n_stats, const uint32_t* __restrict__ view_src,
-                                                      uint32_t* __restrict__ view_dst, uint32_t n_view)
+                                                      uint32_t* __restrict__ view_dst, uint32_t n_view, uint32_t* __restrict__ n_vis_work, uint32_t rebuild_lists)
 {
     const uint32_t i0 = blockIdx.x * 1024u + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < n_stats) stats[threadIdx.x] = 0u;
+    // the passes' work lists (k_cull_instances) stand while camera / light matrices and scene do: only a list about to be rebuilt starts from 0
+    if (blockIdx.x == 0 && threadIdx.x < 2u && (rebuild_lists >> threadIdx.x & 1u)) n_vis_work[threadIdx.x] = 0u;
     if (view_src) for (uint32_t i = i0; i < n_view; i += gridDim.x * 1024u) view_dst[i] = view_src[i];
 }
 
@@ -3082,19 +3084,19 @@ void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint3
 }
 #endif
 void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, const ZrHiz& Z, ZrDevStats* stats,
-                        int slot, hipStream_t s, ZrBinEntry* sel, const uint8_t* vis_prev)
+                        int slot, hipStream_t s, ZrBinEntry* sel, const uint8_t* vis_prev, bool reuse_list)
 {
     if (P.n_work == 0) return;
     const dim3 gi((P.n_inst_total + ZR_CI_THREADS * ZR_CI_PER - 1u) / (ZR_CI_THREADS * ZR_CI_PER)), bi(ZR_CI_THREADS), b(256);
     const dim3 g(std::min<uint32_t>((P.n_work + 255u) / 256u, 8192u));
     if (P.mode == ZR_MODE_GBUFFER) {
         if (P.use_worklist) {
-            hipLaunchKernelGGL(k_cull_instances<ZR_MODE_GBUFFER>, gi, bi, 0, s, P, objs, work, stats, slot);
+            if (!reuse_list) hipLaunchKernelGGL(k_cull_instances<ZR_MODE_GBUFFER>, gi, bi, 0, s, P, objs, work, stats, slot);
             hipLaunchKernelGGL((k_cull_box<ZR_MODE_GBUFFER, true>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot, sel, vis_prev);
         } else hipLaunchKernelGGL((k_cull_box<ZR_MODE_GBUFFER, false>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot, sel, vis_prev);
     } else {
         if (P.use_worklist) {
-            hipLaunchKernelGGL(k_cull_instances<ZR_MODE_SHADOW>, gi, bi, 0, s, P, objs, work, stats, slot);
+            if (!reuse_list) hipLaunchKernelGGL(k_cull_instances<ZR_MODE_SHADOW>, gi, bi, 0, s, P, objs, work, stats, slot);
             hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, true>), g, b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot, (ZrBinEntry*)nullptr, (const uint8_t*)nullptr);
         } else hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, false>), g, b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot, (ZrBinEntry*)nullptr, (const uint8_t*)nullptr);
     }
@@ -3124,11 +3126,11 @@ void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* w
     hipLaunchKernelGGL(k_bin_fill, dim3((P.n_work + 1023) / 1024), dim3(1024), n_tiles * sizeof(uint32_t), s, P, objs, work, rects,
                        tile_offset, tile_cursor, bins, Z, stats, slot);
 }
-void zr_launch_frame_begin(ZrDevStats* stats, const XkView* view_src_pinned, XkView* view_dst, hipStream_t s)
+void zr_launch_frame_begin(ZrDevStats* stats, const XkView* view_src_pinned, XkView* view_dst, uint32_t rebuild_lists, hipStream_t s)
 {
     static_assert(sizeof(XkView) % 4 == 0 && offsetof(ZrDevStats, overflow_sticky) % 4 == 0, "dword copies");
     hipLaunchKernelGGL(k_frame_begin, dim3(view_src_pinned ? 4 : 1), dim3(1024), 0, s, (uint32_t*)stats, (uint32_t)(offsetof(ZrDevStats, overflow_sticky) / 4),
-                       (const uint32_t*)view_src_pinned, (uint32_t*)view_dst, (uint32_t)(sizeof(XkView) / 4));
+                       (const uint32_t*)view_src_pinned, (uint32_t*)view_dst, (uint32_t)(sizeof(XkView) / 4), stats->n_vis_work, rebuild_lists);
 }
 void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s)
 {

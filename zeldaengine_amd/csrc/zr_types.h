@@ -131,12 +131,13 @@ struct ZrDevStats {
     uint32_t overflow;
     uint32_t n_chunks[3];
     uint32_t chunk_counter[3];
-    uint32_t n_vis_work[2];          // meshlet-instances of the instances that passed the instance-level frustum test
     uint32_t hiz_culled;             // meshlet-instances rejected by the Hi-Z test
     uint32_t n_sel[3];               // triangle-binned camera pass: meshlet-instances selected for a round (slots as above)
     uint32_t n_slow[3];              //   triangles of the round that need the clipper / the 64-bit walk
     uint32_t pool_next[3], pool_used[3];   // record chunks taken from the pool: running (k_geom) / final
-    uint32_t overflow_sticky;        // LAST member: not cleared at frame begin; set with `overflow`, cleared by zr_finish when it reports it
+    uint32_t overflow_sticky;        // from here on: NOT cleared at frame begin.  Set with `overflow`, cleared by zr_finish when it reports it
+    uint32_t n_vis_work[2];          // meshlet-instances on the pass's work list (k_cull_instances); the list and its length stand while the
+                                     // pass's matrices and the scene do - k_frame_begin zeroes a slot when the host is about to rebuild it
 };
 
 // Two-pass Hi-Z occlusion culling of the camera pass (config 5; conservative).
@@ -224,10 +225,10 @@ void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B,
 void zr_launch_tile_slow_camera(const ZrPass& P, const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned, ZrDevStats* stats, int slot,
                                 unsigned long long* vis64, hipStream_t s);
 void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, const ZrHiz& Z, ZrDevStats* stats,
-                        int slot, hipStream_t s, ZrBinEntry* sel = nullptr, const uint8_t* vis_prev = nullptr);      // sel: round 1's list (camera)
+                        int slot, hipStream_t s, ZrBinEntry* sel = nullptr, const uint8_t* vis_prev = nullptr, bool reuse_list = false);      // sel: round 1's list (camera)
 void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
                         uint32_t* tile_cursor, ZrBinEntry* bins, const ZrHiz& Z, ZrDevStats* stats, int slot, hipStream_t s);
-void zr_launch_frame_begin(ZrDevStats* stats, const XkView* view_src_pinned, XkView* view_dst, hipStream_t s);
+void zr_launch_frame_begin(ZrDevStats* stats, const XkView* view_src_pinned, XkView* view_dst, uint32_t rebuild_lists, hipStream_t s);
 void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s);
 void zr_launch_fill64(unsigned long long* p, unsigned long long v, size_t n, hipStream_t s);
 void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4* chunk_tab,
