@@ -747,12 +747,19 @@ static zo_varyings zo_interp(const float b[3], const zo_v3 P[3], const zo_v3 N[3
     return r;
 }
 
+/* A texel as the filter sees it: sRGB channels decoded to linear (the format conversion comes before filtering), UNORM channels as
+ * their 8-bit CODE.  The filter (bilinear, trilinear, the anisotropic average) is linear, so the codes are filtered and the result is
+ * scaled by 1 / 255 ONCE (zo_unorm8_scale, at the end of zo_tex_sample) instead of every texel being divided first: the same real
+ * number, rounded once at the end - Vulkan leaves the precision of filtering to the implementation.  csrc states the same. */
 static void zo_tex_fetch(const zo_ctx* c, const zo_tex* t, int srgb, int level, int x, int y, float out[4])
 {
     uint32_t w = t->w >> level, h = t->h >> level; if (!w) w = 1; if (!h) h = 1;
     const uint8_t* p = t->mip[level] + ((size_t)y * w + (size_t)x) * 4;
-    for (int ch = 0; ch < 4; ++ch) out[ch] = zo_decode8(c, p[ch], srgb && ch < 3);
+    for (int ch = 0; ch < 4; ++ch) out[ch] = (srgb && ch < 3) ? c->srgb_lut[p[ch]] : (float)p[ch];
 }
+/* x / 255 for a filtered code x: fma(x, k_hi, x * k_lo) with k_hi + k_lo = 1 / 255 to 48 bits (exactly c / 255 rounded for an integer c) */
+static float zo_unorm8_scale(float x) { return fmaf(x, 0x1.010102p-8f, x * -0x1.fdfdfep-33f); }
+static void zo_tex_finish(int srgb, float out[4]) { for (int ch = 0; ch < 4; ++ch) if (!(srgb && ch < 3)) out[ch] = zo_unorm8_scale(out[ch]); }
 /* bilinear, REPEAT addressing (RHICreateSampler defaults, ZE:6523-6557) */
 static void zo_tex_bilinear(const zo_ctx* c, const zo_tex* t, int srgb, int level, float u, float v, float out[4])
 {
@@ -807,11 +814,11 @@ void zo_kat_aniso(float ax, float ay, float bx, float by, int levels, float out[
 }
 static void zo_tex_sample(const zo_ctx* c, const zo_tex* t, int srgb, float u, float v, float dudx, float dvdx, float dudy, float dvdy, float out[4])
 {
-    if (t->constant) { zo_tex_fetch(c, t, srgb, 0, 0, 0, out); return; }
+    if (t->constant) { zo_tex_fetch(c, t, srgb, 0, 0, 0, out); zo_tex_finish(srgb, out); return; }
     float W = (float)t->w, H = (float)t->h;
     int N, xmajor; float lambda;
     zo_aniso_setup(dudx * W, dvdx * H, dudy * W, dvdy * H, t->levels, &N, &lambda, &xmajor);
-    if (N == 1) { zo_tex_trilinear(c, t, srgb, lambda, u, v, out); return; }
+    if (N == 1) { zo_tex_trilinear(c, t, srgb, lambda, u, v, out); zo_tex_finish(srgb, out); return; }
     float du = xmajor ? dudx : dudy, dv = xmajor ? dvdx : dvdy;
     float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     for (int i = 1; i <= N; ++i) {
@@ -821,6 +828,7 @@ static void zo_tex_sample(const zo_ctx* c, const zo_tex* t, int srgb, float u, f
         for (int ch = 0; ch < 4; ++ch) acc[ch] += s[ch];
     }
     for (int ch = 0; ch < 4; ++ch) out[ch] = acc[ch] / (float)N;
+    zo_tex_finish(srgb, out);
 }
 
 /* ComputeNormal(fragPosition, fragTexCoord, fragNormal, texNormal), SH/Common.glsl:113-127 */

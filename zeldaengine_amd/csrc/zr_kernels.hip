@@ -1202,9 +1202,20 @@ __device__ __forceinline__ zf3 compute_normal(zf3 pos_dx, zf3 pos_dy, float s1, 
 
 // ---- material sampling: texture(sampler2D, uv) with LINEAR mag/min/mip, REPEAT (RHICreateSampler, ZE:6523-6557) ----
 __device__ __forceinline__ int tex_idx_clamp(float f, int hi) { f = __builtin_fminf(__builtin_fmaxf(f, 0.0f), (float)hi); return (int)f; }
-// `lut` = 512 floats: [0, 256) the sRGB decode table, [256, 512) c / 255 (UNORM load, the IEEE quotient formed once on the host): a
-// sampled texel costs a table read per channel instead of a division per channel (192 of them per pixel with seven images)
-__device__ __forceinline__ float tex_decode(uint32_t v, bool srgb, const float* __restrict__ lut) { return lut[(srgb ? 0u : 256u) + v]; }
+// A texel as the filter sees it: sRGB channels decoded to linear through `lut` (the format conversion comes before filtering), UNORM
+// channels as their 8-bit CODE.  The filter - bilinear, trilinear, the anisotropic average - is linear, so the codes are filtered and the
+// result is scaled by 1 / 255 ONCE per channel (tex_unorm8_scale, where a sample is finished) instead of every texel being divided first:
+// the same real number, rounded once at the end (Vulkan leaves the precision of filtering to the implementation; the oracle states the
+// same).  Decoding was two thirds of the sampled resolve's instructions: 8 texels x 13 channels per tap.
+__device__ __forceinline__ float tex_decode(uint32_t v, bool srgb, const float* __restrict__ lut) { return srgb ? lut[v] : (float)v; }
+// x / 255 of a filtered code: fma(x, k_hi, x * k_lo), k_hi + k_lo = 1 / 255 to 48 bits (c / 255 correctly rounded for an integer c)
+__device__ __forceinline__ float tex_unorm8_scale(float x) { return __builtin_fmaf(x, ZR_UNORM8_HI, x * ZR_UNORM8_LO); }
+__device__ __forceinline__ zf4 tex_finish(zf4 r, bool srgb)
+{
+    if (!srgb) { r.x = tex_unorm8_scale(r.x); r.y = tex_unorm8_scale(r.y); r.z = tex_unorm8_scale(r.z); }
+    r.w = tex_unorm8_scale(r.w);
+    return r;
+}
 __device__ __forceinline__ zf4 tex_fetch(const uint8_t* __restrict__ lvl, uint32_t w, int x, int y, bool srgb, const float* __restrict__ lut)
 {
     const uint32_t t = *(const uint32_t*)(lvl + ((size_t)y * w + (size_t)x) * 4);
@@ -1280,7 +1291,7 @@ __device__ __forceinline__ TexFootprint tex_footprint(const ZrTex& T, float dudx
 __device__ __forceinline__ zf4 tex_sample_footprint(const ZrTex& T, const TexFootprint& F, bool srgb, const float* __restrict__ lut, float u, float v)
 {
     const int N = F.N;
-    if (N == 1) return tex_trilinear(T, F.lambda, u, v, srgb, lut);
+    if (N == 1) return tex_finish(tex_trilinear(T, F.lambda, u, v, srgb, lut), srgb);
     zf4 acc; acc.x = acc.y = acc.z = acc.w = 0.0f;
     for (int i = 1; i <= N; ++i) {
         const float off = (float)i / (float)(N + 1) - 0.5f;
@@ -1288,7 +1299,7 @@ __device__ __forceinline__ zf4 tex_sample_footprint(const ZrTex& T, const TexFoo
         acc.x += s.x; acc.y += s.y; acc.z += s.z; acc.w += s.w;
     }
     zf4 r; r.x = acc.x / (float)N; r.y = acc.y / (float)N; r.z = acc.z / (float)N; r.w = acc.w / (float)N;
-    return r;
+    return tex_finish(r, srgb);
 }
 __device__ __forceinline__ zf4 tex_sample_image(const ZrTex& T, bool srgb, const float* __restrict__ lut,
                                              float u, float v, float dudx, float dvdx, float dudy, float dvdy)
@@ -1355,11 +1366,8 @@ __device__ __forceinline__ zr_f2 pk_decode2(const uint4& t, int j, const float* 
 {
     const uint32_t w = j < 2 ? t.x : j < 4 ? t.y : j < 6 ? t.z : t.w;
     const uint32_t v0 = (w >> (16 * (j & 1))) & 255u, v1 = (w >> (16 * (j & 1) + 8)) & 255u;
-    // UNORM: the IEEE quotient c / 255 of an integer c in 0..255 is fma(c, k_hi, c * k_lo) with k_hi + k_lo = 1 / 255 to 48 bits (all 256
-    // values: zr_create checks them against the table) - no division, and no LDS read whose 64 random addresses collide in the banks
-    zr_f2 c; c.x = (float)v0; c.y = (float)v1;
-    const zr_f2 hi = { ZR_UNORM8_HI, ZR_UNORM8_HI }, lo = { ZR_UNORM8_LO, ZR_UNORM8_LO };
-    zr_f2 r = __builtin_elementwise_fma(c, hi, c * lo);
+    // UNORM channels enter the filter as their codes (one byte -> float conversion each; scaled by 1 / 255 once, after the filter)
+    zr_f2 r; r.x = (float)v0; r.y = (float)v1;
     if (j == 0) { r.x = lut[v0]; r.y = lut[v1]; }          // bytes 0..2: base colour rgb, through the sRGB table
     if (j == 1) r.x = lut[v0];
     return r;
@@ -1404,7 +1412,8 @@ __device__ __forceinline__ void tex_sample_packed(const ZrTex& T, const float* _
 #pragma unroll
     for (int k = 0; k < ZR_PK_CHANNELS; ++k) {
         const float a = (k & 1) ? acc[k / 2].y : acc[k / 2].x;
-        out[k] = N > 1 ? a / (float)N : a;
+        const float m = N > 1 ? a / (float)N : a;
+        out[k] = k < 3 ? m : tex_unorm8_scale(m);          // channels 0..2 = base colour (sRGB, already linear); the rest are filtered codes
     }
 }
 #define ZR_MATERIAL_SLOTS 7
@@ -1453,7 +1462,7 @@ __device__ __forceinline__ void tex_sample_material(const ZrObject* __restrict__
         for (int s = 0; s < ZR_MATERIAL_SLOTS; ++s) {
             if (!(grp >> s & 1u)) continue;
             if (N > 1) { acc[s].x = acc[s].x / (float)N; acc[s].y = acc[s].y / (float)N; acc[s].z = acc[s].z / (float)N; acc[s].w = acc[s].w / (float)N; }
-            out[s] = acc[s];
+            out[s] = tex_finish(acc[s], s == 0);
         }
     }
 }
