@@ -271,7 +271,7 @@ static void free_mesh_buffers(ZrMesh& m)
 
 static void free_tri_bins(zr_ctx* c)
 {
-    dev_free(c->tb.sel); dev_free(c->tb.recA); dev_free(c->tb.recB); dev_free(c->tb.rtile); dev_free(c->tb.srtA); dev_free(c->tb.srtB);
+    dev_free(c->tb.sel); dev_free(c->tb.recA); dev_free(c->tb.recB); dev_free(c->tb.rtile); dev_free(c->tb.srtA); dev_free(c->tb.srtB); dev_free(c->tb.sidx);
     dev_free(c->tb.slow); dev_free(c->tb.chunk_fill); dev_free(c->tb.wave_culled);
 }
 
@@ -807,8 +807,12 @@ static int finalize_scene(zr_ctx* c)
         HIPCHK(c, dev_alloc(&c->tb.recA, (size_t)c->tb.n_chunks * ZR_TPOOL_CHUNK));
         HIPCHK(c, dev_alloc(&c->tb.recB, (size_t)c->tb.n_chunks * ZR_TPOOL_CHUNK));
         HIPCHK(c, dev_alloc(&c->tb.rtile, (size_t)c->tb.n_chunks * ZR_TPOOL_CHUNK));
+#if ZR_INDEX_LIST
+        HIPCHK(c, dev_alloc(&c->tb.sidx, c->tb.sorted_cap));
+#else
         HIPCHK(c, dev_alloc(&c->tb.srtA, c->tb.sorted_cap));
         HIPCHK(c, dev_alloc(&c->tb.srtB, c->tb.sorted_cap));
+#endif
         HIPCHK(c, dev_alloc(&c->tb.chunk_fill, c->tb.n_chunks));
         HIPCHK(c, hipMemset(c->tb.chunk_fill, 0, (size_t)c->tb.n_chunks * 4));
         HIPCHK(c, dev_alloc(&c->tb.wave_culled, c->tb.n_waves));

@@ -2134,19 +2134,24 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
                 const unsigned long long me = __ballot(emit);
                 if (!me) continue;
                 if (!rec_reserve(Wd, (uint32_t)__popcll(me), lane, B, stats, slot)) continue;
-                // count per tile: one add per (wave, tile), all of a step's in one instruction, and nobody waits for them
+                // count per tile: one add per (wave, tile), all of a step's in one instruction, and nobody waits for them.  The step's records
+                // are laid down tile by tile (a lane's place = its tile group's start + its rank in the group): a tile's records then form
+                // runs of whole cache lines in the chunk, which is what k_tile's gather through the index list reads
                 unsigned long long pend = me;
-                uint32_t cnt = 0;
+                uint32_t cnt = 0, mypos = 0, gbase = 0;
                 while (pend) {
                     const int leader = __builtin_ctzll(pend);
                     const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
                     const unsigned long long same = __ballot(emit && tile == tl) & pend;
-                    if ((int)lane == leader) cnt = (uint32_t)__popcll(same);
+                    const uint32_t ns = (uint32_t)__popcll(same);
+                    if ((int)lane == leader) cnt = ns;
+                    if (same >> lane & 1ull) mypos = gbase + (uint32_t)__popcll(same & lt);
+                    gbase += ns;
                     pend &= ~same;
                 }
                 if (cnt) atomicAdd(&tile_count[tile * ZR_TSTRIDE], cnt);
-                if (emit) rec_store(B, Wd.cur * ZR_TPOOL_CHUNK + Wd.fill + (uint32_t)__popcll(me & lt), r0, r1, r2, prim, tile, rtx, rty);
-                Wd.fill += (uint32_t)__popcll(me);
+                if (emit) rec_store(B, Wd.cur * ZR_TPOOL_CHUNK + Wd.fill + mypos, r0, r1, r2, prim, tile, rtx, rty);
+                Wd.fill += gbase;
             }
         }
     }
@@ -2216,7 +2221,9 @@ __global__ __launch_bounds__(256) void k_index(ZrTriBins B, const ZrDevStats* __
     for (uint32_t ch = blockIdx.x * 4u + wv; ch < used; ch += gridDim.x * 4u) {
         const uint32_t n = B.chunk_fill[ch], r0 = ch * ZR_TPOOL_CHUNK;
         bool have[NB]; uint32_t tile[NB], off[NB], rank[NB], cnt[NB], b[NB]; int first[NB];
+#if !ZR_INDEX_LIST
         uint4 qa[NB], qb[NB];
+#endif
 #pragma unroll
         for (uint32_t k = 0; k < NB; ++k) {
             const uint32_t j = k * 64u + lane;
@@ -2226,8 +2233,10 @@ __global__ __launch_bounds__(256) void k_index(ZrTriBins B, const ZrDevStats* __
 #pragma unroll
         for (uint32_t k = 0; k < NB; ++k) {
             const uint32_t j = k * 64u + lane;
+#if !ZR_INDEX_LIST
             qa[k] = make_uint4(0, 0, 0, 0); qb[k] = qa[k];
             if (have[k]) { qa[k] = B.recA[r0 + j]; qb[k] = B.recB[r0 + j]; }
+#endif
             off[k] = have[k] ? tile_offset[tile[k]] : 0u;
         }
 #pragma unroll
@@ -2248,7 +2257,11 @@ __global__ __launch_bounds__(256) void k_index(ZrTriBins B, const ZrDevStats* __
         for (uint32_t k = 0; k < NB; ++k) {
             const uint32_t bb = (uint32_t)__shfl((int)b[k], first[k]);
             const uint32_t dst = off[k] + bb + rank[k];
+#if ZR_INDEX_LIST
+            if (have[k] && dst < B.sorted_cap) B.sidx[dst] = r0 + k * 64u + lane;
+#else
             if (have[k] && dst < B.sorted_cap) { B.srtA[dst] = qa[k]; B.srtB[dst] = qb[k]; }
+#endif
         }
     }
 }
@@ -2296,7 +2309,12 @@ __global__ __launch_bounds__(256) void k_tile(ZrPass P, const uint4* __restrict_
             const uint32_t j = tid + (uint32_t)k * 256u;
             key[k] = 0u; rank[k] = 0u;
             if (j < n) {
+#if ZR_INDEX_LIST
+                const uint32_t src = B.sidx[rbeg + j];      // (a tile's records come in runs of one meshlet's: the gather reads whole cache lines mostly)
+                qa[k] = B.recA[src]; qb[k] = B.recB[src];
+#else
                 qa[k] = B.srtA[rbeg + j]; qb[k] = B.srtB[rbeg + j];
+#endif
                 const int X0 = (int)(short)(qa[k].x & 0xFFFFu), Y0 = (int)qa[k].x >> 16, X1 = (int)(short)(qa[k].z & 0xFFFFu), Y1 = (int)qa[k].z >> 16;
                 const int X2 = (int)(short)(qb[k].x & 0xFFFFu), Y2 = (int)qb[k].x >> 16;
                 const int x0 = max((imin3(X0, X1, X2) - 128 + 255) >> 8, 0), x1 = min((imax3(X0, X1, X2) - 128) >> 8, wx1);

@@ -201,11 +201,15 @@ struct ZrTriBins {
     uint32_t* chunk_fill;            //   records in each chunk
     uint32_t  n_waves;               // waves of the k_geom grid
     uint32_t* wave_culled;           // per wave: meshlets it dropped behind the Hi-Z pyramid (round 2)
-    uint4*    srtA; uint4* srtB;     // the drawn records moved into tile order by k_index: k_tile streams them
+    uint4*    srtA; uint4* srtB;     // ZR_INDEX_LIST 0: the drawn records moved into tile order by k_index: k_tile streams them
+    uint32_t* sidx;                  // ZR_INDEX_LIST 1: the records' positions in tile order (k_index writes 4 B per record, k_tile gathers 2 x 16 B)
     uint32_t  sorted_cap;
     uint4*    slow; uint32_t slow_cap;      // 4 x uint4 per slow triangle: three clip-space vertices, (prim, 0, 0, 0)
 };
 #define ZR_TPOOL_CHUNK 256u          // records per chunk of the record pool
+#ifndef ZR_INDEX_LIST
+#define ZR_INDEX_LIST 1              // k_index writes an index list instead of moving the records (see k_index)
+#endif
 #ifndef ZR_TSTRIDE
 #define ZR_TSTRIDE 4u                 // words between the per-tile record counters (and cursors) of neighbouring tiles
 #endif
