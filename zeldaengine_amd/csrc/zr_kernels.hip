@@ -2063,6 +2063,7 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
             bool alive = false, is_slow = false, hidden = false;
             int x0 = 0, y0 = 0, x1 = -1, y1 = -1;
             uint32_t i0 = 0, i1 = 0, i2 = 0;
+            uint32_t slow_rect = 0xFFFF0000u;         // the tiles a slow triangle can touch: (0, 0)-(255, 255) = every tile, or an unclipped one's snapped box
             if (t < tcount) {
                 i0 = tri_w[round].x & 255u; i1 = (tri_w[round].x >> 8) & 255u; i2 = (tri_w[round].x >> 16) & 255u;
                 r0 = vstage[wv][i0]; r1 = vstage[wv][i1]; r2 = vstage[wv][i2];
@@ -2074,6 +2075,7 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
                     const int bx0 = max((imin3(r0.x, r1.x, r2.x) - 128 + 255) >> 8, 0), bx1 = min((imax3(r0.x, r1.x, r2.x) - 128) >> 8, (int)P.W - 1);
                     const int by0 = max((imin3(r0.y, r1.y, r2.y) - 128 + 255) >> 8, 0), by1 = min((imax3(r0.y, r1.y, r2.y) - 128) >> 8, (int)P.H - 1);
                     cls = (A < 0 && bx0 <= bx1 && by0 <= by1) ? 2 : 0;
+                    if (cls == 2) slow_rect = (uint32_t)(bx0 / TILE) | (uint32_t)(by0 / TILE) << 8 | (uint32_t)(bx1 / TILE) << 16 | (uint32_t)(by1 / TILE) << 24;
                 }
                 if (cls == 2) is_slow = true;
                 else if (cls == 1) {
@@ -2112,7 +2114,7 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
                             const zf4 cc = zr_mat4_point(P.PVM, vs_position(zr3(pk.x, pk.y, pk.z), I, instanced));
                             B.slow[4u * pos + (uint32_t)k] = make_uint4(zr_f2u(cc.x), zr_f2u(cc.y), zr_f2u(cc.z), zr_f2u(cc.w));
                         }
-                        B.slow[4u * pos + 3u] = make_uint4(prim, 0u, 0u, 0u);
+                        B.slow[4u * pos + 3u] = make_uint4(prim, slow_rect, 0u, 0u);
                     } else { stats->overflow = 1u; stats->overflow_sticky = 1u; }
                 }
             }
@@ -2416,6 +2418,10 @@ __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __r
             const uint32_t j = jj < n_a ? jj : half + (jj - n_a);
             const uint4 q3 = slow[4u * j + 3u];
             if (BY_TILE && q3.y != tile) continue;          // (the meshlet-binned rasteriser lists a triangle once per tile of its meshlet)
+            if (!BY_TILE) {                                 // camera pass: the tiles the triangle's snapped box reaches (k_geom), or all of them
+                const uint32_t ttx = tile % P.tiles_x, tty = tile / P.tiles_x;
+                if (ttx < (q3.y & 255u) || tty < ((q3.y >> 8) & 255u) || ttx > ((q3.y >> 16) & 255u) || tty > (q3.y >> 24)) continue;
+            }
             const uint4 q0 = slow[4u * j], q1 = slow[4u * j + 1u], q2 = slow[4u * j + 2u];
             zf4 c0, c1, c2;
             c0.x = zr_u2f(q0.x); c0.y = zr_u2f(q0.y); c0.z = zr_u2f(q0.z); c0.w = zr_u2f(q0.w);
