@@ -113,7 +113,7 @@ struct zr_ctx {
     // streams of their own as well, so that frame N's lighting, frame N + 1's shadow pipeline and frame N + 1's camera pipeline all run
     // side by side and the host's stream only joins the finished frame.  Measured SLOWER than two lanes: the
     // camera pipeline - a chain of short kernels - is then starved by two heavy neighbours instead of one.
-    hipStream_t shadow_s = nullptr, light_s = nullptr; bool in_render = false, three_lanes = false, lanes3_now = false;
+    bool in_render = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cam = nullptr;
     unsigned long long* d_sky_keys = nullptr; uint32_t sky_object = 0;      // the skydome's key plane (k_sky_tiles) and its draw record
     // End of every frame's lighting pass, one (timing-enabled) event per frame in a ring: the next-but-one frame waits for it before
@@ -133,6 +133,9 @@ struct zr_ctx {
     uint2* d_pxrect = nullptr; float* d_zmin = nullptr; uint8_t* d_visflag[2] = { nullptr, nullptr };
     float* d_hiz = nullptr; ZrHiz hiz = {}; int vis_cur = 0; bool vis_history = false, last_two_round = false;
     ZrDevStats* d_stats = nullptr; ZrDevStats h_stats = {};
+    // The shadow pipeline's statistics / work counters (slot 0) live in a block of their own: the pipeline resets what it counts itself
+    // (k_scan), so it does not wait for the camera lane's k_frame_begin, and the camera lane does not wait for it.
+    ZrDevStats* d_sstats = nullptr; uint32_t list_rebuild_mask = 0;
     uint64_t last_work[2] = { 0, 0 };
 
     std::vector<uint8_t*> d_cube; CubeDesc cube = {}; uint32_t cube_dim = 0, cube_levels = 0;

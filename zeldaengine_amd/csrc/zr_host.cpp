@@ -28,8 +28,6 @@ hipError_t zr_sync_all(zr_ctx* c)
 {
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess && c->cam_s) e = hipStreamSynchronize(c->cam_s);
-    if (e == hipSuccess && c->shadow_s) e = hipStreamSynchronize(c->shadow_s);
-    if (e == hipSuccess && c->light_s) e = hipStreamSynchronize(c->light_s);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);      // (the host's stream may have been made to wait for the lanes)
     if (e == hipSuccess) e = zr_dist_sync(c);           // the native multi-GPU host's collective stream, if any
     return e;
@@ -124,6 +122,8 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     ok &= dev_alloc(&c->d_color, n) == hipSuccess;
     ok &= dev_alloc(&c->d_stats, 1) == hipSuccess;
     if (ok) ok &= hipMemset(c->d_stats, 0, sizeof(ZrDevStats)) == hipSuccess;
+    ok &= dev_alloc(&c->d_sstats, 1) == hipSuccess;       // the shadow pipeline's own block (see zr_ctx.h)
+    if (ok) ok &= hipMemset(c->d_sstats, 0, sizeof(ZrDevStats)) == hipSuccess;
     ok &= dev_alloc(&c->d_lut, 256) == hipSuccess;
     if (ok) ok &= hipMemcpy(c->d_lut, c->lut, sizeof c->lut, hipMemcpyHostToDevice) == hipSuccess;
     {
@@ -192,7 +192,6 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         if ((e = getenv("ZR_LIGHT_LIST_MIN"))) c->env_light_list_min = atoi(e);
         c->env_no_empty_px = getenv("ZR_NO_EMPTY_PIXEL") != nullptr;
         c->env_serial = getenv("ZR_SERIAL_PASSES") != nullptr;      // same frame, one stream (= ZR_FLAG_SERIAL_PASSES)
-        if ((e = getenv("ZR_LANES"))) c->three_lanes = atoi(e) >= 3;
         if ((e = getenv("ZR_SHADOW_BOX_CULL"))) c->env_shadow_box = atoi(e) != 0;
         if ((e = getenv("ZR_SHADOW_DEFER"))) c->env_shadow_defer = atoi(e) != 0;
 #endif
@@ -221,10 +220,6 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         else
 #endif
         ok &= hipStreamCreateWithPriority(&c->cam_s, hipStreamNonBlocking, greatest) == hipSuccess;
-        if (c->three_lanes) {      // (only then: every stream takes one of the process's few hardware queues)
-            ok &= hipStreamCreateWithPriority(&c->shadow_s, hipStreamNonBlocking, least) == hipSuccess;
-            ok &= hipStreamCreateWithPriority(&c->light_s, hipStreamNonBlocking, least) == hipSuccess;
-        }
     }
     ok &= hipEventCreateWithFlags(&c->ev_cam, hipEventDisableTiming) == hipSuccess;
     ok &= hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -302,7 +297,7 @@ extern "C" void zr_destroy(zr_ctx* c)
         dev_free(G.depth); dev_free(G.scene_color); dev_free(G.gA); dev_free(G.gB); dev_free(G.gC); dev_free(G.gD); dev_free(G.overlay);
         dev_free(c->d_shadow_b[b]); dev_free(c->d_view_b[b]); dev_free(c->d_empty_b[b]);
     }
-    dev_free(c->d_color); dev_free(c->d_stats); dev_free(c->d_lut); dev_free(c->d_unorm_lut); dev_free(c->d_sky_keys);
+    dev_free(c->d_color); dev_free(c->d_stats); dev_free(c->d_sstats); dev_free(c->d_lut); dev_free(c->d_unorm_lut); dev_free(c->d_sky_keys);
     dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles); dev_free(c->d_tile_map);
     for (auto& sc : c->sc) {
         dev_free(sc.tile_count); dev_free(sc.tile_offset); dev_free(sc.tile_cursor); dev_free(sc.chunk_offset);
@@ -312,8 +307,6 @@ extern "C" void zr_destroy(zr_ctx* c)
     if (c->h_view_ring) (void)hipHostFree(c->h_view_ring);
     for (auto& e : c->view_ev) if (e) (void)hipEventDestroy(e);
     if (c->cam_s) (void)hipStreamDestroy(c->cam_s);
-    if (c->shadow_s) (void)hipStreamDestroy(c->shadow_s);
-    if (c->light_s) (void)hipStreamDestroy(c->light_s);
     if (c->ev_cam) (void)hipEventDestroy(c->ev_cam);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1139,9 +1132,10 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
 static void bin_and_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, uint32_t n_tiles, hipStream_t s)
 {
     const zr_ctx::Scratch& sc = c->sc[slot ? 1 : 0];
-    zr_launch_bin_count(P, sc.work, sc.rects, sc.tile_count, Z, c->d_stats, slot, s);
-    zr_launch_scan(sc.tile_count, sc.tile_offset, sc.tile_cursor, sc.chunk_offset, sc.chunk_tab, c->chunk_capacity, n_tiles, c->bin_capacity, c->d_stats, slot, s);
-    zr_launch_bin_fill(P, c->d_objs, sc.work, sc.rects, sc.tile_offset, sc.tile_cursor, sc.bins, Z, c->d_stats, slot, s);
+    ZrDevStats* st = slot ? c->d_stats : c->d_sstats;        // the shadow pipeline (slot 0) has a block of its own
+    zr_launch_bin_count(P, sc.work, sc.rects, sc.tile_count, Z, st, slot, s);
+    zr_launch_scan(sc.tile_count, sc.tile_offset, sc.tile_cursor, sc.chunk_offset, sc.chunk_tab, c->chunk_capacity, n_tiles, c->bin_capacity, st, slot, s);
+    zr_launch_bin_fill(P, c->d_objs, sc.work, sc.rects, sc.tile_offset, sc.tile_cursor, sc.bins, Z, st, slot, s);
 }
 // One round of the triangle-binned camera pass: which meshlet-instances (k_select: timed with the cull), then their triangles as
 // records (k_geom), the records' places per tile (k_scan, k_index) and the tile kernel: those four are what the meshlet-binned
@@ -1168,7 +1162,7 @@ static void raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStre
     const bool shadow = slot == 0;
     const zr_ctx::Scratch& sc = c->sc[shadow ? 0 : 1];
     const bool defer = shadow && c->env_shadow_defer && c->d_slow0 != nullptr;
-    zr_launch_raster_chunks(P, c->d_objs, sc.chunk_tab, sc.bins, c->d_stats, slot, c->d_vis,
+    zr_launch_raster_chunks(P, c->d_objs, sc.chunk_tab, sc.bins, shadow ? c->d_sstats : c->d_stats, slot, c->d_vis,
                             (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), shadow ? c->shadow_blocks : c->raster_blocks, Z, s,
                             defer ? c->d_slow0 : nullptr, c->slow0_cap, c->d_sowned, c->sn_tiles);
 }
@@ -1195,12 +1189,9 @@ static int frame_begin(zr_ctx* c, hipStream_t s)
     if (c->view.LightsCount[3] != (int32_t)c->cube_levels) { c->view.LightsCount[3] = (int32_t)c->cube_levels; c->view_dirty = true; }
     const int par = (int)(c->frame_no & 1u);
     c->G = c->Gb[par]; c->d_shadow = c->d_shadow_b[par]; c->d_view = c->d_view_b[par]; c->d_empty_rgba = c->d_empty_b[par];
-    if (s != c->stream) {
-        // (two lanes: the shadow pipeline of the previous frame ran on the host's stream AFTER the lighting pass of the frame before
-        // it, so waiting for the former covers the latter - one barrier packet less on the lane the frame rate hangs on)
-        if (c->frame_no >= 2 && c->lanes3_now) HIPCHK(c, hipStreamWaitEvent(s, c->ev_end[(c->frame_no - 2) % zr_ctx::END_RING], 0));
-        HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0));
-    }
+    // (two lanes: this frame's copies of the double-buffered resources were last read by the lighting pass of two frames ago, on the
+    // host's stream.  Nothing else ties the lanes together here: the shadow pipeline keeps statistics of its own)
+    if (s != c->stream && c->frame_no >= 2) HIPCHK(c, hipStreamWaitEvent(s, c->ev_end[(c->frame_no - 2) % zr_ctx::END_RING], 0));
     c->timing_now = c->timing_interval != 0 && c->frame_no % c->timing_interval == 0;     // pass events cost ~6 us of stream bubble each
     hipEvent_t* ev = c->timing_now ? c->evr[c->sample_no % zr_ctx::EV_RING] : nullptr;
     if (ev) HIPCHK(c, hipEventRecord(ev[0], s));
@@ -1223,7 +1214,8 @@ static int frame_begin(zr_ctx* c, hipStream_t s)
         memcpy(&c->h_view_ring[k], &c->view, sizeof(XkView));
         src = &c->h_view_ring[k];
     }
-    zr_launch_frame_begin(c->d_stats, src, c->d_view, rebuild, s);      // zeroes the statistics (the sticky overflow latch survives), uploads XkView
+    c->list_rebuild_mask = rebuild;
+    zr_launch_frame_begin(c->d_stats, c->d_sstats, src, c->d_view, rebuild, s);      // zeroes the statistics (the sticky overflow latch survives), uploads XkView
     if (src) { HIPCHK(c, hipEventRecord(c->view_ev[k], s)); c->view_uploaded[par] = c->view_version; }
     return ZR_OK;
 }
@@ -1243,7 +1235,7 @@ static int shadow_pass(zr_ctx* c, hipStream_t s)
     if (!c->env_shadow_box) zr_launch_cull(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, c->raster_blocks * 4u, s);
     else
 #endif
-    zr_launch_cull_box(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, s, nullptr, nullptr, c->list_reuse[0]);
+    zr_launch_cull_box(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_sstats, 0, s, nullptr, nullptr, c->list_reuse[0]);
     bin_and_raster(c, P, Z, 0, c->sn_tiles, s);
     if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
     raster(c, P, Z, 0, s);
@@ -1352,15 +1344,20 @@ static int geometry_passes(zr_ctx* c)
     const bool lanes = !(c->cfg.flags & ZR_FLAG_SERIAL_PASSES) && c->cam_s != nullptr && !c->env_serial;
     int rc;
     c->camera_on_lane = false;
-    c->lanes3_now = lanes && c->in_render && c->three_lanes && c->shadow_s && c->light_s && !c->d_shadow_ext;
     if (lanes) {
-        hipStream_t ss = c->lanes3_now ? c->shadow_s : c->stream;
+        // Every event record / wait is a barrier packet, worth 5-10 us of bubble on the stream it sits on, and the host's stream
+        // (lighting -> shadow pipeline -> lighting ...) is the lane the frame rate hangs on: it waits for the camera lane once per frame
+        // (before the lighting pass) and for nothing else.  The shadow pipeline needs nothing of frame_begin's - its matrices are kernel
+        // arguments, its statistics a block of its own that it resets itself - except a zeroed list length in the (rare) frame that
+        // rebuilds the shadow pass's work list.
         rc = frame_begin(c, c->cam_s);
         if (rc != ZR_OK) return rc;
-        HIPCHK(c, hipEventRecord(c->ev_fork, c->cam_s));
-        HIPCHK(c, hipStreamWaitEvent(ss, c->ev_fork, 0));                 // the uniforms and the zeroed statistics
-        rc = shadow_pass(c, ss);
-        if (rc == ZR_OK) HIPCHK(c, hipEventRecord(c->ev_join, ss));
+        if (c->list_rebuild_mask & 1u) {
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->cam_s));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fork, 0));
+        }
+        rc = shadow_pass(c, c->stream);
+        if (rc == ZR_OK && !c->in_render) HIPCHK(c, hipEventRecord(c->ev_join, c->stream));      // (zr_stream_wait_shadow: a host that puts a collective behind the shadow pass)
         if (rc == ZR_OK) rc = gbuffer_pass(c, c->cam_s);
         if (rc == ZR_OK) { HIPCHK(c, hipEventRecord(c->ev_cam, c->cam_s)); c->camera_on_lane = true; }
     } else {
@@ -1447,14 +1444,12 @@ extern "C" int zr_render_lighting(zr_ctx* c)
     if (!c) return ZR_ERR_ARG;
     if (c->stage != 2) return zr_fail(c, ZR_ERR_STATE, "zr_render_lighting out of order");
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t ls = (c->lanes3_now && c->camera_on_lane) ? c->light_s : c->stream;
-    if (ls != c->stream) HIPCHK(c, hipStreamWaitEvent(ls, c->ev_join, 0));      // this frame's shadow pipeline (on its own lane)
+    hipStream_t ls = c->stream;
     int rc = empty_pixel_pass(c, ls);              // the shadow map (possibly reduced over ranks by the host) is final only now
     if (rc == ZR_OK && c->camera_on_lane) HIPCHK(c, hipStreamWaitEvent(ls, c->ev_cam, 0));
     const uint64_t k = c->frame_no;
     if (rc == ZR_OK) rc = lighting_pass(c, ls);
-    // whatever the host enqueues on its stream next is ordered after the finished frame
-    if (rc == ZR_OK && ls != c->stream) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_end[k % zr_ctx::END_RING], 0));
+    (void)k;
     return rc;
 }
 
@@ -1504,9 +1499,17 @@ extern "C" int zr_finish(zr_ctx* c)
     HIPCHK(c, zr_sync_all(c));
     if (c->rendered) {
         HIPCHK(c, hipMemcpy(&c->h_stats, c->d_stats, sizeof(ZrDevStats), hipMemcpyDeviceToHost));
+        {   // the shadow pipeline's block: its slot-0 counters and its overflow latch belong to the frame's statistics
+            ZrDevStats sh;
+            HIPCHK(c, hipMemcpy(&sh, c->d_sstats, sizeof(ZrDevStats), hipMemcpyDeviceToHost));
+            c->h_stats.survivors[0] = sh.survivors[0]; c->h_stats.bin_entries[0] = sh.bin_entries[0]; c->h_stats.n_chunks[0] = sh.n_chunks[0];
+            c->h_stats.n_slow[0] = sh.n_slow[0]; c->h_stats.n_vis_work[0] = sh.n_vis_work[0];
+            c->h_stats.overflow |= sh.overflow; c->h_stats.overflow_sticky |= sh.overflow_sticky;
+        }
         c->h_stats.covered_shadow = 0;
         if (c->h_stats.overflow_sticky) {     // latched by ANY frame since the last zr_finish, not only the newest one
             HIPCHK(c, hipMemset(&c->d_stats->overflow_sticky, 0, sizeof(uint32_t)));
+            HIPCHK(c, hipMemset(&c->d_sstats->overflow_sticky, 0, sizeof(uint32_t)));
             c->h_stats.overflow = 1u;
             return zr_fail(c, ZR_ERR_OVERFLOW, "tile bin list overflow: a frame since the last zr_finish is incomplete");
         }
@@ -1601,7 +1604,10 @@ extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out)
         (void)hipMemcpy(&c->d_stats->covered_shadow, &zero, 4, hipMemcpyHostToDevice);
         zr_launch_count_shadow((const uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), (size_t)c->SD * c->SD, c->d_stats, c->stream);
         (void)hipStreamSynchronize(c->stream);
+        const ZrDevStats keep = c->h_stats;      // (zr_finish merged the shadow pipeline's block into it)
         (void)hipMemcpy(&c->h_stats, c->d_stats, sizeof(ZrDevStats), hipMemcpyDeviceToHost);
+        c->h_stats.survivors[0] = keep.survivors[0]; c->h_stats.bin_entries[0] = keep.bin_entries[0]; c->h_stats.n_chunks[0] = keep.n_chunks[0];
+        c->h_stats.n_slow[0] = keep.n_slow[0]; c->h_stats.overflow |= keep.overflow;
     }
 #ifdef ZR_DIAG
     if (getenv("ZR_DUMP_STATS")) {     // diagnostics: the raw device block

@@ -857,7 +857,10 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
         stats->bin_entries[slot] = part[1023];
         stats->n_chunks[slot] = min(cpart[1023], chunk_cap);
         stats->chunk_counter[slot] = 0;
-        if (part[1023] > capacity) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
+        // what the kernels after this one accumulate for the pass starts from zero here: the shadow pipeline's block is not touched by
+        // k_frame_begin (the pipeline does not wait for the camera lane)
+        stats->survivors[slot] = 0; stats->n_slow[slot] = 0; stats->overflow = part[1023] > capacity ? 1u : 0u;
+        if (part[1023] > capacity) stats->overflow_sticky = 1u;
     }
 }
 
@@ -1114,8 +1117,8 @@ __device__ __forceinline__ zf4 lerp4(zf4 in, zf4 out, float t)
 }
 // T and the keys are tile-relative (see k_raster_chunks): (ox, oy) = the tile's origin in sub-pixel units is taken off after projecting.
 template <int MODE>
-__device__ __noinline__ void raster_clipped(zf4 c0, zf4 c1, zf4 c2, uint32_t prim, TileCtx T, float hw, float hh, int ox, int oy,
-                                            unsigned long long* keys64, uint32_t* keys32)
+__device__ __forceinline__ void raster_clipped_body(zf4 c0, zf4 c1, zf4 c2, uint32_t prim, TileCtx T, float hw, float hh, int ox, int oy,
+                                                    unsigned long long* keys64, uint32_t* keys32)
 {
     zf4 a[10], b[10];
     int na = 3;
@@ -1141,6 +1144,14 @@ __device__ __noinline__ void raster_clipped(zf4 c0, zf4 c1, zf4 c2, uint32_t pri
         raster_sub<MODE, false>(s0, sp, sn, prim, T, keys64, keys32);
         sp = sn;
     }
+}
+// (a call in the rasterisers' loops - their register budget must not carry the clipper's; inlined in k_tile_slow, whose own budget is set
+// so that it finds room beside the shadow rasteriser)
+template <int MODE>
+__device__ __noinline__ void raster_clipped(zf4 c0, zf4 c1, zf4 c2, uint32_t prim, TileCtx T, float hw, float hh, int ox, int oy,
+                                            unsigned long long* keys64, uint32_t* keys32)
+{
+    raster_clipped_body<MODE>(c0, c1, c2, prim, T, hw, hh, ox, oy, keys64, keys32);
 }
 
 // ------------------------------------------------------------------------------------------------ GBuffer resolve
@@ -1622,12 +1633,15 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
 // XkView from the pinned host ring slot into this frame's device copy.  (The runtime's own hipMemcpyAsync / hipMemsetAsync
 // paths cost two extra launches per frame, and the copy path stalls the host for milliseconds the first times it is used.)
 __global__ __launch_bounds__(1024) void k_frame_begin(uint32_t* __restrict__ stats, uint32_t n_stats, const uint32_t* __restrict__ view_src,
-                                                      uint32_t* __restrict__ view_dst, uint32_t n_view, uint32_t* __restrict__ n_vis_work, uint32_t rebuild_lists)
+                                                      uint32_t* __restrict__ view_dst, uint32_t n_view, uint32_t* __restrict__ n_vis_shadow,
+                                                      uint32_t* __restrict__ n_vis_camera, uint32_t rebuild_lists)
 {
     const uint32_t i0 = blockIdx.x * 1024u + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < n_stats) stats[threadIdx.x] = 0u;
     // the passes' work lists (k_cull_instances) stand while camera / light matrices and scene do: only a list about to be rebuilt starts from 0
-    if (blockIdx.x == 0 && threadIdx.x < 2u && (rebuild_lists >> threadIdx.x & 1u)) n_vis_work[threadIdx.x] = 0u;
+    // (the shadow pass's length sits in the shadow pipeline's own block: a frame that rebuilds it makes that pipeline wait for this kernel)
+    if (blockIdx.x == 0 && threadIdx.x == 0u && (rebuild_lists & 1u)) *n_vis_shadow = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 1u && (rebuild_lists & 2u)) *n_vis_camera = 0u;
     if (view_src) for (uint32_t i = i0; i < n_view; i += gridDim.x * 1024u) view_dst[i] = view_src[i];
 }
 
@@ -2446,6 +2460,62 @@ __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __r
     }
 }
 
+// The camera pass's slow triangles (both rounds: round 1's sit in the first half of the list, round 2's in the second; slot = 2 after a
+// two-round frame, 1 after a one-round one).  The usual frame has none - and this launch sits on the camera lane's critical path, right
+// where the shadow rasteriser's persistent workgroups hold every CU down to ~6 KB of LDS and 80 VGPRs per SIMD: with a tile's 8 KB of keys
+// and the clipper's 118 registers the empty launch waited 35-50 us for room (timeline of the two-lane frame).  Hence: half a tile of
+// keys (32 x 16 pixels, 4 KB), the clipper inlined under this kernel's own budget of six waves per SIMD (<= 80 VGPRs, the rest spills:
+// the path is rare), a small grid that strides over (tile, half) pairs.  Also folds k_geom's per-wave Hi-Z tallies into the statistics.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
+void k_tile_slow_cam(ZrPass P, const uint32_t* __restrict__ owned_tiles, uint32_t n_owned, const uint4* __restrict__ slow, uint32_t slow_cap,
+                     ZrDevStats* __restrict__ stats, int slot, unsigned long long* __restrict__ vis64,
+                     const uint32_t* __restrict__ wave_culled, uint32_t n_waves)
+{
+    constexpr int HALF = TILE / 2;
+    __shared__ unsigned long long keys64[TILE * HALF];
+    const uint32_t half_cap = slow_cap / 2u;
+    const uint32_t n_a = min(stats->n_slow[1], half_cap), n_b = slot == 2 ? min(stats->n_slow[2], half_cap) : 0u;
+    if (slot == 2 && wave_culled) {
+        uint32_t nc = 0;
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_waves; i += gridDim.x * 256u) nc += wave_culled[i];
+        nc = (uint32_t)wave_sum((int)nc);
+        if ((threadIdx.x & 63u) == 0u && nc) { atomicAdd(&stats->hiz_culled, nc); atomicSub(&stats->survivors[2], nc); }
+    }
+    if (n_a + n_b == 0u) return;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t it = blockIdx.x; it < 2u * n_owned; it += gridDim.x) {
+        const uint32_t tile = owned_tiles[it >> 1];
+        const int tpx0 = (int)(tile % P.tiles_x) * TILE, tpy0 = (int)(tile / P.tiles_x) * TILE + (int)(it & 1u) * HALF;
+        if (tpy0 >= (int)P.H) continue;
+        for (uint32_t i = tid; i < (uint32_t)(TILE * HALF); i += 256u) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
+        __syncthreads();
+        TileCtx T;      // relative to the half tile's first pixel; T.H ends the rows after HALF
+        T.px0 = 0; T.py0 = 0; T.W = (int)P.W - tpx0; T.H = min((int)P.H - tpy0, HALF);
+        const uint32_t ttx = tile % P.tiles_x, tty = tile / P.tiles_x;
+        for (uint32_t jj = tid; jj < n_a + n_b; jj += 256u) {
+            const uint32_t j = jj < n_a ? jj : half_cap + (jj - n_a);
+            const uint4 q3 = slow[4u * j + 3u];
+            // the tiles the triangle's snapped box reaches (k_geom), or all of them
+            if (ttx < (q3.y & 255u) || tty < ((q3.y >> 8) & 255u) || ttx > ((q3.y >> 16) & 255u) || tty > (q3.y >> 24)) continue;
+            const uint4 q0 = slow[4u * j], q1 = slow[4u * j + 1u], q2 = slow[4u * j + 2u];
+            zf4 c0, c1, c2;
+            c0.x = zr_u2f(q0.x); c0.y = zr_u2f(q0.y); c0.z = zr_u2f(q0.z); c0.w = zr_u2f(q0.w);
+            c1.x = zr_u2f(q1.x); c1.y = zr_u2f(q1.y); c1.z = zr_u2f(q1.z); c1.w = zr_u2f(q1.w);
+            c2.x = zr_u2f(q2.x); c2.y = zr_u2f(q2.y); c2.z = zr_u2f(q2.z); c2.w = zr_u2f(q2.w);
+            raster_clipped_body<ZR_MODE_GBUFFER>(c0, c1, c2, q3.x, T, P.hw, P.hh, tpx0 * 256, tpy0 * 256, keys64, nullptr);
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < (uint32_t)(TILE * HALF); i += 256u) {
+            const int px = tpx0 + (int)(i & (TILE - 1)), py = tpy0 + (int)(i / TILE);
+            if (px >= (int)P.W || py >= (int)P.H) continue;
+            const size_t p = (size_t)py * P.W + (size_t)px;
+            const unsigned long long k = keys64[i];
+            if ((uint32_t)k != ZR_EMPTY_PRIM && k < vis64[p]) atomicMin(&vis64[p], k);
+        }
+        __syncthreads();
+    }
+}
+
 // The skydome pass's visibility (ZE:3681-3691, SH/Skydome.vert): the dome's triangles against each other, LESS in draw order, into a key
 // plane of their own (depth bits << 32 | triangle).  Workgroup per owned tile; every thread takes its share of the dome's few hundred
 // triangles through the general path (classification, clipper, 64-bit walk: the dome surrounds the eye, most of its triangles cross
@@ -3159,11 +3229,11 @@ void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* w
     hipLaunchKernelGGL(k_bin_fill, dim3((P.n_work + 1023) / 1024), dim3(1024), n_tiles * sizeof(uint32_t), s, P, objs, work, rects,
                        tile_offset, tile_cursor, bins, Z, stats, slot);
 }
-void zr_launch_frame_begin(ZrDevStats* stats, const XkView* view_src_pinned, XkView* view_dst, uint32_t rebuild_lists, hipStream_t s)
+void zr_launch_frame_begin(ZrDevStats* stats, ZrDevStats* shadow_stats, const XkView* view_src_pinned, XkView* view_dst, uint32_t rebuild_lists, hipStream_t s)
 {
     static_assert(sizeof(XkView) % 4 == 0 && offsetof(ZrDevStats, overflow_sticky) % 4 == 0, "dword copies");
     hipLaunchKernelGGL(k_frame_begin, dim3(view_src_pinned ? 4 : 1), dim3(1024), 0, s, (uint32_t*)stats, (uint32_t)(offsetof(ZrDevStats, overflow_sticky) / 4),
-                       (const uint32_t*)view_src_pinned, (uint32_t*)view_dst, (uint32_t)(sizeof(XkView) / 4), stats->n_vis_work, rebuild_lists);
+                       (const uint32_t*)view_src_pinned, (uint32_t*)view_dst, (uint32_t)(sizeof(XkView) / 4), &shadow_stats->n_vis_work[0], &stats->n_vis_work[1], rebuild_lists);
 }
 void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s)
 {
@@ -3225,8 +3295,8 @@ void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B,
 void zr_launch_tile_slow_camera(const ZrPass& P, const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned, ZrDevStats* stats, int slot,
                                 unsigned long long* vis64, hipStream_t s)
 {
-    if (n_owned) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_GBUFFER, false>), dim3(std::min<uint32_t>(n_owned, ZR_SLOW_BLOCKS)), dim3(256), 0, s, P, owned_tiles, n_owned, B.slow, B.slow_cap,
-                                    stats, slot, vis64, (uint32_t*)nullptr, B.wave_culled, B.n_waves);
+    if (n_owned) hipLaunchKernelGGL(k_tile_slow_cam, dim3(std::min<uint32_t>(2u * n_owned, ZR_SLOW_BLOCKS)), dim3(256), 0, s, P, owned_tiles, n_owned, B.slow, B.slow_cap,
+                                    stats, slot, vis64, B.wave_culled, B.n_waves);
 }
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, const float* unorm_lut, uint8_t* vis_now,

@@ -232,7 +232,7 @@ void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, u
                         int slot, hipStream_t s, ZrBinEntry* sel = nullptr, const uint8_t* vis_prev = nullptr, bool reuse_list = false);      // sel: round 1's list (camera)
 void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
                         uint32_t* tile_cursor, ZrBinEntry* bins, const ZrHiz& Z, ZrDevStats* stats, int slot, hipStream_t s);
-void zr_launch_frame_begin(ZrDevStats* stats, const XkView* view_src_pinned, XkView* view_dst, uint32_t rebuild_lists, hipStream_t s);
+void zr_launch_frame_begin(ZrDevStats* stats, ZrDevStats* shadow_stats, const XkView* view_src_pinned, XkView* view_dst, uint32_t rebuild_lists, hipStream_t s);
 void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s);
 void zr_launch_fill64(unsigned long long* p, unsigned long long v, size_t n, hipStream_t s);
 void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4* chunk_tab,
