@@ -1154,8 +1154,8 @@ static void tri_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hip
     zr_launch_geom(P, Z, c->tb, sc.tile_count, c->d_stats, slot, c->d_vis, s);
     zr_launch_scan_tri(sc.tile_count, sc.tile_offset, sc.chunk_tab, c->chunk_capacity, c->n_tiles, c->tb, c->d_stats, slot, s);
     zr_launch_index(c->tb, sc.tile_offset, sc.tile_cursor, c->d_stats, slot, s);
-    zr_launch_tile(P, sc.chunk_tab, c->tb, sc.tile_count, sc.tile_cursor, c->n_tiles, c->d_stats, slot, c->d_vis, c->raster_blocks, s);
-    if (last) zr_launch_tile_slow_camera(P, c->tb, c->d_owned, c->n_owned, c->d_stats, slot, c->d_vis, s);
+    // (the frame's last round also draws the slow triangles of both rounds: k_tile<LAST>)
+    zr_launch_tile(P, sc.chunk_tab, c->tb, sc.tile_count, sc.tile_cursor, c->n_tiles, c->d_stats, slot, c->d_vis, c->raster_blocks, s, last, c->d_owned, c->n_owned);
 }
 static void raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s)
 {

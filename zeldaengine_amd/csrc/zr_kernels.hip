@@ -2291,10 +2291,15 @@ __global__ __launch_bounds__(256) void k_index(ZrTriBins B, const ZrDevStats* __
 // records therefore go through a counting sort in LDS first, keyed by the clipped box (height, then width, each capped at 15): the
 // waves then walk batches of like boxes (31.9 iterations in the same simulation).  The order of the keys' minimum does not matter.
 #define ZR_TSORT_BINS 256u
-template <int MODE>
-__global__ __launch_bounds__(256) void k_tile(ZrPass P, const uint4* __restrict__ chunk_tab, ZrTriBins B, uint32_t* __restrict__ tile_count,
-                                              uint32_t* __restrict__ tile_cursor, uint32_t n_tiles, ZrDevStats* __restrict__ stats, int slot,
-                                              unsigned long long* __restrict__ vis64)
+// LAST (the frame's last round): the workgroups then also draw the frame's SLOW triangles (clipped, or with an edge of 64 px or more:
+// round 1's in the first half of the list, round 2's in the second) - the usual frame has none, and as a kernel of its own that check
+// cost the camera lane 25-50 us of waiting for room beside the shadow rasteriser - and fold k_geom's per-wave Hi-Z tallies into the
+// statistics.  The clipper is inlined under this kernel's own register budget (it spills; the path is rare).
+template <int MODE, bool LAST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
+void k_tile(ZrPass P, const uint4* __restrict__ chunk_tab, ZrTriBins B, uint32_t* __restrict__ tile_count,
+            uint32_t* __restrict__ tile_cursor, uint32_t n_tiles, ZrDevStats* __restrict__ stats, int slot,
+            unsigned long long* __restrict__ vis64, const uint32_t* __restrict__ owned_tiles, uint32_t n_owned)
 {
     static_assert(ZR_TCHUNK == 512u && TILE == 32, "two records per thread; box coordinates in 5 bits");
     __shared__ unsigned long long keys64[TILE_PIX];
@@ -2387,6 +2392,48 @@ __global__ __launch_bounds__(256) void k_tile(ZrPass P, const uint4* __restrict_
         __syncthreads();
         unit = cur_unit;
     }
+    if (LAST) {
+        if (slot == 2) {        // the meshlets round 2's k_geom dropped behind the pyramid: per-wave counts, strided over this grid
+            uint32_t nc = 0;
+            for (uint32_t i = blockIdx.x * 256u + tid; i < B.n_waves; i += gridDim.x * 256u) nc += B.wave_culled[i];
+            nc = (uint32_t)wave_sum((int)nc);
+            if (lane == 0u && nc) { atomicAdd(&stats->hiz_culled, nc); atomicSub(&stats->survivors[2], nc); }
+        }
+        const uint32_t half_cap = B.slow_cap / 2u;
+        const uint32_t n_a = min(stats->n_slow[1], half_cap), n_b = slot == 2 ? min(stats->n_slow[2], half_cap) : 0u;
+        if (n_a + n_b == 0u) return;
+        __syncthreads();
+        for (uint32_t ti = blockIdx.x; ti < n_owned; ti += gridDim.x) {
+            const uint32_t tile = owned_tiles[ti];
+            for (uint32_t i = tid; i < TILE_PIX; i += 256u) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
+            __syncthreads();
+            const int tpx0 = (int)(tile % P.tiles_x) * TILE, tpy0 = (int)(tile / P.tiles_x) * TILE;
+            TileCtx T;
+            T.px0 = 0; T.py0 = 0; T.W = (int)P.W - tpx0; T.H = (int)P.H - tpy0;
+            const uint32_t ttx = tile % P.tiles_x, tty = tile / P.tiles_x;
+            for (uint32_t jj = tid; jj < n_a + n_b; jj += 256u) {
+                const uint32_t j = jj < n_a ? jj : half_cap + (jj - n_a);
+                const uint4 q3 = B.slow[4u * j + 3u];
+                // the tiles the triangle's snapped box reaches (k_geom), or all of them
+                if (ttx < (q3.y & 255u) || tty < ((q3.y >> 8) & 255u) || ttx > ((q3.y >> 16) & 255u) || tty > (q3.y >> 24)) continue;
+                const uint4 q0 = B.slow[4u * j], q1 = B.slow[4u * j + 1u], q2 = B.slow[4u * j + 2u];
+                zf4 c0, c1, c2;
+                c0.x = zr_u2f(q0.x); c0.y = zr_u2f(q0.y); c0.z = zr_u2f(q0.z); c0.w = zr_u2f(q0.w);
+                c1.x = zr_u2f(q1.x); c1.y = zr_u2f(q1.y); c1.z = zr_u2f(q1.z); c1.w = zr_u2f(q1.w);
+                c2.x = zr_u2f(q2.x); c2.y = zr_u2f(q2.y); c2.z = zr_u2f(q2.z); c2.w = zr_u2f(q2.w);
+                raster_clipped_body<MODE>(c0, c1, c2, q3.x, T, P.hw, P.hh, tpx0 * 256, tpy0 * 256, keys64, nullptr);
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
+                const int px = tpx0 + (int)(i & (TILE - 1)), py = tpy0 + (int)(i / TILE);
+                if (px >= (int)P.W || py >= (int)P.H) continue;
+                const size_t p = (size_t)py * P.W + (size_t)px;
+                const unsigned long long k = keys64[i];
+                if ((uint32_t)k != ZR_EMPTY_PRIM && k < vis64[p]) atomicMin(&vis64[p], k);
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // The slow triangles of the round (they need the clipper, or have an edge of 64 px or more): every owned tile tries every one of
@@ -2457,62 +2504,6 @@ __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __r
             }
         }
         __syncthreads();      // the keys are cleared again for the next tile
-    }
-}
-
-// The camera pass's slow triangles (both rounds: round 1's sit in the first half of the list, round 2's in the second; slot = 2 after a
-// two-round frame, 1 after a one-round one).  The usual frame has none - and this launch sits on the camera lane's critical path, right
-// where the shadow rasteriser's persistent workgroups hold every CU down to ~6 KB of LDS and 80 VGPRs per SIMD: with a tile's 8 KB of keys
-// and the clipper's 118 registers the empty launch waited 35-50 us for room (timeline of the two-lane frame).  Hence: half a tile of
-// keys (32 x 16 pixels, 4 KB), the clipper inlined under this kernel's own budget of six waves per SIMD (<= 80 VGPRs, the rest spills:
-// the path is rare), a small grid that strides over (tile, half) pairs.  Also folds k_geom's per-wave Hi-Z tallies into the statistics.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
-void k_tile_slow_cam(ZrPass P, const uint32_t* __restrict__ owned_tiles, uint32_t n_owned, const uint4* __restrict__ slow, uint32_t slow_cap,
-                     ZrDevStats* __restrict__ stats, int slot, unsigned long long* __restrict__ vis64,
-                     const uint32_t* __restrict__ wave_culled, uint32_t n_waves)
-{
-    constexpr int HALF = TILE / 2;
-    __shared__ unsigned long long keys64[TILE * HALF];
-    const uint32_t half_cap = slow_cap / 2u;
-    const uint32_t n_a = min(stats->n_slow[1], half_cap), n_b = slot == 2 ? min(stats->n_slow[2], half_cap) : 0u;
-    if (slot == 2 && wave_culled) {
-        uint32_t nc = 0;
-        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_waves; i += gridDim.x * 256u) nc += wave_culled[i];
-        nc = (uint32_t)wave_sum((int)nc);
-        if ((threadIdx.x & 63u) == 0u && nc) { atomicAdd(&stats->hiz_culled, nc); atomicSub(&stats->survivors[2], nc); }
-    }
-    if (n_a + n_b == 0u) return;
-    const uint32_t tid = threadIdx.x;
-    for (uint32_t it = blockIdx.x; it < 2u * n_owned; it += gridDim.x) {
-        const uint32_t tile = owned_tiles[it >> 1];
-        const int tpx0 = (int)(tile % P.tiles_x) * TILE, tpy0 = (int)(tile / P.tiles_x) * TILE + (int)(it & 1u) * HALF;
-        if (tpy0 >= (int)P.H) continue;
-        for (uint32_t i = tid; i < (uint32_t)(TILE * HALF); i += 256u) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
-        __syncthreads();
-        TileCtx T;      // relative to the half tile's first pixel; T.H ends the rows after HALF
-        T.px0 = 0; T.py0 = 0; T.W = (int)P.W - tpx0; T.H = min((int)P.H - tpy0, HALF);
-        const uint32_t ttx = tile % P.tiles_x, tty = tile / P.tiles_x;
-        for (uint32_t jj = tid; jj < n_a + n_b; jj += 256u) {
-            const uint32_t j = jj < n_a ? jj : half_cap + (jj - n_a);
-            const uint4 q3 = slow[4u * j + 3u];
-            // the tiles the triangle's snapped box reaches (k_geom), or all of them
-            if (ttx < (q3.y & 255u) || tty < ((q3.y >> 8) & 255u) || ttx > ((q3.y >> 16) & 255u) || tty > (q3.y >> 24)) continue;
-            const uint4 q0 = slow[4u * j], q1 = slow[4u * j + 1u], q2 = slow[4u * j + 2u];
-            zf4 c0, c1, c2;
-            c0.x = zr_u2f(q0.x); c0.y = zr_u2f(q0.y); c0.z = zr_u2f(q0.z); c0.w = zr_u2f(q0.w);
-            c1.x = zr_u2f(q1.x); c1.y = zr_u2f(q1.y); c1.z = zr_u2f(q1.z); c1.w = zr_u2f(q1.w);
-            c2.x = zr_u2f(q2.x); c2.y = zr_u2f(q2.y); c2.z = zr_u2f(q2.z); c2.w = zr_u2f(q2.w);
-            raster_clipped_body<ZR_MODE_GBUFFER>(c0, c1, c2, q3.x, T, P.hw, P.hh, tpx0 * 256, tpy0 * 256, keys64, nullptr);
-        }
-        __syncthreads();
-        for (uint32_t i = tid; i < (uint32_t)(TILE * HALF); i += 256u) {
-            const int px = tpx0 + (int)(i & (TILE - 1)), py = tpy0 + (int)(i / TILE);
-            if (px >= (int)P.W || py >= (int)P.H) continue;
-            const size_t p = (size_t)py * P.W + (size_t)px;
-            const unsigned long long k = keys64[i];
-            if ((uint32_t)k != ZR_EMPTY_PRIM && k < vis64[p]) atomicMin(&vis64[p], k);
-        }
-        __syncthreads();
     }
 }
 
@@ -3288,15 +3279,10 @@ void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* 
     hipLaunchKernelGGL(k_index, dim3(B.n_waves / 4u), dim3(256), 0, s, B, stats, slot, tile_offset, tile_cursor);
 }
 void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B, uint32_t* tile_count, uint32_t* tile_cursor, uint32_t n_tiles,
-                    ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s)
+                    ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s, bool last, const uint32_t* owned_tiles, uint32_t n_owned)
 {
-    hipLaunchKernelGGL(k_tile<ZR_MODE_GBUFFER>, dim3(n_blocks), dim3(256), 0, s, P, chunk_tab, B, tile_count, tile_cursor, n_tiles, stats, slot, vis64);
-}
-void zr_launch_tile_slow_camera(const ZrPass& P, const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned, ZrDevStats* stats, int slot,
-                                unsigned long long* vis64, hipStream_t s)
-{
-    if (n_owned) hipLaunchKernelGGL(k_tile_slow_cam, dim3(std::min<uint32_t>(2u * n_owned, ZR_SLOW_BLOCKS)), dim3(256), 0, s, P, owned_tiles, n_owned, B.slow, B.slow_cap,
-                                    stats, slot, vis64, B.wave_culled, B.n_waves);
+    if (last) hipLaunchKernelGGL((k_tile<ZR_MODE_GBUFFER, true>), dim3(n_blocks), dim3(256), 0, s, P, chunk_tab, B, tile_count, tile_cursor, n_tiles, stats, slot, vis64, owned_tiles, n_owned);
+    else hipLaunchKernelGGL((k_tile<ZR_MODE_GBUFFER, false>), dim3(n_blocks), dim3(256), 0, s, P, chunk_tab, B, tile_count, tile_cursor, n_tiles, stats, slot, vis64, owned_tiles, n_owned);
 }
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, const float* unorm_lut, uint8_t* vis_now,

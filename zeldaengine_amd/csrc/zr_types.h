@@ -225,9 +225,7 @@ void zr_launch_scan_tri(const uint32_t* tile_count, uint32_t* tile_offset, uint4
                         ZrDevStats* stats, int slot, hipStream_t s);
 void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* tile_cursor, const ZrDevStats* stats, int slot, hipStream_t s);
 void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B, uint32_t* tile_count, uint32_t* tile_cursor, uint32_t n_tiles,
-                    ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s);
-void zr_launch_tile_slow_camera(const ZrPass& P, const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned, ZrDevStats* stats, int slot,
-                                unsigned long long* vis64, hipStream_t s);
+                    ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s, bool last, const uint32_t* owned_tiles, uint32_t n_owned);
 void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, const ZrHiz& Z, ZrDevStats* stats,
                         int slot, hipStream_t s, ZrBinEntry* sel = nullptr, const uint8_t* vis_prev = nullptr, bool reuse_list = false);      // sel: round 1's list (camera)
 void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
