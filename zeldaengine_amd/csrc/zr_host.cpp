@@ -226,8 +226,8 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     ok &= hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     ok &= dev_alloc(&c->d_vis, n) == hipSuccess;
     if (ok) { zr_launch_fill64(c->d_vis, (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM, n, c->stream); ok &= hipStreamSynchronize(c->stream) == hipSuccess; }
-    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->raster_blocks = (uint32_t)prop.multiProcessorCount * 8u; }
-    c->shadow_blocks = c->raster_blocks;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) c->raster_blocks = (uint32_t)prop.multiProcessorCount * 12u; }      // k_tile's persistent grid (6 workgroups fit a CU: two rounds of them; A/B 4 / 6 / 8 / 12 / 16 / 32 per CU -> 5 133 / 5 250 / 5 294 / 5 344 / 5 327 / 5 277 Mpixel/s)
+    c->shadow_blocks = c->raster_blocks / 12u * 8u;      // the shadow rasteriser's persistent grid stays at 8 per CU
     c->slow0_cap = std::max<uint32_t>(c->slow0_cap, 128u * c->sn_tiles);      // (a clipped triangle is listed once per tile of its meshlet)
     if (ok) ok &= dev_alloc(&c->d_slow0, 4ull * c->slow0_cap) == hipSuccess;
 #ifdef ZR_DIAG
