@@ -43,9 +43,9 @@ PROFILE_INDEX = os.path.join(ROOT, "profiles", "current.json")     # written by 
 # pass is k_geom (vertices -> triangle records) + k_scan_tri + k_index (records -> per-tile lists) + k_tile (+ k_tile_slow); k_scan_tri,
 # k_index, k_tile and k_tile_slow run once per round under one name, so their profile rows hold both rounds.
 KERNEL_OF_PASS = {"shadow": ("k_raster<SHADOW>", "k_tile_slow<SHADOW>"), "gbuffer": ("k_geom<false>", "k_scan_tri", "k_index", "k_tile<0>"),
-                  "gbuffer2": ("k_geom<true>", "k_tile_slow<GBUFFER>"), "resolve": ("k_resolve_gbuffer",), "lighting": ("k_lighting",)}
+                  "gbuffer2": ("k_geom<true>",), "resolve": ("k_resolve_gbuffer",), "lighting": ("k_lighting",)}
 GBUFFER_WRITE_PASS = ("gbuffer", "gbuffer2", "resolve")
-GBUFFER_WRITE_KERNELS = "k_geom + k_scan_tri + k_index + k_tile (x2 rounds) + k_tile_slow + k_resolve_gbuffer"
+GBUFFER_WRITE_KERNELS = "k_geom + k_scan_tri + k_index + k_tile (x2 rounds; the last one also draws the slow triangles) + k_resolve_gbuffer"
 
 
 def workload_name(config, n_inst, n_work, W, H, n_point, cube_dim):

@@ -2161,10 +2161,13 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
                     const unsigned long long same = __ballot(emit && tile == tl) & pend;
                     const uint32_t ns = (uint32_t)__popcll(same);
                     if ((int)lane == leader) cnt = ns;
-                    if (same >> lane & 1ull) mypos = gbase + (uint32_t)__popcll(same & lt);
+                    if (!HIZ && (same >> lane & 1ull)) mypos = gbase + (uint32_t)__popcll(same & lt);
                     gbase += ns;
                     pend &= ~same;
                 }
+                // (round 2 emits a few records per step: laid down in lane order they leave the wave as whole-line stores; grouped, the same
+                // bytes went out as scattered 16-byte writes - 20 MB of write requests for 5.5 MB of records)
+                if (HIZ) mypos = (uint32_t)__popcll(me & lt);
                 if (cnt) atomicAdd(&tile_count[tile * ZR_TSTRIDE], cnt);
                 if (emit) rec_store(B, Wd.cur * ZR_TPOOL_CHUNK + Wd.fill + mypos, r0, r1, r2, prim, tile, rtx, rty);
                 Wd.fill += gbase;
