@@ -296,8 +296,13 @@ def main():
                 "frame_gpu_ms_median": round(pct(periods, 0.5), 4) if periods else None,
                 "passes_ms": {k: round(v, 4) for k, v in times.items()},
                 "survivors": stats["survivors"], "covered_pixels": stats["covered_pixels"], "overflow": stats["overflow"]}
-        rows = [None] * world
-        dist.all_gather_object(rows, mine)
+        # (CPU tensors: gloo, like the barrier - nothing here may make torch open an RCCL communicator of its own beside the library's)
+        raw = json.dumps(mine).encode()
+        buf = torch.zeros(8192, dtype=torch.uint8)
+        buf[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        outs = [torch.zeros_like(buf) for _ in range(world)]
+        dist.all_gather(outs, buf)
+        rows = [json.loads(bytes(o.tolist()).rstrip(b"\0").decode()) for o in outs]
         rank_rows = {"slowest": max(rows, key=lambda r: r["frame_gpu_ms_median"] or r["loop_ms_per_step"])["rank"], "per_rank": rows}
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
