@@ -86,7 +86,7 @@ enum { ZR_PASS_CULL_SHADOW = 0,   /* k_cull_box<SHADOW> + k_bin_count + k_scan +
        ZR_PASS_GBUFFER,           /* round 1 (the whole pass when the frame runs in one round): k_geom + k_scan_tri + k_index + k_tile
                                      [ZR_FLAG_MESHLET_BINS: k_raster_chunks<GBUFFER>] */
        ZR_PASS_HIZ,               /* k_hiz_build + round 2's k_select [.. k_bin_count + k_scan + k_bin_fill] (0 in a one-round frame) */
-       ZR_PASS_GBUFFER2,          /* round 2: k_geom<Hi-Z> + k_scan_tri + k_index + k_tile + k_tile_slow (both rounds' clipped triangles) [.. k_raster_chunks<GBUFFER, Hi-Z>] */
+       ZR_PASS_GBUFFER2,          /* round 2: k_geom<Hi-Z> + k_scan_tri + k_index + k_tile (the last round also draws both rounds' clipped triangles) [.. k_raster_chunks<GBUFFER, Hi-Z>] */
        ZR_PASS_RESOLVE,           /* k_resolve_gbuffer: the GBuffer write */
        ZR_PASS_LIGHTING,          /* k_lighting */
        ZR_PASS_COMPOSITE, ZR_PASS_TOTAL, ZR_PASS_COUNT };
