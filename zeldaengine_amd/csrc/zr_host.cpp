@@ -1445,11 +1445,11 @@ extern "C" int zr_render_lighting(zr_ctx* c)
     if (c->stage != 2) return zr_fail(c, ZR_ERR_STATE, "zr_render_lighting out of order");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t ls = c->stream;
+    // The one wait of the host's stream per frame: the camera lane's GBuffer - and, ahead of it on that lane, this frame's k_frame_begin,
+    // whose uniforms the empty-pixel pass below reads (the shadow pipeline before it needed nothing of them and did not wait).
+    if (c->camera_on_lane) HIPCHK(c, hipStreamWaitEvent(ls, c->ev_cam, 0));
     int rc = empty_pixel_pass(c, ls);              // the shadow map (possibly reduced over ranks by the host) is final only now
-    if (rc == ZR_OK && c->camera_on_lane) HIPCHK(c, hipStreamWaitEvent(ls, c->ev_cam, 0));
-    const uint64_t k = c->frame_no;
     if (rc == ZR_OK) rc = lighting_pass(c, ls);
-    (void)k;
     return rc;
 }
 
