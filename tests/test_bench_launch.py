@@ -17,3 +17,18 @@ def test_bench_starts_its_own_ranks():
     assert "needs `python -m torch.distributed.run" not in text
     assert "bench.py needs an MI355X" in text or "this node shows" in text, text[-2000:]
     assert "torch.distributed" in text or "local_rank" in text, text[-2000:]          # the elastic launcher ran
+
+
+def test_bench_quotes_counters_only_from_the_same_build():
+    """profiles/<tag>_pmc.json records the library its counters were collected with (lib_sha16); bench.py's line quotes them only
+    when the workload AND the library match - a kernel change without a fresh profile must not ship stale traffic / issue numbers."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    idx = json.load(open(os.path.join(ROOT, "profiles", "current.json")))
+    prof = json.load(open(os.path.join(ROOT, "profiles", idx["pmc"])))
+    assert prof.get("lib_sha16") and prof.get("workload")
+    got = bench.load_profile(prof["workload"], prof["lib_sha16"])
+    assert got is not None and got["_file"].endswith(idx["pmc"]) and got["kernels"]["k_tile<0>"]["hbm_bytes_per_frame"] > 0
+    assert bench.load_profile(prof["workload"], "0" * 16) is None                      # another build of the library
+    assert bench.load_profile(prof["workload"] + " [other]", prof["lib_sha16"]) is None  # another workload
