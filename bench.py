@@ -218,6 +218,16 @@ def main():
         dr_.r.update_uniforms(cam, cfg["dir"], cfg["point"], cfg["spot"], 0.0, 0.002 * i, 0.016 * i)
 
     def timed_loop(dr_, steps, warmup, per_frame):
+        # (CPython's cyclic collector off while frames are enqueued: with torch imported a full collection takes ~37 ms of host time - a hole
+        # of a hundred frames in the GPU's queue - and falls around the 160th frame of any loop that long: tools/host_variant_check.py)
+        import gc
+        gc.collect(); gc.disable()
+        try:
+            return timed_loop_body(dr_, steps, warmup, per_frame)
+        finally:
+            gc.enable()
+
+    def timed_loop_body(dr_, steps, warmup, per_frame):
         for i in range(warmup):
             per_frame(dr_, i)
             dr_.frame()
