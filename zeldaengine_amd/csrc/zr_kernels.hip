@@ -2711,6 +2711,9 @@ __device__ __forceinline__ float shadow_tap(const float* __restrict__ S, int SD,
 #ifndef ZR_LIGHT_TB
 #define ZR_LIGHT_TB 512
 #endif
+#ifndef ZR_LIGHT_WAVES
+#define ZR_LIGHT_WAVES 4             // waves per SIMD k_lighting is compiled for (see the note at the kernel)
+#endif
 #ifndef ZR_PIXELS_PER_THREAD
 #define ZR_PIXELS_PER_THREAD 1       // of k_resolve_gbuffer and k_lighting: 1, 2 or 4 (a tile is 1 024 pixels; workgroups per tile follow)
 #endif
@@ -2721,7 +2724,7 @@ static_assert(TILE_PIX / ZR_PIXELS_PER_THREAD >= ZR_LIGHT_TB && TILE_PIX / ZR_PI
 template <bool LIGHT_LIST, bool BACKGROUND, int TB, int PPT>      // PPT: pixels per thread, 4 or 1 (as in k_resolve_gbuffer)
 // (compiled for exactly 4 waves per SIMD: left to itself the allocator takes 127 VGPRs, told so it makes do with 97 - the same four
 // waves, but 120 registers per SIMD left for the other lane's kernels; 5 or 6 waves (95 / 80 VGPRs) are faster alone, not beside)
-__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_lighting(ZrLightParams L, const XkView* __restrict__ view,
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(ZR_LIGHT_WAVES, ZR_LIGHT_WAVES))) void k_lighting(ZrLightParams L, const XkView* __restrict__ view,
                                                   const uint32_t* __restrict__ owned_tiles, GBufferPtrs G,
                                                   const float* __restrict__ shadowmap, CubeDesc C,
                                                   const float* __restrict__ srgb_lut, const float* __restrict__ unorm_lut,
