@@ -59,6 +59,10 @@ typedef struct zr_ctx zr_ctx;
 #define ZR_FLAG_NO_RECT_CULL    64u /* tile_world > 1: do not reject meshlets by the rank's owned screen region before stage B (parity A/B) */
 #define ZR_FLAG_NO_LIST_REUSE  256u /* rebuild the passes' instance-level work lists every frame instead of only when camera / light matrices or the
                                      * scene change (parity A/B; the lists are an acceleration structure, never pixels) */
+#define ZR_FLAG_NO_SHADOW_OCCLUSION 512u /* shadow pass: draw every survivor of the cull instead of leaving out what the map's own depths already hide
+                                     * (parity A/B: the map is the same bit for bit either way) */
+#define ZR_FLAG_SHADOW_OCCLUSION 1024u  /* ... and the opposite: occlusion-cull the shadow pass of a scene of any size (by default only from one
+                                     * meshlet-instance per two texels of the map on, where it pays) */
 
 typedef struct zr_config {
     uint32_t width, height;   /* swapchain extent, ZE:78-79 (default 1920x1080) */
@@ -101,6 +105,8 @@ typedef struct zr_stats {
     uint32_t overflow;          /* nonzero: a bin list overflowed; frame invalid */
     uint32_t hiz_culled;        /* camera meshlet-instances rejected by the Hi-Z occlusion test (0 on a scene's first frame) */
     uint64_t round1_survivors;  /* of survivors[1]: drawn in round 1 (visible last frame); 0 when the frame ran in one round */
+    uint32_t shadow_occluded;   /* of survivors[0]: not drawn - every texel their box reaches already held a nearer depth (the map is the same) */
+    uint32_t shadow_late;       /* of survivors[0]: hidden last frame, not hidden now: drawn by the shadow pass's late launch */
 } zr_stats;
 
 /* --- lifetime (replaces InitVulkan/Cleanup, ZE:1714, 3747) --- */

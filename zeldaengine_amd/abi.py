@@ -54,7 +54,7 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("work_items", C.c_uint64 * 2), ("survivors", C.c_uint64 * 2), ("bin_entries", C.c_uint64 * 2),
                 ("covered_pixels", C.c_uint64), ("covered_shadow_texels", C.c_uint64), ("overflow", C.c_uint32), ("hiz_culled", C.c_uint32),
-                ("round1_survivors", C.c_uint64)]
+                ("round1_survivors", C.c_uint64), ("shadow_occluded", C.c_uint32), ("shadow_late", C.c_uint32)]
 
 
 PASS_NAMES = ["cull_shadow", "shadow", "cull_camera", "gbuffer", "hiz", "gbuffer2", "resolve", "lighting", "composite", "total"]
@@ -69,6 +69,8 @@ FLAG_PACKED_TILES = 32
 FLAG_NO_RECT_CULL = 64
 FLAG_MESHLET_BINS = 128
 FLAG_NO_LIST_REUSE = 256
+FLAG_NO_SHADOW_OCCLUSION = 512
+FLAG_SHADOW_OCCLUSION = 1024
 
 OK, ERR_ARG, ERR_DEVICE, ERR_OOM, ERR_PARSE, ERR_IO, ERR_STATE, ERR_OVERFLOW, ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7, -8
 

@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __re
         }
         if (k < n) {
             rects[k] = r;
-            if (MODE == ZR_MODE_GBUFFER && pxrect) { pxrect[k] = pr; zmin[k] = zm; }
+            if (pxrect) { pxrect[k] = pr; zmin[k] = zm; }       // camera pass: round 2's Hi-Z test; shadow pass: k_shadow_occlusion
         }
         if (MODE == ZR_MODE_GBUFFER && sel) {
             const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -851,6 +851,7 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
         run += c; crun += nu;
         tile_count[i] = 0; tile_cursor[i] = 0;
     }
+    if (slot == 0 && tid < 32u) stats->covered_part[tid] = 0;      // shadow pipeline: k_shadow_occlusion's tally (32 partial sums)
     if (tid == 1023) {
         tile_offset[n] = part[1023];
         chunk_offset[n] = cpart[1023];
@@ -860,6 +861,7 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
         // what the kernels after this one accumulate for the pass starts from zero here: the shadow pipeline's block is not touched by
         // k_frame_begin (the pipeline does not wait for the camera lane)
         stats->survivors[slot] = 0; stats->n_slow[slot] = 0; stats->overflow = part[1023] > capacity ? 1u : 0u;
+        if (slot == 0) { stats->n_chunks[1] = 0; stats->chunk_counter[1] = 0; stats->shadow_late = 0; }      // (k_shadow_occlusion's late units)
         if (part[1023] > capacity) stats->overflow_sticky = 1u;
     }
 }
@@ -1664,7 +1666,9 @@ __global__ void k_fill64(unsigned long long* __restrict__ p, unsigned long long 
 // DEFER: triangles that need the clipper (or the 64-bit walk) are not rasterised here but appended, with their tile, to `slow` for
 // k_tile_slow: without the call to raster_clipped in its loop the kernel needs half the registers, i.e. twice the waves per SIMD
 // fit - next to each other and next to the other lane's kernels.
-template <int MODE, bool HIZ, bool DEFER>
+// LATE (shadow pass, after k_shadow_occlusion): unit u is the ONE entry bins[bin_capacity - 1 - u], its tile in the record's prim_base
+// (the shadow pass has no use for a primitive id); the units are counted in slot 1 of the pipeline's block, slow triangles stay in `slot`.
+template <int MODE, bool HIZ, bool DEFER, bool LATE = false>
 __global__ __launch_bounds__(RTHREADS) __attribute__((amdgpu_waves_per_eu(DEFER ? ZR_RASTER_WAVES_DEFER : ZR_RASTER_WAVES)))
 void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* __restrict__ chunk_tab,
                      const ZrBinEntry* __restrict__ bins, ZrDevStats* __restrict__ stats, int slot,
@@ -1684,7 +1688,8 @@ void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* _
     // then live in SGPRs and are fetched with scalar loads - some 30 VGPRs less in the hot loop (one more wave per SIMD, and this
     // kernel waits on dependent loads most of the time)
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = wave_uniform(tid >> 6);
-    const uint32_t n_chunks = stats->n_chunks[slot];
+    const int cslot = LATE ? 1 : slot;
+    const uint32_t n_chunks = LATE ? min(stats->n_chunks[1], P.bin_capacity - min(stats->bin_entries[slot], P.bin_capacity)) : stats->n_chunks[slot];
 
     // the first two chunks of a workgroup are its own index and that + the grid (no atomic: an empty pass costs nothing), later ones
     // come from the counter
@@ -1698,7 +1703,9 @@ void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* _
         }
         __syncthreads();
         // this work unit: (tile, first entry, end) as k_scan laid it out: one load, not a search over the tiles' chunk offsets
-        const uint4 ct = chunk_tab[chunk];
+        uint4 ct;
+        if (LATE) { const uint32_t idx = P.bin_capacity - 1u - chunk; ct = make_uint4(((const uint4*)bins)[2u * idx + 1u].w, idx, idx + 1u, 0u); }
+        else ct = chunk_tab[chunk];
         const uint32_t tile = ct.x, beg = ct.y, end = min(ct.z, P.bin_capacity);
         // Everything below works in TILE-RELATIVE coordinates (origin = the tile's first pixel): edge functions, depth planes and
         // bounding boxes are built from coordinate differences, so the integers and floats are the ones absolute coordinates give.
@@ -1848,9 +1855,120 @@ void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* _
         // (the next unit is claimed only when this one is done: claiming early costs more in tail balance than the atomic's latency)
         // ... and the second unit of a workgroup is fixed like the first (b + grid): claims on one counter queue up for ~10 ns apiece
         if (first) { first = false; __syncthreads(); chunk += gridDim.x; continue; }
-        if (tid == 0) cur_chunk = 2u * gridDim.x + atomicAdd(&stats->chunk_counter[slot], 1u);
+        if (tid == 0) cur_chunk = 2u * gridDim.x + atomicAdd(&stats->chunk_counter[cslot], 1u);
         __syncthreads();   // keys are re-cleared at the top of the loop
         chunk = cur_chunk;
+    }
+}
+
+// Occlusion culling of the shadow pass.  The map is a running minimum: a meshlet-instance whose least possible depth lies behind EVERY texel
+// its box can reach, at any moment of the pass, cannot change the map - then or later - and need not be drawn; what is drawn is the same
+// whatever was left out, so the map is bit for bit the one the full pass writes.  Which ones to try first is a guess taken from the
+// previous frame (one byte per work item): the rasteriser's first launch draws the flagged ones (everything, on a scene's first frame),
+// then this kernel tests EVERY survivor of the cull against the map as it stands (box and least depth from k_cull_box: conservative, the
+// camera pass's Hi-Z bounds), flags "not hidden" for the next frame, and hands the unflagged ones that are not hidden to a late launch
+// of the rasteriser.  A light or a scene that moves costs late work, never a wrong texel.
+// A wave takes 64 consecutive work items, a lane each for the item's record (box, least depth, flag: coalesced loads, and later ONE store
+// of the 64 flags - a byte stored per item by whichever lane happened to test it is a partial write of a cache line that lanes of other
+// waves write too: 110 000 of those took 150 us).  The texels are read by TASKS: one per (item, row of its box), dealt out to the lanes by a
+// prefix sum over the boxes' heights, so a 4 x 4 box costs 4 lane-loads and a 40 x 40 one 400, whatever mix a wave meets.  (What the
+// test costs at 1 M instances - 290 us for 2.75 M survivors, the same for three different lane layouts - is the map's rows coming in from
+// L2 / MALL: every row of every box is a cache line of its own, ~11 M of them in work-list order.)
+// A task loads its row in spans of 4 texels (the map's rows are 4-byte aligned, nothing more is asked of a global load), masks what lies
+// beyond the box's right edge, and folds its maximum into the item's word in LDS (ds_max).
+struct __attribute__((packed, aligned(4))) ZrTexel4 { uint32_t x, y, z, w; };      // four texels of a map row, from any texel on
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)      // inclusive prefix sum over the wave's lanes (rows on the DPP network, then across)
+{
+    const int idn = 0;
+    int r = (int)v;
+    ZR_DPP_STEP(op_add, 0x111, 0xF); ZR_DPP_STEP(op_add, 0x112, 0xF); ZR_DPP_STEP(op_add, 0x114, 0xF); ZR_DPP_STEP(op_add, 0x118, 0xF);
+    ZR_DPP_STEP(op_add, 0x142, 0xA); ZR_DPP_STEP(op_add, 0x143, 0xC);
+    return (uint32_t)r;
+}
+template <bool WORKLIST>
+__global__ __launch_bounds__(256) void k_shadow_occlusion(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
+                                                          const uint32_t* __restrict__ rects, const uint2* __restrict__ pxrect,
+                                                          const float* __restrict__ zmin, uint8_t* __restrict__ flags,
+                                                          const uint32_t* __restrict__ shadow_bits, ZrBinEntry* __restrict__ bins,
+                                                          ZrDevStats* __restrict__ stats)
+{
+    __shared__ uint32_t s_first[4][WAVE], s_far[4][WAVE];      // per wave: an item's first task, the farthest texel of its box so far
+    __shared__ uint2 s_box[4][WAVE];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t n = WORKLIST ? stats->n_vis_work[0] : P.n_work;
+    uint32_t n_occl = 0, n_late = 0;
+    for (uint32_t base = (blockIdx.x * 4u + wv) * 64u; base < n; base += gridDim.x * 256u) {
+        const uint32_t k = base + lane;
+        uint32_t r = ZR_RECT_CULLED, w = 0, zb = 0x80000000u;
+        uint2 pr = make_uint2(0u, 0u);
+        bool flagged = true;
+        if (k < n) {
+            r = rects[k]; pr = pxrect[k]; zb = zr_f2u(zmin[k]); w = WORKLIST ? work[k] : k;
+            flagged = flags[w] != 0;
+        }
+        const bool live = r != ZR_RECT_CULLED;
+        const uint32_t x0 = pr.x & 0xFFFFu, y0 = pr.x >> 16, x1 = pr.y & 0xFFFFu, y1 = pr.y >> 16;
+        // (zmin < 0: the box touches the near plane or the guard band, or is not finite: drawn, never tested; boxes wider than 64 texels neither)
+        const bool test = live && (int)zb >= 0 && x1 - x0 < 64u && y1 - y0 < 64u;
+        const uint32_t rows = test ? y1 - y0 + 1u : 0u;
+        const uint32_t incl = wave_incl_scan(rows), total = lane_bcast(incl, 63u);
+        lds_fence();      // the previous stretch's readers are done
+        s_first[wv][lane] = incl - rows; s_far[wv][lane] = 0u; s_box[wv][lane] = pr;
+        lds_fence();
+        for (uint32_t t0 = 0; t0 < total; t0 += 64u) {
+            const uint32_t t = t0 + lane;
+            if (t < total) {
+                // the item this task belongs to: the last one whose first task is <= t (items without rows share their successor's first task)
+                uint32_t i = 0;
+#pragma unroll
+                for (uint32_t step = 32u; step; step >>= 1) if (s_first[wv][i + step] <= t) i += step;
+                const uint2 b = s_box[wv][i];
+                const uint32_t bx0 = b.x & 0xFFFFu, bx1 = b.y & 0xFFFFu, y = (b.x >> 16) + (t - s_first[wv][i]);
+                const uint32_t* __restrict__ row = shadow_bits + (size_t)y * P.W;
+                uint32_t far = 0;
+                for (uint32_t x = bx0; x <= bx1; x += 4u) {
+                    const uint32_t xs = min(x, P.W - 4u);
+                    const ZrTexel4 v = *(const ZrTexel4*)(row + xs);
+                    if (xs >= bx0 && xs <= bx1) far = max(far, v.x);
+                    if (xs + 1u >= bx0 && xs + 1u <= bx1) far = max(far, v.y);
+                    if (xs + 2u >= bx0 && xs + 2u <= bx1) far = max(far, v.z);
+                    if (xs + 3u >= bx0 && xs + 3u <= bx1) far = max(far, v.w);
+                }
+                atomicMax(&s_far[wv][i], far);
+            }
+        }
+        lds_fence();
+        const bool hidden = test && zb > s_far[wv][lane];        // depth bits of [0, 1]: ordered as integers
+        if (live) flags[w] = hidden ? 0u : 1u;
+        if (live && !flagged && hidden) ++n_occl;
+        if (live && !flagged && !hidden) {
+            // late: one self-contained record per (tile, meshlet-instance), as k_bin_fill writes them, with the tile in prim_base
+            ++n_late;
+            const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w);
+            const uint32_t local = w - O->work_base;
+            const uint32_t inst_i = local / O->n_meshlets, m = local - inst_i * O->n_meshlets;
+            const XkMeshlet* __restrict__ ml = O->meshlets + m;
+            ZrBinEntry be;
+            be.mpos = O->mpos + ml->VertexOffset; be.mtri = O->mtri + ml->BindlessContext; be.inst = O->inst + inst_i;
+            be.counts = ml->VertexCount | ml->TriangleCount << 8 | (O->instanced ? 1u << 16 : 0u);
+            const uint32_t room = P.bin_capacity - min(stats->bin_entries[0], P.bin_capacity);      // above the first launch's entries
+            const uint32_t tx0 = r & 255u, ty0 = (r >> 8) & 255u, tx1 = (r >> 16) & 255u, ty1 = r >> 24;
+            for (uint32_t ty = ty0; ty <= ty1; ++ty)
+                for (uint32_t tx = tx0; tx <= tx1; ++tx) {
+                    if (tile_owner(tx, ty, P.tile_world) != P.tile_rank) continue;
+                    const uint32_t pos = atomicAdd(&stats->n_chunks[1], 1u);      // (late entries are few; a light that jumps pays ~10 ns apiece here)
+                    be.prim_base = ty * P.tiles_x + tx;
+                    if (pos < room) bins[P.bin_capacity - 1u - pos] = be;
+                    else { stats->overflow = 1u; stats->overflow_sticky = 1u; }
+                }
+        }
+    }
+    // the tally in 32 partial sums (the shadow pipeline's block has no other use for covered_part; zr_finish adds them up): one atomic per
+    // workgroup on ONE word queued up for ~10 ns apiece - 17 us for config 3's 1 719 workgroups
+    n_occl = (uint32_t)wave_sum((int)n_occl); n_late = (uint32_t)wave_sum((int)n_late);
+    if (lane == 0u) {
+        if (n_occl) atomicAdd(&stats->covered_part[(blockIdx.x * 4u + wv) & 31u], n_occl);
+        if (n_late) atomicAdd(&stats->shadow_late, n_late);
     }
 }
 
@@ -3197,8 +3315,8 @@ void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, u
     } else {
         if (P.use_worklist) {
             if (!reuse_list) hipLaunchKernelGGL(k_cull_instances<ZR_MODE_SHADOW>, gi, bi, 0, s, P, objs, work, stats, slot);
-            hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, true>), g, b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot, (ZrBinEntry*)nullptr, (const uint8_t*)nullptr);
-        } else hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, false>), g, b, 0, s, P, objs, work, rects, (uint2*)nullptr, (float*)nullptr, (uint8_t*)nullptr, stats, slot, (ZrBinEntry*)nullptr, (const uint8_t*)nullptr);
+            hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, true>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, (uint8_t*)nullptr, stats, slot, (ZrBinEntry*)nullptr, (const uint8_t*)nullptr);
+        } else hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, false>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, (uint8_t*)nullptr, stats, slot, (ZrBinEntry*)nullptr, (const uint8_t*)nullptr);
     }
 }
 void zr_launch_bin_count(const ZrPass& P, const uint32_t* work, uint32_t* rects, uint32_t* tile_count, const ZrHiz& Z, ZrDevStats* stats,
@@ -3242,7 +3360,7 @@ void zr_launch_fill64(unsigned long long* p, unsigned long long v, size_t n, hip
 }
 void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4* chunk_tab,
                              const ZrBinEntry* bins, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t* shadow_bits,
-                             uint32_t n_blocks, const ZrHiz& Z, hipStream_t s, uint4* slow, uint32_t slow_cap, const uint32_t* tiles, uint32_t n_tiles)
+                             uint32_t n_blocks, const ZrHiz& Z, hipStream_t s, uint4* slow, uint32_t slow_cap, const uint32_t* tiles, uint32_t n_tiles, int stage)
 {
     const float* none = nullptr;
 #ifdef ZR_DIAG      // the camera pass through this rasteriser: A/B builds only (ZR_FLAG_MESHLET_BINS)
@@ -3257,11 +3375,23 @@ void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4*
 #endif
     if (P.mode == ZR_MODE_GBUFFER) return;      // (not reached: the product's camera pass is triangle-binned)
     if (slow) {    // shadow pass: clipped triangles go through a list + k_tile_slow
-        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false, true>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u, slow, slow_cap);
-        if (n_tiles) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_SHADOW, true>), dim3(std::min<uint32_t>(n_tiles, ZR_SLOW_BLOCKS)), dim3(256), 0, s, P, tiles, n_tiles, slow, slow_cap, stats, slot,
+        if (stage == 2) hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false, true, true>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u, slow, slow_cap);
+        else hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false, true>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u, slow, slow_cap);
+        if (n_tiles && stage != 1) hipLaunchKernelGGL((k_tile_slow<ZR_MODE_SHADOW, true>), dim3(std::min<uint32_t>(n_tiles, ZR_SLOW_BLOCKS)), dim3(256), 0, s, P, tiles, n_tiles, slow, slow_cap, stats, slot,
                                         (unsigned long long*)nullptr, shadow_bits, (const uint32_t*)nullptr, 0u);
-    } else
+    } else if (stage == 2)
+        hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false, false, true>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u, (uint4*)nullptr, 0u);
+    else
         hipLaunchKernelGGL((k_raster_chunks<ZR_MODE_SHADOW, false, false>), dim3(n_blocks), dim3(RTHREADS), 0, s, P, objs, chunk_tab, bins, stats, slot, vis64, shadow_bits, none, 0u, 0u, (uint4*)nullptr, 0u);
+}
+void zr_launch_shadow_occlusion(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint2* pxrect,
+                                const float* zmin, uint8_t* flags, const uint32_t* shadow_bits, ZrBinEntry* bins, ZrDevStats* stats,
+                                uint32_t n_blocks, hipStream_t s)
+{
+    if (P.n_work == 0) return;
+    const dim3 g(std::min<uint32_t>((P.n_work + 255u) / 256u, n_blocks)), b(256);
+    if (P.use_worklist) hipLaunchKernelGGL(k_shadow_occlusion<true>, g, b, 0, s, P, objs, work, rects, pxrect, zmin, flags, shadow_bits, bins, stats);
+    else hipLaunchKernelGGL(k_shadow_occlusion<false>, g, b, 0, s, P, objs, work, rects, pxrect, zmin, flags, shadow_bits, bins, stats);
 }
 void zr_launch_select(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats,
                       int slot, hipStream_t s)

@@ -135,6 +135,9 @@ struct ZrDevStats {
     uint32_t n_sel[3];               // triangle-binned camera pass: meshlet-instances selected for a round (slots as above)
     uint32_t n_slow[3];              //   triangles of the round that need the clipper / the 64-bit walk
     uint32_t pool_next[3], pool_used[3];   // record chunks taken from the pool: running (k_geom) / final
+    uint32_t shadow_occluded;        // shadow pass: meshlet-instances left out because the map's depths already hide them (host copy: the sum of
+                                     //   the 32 partial sums k_shadow_occlusion keeps in the shadow pipeline's covered_part)
+    uint32_t shadow_late;            //   ... and drawn in the late launch (not drawn last frame, not hidden this frame)
     uint32_t overflow_sticky;        // from here on: NOT cleared at frame begin.  Set with `overflow`, cleared by zr_finish when it reports it
     uint32_t n_vis_work[2];          // meshlet-instances on the pass's work list (k_cull_instances); the list and its length stand while the
                                      // pass's matrices and the scene do - k_frame_begin zeroes a slot when the host is about to rebuild it
@@ -233,10 +236,16 @@ void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* w
 void zr_launch_frame_begin(ZrDevStats* stats, ZrDevStats* shadow_stats, const XkView* view_src_pinned, XkView* view_dst, uint32_t rebuild_lists, hipStream_t s);
 void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s);
 void zr_launch_fill64(unsigned long long* p, unsigned long long v, size_t n, hipStream_t s);
+// shadow pass with occlusion culling: after the rasteriser has drawn the meshlet-instances flagged in `flags`, test every survivor of the
+// cull against the map, rewrite the flags, list the unflagged ones that are not hidden (from the top of `bins` downwards)
+void zr_launch_shadow_occlusion(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint2* pxrect,
+                                const float* zmin, uint8_t* flags, const uint32_t* shadow_bits, ZrBinEntry* bins, ZrDevStats* stats,
+                                uint32_t n_blocks, hipStream_t s);
 void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4* chunk_tab,
                              const ZrBinEntry* bins, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t* shadow_bits,
                              uint32_t n_blocks, const ZrHiz& Z, hipStream_t s, uint4* slow = nullptr, uint32_t slow_cap = 0, const uint32_t* tiles = nullptr,
-                             uint32_t n_tiles = 0);      // slow != nullptr (shadow pass): clipped triangles via the list + k_tile_slow
+                             uint32_t n_tiles = 0, int stage = 0);      // slow != nullptr (shadow pass): clipped triangles via the list + k_tile_slow
+                                                                        // stage 1: the flagged share only (k_tile_slow waits); 2: the late list, then k_tile_slow
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, const float* unorm_lut, uint8_t* vis_now,
                                ZrDevStats* stats, hipStream_t s);

@@ -417,7 +417,8 @@ class Renderer:
         self._chk(self.L.zr_get_stats(self.h, C.byref(s)))
         return {"work_items": list(s.work_items), "survivors": list(s.survivors), "bin_entries": list(s.bin_entries),
                 "covered_pixels": int(s.covered_pixels), "covered_shadow_texels": int(s.covered_shadow_texels), "overflow": int(s.overflow),
-                "hiz_culled": int(s.hiz_culled), "round1_survivors": int(s.round1_survivors)}
+                "hiz_culled": int(s.hiz_culled), "round1_survivors": int(s.round1_survivors),
+                "shadow_occluded": int(s.shadow_occluded), "shadow_late": int(s.shadow_late)}
 
     # ---- read-back
     def color(self):
