@@ -92,6 +92,8 @@ def _scene(seed):
     look = (float(rng.uniform(-2, 2)), float(rng.uniform(-2, 2)), float(rng.uniform(0.0, 1.0)))
     cam = dict(position=eye, lookat=look, fov=float(rng.choice([35.0, 45.0, 70.0])), znear=float(rng.choice([0.05, 0.1, 0.5])), zfar=float(rng.choice([20.0, 45.0, 200.0])))
     flags = int(rng.choice([0, 0, 0, abi.FLAG_NO_HIZ, abi.FLAG_NO_FRUSTUM_CULL | abi.FLAG_NO_CONE_CULL, abi.FLAG_SERIAL_PASSES]))
+    if seed % 2:          # every other scene: the shadow pass's occlusion culling whatever the scene's size (frame 2 runs on frame 1's flags)
+        flags |= abi.FLAG_SHADOW_OCCLUSION
     view = int(rng.choice([0, 0, 0, 0, 1, 2, 3, 4, 5, 7, 8, 9]))
     # rarer ingredients
     extra = {}

@@ -15,9 +15,11 @@ for seed in range(lo, hi):
     g = engine.Renderer(sc["W"], sc["H"], sc["SD"], flags=sc["flags"])
     t._build(g, sc)
     d, p, s = sc["lights"]
-    g.update_uniforms(abi.make_camera(**sc["cam"]), d, p, s, sc["roll"][0], sc["roll"][1], 1.0); t._raw_frame(g, sc)
     try:
-        g.render(sc["view"]); g.finish()
+        # two frames, the lights rolled between them: the second runs on the first one's visibility history and shadow-occlusion flags
+        for frame in range(2):
+            g.update_uniforms(abi.make_camera(**sc["cam"]), d, p, s, sc["roll"][0], sc["roll"][1] + 0.05 * (frame - 1), 1.0); t._raw_frame(g, sc)
+            g.render(sc["view"]); g.finish()
     except engine.ZeldaRenderError as e:
         print("seed", seed, sc["W"], sc["H"], sc["SD"], "flags", sc["flags"], list(sc["extra"]), [(dd[0], None if dd[2] is None else len(dd[2])) for dd in sc["draws"]], str(e)[:60], flush=True)
         try: print("   stats", g.stats(), flush=True)
