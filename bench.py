@@ -217,6 +217,15 @@ def main():
         cam = abi.make_camera((math.sqrt(50.0) * math.cos(a), math.sqrt(50.0) * math.sin(a), 5.0), (0.0, 0.0, 0.0))
         dr_.r.update_uniforms(cam, cfg["dir"], cfg["point"], cfg["spot"], 0.0, 0.002 * i, 0.016 * i)
 
+    def uniforms_light_orbit(dr_, i):
+        # the directional light (the shadow caster) circles the scene at its own radius and height, 1 degree per frame: the shadow pass's work
+        # list is rebuilt every frame and its occlusion flags (scenes dense enough to have them on) are a frame stale
+        d = cfg["dir"].copy()
+        p0 = np.array(cfg["dir"]["Position"][0][:3], dtype=np.float64)
+        rad, a = math.hypot(p0[0], p0[1]), math.atan2(p0[1], p0[0]) + math.radians(1.0 * i)
+        d["Position"][0][:3] = (rad * math.cos(a), rad * math.sin(a), p0[2]); d["Direction"][0][:3] = d["Position"][0][:3]
+        dr_.r.update_uniforms(cam0, d, cfg["point"], cfg["spot"], 0.0, 0.002 * i, 0.016 * i)
+
     def timed_loop(dr_, steps, warmup, per_frame):
         # (CPython's cyclic collector off while frames are enqueued: with torch imported a full collection takes ~37 ms of host time - a hole
         # of a hundred frames in the GPU's queue - and falls around the 160th frame of any loop that long: tools/host_variant_check.py)
@@ -270,6 +279,9 @@ def main():
         el = timed_loop(dr, k, 5, uniforms_orbit)
         extras["value_moving_camera"] = round(W * H * k / el / 1e6, 3)
         extras["moving_camera_note"] = "same workload, camera orbiting 2 deg/frame (stale Hi-Z history every frame), %d frames" % k
+        el = timed_loop(dr, k, 5, uniforms_light_orbit)
+        extras["value_moving_light"] = round(W * H * k / el / 1e6, 3)
+        extras["moving_light_note"] = "same workload, the directional light orbiting 1 deg/frame (shadow work list rebuilt, shadow occlusion flags stale every frame), %d frames" % k
         if world == 1:
             n_rb = max(5, min(20, args.steps))        # informative only (never `value`): every frame read back over PCIe
             t1 = time.perf_counter()
