@@ -132,7 +132,8 @@ struct zr_ctx {
     // visibility of the previous / current frame (one byte per meshlet-instance, marked by the resolve), the pyramid
     uint2* d_pxrect = nullptr; float* d_zmin = nullptr; uint8_t* d_visflag[2] = { nullptr, nullptr };
     // shadow pass occlusion culling (k_shadow_occlusion): the cull's box + least depth per work item, "not hidden last frame" per meshlet-instance
-    uint2* d_spxrect = nullptr; float* d_szmin = nullptr; uint8_t* d_sflag = nullptr; uint32_t occl_blocks = 0;
+    uint2* d_spxrect = nullptr; float* d_szmin = nullptr; uint8_t* d_sflag = nullptr;
+    bool sflag_history = false;          // the flags come from a frame of this scene (else: all set, and the first test takes every item)
     float* d_hiz = nullptr; ZrHiz hiz = {}; int vis_cur = 0; bool vis_history = false, last_two_round = false;
     ZrDevStats* d_stats = nullptr; ZrDevStats h_stats = {};
     // The shadow pipeline's statistics / work counters (slot 0) live in a block of their own: the pipeline resets what it counts itself

@@ -824,6 +824,7 @@ static int finalize_scene(zr_ctx* c)
     for (const auto& o : c->objects) if (o.mixed_sizes) c->mixed_images = true;      // (the skydome's one image is sampled by itself)
     c->vis_history = false;         // work item numbering changed: last frame's visibility says nothing about this scene
     if (c->n_work) HIPCHK(c, hipMemsetAsync(c->d_sflag, 1, c->n_work, c->stream));      // shadow pass: everything is drawn in the first launch
+    c->sflag_history = false;
     c->list_valid[0] = c->list_valid[1] = false;      // ... and neither do the passes' work lists
     c->scene_dirty = false;
     return ZR_OK;
@@ -1254,7 +1255,8 @@ static int shadow_pass(zr_ctx* c, hipStream_t s)
     raster(c, P, Z, 0, s, occl ? 1 : 0);
     if (occl) {
         zr_launch_shadow_occlusion(P, c->d_objs, c->sc[0].work, c->sc[0].rects, c->d_spxrect, c->d_szmin, c->d_sflag, (const uint32_t*)shadow_buf(c),
-                                   c->sc[0].bins, c->d_sstats, c->shadow_blocks * 8u, s);
+                                   c->sc[0].bins, c->d_sstats, c->shadow_blocks * 8u, c->sflag_history ? (uint32_t)(c->frame_no & 3u) : 4u, s);
+        c->sflag_history = true;
         raster(c, P, Z, 0, s, 2);
     }
     if (ev) HIPCHK(c, hipEventRecord(ev[2], s));

@@ -1868,14 +1868,12 @@ void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* _
 // then this kernel tests EVERY survivor of the cull against the map as it stands (box and least depth from k_cull_box: conservative, the
 // camera pass's Hi-Z bounds), flags "not hidden" for the next frame, and hands the unflagged ones that are not hidden to a late launch
 // of the rasteriser.  A light or a scene that moves costs late work, never a wrong texel.
-// A wave takes 64 consecutive work items, a lane each for the item's record (box, least depth, flag: coalesced loads, and later ONE store
-// of the 64 flags - a byte stored per item by whichever lane happened to test it is a partial write of a cache line that lanes of other
-// waves write too: 110 000 of those took 150 us).  The texels are read by TASKS: one per (item, row of its box), dealt out to the lanes by a
-// prefix sum over the boxes' heights, so a 4 x 4 box costs 4 lane-loads and a 40 x 40 one 400, whatever mix a wave meets.  (What the
-// test costs at 1 M instances - 290 us for 2.75 M survivors, the same for three different lane layouts - is the map's rows coming in from
-// L2 / MALL: every row of every box is a cache line of its own, ~11 M of them in work-list order.)
-// A task loads its row in spans of 4 texels (the map's rows are 4-byte aligned, nothing more is asked of a global load), masks what lies
-// beyond the box's right edge, and folds its maximum into the item's word in LDS (ds_max).
+// A wave takes 64 survivors of the cull, a lane each for the item's record (box, least depth, flag), and writes their flags with ONE store
+// (a byte stored per item by whichever lane happened to test it is a partial write of a cache line that lanes of other waves write too:
+// 110 000 of those took 150 us).  The texels are read by TASKS: one per (item, row of its box), dealt out to the lanes by a prefix sum
+// over the boxes' heights, so a 4 x 4 box costs 4 lane-loads and a 40 x 40 one 400, whatever mix a wave meets.  A task loads its row in
+// spans of 4 texels (the map's rows are 4-byte aligned, nothing more is asked of a global load), masks what lies beyond the box's right
+// edge, and folds its maximum into the item's word in LDS (ds_max).
 struct __attribute__((packed, aligned(4))) ZrTexel4 { uint32_t x, y, z, w; };      // four texels of a map row, from any texel on
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)      // inclusive prefix sum over the wave's lanes (rows on the DPP network, then across)
 {
@@ -1890,26 +1888,53 @@ __global__ __launch_bounds__(256) void k_shadow_occlusion(ZrPass P, const ZrObje
                                                           const uint32_t* __restrict__ rects, const uint2* __restrict__ pxrect,
                                                           const float* __restrict__ zmin, uint8_t* __restrict__ flags,
                                                           const uint32_t* __restrict__ shadow_bits, ZrBinEntry* __restrict__ bins,
-                                                          ZrDevStats* __restrict__ stats)
+                                                          ZrDevStats* __restrict__ stats, uint32_t retest)
 {
+    // retest: which quarter of the FLAGGED items is tested this frame (work id + retest divisible by 4; >= 4: all of them, a scene's first
+    // frame).  A flagged item was drawn by the first launch whatever the test says - the test only decides whether it is drawn again next
+    // frame - so it can wait up to three frames; an unflagged item is tested every frame (it is drawn if the test does not hide it).
     __shared__ uint32_t s_first[4][WAVE], s_far[4][WAVE];      // per wave: an item's first task, the farthest texel of its box so far
     __shared__ uint2 s_box[4][WAVE];
+    // A workgroup takes 1 024 consecutive work items and first lists the survivors of the cull among them (a quarter, at 1 M instances):
+    // the waves then work on full sets of 64 survivors.  (A wave's stretch is a chain of three or four dependent round trips to memory, and
+    // 8 waves per SIMD is all there is to hide it: with the dead items in the lanes the kernel took 300 us for 11 M items, 2.75 M alive.)
+    __shared__ uint32_t s_live[1024], s_nlive;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t n = WORKLIST ? stats->n_vis_work[0] : P.n_work;
     uint32_t n_occl = 0, n_late = 0;
-    for (uint32_t base = (blockIdx.x * 4u + wv) * 64u; base < n; base += gridDim.x * 256u) {
-        const uint32_t k = base + lane;
+    for (uint32_t blk = blockIdx.x * 1024u; blk < n; blk += gridDim.x * 1024u) {
+      if (threadIdx.x == 0u) s_nlive = 0u;
+      __syncthreads();
+      {
+        uint32_t rr[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) { const uint32_t k = blk + j * 256u + threadIdx.x; rr[j] = k < n ? rects[k] : ZR_RECT_CULLED; }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const unsigned long long m = __ballot(rr[j] != ZR_RECT_CULLED);
+            uint32_t at = 0;
+            if (lane == 0u && m) at = atomicAdd(&s_nlive, (uint32_t)__popcll(m));
+            at = lane_bcast(at, 0u);
+            if (rr[j] != ZR_RECT_CULLED) s_live[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = blk + j * 256u + threadIdx.x;
+        }
+      }
+      __syncthreads();
+      const uint32_t n_live = s_nlive;
+      for (uint32_t base = wv * 64u; base < n_live; base += 256u) {
+        const bool have = base + lane < n_live;
+        const uint32_t k = have ? s_live[base + lane] : 0u;
         uint32_t r = ZR_RECT_CULLED, w = 0, zb = 0x80000000u;
         uint2 pr = make_uint2(0u, 0u);
         bool flagged = true;
-        if (k < n) {
+        if (have) {
             r = rects[k]; pr = pxrect[k]; zb = zr_f2u(zmin[k]); w = WORKLIST ? work[k] : k;
             flagged = flags[w] != 0;
         }
         const bool live = r != ZR_RECT_CULLED;
         const uint32_t x0 = pr.x & 0xFFFFu, y0 = pr.x >> 16, x1 = pr.y & 0xFFFFu, y1 = pr.y >> 16;
         // (zmin < 0: the box touches the near plane or the guard band, or is not finite: drawn, never tested; boxes wider than 64 texels neither)
-        const bool test = live && (int)zb >= 0 && x1 - x0 < 64u && y1 - y0 < 64u;
+        const bool due = !flagged || retest >= 4u || ((w + retest) & 3u) == 0u;
+        const bool test = live && due && (int)zb >= 0 && x1 - x0 < 64u && y1 - y0 < 64u;
         const uint32_t rows = test ? y1 - y0 + 1u : 0u;
         const uint32_t incl = wave_incl_scan(rows), total = lane_bcast(incl, 63u);
         lds_fence();      // the previous stretch's readers are done
@@ -1962,6 +1987,8 @@ __global__ __launch_bounds__(256) void k_shadow_occlusion(ZrPass P, const ZrObje
                     else { stats->overflow = 1u; stats->overflow_sticky = 1u; }
                 }
         }
+      }
+      __syncthreads();      // the list is rewritten by the next stretch
     }
     // the tally in 32 partial sums (the shadow pipeline's block has no other use for covered_part; zr_finish adds them up): one atomic per
     // workgroup on ONE word queued up for ~10 ns apiece - 17 us for config 3's 1 719 workgroups
@@ -3386,12 +3413,12 @@ void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4*
 }
 void zr_launch_shadow_occlusion(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint2* pxrect,
                                 const float* zmin, uint8_t* flags, const uint32_t* shadow_bits, ZrBinEntry* bins, ZrDevStats* stats,
-                                uint32_t n_blocks, hipStream_t s)
+                                uint32_t n_blocks, uint32_t retest, hipStream_t s)
 {
     if (P.n_work == 0) return;
-    const dim3 g(std::min<uint32_t>((P.n_work + 255u) / 256u, n_blocks)), b(256);
-    if (P.use_worklist) hipLaunchKernelGGL(k_shadow_occlusion<true>, g, b, 0, s, P, objs, work, rects, pxrect, zmin, flags, shadow_bits, bins, stats);
-    else hipLaunchKernelGGL(k_shadow_occlusion<false>, g, b, 0, s, P, objs, work, rects, pxrect, zmin, flags, shadow_bits, bins, stats);
+    const dim3 g(std::min<uint32_t>((P.n_work + 1023u) / 1024u, n_blocks)), b(256);
+    if (P.use_worklist) hipLaunchKernelGGL(k_shadow_occlusion<true>, g, b, 0, s, P, objs, work, rects, pxrect, zmin, flags, shadow_bits, bins, stats, retest);
+    else hipLaunchKernelGGL(k_shadow_occlusion<false>, g, b, 0, s, P, objs, work, rects, pxrect, zmin, flags, shadow_bits, bins, stats, retest);
 }
 void zr_launch_select(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats,
                       int slot, hipStream_t s)

@@ -240,7 +240,7 @@ void zr_launch_fill64(unsigned long long* p, unsigned long long v, size_t n, hip
 // cull against the map, rewrite the flags, list the unflagged ones that are not hidden (from the top of `bins` downwards)
 void zr_launch_shadow_occlusion(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint2* pxrect,
                                 const float* zmin, uint8_t* flags, const uint32_t* shadow_bits, ZrBinEntry* bins, ZrDevStats* stats,
-                                uint32_t n_blocks, hipStream_t s);
+                                uint32_t n_blocks, uint32_t retest, hipStream_t s);
 void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4* chunk_tab,
                              const ZrBinEntry* bins, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t* shadow_bits,
                              uint32_t n_blocks, const ZrHiz& Z, hipStream_t s, uint4* slow = nullptr, uint32_t slow_cap = 0, const uint32_t* tiles = nullptr,
