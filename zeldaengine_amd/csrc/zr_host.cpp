@@ -1239,7 +1239,7 @@ static int shadow_pass(zr_ctx* c, hipStream_t s)
     // occlusion culling (k_shadow_occlusion): the first launch draws what was not hidden last frame, the rest is tested against the map.
     // It pays when casters pile up behind each other: the test + the late launch cost what a quarter of config 3's rasteriser does
     // (0.1 meshlet-instances per texel: 25 % hidden, frame 2.7 % slower) and a fifth of what they save at 1 M instances (10 per texel:
-    // 37 % hidden, frame 5 % faster) - on by itself from one meshlet-instance per two texels of the map.
+    // 37 % hidden, frame 10 % faster) - on by itself from one meshlet-instance per two texels of the map.
     bool occl = !(c->cfg.flags & ZR_FLAG_NO_SHADOW_OCCLUSION) && P.n_work != 0 && ZR_TILE == 32 && c->SD >= 4u &&
                 ((c->cfg.flags & ZR_FLAG_SHADOW_OCCLUSION) || 2ull * P.n_work >= (uint64_t)c->SD * c->SD);
 #ifdef ZR_DIAG
