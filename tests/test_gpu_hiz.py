@@ -136,17 +136,32 @@ def test_tile_partitioned_ranks_keep_their_own_history(oracle_lib, gpu_engine):
             assert all(g.stats()["round1_survivors"] > 0 for g in ranks)
 
 
+def _three_frames_with_a_light_step(g, cfg):
+    """Two still frames, then the shadow-casting light turns one degree about the scene: the third frame runs on a visibility history
+    and on shadow-occlusion flags that belong to the old light."""
+    import math
+    d = cfg["dir"].copy()
+    p0 = np.array(cfg["dir"]["Position"][0][:3], dtype=np.float64)
+    rad, a0 = math.hypot(p0[0], p0[1]), math.atan2(p0[1], p0[0])
+    for i, deg in enumerate((0.0, 0.0, 1.0)):
+        a = a0 + math.radians(deg)
+        d["Position"][0][:3] = (rad * math.cos(a), rad * math.sin(a), p0[2]); d["Direction"][0][:3] = d["Position"][0][:3]
+        g.update_uniforms(cfg["camera"], d, cfg["point"], cfg["spot"], 0.0, 0.0, 0.0)
+        g.render()
+    g.finish()
+
+
 def test_config4_scale_culling_paths_agree(gpu_engine):
-    """BASELINE config 4's size (1 M instances = 14 M meshlet-instances, 3840x2160; too big for the scalar oracle): the frame with
-    every conservative cull on (instance pre-pass + work list, frustum, cone, two-pass Hi-Z, second frame = history in use) must
-    equal the frame with all of them off, in every target."""
+    """BASELINE config 4's size (1 M instances = 11 M meshlet-instances, 3840x2160; too big for the scalar oracle): the frame with
+    every conservative cull on (instance pre-pass + work list, frustum, cone, two-pass Hi-Z, the shadow pass's occlusion culling; third
+    frame, after the light has moved = histories in use and stale) must equal the frame with all of them off, in every target."""
     from zeldaengine_amd import engine as eng
     cfg = scenes.config4(1000000, 16)
     frames = []
-    for flags in (0, abi.FLAG_NO_FRUSTUM_CULL | abi.FLAG_NO_CONE_CULL | abi.FLAG_NO_HIZ):
+    for flags in (0, abi.FLAG_NO_FRUSTUM_CULL | abi.FLAG_NO_CONE_CULL | abi.FLAG_NO_HIZ | abi.FLAG_NO_SHADOW_OCCLUSION):
         g = gpu_engine.Renderer(cfg["width"], cfg["height"], 1024, flags=flags)
         eng.load_scene(g, cfg)
-        g.render(); g.render(); g.finish()
+        _three_frames_with_a_light_step(g, cfg)
         frames.append((g.color(), [g.gbuffer(t) for t in range(6)], g.shadowmap(), g.stats()))
         g.close()
     a, b = frames
@@ -155,6 +170,9 @@ def test_config4_scale_culling_paths_agree(gpu_engine):
         assert np.array_equal(a[1][t].view(np.uint8), b[1][t].view(np.uint8)), "GBuffer target %d" % t
     assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
     assert a[3]["covered_pixels"] == b[3]["covered_pixels"] and a[3]["overflow"] == 0 and b[3]["overflow"] == 0
+    # the shadow pass's occlusion culling switches itself on at this density (10 meshlet-instances per texel): a third of the casters is
+    # left out, the light's step brings some back late
+    assert a[3]["shadow_occluded"] > 500000 and a[3]["shadow_late"] > 0 and b[3]["shadow_occluded"] == 0 and b[3]["shadow_late"] == 0, (a[3], b[3])
     # (the bound was // 4 with round 2's 14-meshlet spheres: the 11 fuller meshlets of the slab x sector clusteriser have wider normal
     # cones - frustum + cone culls remove 33 % of the meshlet-instances where they removed 41 % - so fewer fall before the rasteriser)
     assert a[3]["hiz_culled"] > 100000 and a[3]["survivors"][1] < b[3]["survivors"][1] // 3
@@ -191,10 +209,10 @@ def test_config5_full_size_culling_paths_agree(gpu_engine):
     cfg = scenes.config4(1000000, 256)
     assert len(cfg["point"]) == 256 and (cfg["width"], cfg["height"]) == (3840, 2160)
     frames = []
-    for flags in (0, abi.FLAG_NO_FRUSTUM_CULL | abi.FLAG_NO_CONE_CULL | abi.FLAG_NO_HIZ):
+    for flags in (0, abi.FLAG_NO_FRUSTUM_CULL | abi.FLAG_NO_CONE_CULL | abi.FLAG_NO_HIZ | abi.FLAG_NO_SHADOW_OCCLUSION):
         g = gpu_engine.Renderer(cfg["width"], cfg["height"], 1024, flags=flags)
         eng.load_scene(g, cfg)
-        g.render(); g.render(); g.finish()
+        _three_frames_with_a_light_step(g, cfg)
         frames.append((g.color(), [g.gbuffer(t) for t in range(6)], g.shadowmap(), g.stats()))
         g.close()
     a, b = frames
@@ -203,6 +221,7 @@ def test_config5_full_size_culling_paths_agree(gpu_engine):
         assert np.array_equal(a[1][t].view(np.uint8), b[1][t].view(np.uint8)), "GBuffer target %d" % t
     assert np.array_equal(a[2].view(np.uint32), b[2].view(np.uint32))
     assert a[3]["covered_pixels"] == b[3]["covered_pixels"] and a[3]["overflow"] == 0 and b[3]["overflow"] == 0
+    assert a[3]["shadow_occluded"] > 500000 and b[3]["shadow_occluded"] == 0, (a[3], b[3])
     # (// 1.9, not // 4: same clusteriser effect as above, and with 256 lights nothing else changes what the culls see; survivors[1]
     # counts the meshlet-instances that reach k_geom in either round - triangles the per-triangle pyramid test drops are not taken off)
     assert a[3]["round1_survivors"] > 0 and a[3]["hiz_culled"] > 100000 and a[3]["survivors"][1] < b[3]["survivors"][1] // 1.9
