@@ -62,7 +62,7 @@ typedef struct zr_ctx zr_ctx;
 #define ZR_FLAG_NO_SHADOW_OCCLUSION 512u /* shadow pass: draw every survivor of the cull instead of leaving out what the map's own depths already hide
                                      * (parity A/B: the map is the same bit for bit either way) */
 #define ZR_FLAG_SHADOW_OCCLUSION 1024u  /* ... and the opposite: occlusion-cull the shadow pass of a scene of any size (by default only from one
-                                     * meshlet-instance per two texels of the map on, where it pays) */
+                                     * meshlet-instance per five texels of the map on, where it pays) */
 
 typedef struct zr_config {
     uint32_t width, height;   /* swapchain extent, ZE:78-79 (default 1920x1080) */

@@ -4,7 +4,7 @@ The rasteriser's first launch draws the meshlet-instances that were not hidden l
 cull against the map (conservative box + least depth from k_cull_box), rewrites the flags and hands the unflagged ones that are not hidden
 to a late launch.  Every frame of a sequence - no history, exact history, a light that moves a little / jumps, a scene that changes - is
 compared bit for bit with the oracle (which draws every triangle) or, at sizes the oracle cannot reach, with a context that has the
-culling off (ZR_FLAG_NO_SHADOW_OCCLUSION).  It is on by itself from one meshlet-instance per two texels of the map on (the 70 000-instance
+culling off (ZR_FLAG_NO_SHADOW_OCCLUSION).  It is on by itself from one meshlet-instance per five texels of the map on (the 70 000-instance
 scenes of test_gpu_hiz.py run it against the oracle that way); ZR_FLAG_SHADOW_OCCLUSION forces it for the small scenes here.
 """
 import math

@@ -1238,10 +1238,10 @@ static int shadow_pass(zr_ctx* c, hipStream_t s)
     ZrHiz Z; memset(&Z, 0, sizeof Z);
     // occlusion culling (k_shadow_occlusion): the first launch draws what was not hidden last frame, the rest is tested against the map.
     // It pays when casters pile up behind each other: the test + the late launch cost what a quarter of config 3's rasteriser does
-    // (0.1 meshlet-instances per texel: 25 % hidden, frame 2.7 % slower) and a fifth of what they save at 1 M instances (10 per texel:
-    // 37 % hidden, frame 10 % faster) - on by itself from one meshlet-instance per two texels of the map.
+    // (0.1 meshlet-instances per texel: 25 % hidden, frame 2.7 % slower); the same spheres at 0.21 / 0.31 / 0.52 per texel: frame 2 /
+    // 8 / 10.5 % faster (tools/occlusion_threshold.py); 1 M instances (10 per texel): 10 % - on by itself from one per five texels.
     bool occl = !(c->cfg.flags & ZR_FLAG_NO_SHADOW_OCCLUSION) && P.n_work != 0 && ZR_TILE == 32 && c->SD >= 4u &&
-                ((c->cfg.flags & ZR_FLAG_SHADOW_OCCLUSION) || 2ull * P.n_work >= (uint64_t)c->SD * c->SD);
+                ((c->cfg.flags & ZR_FLAG_SHADOW_OCCLUSION) || 5ull * P.n_work >= (uint64_t)c->SD * c->SD);
 #ifdef ZR_DIAG
     if (!c->env_shadow_box) { occl = false; zr_launch_cull(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, c->raster_blocks * 4u, s); }
     else
