@@ -44,6 +44,8 @@ PROFILE_INDEX = os.path.join(ROOT, "profiles", "current.json")     # written by 
 # k_index, k_tile and k_tile_slow run once per round under one name, so their profile rows hold both rounds.
 KERNEL_OF_PASS = {"shadow": ("k_raster<SHADOW>", "k_tile_slow<SHADOW>"), "gbuffer": ("k_geom<false>", "k_scan_tri", "k_index", "k_tile<0>"),
                   "gbuffer2": ("k_geom<true>",), "resolve": ("k_resolve_gbuffer",), "lighting": ("k_lighting",)}
+# kernels a pass runs only in some scenes (the shadow pass's occlusion culling: on from one meshlet-instance per five texels of the map)
+KERNEL_OF_PASS_OPTIONAL = {"shadow": ("k_shadow_occlusion", "k_raster<SHADOW,late>")}
 GBUFFER_WRITE_PASS = ("gbuffer", "gbuffer2", "resolve")
 GBUFFER_WRITE_KERNELS = "k_geom + k_scan_tri + k_index + k_tile (x2 rounds; the last one also draws the slow triangles) + k_resolve_gbuffer"
 
@@ -343,16 +345,19 @@ def main():
         prof = load_profile(workload, sha) if world == 1 else None
         ptraffic = (prof or {}).get("kernels", {})
 
+        def pass_kernels(p):
+            return tuple(KERNEL_OF_PASS[p]) + tuple(k for k in KERNEL_OF_PASS_OPTIONAL.get(p, ()) if k in ptraffic)
+
         def pass_traffic(p):
-            t = [ptraffic.get(k, {}).get("hbm_bytes_per_frame") for k in KERNEL_OF_PASS[p]]
+            t = [ptraffic.get(k, {}).get("hbm_bytes_per_frame") for k in pass_kernels(p)]
             return int(sum(t)) if t and all(x is not None for x in t) else None
 
         def kernel_row(p, ms):
-            row = {"pass": p, "kernels": list(KERNEL_OF_PASS[p]), "ms": round(ms[p], 4), "algorithmic_bytes": int(alg[p]),
+            row = {"pass": p, "kernels": list(pass_kernels(p)), "ms": round(ms[p], 4), "algorithmic_bytes": int(alg[p]),
                    "achieved_gbs": round(alg[p] / (ms[p] * 1e-3) / 1e9, 2) if ms[p] > 0 else None, "traffic": pass_traffic(p)}
             # what bounds each kernel, from the SQ counters of the committed profile (tools/make_profile_summary.py: share of a wave's life
             # with a vector instruction in execution / parked on memory or a barrier / ready but not issued; mean resident waves per SIMD)
-            iss = {k: ptraffic[k]["issue"] for k in KERNEL_OF_PASS[p] if k in ptraffic and "issue" in ptraffic[k]}
+            iss = {k: ptraffic[k]["issue"] for k in pass_kernels(p) if k in ptraffic and "issue" in ptraffic[k]}
             if iss:
                 row["issue"] = {k: {f: v.get(f) for f in ("valu_active_frac", "wait_mem_frac", "wait_issue_frac", "waves_per_simd", "valu_simd_busy", "lanes_active_frac",
                                                           "valu_cycles_per_inst_simd")} for k, v in iss.items()}

@@ -35,6 +35,9 @@ CLOCK_HZ, SIMDS = 2.4e9, 1024
 
 SHORT = {"k_raster_chunks<0, false>": "k_raster<GBUFFER>", "k_raster_chunks<0, true>": "k_raster<GBUFFER,HiZ>",
          "k_raster_chunks<1, false>": "k_raster<SHADOW>", "k_raster_chunks<1, false, true>": "k_raster<SHADOW>", "k_raster_chunks<1, false, false>": "k_raster<SHADOW>",
+         "k_raster_chunks<1, false, true, false>": "k_raster<SHADOW>", "k_raster_chunks<1, false, false, false>": "k_raster<SHADOW>",
+         "k_raster_chunks<1, false, true, true>": "k_raster<SHADOW,late>", "k_raster_chunks<1, false, false, true>": "k_raster<SHADOW,late>",      # after k_shadow_occlusion
+         "k_shadow_occlusion<true>": "k_shadow_occlusion", "k_shadow_occlusion<false>": "k_shadow_occlusion",
          "k_raster_chunks<0, false, false>": "k_raster<GBUFFER>", "k_raster_chunks<0, true, false>": "k_raster<GBUFFER,HiZ>",
          "k_tile_slow<0, false>": "k_tile_slow<GBUFFER>", "k_tile_slow<1, true>": "k_tile_slow<SHADOW>",
          "k_tile<0, false>": "k_tile<0>", "k_tile<0, true>": "k_tile<0>",      # (the frame's last round also draws the slow triangles)
