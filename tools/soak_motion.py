@@ -1,12 +1,13 @@
 """Soak: config 4 (1 M instances, 3840x2160) for N frames with the camera AND the shadow-casting light moving every frame, two contexts
-side by side - every cull on / every cull off - compared bit for bit every K-th frame.  python tools/soak_motion.py [frames] [every]"""
+side by side - every cull on / every cull off - compared bit for bit every K-th frame.  python tools/soak_motion.py [frames] [every] [point lights: 16 = config 4, 256 = config 5]"""
 import sys, math, time
 sys.path.insert(0, '.')
 import numpy as np
 from zeldaengine_amd import engine, scenes, abi
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 25
-cfg = scenes.config4(1000000, 16, cube_dim=64)
+NP = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+cfg = scenes.config4(1000000, NP, cube_dim=64)
 on = engine.Renderer(cfg["width"], cfg["height"], 1024)
 off = engine.Renderer(cfg["width"], cfg["height"], 1024, flags=abi.FLAG_NO_FRUSTUM_CULL | abi.FLAG_NO_CONE_CULL | abi.FLAG_NO_HIZ | abi.FLAG_NO_SHADOW_OCCLUSION | abi.FLAG_NO_LIST_REUSE)
 off.set_limits(record_chunks=1 << 20)      # without the culls one round draws everything: up to ~200 M records at some camera positions
