@@ -35,6 +35,10 @@ extern "C" {
 #define ZR_ERR_OVERFLOW -7
 #define ZR_ERR_UNSUPPORTED -8
 
+/* Version of this header's structs and entry points.  A host checks zr_abi_version() == ZR_ABI_VERSION after loading the library
+ * (INTEGRATION.md); structs that may grow (zr_stats) are passed with their size as the caller knows it and only ever grow at the end. */
+#define ZR_ABI_VERSION 5u
+
 #ifndef ZR_TILE
 #define ZR_TILE 32            /* screen tile edge in pixels (raster + multi-GPU partition unit); 32 or 64 */
 #endif
@@ -107,6 +111,9 @@ typedef struct zr_stats {
     uint64_t round1_survivors;  /* of survivors[1]: drawn in round 1 (visible last frame); 0 when the frame ran in one round */
     uint32_t shadow_occluded;   /* of survivors[0]: not drawn - every texel their box reaches already held a nearer depth (the map is the same) */
     uint32_t shadow_late;       /* of survivors[0]: hidden last frame, not hidden now: drawn by the shadow pass's late launch */
+    uint32_t hiz_culled_geom;   /* of hiz_culled: rejected only after a wave had transformed the meshlet's vertices (exact vertex box, every triangle
+                                 * hidden); hiz_culled - hiz_culled_geom fell to the box bounds before any vertex work */
+    uint32_t struct_bytes;      /* sizeof(zr_stats) as the LIBRARY knows it (ABI version 5: 96) */
 } zr_stats;
 
 /* --- lifetime (replaces InitVulkan/Cleanup, ZE:1714, 3747) --- */
@@ -116,6 +123,7 @@ const char* zr_last_error(const zr_ctx* ctx);
 /* Render on a caller-owned hipStream_t (NULL = the context's own stream). */
 int  zr_set_stream(zr_ctx* ctx, void* hip_stream);
 int  zr_tile_size(void);                            /* the ZR_TILE this library was built with */
+uint32_t zr_abi_version(void);                      /* the ZR_ABI_VERSION this library was built with */
 
 /* --- scene submission (replaces CreateRenderObjectsFromProfabs ZE:4922-5000, CreateMeshVertexBuffers
  *     ZE:4725-4770, CreateInstancedBuffer ZE:4795-4824) --- */
@@ -139,7 +147,7 @@ int  zr_mesh_get_meshlets(zr_ctx* ctx, uint32_t mesh_id, XkMeshlet* m, uint32_t*
 /* n_inst == 0: non-instanced draw (Base.vert); n_inst >= 1: instanced draw (BaseInstanced.vert). */
 int  zr_object_add(zr_ctx* ctx, uint32_t mesh_id, const zr_material* mat,
                    const XkInstanceData* inst, uint32_t n_inst);
-/* Capacities of the camera pass's triangle-record pool (in chunks of 256 records of 68 bytes) and of its clipped-triangle list; 0 =
+/* Capacities of the camera pass's triangle-record pool (in chunks of 256 records of 40 bytes: 32 + a tile id + an index-list entry) and of its clipped-triangle list; 0 =
  * defaults (8 records per meshlet-instance of the scene, at least 32 Mi, plus 8192 chunks the rasteriser's waves start in; 2^18
  * triangles).  A frame that outgrows either reports ZR_ERR_OVERFLOW at zr_finish.  Takes effect at the next frame (the pools are re-made). */
 int  zr_set_limits(zr_ctx* ctx, uint32_t record_chunks, uint32_t slow_triangles);
@@ -193,7 +201,8 @@ int  zr_get_pass_times_avg(zr_ctx* ctx, uint32_t last_n, float ms[ZR_PASS_COUNT]
 int  zr_get_frame_latencies(zr_ctx* ctx, uint32_t n, float* ms);   /* begin-to-end GPU ms of the last n timed frames, newest first; returns the count */
 int  zr_get_frame_periods(zr_ctx* ctx, uint32_t n, float* ms);     /* GPU ms between the ends of consecutive frames, last n <= 511 frames, newest first; returns the count */
 int  zr_set_timing_interval(zr_ctx* ctx, uint32_t interval);  /* pass events on every interval-th frame (default 1, 0 = never) */
-int  zr_get_stats(zr_ctx* ctx, zr_stats* out);
+/* bytes = sizeof(zr_stats) of the caller's header: the library writes min(bytes, its own size), so an older host is never overrun. */
+int  zr_get_stats(zr_ctx* ctx, zr_stats* out, size_t bytes);
 
 /* --- read-back (there is no swapchain; replaces vkQueuePresentKHR ZE:2030) --- */
 int  zr_read_color(zr_ctx* ctx, uint8_t* rgba8, size_t bytes);         /* W*H*4 row-major, top-left origin */
@@ -201,6 +210,10 @@ int  zr_read_color(zr_ctx* ctx, uint8_t* rgba8, size_t bytes);         /* W*H*4 
  * 5 GBufferD RGBA16F (ZE:2807-2843); W*H*{4,4,4,4,4,8} bytes. */
 int  zr_read_gbuffer(zr_ctx* ctx, int target, void* dst, size_t bytes);
 int  zr_read_shadowmap(zr_ctx* ctx, float* dst, size_t bytes);        /* dim*dim*4 */
+/* The frame enqueued last, copied into caller-owned DEVICE buffers (W*H*4 bytes of RGBA8; dim*dim*4 of depth; either may be NULL) in
+ * stream order, without synchronising the host: the copies run behind that frame's lighting pass and ahead of anything the next
+ * zr_render puts on the render stream - what a presenting host with two frames in flight uses instead of zr_read_color. */
+int  zr_copy_frame_async(zr_ctx* ctx, void* color_dev, void* shadow_dev);
 
 /* --- multi-GPU screen-tile partition --- */
 /* Owner of tile (tx, ty) in a world of `world` ranks, and the list of tiles a rank owns in increasing tile index (= its slot order

@@ -15,20 +15,24 @@ _LIB = os.path.join(_HERE, "_build", "liboracle.so")
 
 def build(force=False):
     src = [os.path.join(_HERE, f) for f in ("zo_oracle.c", "zo_math.h", "zo_oracle.h")]
-    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src):
+    outs = (_LIB, os.path.join(_HERE, "_build", "liboracle_literal.so"))
+    if force or any(not os.path.exists(o) or any(os.path.getmtime(s) > os.path.getmtime(o) for s in src) for o in outs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB
 
 
-_lib = None
+_LIB_LITERAL = os.path.join(_HERE, "_build", "liboracle_literal.so")      # -DZO_LITERAL: the IEEE-literal evaluation (oracle/CONTRACT.md)
+_libs = {}
 
 
-def lib():
-    global _lib
+def lib(literal=False):
+    """The oracle (the contract's evaluation) or, literal=True, its IEEE-literal twin: same entry points."""
+    path = _LIB_LITERAL if literal else _LIB
+    _lib = _libs.get(path)
     if _lib is None:
-        if not os.path.exists(_LIB):
-            build()
-        L = C.CDLL(_LIB)
+        if not os.path.exists(path):
+            build(force=True)
+        L = C.CDLL(path)
         L.zo_create.restype = C.c_void_p
         L.zo_create.argtypes = [C.c_uint32] * 3
         L.zo_destroy.argtypes = [C.c_void_p]
@@ -77,7 +81,7 @@ def lib():
         L.zo_kat_tex_mip.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
         L.zo_kat_cube_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
         L.zo_kat_cube_mip.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-        _lib = L
+        _lib = _libs[path] = L
     return _lib
 
 
@@ -88,8 +92,8 @@ def _ptr(a):
 class Oracle:
     """Same call sequence as zeldaengine_amd.engine.Renderer, on the CPU."""
 
-    def __init__(self, width, height, shadow_dim=1024):
-        self.L = lib()
+    def __init__(self, width, height, shadow_dim=1024, literal=False):
+        self.L = lib(literal)
         self.W, self.H, self.SD = width, height, shadow_dim
         self.h = self.L.zo_create(width, height, shadow_dim)
         self._keep = []
@@ -191,7 +195,7 @@ class Oracle:
         """texture(sampler2D, uv) of an (h, w, 4) uint8 image with the screen-space derivatives duv = (dudx, dvdx, dudy, dvdy)"""
         im = np.ascontiguousarray(image, np.uint8)
         a = np.asarray(uv, np.float32); d = np.asarray(duv, np.float32); out = np.zeros(4, np.float32)
-        lib().zo_kat_tex_sample(self.h, _ptr(im), im.shape[1], im.shape[0], int(srgb), _ptr(a), _ptr(d), _ptr(out))
+        self.L.zo_kat_tex_sample(self.h, _ptr(im), im.shape[1], im.shape[0], int(srgb), _ptr(a), _ptr(d), _ptr(out))
         return out
 
     def tex_mips(self, image, srgb):
@@ -201,14 +205,14 @@ class Oracle:
         while True:
             lw, lh = max(1, w >> level), max(1, h >> level)
             buf = np.zeros((lh, lw, 4), np.uint8)
-            n = lib().zo_kat_tex_mip(self.h, _ptr(im), w, h, int(srgb), level, _ptr(buf))
+            n = self.L.zo_kat_tex_mip(self.h, _ptr(im), w, h, int(srgb), level, _ptr(buf))
             out.append(buf); level += 1
             if level >= n:
                 return out
 
     def cube_sample(self, direction, lod):
         d = np.asarray(direction, np.float32); out = np.zeros(3, np.float32)
-        lib().zo_kat_cube_sample(self.h, _ptr(d), float(lod), _ptr(out))
+        self.L.zo_kat_cube_sample(self.h, _ptr(d), float(lod), _ptr(out))
         return out
 
     def cube_mips(self, dim):
@@ -216,7 +220,7 @@ class Oracle:
         while (dim >> level) >= 1:
             d = dim >> level
             buf = np.zeros((6, d, d, 4), np.uint8)
-            if lib().zo_kat_cube_mip(self.h, level, _ptr(buf)) != d:
+            if self.L.zo_kat_cube_mip(self.h, level, _ptr(buf)) != d:
                 break
             out.append(buf); level += 1
         return out

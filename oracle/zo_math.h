@@ -135,11 +135,38 @@ static inline float zo_rsqrt(float x)
     float sp = (x == INFINITY) ? 0.0f : INFINITY;
     return ((x >= 1.17549435e-38f && x < INFINITY) || x != x) ? y : sp;
 }
+/* -DZO_LITERAL (oracle/_build/liboracle_literal.so, oracle/CONTRACT.md): the IEEE-literal reading of the same GLSL - inversesqrt as
+ * 1 / sqrt, every `/` a correctly rounded division per component, texels converted (/ 255) before they are filtered.  It is what this
+ * oracle was before the contract fixed cheaper admissible forms; tests/test_oracle_contract.py renders both and bounds the distance. */
+#ifdef ZO_LITERAL
+#define ZO_IS_LITERAL 1
+static inline float zo_shader_rsqrt(float x) { return 1.0f / sqrtf(x); }
+#else
+#define ZO_IS_LITERAL 0
+static inline float zo_shader_rsqrt(float x) { return zo_rsqrt(x); }
+#endif
 /* normalize(v) = v * inversesqrt(dot(v,v)) in shader code */
-static inline zo_v3 zo_normalize(zo_v3 a) { return zo_scale(a, zo_rsqrt(zo_dot(a, a))); }
+static inline zo_v3 zo_normalize(zo_v3 a) { return zo_scale(a, zo_shader_rsqrt(zo_dot(a, a))); }
+/* vec3 / scalar (contract: one IEEE reciprocal and three multiplies; literal: three divisions) */
+static inline zo_v3 zo_div_scalar(zo_v3 a, float s)
+{
+#ifdef ZO_LITERAL
+    return zo_v3make(a.x / s, a.y / s, a.z / s);
+#else
+    const float r = 1.0f / s;
+    return zo_v3make(a.x * r, a.y * r, a.z * r);
+#endif
+}
 /* glm::normalize on the host (lookAt): v * (1 / sqrt(dot)), IEEE - the engine's own x86 arithmetic, not a shader's */
 static inline zo_v3 zo_normalize_ieee(zo_v3 a) { return zo_scale(a, 1.0f / sqrtf(zo_dot(a, a))); }
 #define ZO_INV_PI 0.318309886f     /* x / PI (Common.glsl) is evaluated as x * fl(1 / 3.14159265359) */
+#ifdef ZO_LITERAL
+static inline float zo_div_pi(float x) { return x / 3.14159265359f; }
+static inline float zo_div_25(float x) { return x / 25.0f; }
+#else
+static inline float zo_div_pi(float x) { return x * ZO_INV_PI; }
+static inline float zo_div_25(float x) { return x * 0.04f; }
+#endif
 
 /* column-major mat4 (glm): m[c*4+r] */
 static inline void zo_mat4_mul(const float* A, const float* B, float* C) /* C = A*B; C may not alias */

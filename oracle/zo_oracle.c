@@ -297,8 +297,8 @@ static zo_v3 zo_cube_sample(const zo_ctx* c, zo_v3 R, float lod)
     if (az >= ax && az >= ay) { ma = az; if (R.z >= 0.0f) { face = 4; sc = R.x; tc = -R.y; } else { face = 5; sc = -R.x; tc = -R.y; } }
     else if (ay >= ax)        { ma = ay; if (R.y >= 0.0f) { face = 2; sc = R.x; tc = R.z; }  else { face = 3; sc = R.x; tc = -R.z; } }
     else                      { ma = ax; if (R.x >= 0.0f) { face = 0; sc = -R.z; tc = -R.y; } else { face = 1; sc = R.z; tc = -R.y; } }
-    float rma = 1.0f / ma;
-    float s = fmaf(sc * rma, 0.5f, 0.5f), t = fmaf(tc * rma, 0.5f, 0.5f);
+    zo_v3 st = zo_div_scalar(zo_v3make(sc, tc, 0.0f), ma);     /* (sc, tc) / ma */
+    float s = fmaf(st.x, 0.5f, 0.5f), t = fmaf(st.y, 0.5f, 0.5f);
     float maxl = (float)(c->cube_levels - 1);
     float l = fminf(fmaxf(lod, 0.0f), maxl);
     float fl = floorf(l);
@@ -755,11 +755,19 @@ static void zo_tex_fetch(const zo_ctx* c, const zo_tex* t, int srgb, int level, 
 {
     uint32_t w = t->w >> level, h = t->h >> level; if (!w) w = 1; if (!h) h = 1;
     const uint8_t* p = t->mip[level] + ((size_t)y * w + (size_t)x) * 4;
+#ifdef ZO_LITERAL
+    for (int ch = 0; ch < 4; ++ch) out[ch] = zo_decode8(c, p[ch], srgb && ch < 3);      /* every texel converted before the filter */
+#else
     for (int ch = 0; ch < 4; ++ch) out[ch] = (srgb && ch < 3) ? c->srgb_lut[p[ch]] : (float)p[ch];
+#endif
 }
 /* x / 255 for a filtered code x: fma(x, k_hi, x * k_lo) with k_hi + k_lo = 1 / 255 to 48 bits (exactly c / 255 rounded for an integer c) */
 static float zo_unorm8_scale(float x) { return fmaf(x, 0x1.010102p-8f, x * -0x1.fdfdfep-33f); }
-static void zo_tex_finish(int srgb, float out[4]) { for (int ch = 0; ch < 4; ++ch) if (!(srgb && ch < 3)) out[ch] = zo_unorm8_scale(out[ch]); }
+static void zo_tex_finish(int srgb, float out[4])
+{
+    if (ZO_IS_LITERAL) return;                              /* (the texels were converted one by one) */
+    for (int ch = 0; ch < 4; ++ch) if (!(srgb && ch < 3)) out[ch] = zo_unorm8_scale(out[ch]);
+}
 /* bilinear, REPEAT addressing (RHICreateSampler defaults, ZE:6523-6557) */
 static void zo_tex_bilinear(const zo_ctx* c, const zo_tex* t, int srgb, int level, float u, float v, float out[4])
 {
@@ -835,10 +843,9 @@ static void zo_tex_sample(const zo_ctx* c, const zo_tex* t, int srgb, float u, f
 static zo_v3 zo_compute_normal(zo_v3 pos_dx, zo_v3 pos_dy, float s1, float t1, float s2, float t2, zo_v3 fragN, zo_v3 texN)
 {
     float det = fmaf(s1, t2, -(s2 * t1));
-    float rdet = 1.0f / det;                                /* vec3 / scalar: one reciprocal, three multiplies */
-    zo_v3 T = zo_v3make(fmaf(t2, pos_dx.x, -(t1 * pos_dy.x)) * rdet,
-                        fmaf(t2, pos_dx.y, -(t1 * pos_dy.y)) * rdet,
-                        fmaf(t2, pos_dx.z, -(t1 * pos_dy.z)) * rdet);
+    zo_v3 T = zo_div_scalar(zo_v3make(fmaf(t2, pos_dx.x, -(t1 * pos_dy.x)),     /* vec3 / scalar */
+                                      fmaf(t2, pos_dx.y, -(t1 * pos_dy.y)),
+                                      fmaf(t2, pos_dx.z, -(t1 * pos_dy.z))), det);
     zo_v3 N = zo_normalize(fragN);
     T = zo_normalize(zo_sub(T, zo_scale(N, zo_dot(N, T))));
     zo_v3 B = zo_normalize(zo_cross(N, T));
@@ -1047,12 +1054,16 @@ static void zo_gbuffer_sample(const zo_ctx* c, float u, float v, zo_gtexel* out)
 static float zo_pcf(const zo_ctx* c, const float* SB, zo_v3 P, float dxy)
 {
     zo_v4 s4 = zo_mat4_point(SB, P);
+#ifdef ZO_LITERAL
+    float sx = s4.x / s4.w, sy = s4.y / s4.w, sz = s4.z / s4.w, sw = s4.w / s4.w;
+#else
     float rsw = 1.0f / s4.w;                                /* shadowCoord / shadowCoord.w */
     float sx = s4.x * rsw, sy = s4.y * rsw, sz = s4.z * rsw, sw = s4.w * rsw;
+#endif
     float sum = 0.0f;
     for (int x = -2; x <= 2; ++x) for (int y = -2; y <= 2; ++y)               /* ComputePCF r=2, :323-342 */
         sum += zo_shadow_tap(c, sx, sy, sz, sw, dxy * (float)x, dxy * (float)y);
-    return sum * 0.04f;                                     /* ShadowFactor / Count */
+    return zo_div_25(sum);                                  /* ShadowFactor / Count */
 }
 
 static zo_v3 zo_gbuffer_vis(const zo_ctx* c, uint32_t px, uint32_t py, zo_v3 FinalColor, const float* SB, zo_v3 cam, float dxy)
@@ -1143,7 +1154,7 @@ static void zo_lighting(zo_ctx* c, uint32_t debug_view)
             zo_v3 lp = zo_v3make(Lt->Position[0], Lt->Position[1], Lt->Position[2]);
             /* point light: distance() and normalize() of light_pos - position share one inversesqrt: length = d2 * inversesqrt(d2) */
             zo_v3 dl = zo_sub(lp, P);
-            float d2 = zo_dot(dl, dl), rd = zo_rsqrt(d2);
+            float d2 = zo_dot(dl, dl), rd = zo_shader_rsqrt(d2);
             zo_v3 L = isdir ? zo_normalize(zo_v3make(Lt->Direction[0], Lt->Direction[1], Lt->Direction[2])) : zo_scale(dl, rd);
             zo_v3 Hh = zo_normalize(zo_add(Vv, L));
             float LdotH = zo_saturate(zo_dot(L, Hh)), NdotH = zo_saturate(zo_dot(N, Hh)), NdotL = zo_saturate(zo_dot(N, L));
@@ -1163,7 +1174,7 @@ static void zo_lighting(zo_ctx* c, uint32_t debug_view)
                 Direct = zo_v3make(fmaf(rad.x * bx.x, ShadowFactor, Direct.x), fmaf(rad.y * bx.y, ShadowFactor, Direct.y),
                                    fmaf(rad.z * bx.z, ShadowFactor, Direct.z));
             } else {
-                float dist = d2 > 0.0f ? d2 * rd : 0.0f;
+                float dist = ZO_IS_LITERAL ? sqrtf(d2) : (d2 > 0.0f ? d2 * rd : 0.0f);      /* distance(): literal = its own sqrt */
                 float falloff = Lt->Direction[3];
                 float att = 1.0f - zo_clampf(dist, 0.0f, falloff) / falloff;   /* remap(dist,0,falloff,0,1), :43-47 */
                 rad = zo_scale(rad, att);
@@ -1171,9 +1182,9 @@ static void zo_lighting(zo_ctx* c, uint32_t debug_view)
             }
         }
         /* (2) indirect, :210 */
-        zo_v3 Indirect = zo_v3make((((DiffuseColor.x * ZO_INV_PI) * AO) * 0.3f) * ShadowFactor,
-                                   (((DiffuseColor.y * ZO_INV_PI) * AO) * 0.3f) * ShadowFactor,
-                                   (((DiffuseColor.z * ZO_INV_PI) * AO) * 0.3f) * ShadowFactor);
+        zo_v3 Indirect = zo_v3make(((zo_div_pi(DiffuseColor.x) * AO) * 0.3f) * ShadowFactor,
+                                   ((zo_div_pi(DiffuseColor.y) * AO) * 0.3f) * ShadowFactor,
+                                   ((zo_div_pi(DiffuseColor.z) * AO) * 0.3f) * ShadowFactor);
         /* (3) reflection, :213-221 */
         zo_v3 bcl = zo_v3make(zo_clampf(BaseColor.x, 0.04f, 1.0f), zo_clampf(BaseColor.y, 0.04f, 1.0f), zo_clampf(BaseColor.z, 0.04f, 1.0f));
         float dsf0 = (0.04f * 2.0f) * 0.5f;

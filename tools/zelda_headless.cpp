@@ -86,7 +86,7 @@ int main(int argc, char** argv)
     if ((rc = zr_finish(c))) return fail(c, "zr_finish", rc);
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     zr_stats st;
-    if ((rc = zr_get_stats(c, &st))) return fail(c, "zr_get_stats", rc);
+    if ((rc = zr_get_stats(c, &st, sizeof st))) return fail(c, "zr_get_stats", rc);
     uint32_t n_obj = 0; zr_object_count(c, &n_obj);
     printf("frames %u  %.3f ms/frame  objects %u  meshlet-instances %llu  camera survivors %llu  covered pixels %llu\n", frames, ms / frames, n_obj,
            (unsigned long long)st.work_items[1], (unsigned long long)st.survivors[1], (unsigned long long)st.covered_pixels);

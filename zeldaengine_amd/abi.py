@@ -54,7 +54,11 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("work_items", C.c_uint64 * 2), ("survivors", C.c_uint64 * 2), ("bin_entries", C.c_uint64 * 2),
                 ("covered_pixels", C.c_uint64), ("covered_shadow_texels", C.c_uint64), ("overflow", C.c_uint32), ("hiz_culled", C.c_uint32),
-                ("round1_survivors", C.c_uint64), ("shadow_occluded", C.c_uint32), ("shadow_late", C.c_uint32)]
+                ("round1_survivors", C.c_uint64), ("shadow_occluded", C.c_uint32), ("shadow_late", C.c_uint32),
+                ("hiz_culled_geom", C.c_uint32), ("struct_bytes", C.c_uint32)]
+
+
+ABI_VERSION = 5      # ZR_ABI_VERSION of include/zelda_render.h
 
 
 PASS_NAMES = ["cull_shadow", "shadow", "cull_camera", "gbuffer", "hiz", "gbuffer2", "resolve", "lighting", "composite", "total"]

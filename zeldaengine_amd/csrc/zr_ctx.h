@@ -114,7 +114,7 @@ struct zr_ctx {
     // side by side and the host's stream only joins the finished frame.  Measured SLOWER than two lanes: the
     // camera pipeline - a chain of short kernels - is then starved by two heavy neighbours instead of one.
     bool in_render = false;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cam = nullptr;
+    hipEvent_t ev_join = nullptr, ev_cam = nullptr;
     unsigned long long* d_sky_keys = nullptr; uint32_t sky_object = 0;      // the skydome's key plane (k_sky_tiles) and its draw record
     // End of every frame's lighting pass, one (timing-enabled) event per frame in a ring: the next-but-one frame waits for it before
     // it reuses the double-buffered copies, and consecutive ones give the per-frame GPU period (zr_get_frame_periods) for free.

@@ -222,7 +222,6 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         ok &= hipStreamCreateWithPriority(&c->cam_s, hipStreamNonBlocking, greatest) == hipSuccess;
     }
     ok &= hipEventCreateWithFlags(&c->ev_cam, hipEventDisableTiming) == hipSuccess;
-    ok &= hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok &= hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     ok &= dev_alloc(&c->d_vis, n) == hipSuccess;
     if (ok) { zr_launch_fill64(c->d_vis, (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM, n, c->stream); ok &= hipStreamSynchronize(c->stream) == hipSuccess; }
@@ -266,7 +265,7 @@ static void free_mesh_buffers(ZrMesh& m)
 
 static void free_tri_bins(zr_ctx* c)
 {
-    dev_free(c->tb.sel); dev_free(c->tb.recA); dev_free(c->tb.recB); dev_free(c->tb.rtile); dev_free(c->tb.srtA); dev_free(c->tb.srtB); dev_free(c->tb.sidx);
+    dev_free(c->tb.sel); dev_free(c->tb.recA); dev_free(c->tb.recB); dev_free(c->tb.rtile); dev_free(c->tb.sidx);
     dev_free(c->tb.slow); dev_free(c->tb.chunk_fill); dev_free(c->tb.wave_culled);
 }
 
@@ -308,7 +307,6 @@ extern "C" void zr_destroy(zr_ctx* c)
     for (auto& e : c->view_ev) if (e) (void)hipEventDestroy(e);
     if (c->cam_s) (void)hipStreamDestroy(c->cam_s);
     if (c->ev_cam) (void)hipEventDestroy(c->ev_cam);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     dev_free(c->d_vis); dev_free(c->d_slow0);
     dev_free(c->d_pxrect); dev_free(c->d_zmin); dev_free(c->d_visflag[0]); dev_free(c->d_visflag[1]); dev_free(c->d_hiz);
@@ -788,9 +786,9 @@ static int finalize_scene(zr_ctx* c)
         }
         // triangle-binned camera pass: triangle records (32 B + a 4-byte tile id) live in chunks of ZR_TPOOL_CHUNK; every wave of k_geom's
         // fixed grid starts in two chunks of its own (drawn / deferred records) and takes further ones from the pool (a pool that runs dry
-        // is reported like a bin overflow); k_index moves the drawn ones into a second array in tile order.  Sized from the scene:
-        // 8 records per meshlet-instance, at least 32 Mi (8192 x 256 on top are the waves' own chunks) - 68 bytes
-        // apiece, 2.6 GB of 288 reserved, touched as far as a frame needs.
+        // is reported like a bin overflow); k_index lists their positions in tile order (4 bytes apiece).  Sized from the scene:
+        // 8 records per meshlet-instance, at least 32 Mi (8192 x 256 on top are the waves' own chunks) - 40 bytes
+        // apiece, 1.6 GB of 288 reserved, touched as far as a frame needs.
         free_tri_bins(c);
         c->tb.n_waves = 8192; c->tb.slow_cap = 1u << 18;
         const uint64_t n_rec = std::min<uint64_t>(std::max<uint64_t>(32ull << 20, 8ull * c->n_work) + 1ull * c->tb.n_waves * ZR_TPOOL_CHUNK, 0x3FFFFFFFull);
@@ -802,12 +800,7 @@ static int finalize_scene(zr_ctx* c)
         HIPCHK(c, dev_alloc(&c->tb.recA, (size_t)c->tb.n_chunks * ZR_TPOOL_CHUNK));
         HIPCHK(c, dev_alloc(&c->tb.recB, (size_t)c->tb.n_chunks * ZR_TPOOL_CHUNK));
         HIPCHK(c, dev_alloc(&c->tb.rtile, (size_t)c->tb.n_chunks * ZR_TPOOL_CHUNK));
-#if ZR_INDEX_LIST
         HIPCHK(c, dev_alloc(&c->tb.sidx, c->tb.sorted_cap));
-#else
-        HIPCHK(c, dev_alloc(&c->tb.srtA, c->tb.sorted_cap));
-        HIPCHK(c, dev_alloc(&c->tb.srtB, c->tb.sorted_cap));
-#endif
         HIPCHK(c, dev_alloc(&c->tb.chunk_fill, c->tb.n_chunks));
         HIPCHK(c, hipMemset(c->tb.chunk_fill, 0, (size_t)c->tb.n_chunks * 4));
         HIPCHK(c, dev_alloc(&c->tb.wave_culled, c->tb.n_waves));
@@ -984,6 +977,9 @@ extern "C" int zr_update_uniforms(zr_ctx* c, const zr_camera* cam, const XkLight
     if (!c) return ZR_ERR_ARG;
     ARGCHK(c, cam && n_dir <= XK_MAX_DIRECTIONAL_LIGHTS_NUM && n_point <= XK_MAX_POINT_LIGHTS_NUM && n_spot <= XK_MAX_SPOT_LIGHTS_NUM);
     ARGCHK(c, (n_dir == 0 || dir) && (n_point == 0 || point) && (n_spot == 0 || spot));
+    // both geometry passes' kernel arguments are fixed when a frame begins (zr_render_shadow / zr_render_geometry): uniforms set between the
+    // stages of a frame would reach its lighting pass only
+    if (c->stage != 0) return zr_fail(c, ZR_ERR_STATE, "zr_update_uniforms between the stages of a frame (finish it with zr_render_lighting first)");
     XkView* V = &c->view;
     c->view_dirty = true;
     for (uint32_t i = 0; i < n_dir; ++i) V->DirectionalLights[i] = dir[i];
@@ -1031,6 +1027,7 @@ extern "C" int zr_set_frame(zr_ctx* c, const XkUniformBufferMVP* cam, const XkUn
     ARGCHK(c, cam && sh && v);
     ARGCHK(c, v->LightsCount[0] >= 0 && v->LightsCount[0] <= XK_MAX_DIRECTIONAL_LIGHTS_NUM && v->LightsCount[1] >= 0 &&
               v->LightsCount[1] <= XK_MAX_POINT_LIGHTS_NUM);
+    if (c->stage != 0) return zr_fail(c, ZR_ERR_STATE, "zr_set_frame between the stages of a frame (finish it with zr_render_lighting first)");
     c->cam = *cam; c->shadow = *sh; c->view = *v; c->view_dirty = true;
     c->frame_valid = true;
     return ZR_OK;
@@ -1209,7 +1206,8 @@ static int frame_begin(zr_ctx* c, hipStream_t s)
         if (!c->pass_live[slot]) P.n_work = 0;      // no finite vertex: the pass is its clear
         c->list_reuse[slot] = P.use_worklist && P.n_work != 0 && c->list_valid[slot] && memcmp(&c->list_key[slot], &P, sizeof P) == 0 &&
                               !(c->cfg.flags & ZR_FLAG_NO_LIST_REUSE);
-        if (P.use_worklist && P.n_work != 0 && !c->list_reuse[slot]) { rebuild |= 1u << slot; c->list_key[slot] = P; c->list_valid[slot] = true; }
+        // (the list counts as standing only once its k_cull_instances has been enqueued: shadow_pass / gbuffer_pass set list_valid)
+        if (P.use_worklist && P.n_work != 0 && !c->list_reuse[slot]) { rebuild |= 1u << slot; c->list_key[slot] = P; c->list_valid[slot] = false; }
     }
     const XkView* src = nullptr;
     uint32_t k = 0;
@@ -1220,7 +1218,10 @@ static int frame_begin(zr_ctx* c, hipStream_t s)
         src = &c->h_view_ring[k];
     }
     c->list_rebuild_mask = rebuild;
-    zr_launch_frame_begin(c->d_stats, c->d_sstats, src, c->d_view, rebuild, s);      // zeroes the statistics (the sticky overflow latch survives), uploads XkView
+    // zeroes the camera lane's statistics (the sticky overflow latch survives) and - when the camera list is rebuilt - its length; uploads
+    // XkView.  The SHADOW list's length lives in the shadow pipeline's block and is reset on that pipeline's own stream (shadow_pass):
+    // the previous frame's shadow pipeline may still be walking it while this kernel runs on the camera lane.
+    zr_launch_frame_begin(c->d_stats, src, c->d_view, rebuild & 2u, s);
     if (src) { HIPCHK(c, hipEventRecord(c->view_ev[k], s)); c->view_uploaded[par] = c->view_version; }
     return ZR_OK;
 }
@@ -1243,12 +1244,20 @@ static int shadow_pass(zr_ctx* c, hipStream_t s)
     bool occl = !(c->cfg.flags & ZR_FLAG_NO_SHADOW_OCCLUSION) && P.n_work != 0 && ZR_TILE == 32 && c->SD >= 4u &&
                 ((c->cfg.flags & ZR_FLAG_SHADOW_OCCLUSION) || 5ull * P.n_work >= (uint64_t)c->SD * c->SD);
 #ifdef ZR_DIAG
-    if (!c->env_shadow_box) { occl = false; zr_launch_cull(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, c->raster_blocks * 4u, s); }
+    if (!c->env_shadow_box) {      // (A/B only: the exact cull always rebuilds its list, in the camera lane's block)
+        occl = false; c->list_valid[0] = false;
+        if (P.use_worklist) zr_launch_fill32(&c->d_stats->n_vis_work[0], 0u, 1, s);
+        zr_launch_cull(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_stats, 0, c->raster_blocks * 4u, s);
+    }
     else
 #endif
     {
         if (occl) { Z.pxrect = c->d_spxrect; Z.zmin = c->d_szmin; Z.vis_prev = c->d_sflag; Z.phase = 1u; }
+        // a rebuilt work list starts from length 0 - zeroed HERE, in stream order behind the previous frame's shadow pipeline (k_cull_instances
+        // grows it, every later kernel of the pipeline reads it)
+        if (c->list_rebuild_mask & 1u) zr_launch_fill32(&c->d_sstats->n_vis_work[0], 0u, 1, s);
         zr_launch_cull_box(P, c->d_objs, c->sc[0].work, c->sc[0].rects, Z, c->d_sstats, 0, s, nullptr, nullptr, c->list_reuse[0]);
+        if (c->list_rebuild_mask & 1u) c->list_valid[0] = true;
     }
     bin_and_raster(c, P, Z, 0, c->sn_tiles, s);
     if (ev) HIPCHK(c, hipEventRecord(ev[1], s));
@@ -1292,7 +1301,10 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
     if (!tri_bins) zr_launch_cull(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, c->raster_blocks * 4u, s);
     else
 #endif
-    zr_launch_cull_box(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, s, c->tb.sel, c->last_two_round ? Z.vis_prev : nullptr, c->list_reuse[1]);
+    {
+        zr_launch_cull_box(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, s, c->tb.sel, c->last_two_round ? Z.vis_prev : nullptr, c->list_reuse[1]);
+        if (c->list_rebuild_mask & 2u) c->list_valid[1] = true;
+    }
     if (hiz_on && P.use_worklist) HIPCHK(c, hipMemsetAsync(c->d_visflag[c->vis_cur], 0, c->n_work, s));     // else k_cull clears them
     const bool two = c->last_two_round;
     auto bin = [&](int slot) { if (!tri_bins) bin_and_raster(c, P, Z, slot, c->n_tiles, s); else if (slot == 2) tri_select(c, P, Z, slot, s); };
@@ -1368,14 +1380,9 @@ static int geometry_passes(zr_ctx* c)
         // Every event record / wait is a barrier packet, worth 5-10 us of bubble on the stream it sits on, and the host's stream
         // (lighting -> shadow pipeline -> lighting ...) is the lane the frame rate hangs on: it waits for the camera lane once per frame
         // (before the lighting pass) and for nothing else.  The shadow pipeline needs nothing of frame_begin's - its matrices are kernel
-        // arguments, its statistics a block of its own that it resets itself - except a zeroed list length in the (rare) frame that
-        // rebuilds the shadow pass's work list.
+        // arguments, its statistics a block of its own that it resets itself, work-list length included.
         rc = frame_begin(c, c->cam_s);
         if (rc != ZR_OK) return rc;
-        if (c->list_rebuild_mask & 1u) {
-            HIPCHK(c, hipEventRecord(c->ev_fork, c->cam_s));
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_fork, 0));
-        }
         rc = shadow_pass(c, c->stream);
         if (rc == ZR_OK && !c->in_render) HIPCHK(c, hipEventRecord(c->ev_join, c->stream));      // (zr_stream_wait_shadow: a host that puts a collective behind the shadow pass)
         if (rc == ZR_OK) rc = gbuffer_pass(c, c->cam_s);
@@ -1618,9 +1625,15 @@ extern "C" int zr_set_timing_interval(zr_ctx* c, uint32_t interval)
     return ZR_OK;
 }
 
-extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out)
+extern "C" uint32_t zr_abi_version(void) { return ZR_ABI_VERSION; }
+
+// `bytes` = sizeof(zr_stats) as the CALLER was compiled: the struct only ever grows at its end, so a host built against an older header
+// gets the fields it knows and is never written past.
+extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out_user, size_t bytes)
 {
-    if (!c || !out) return ZR_ERR_ARG;
+    if (!c || !out_user) return ZR_ERR_ARG;
+    ARGCHK(c, bytes >= offsetof(zr_stats, round1_survivors) && bytes % 4 == 0);      // (the first release's struct ended there)
+    zr_stats out_full; zr_stats* out = &out_full;
     int rc = zr_finish(c);
     if (c->rendered && (rc == ZR_OK || rc == ZR_ERR_OVERFLOW)) {      // shadow coverage is a statistic, counted on demand
         ZrDevStats z; (void)hipMemcpy(&z, c->d_stats, sizeof z, hipMemcpyDeviceToHost);
@@ -1651,6 +1664,8 @@ extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out)
     out->covered_pixels = 0; for (uint32_t v : c->h_stats.covered_part) out->covered_pixels += v;
     out->covered_shadow_texels = c->h_stats.covered_shadow; out->overflow = c->h_stats.overflow;
     out->shadow_occluded = c->h_stats.shadow_occluded; out->shadow_late = c->h_stats.shadow_late;
+    out->hiz_culled_geom = c->h_stats.hiz_culled_geom; out->struct_bytes = (uint32_t)sizeof(zr_stats);
+    memcpy(out_user, out, std::min(bytes, sizeof(zr_stats)));
     return rc;
 }
 
@@ -1683,6 +1698,20 @@ extern "C" int zr_read_shadowmap(zr_ctx* c, float* dst, size_t bytes)
     int rc = zr_finish(c);
     if (rc) return rc;
     HIPCHK(c, hipMemcpy(dst, c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow, bytes, hipMemcpyDeviceToHost));
+    return ZR_OK;
+}
+
+// The frame enqueued last, copied into caller-owned DEVICE buffers in stream order (no host synchronisation): what a host with two frames
+// in flight uses instead of zr_read_color - the copies are ordered behind that frame's lighting pass and ahead of whatever the next
+// zr_render enqueues on the render stream.  Either pointer may be NULL.  (The shadow map is double-buffered inside: the NEXT frame's
+// shadow pipeline draws into the other copy, so the map copied here is this frame's whatever runs beside it.)
+extern "C" int zr_copy_frame_async(zr_ctx* c, void* color_dev, void* shadow_dev)
+{
+    if (!c) return ZR_ERR_ARG;
+    if (!c->rendered || c->stage != 0) return zr_fail(c, ZR_ERR_STATE, "zr_copy_frame_async: no finished frame enqueued");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (color_dev) HIPCHK(c, hipMemcpyAsync(color_dev, c->d_color, (size_t)c->W * c->H * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (shadow_dev) HIPCHK(c, hipMemcpyAsync(shadow_dev, shadow_buf(c), (size_t)c->SD * c->SD * 4, hipMemcpyDeviceToDevice, c->stream));
     return ZR_OK;
 }
 

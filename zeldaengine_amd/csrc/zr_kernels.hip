@@ -860,7 +860,9 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
         stats->chunk_counter[slot] = 0;
         // what the kernels after this one accumulate for the pass starts from zero here: the shadow pipeline's block is not touched by
         // k_frame_begin (the pipeline does not wait for the camera lane)
-        stats->survivors[slot] = 0; stats->n_slow[slot] = 0; stats->overflow = part[1023] > capacity ? 1u : 0u;
+        stats->survivors[slot] = 0; stats->n_slow[slot] = 0;
+        if (slot == 0) stats->overflow = part[1023] > capacity ? 1u : 0u;      // the pipeline's own block: reset here.  (Camera slots - A/B builds -
+        else if (part[1023] > capacity) stats->overflow = 1u;                  // share the lane's block: round 2 must not clear round 1's flag)
         if (slot == 0) { stats->n_chunks[1] = 0; stats->chunk_counter[1] = 0; stats->shadow_late = 0; }      // (k_shadow_occlusion's late units)
         if (part[1023] > capacity) stats->overflow_sticky = 1u;
     }
@@ -1635,14 +1637,13 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
 // XkView from the pinned host ring slot into this frame's device copy.  (The runtime's own hipMemcpyAsync / hipMemsetAsync
 // paths cost two extra launches per frame, and the copy path stalls the host for milliseconds the first times it is used.)
 __global__ __launch_bounds__(1024) void k_frame_begin(uint32_t* __restrict__ stats, uint32_t n_stats, const uint32_t* __restrict__ view_src,
-                                                      uint32_t* __restrict__ view_dst, uint32_t n_view, uint32_t* __restrict__ n_vis_shadow,
+                                                      uint32_t* __restrict__ view_dst, uint32_t n_view,
                                                       uint32_t* __restrict__ n_vis_camera, uint32_t rebuild_lists)
 {
     const uint32_t i0 = blockIdx.x * 1024u + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < n_stats) stats[threadIdx.x] = 0u;
     // the passes' work lists (k_cull_instances) stand while camera / light matrices and scene do: only a list about to be rebuilt starts from 0
-    // (the shadow pass's length sits in the shadow pipeline's own block: a frame that rebuilds it makes that pipeline wait for this kernel)
-    if (blockIdx.x == 0 && threadIdx.x == 0u && (rebuild_lists & 1u)) *n_vis_shadow = 0u;
+    // (the shadow pass's length sits in the shadow pipeline's own block and is reset on that pipeline's stream, see shadow_pass)
     if (blockIdx.x == 0 && threadIdx.x == 1u && (rebuild_lists & 2u)) *n_vis_camera = 0u;
     if (view_src) for (uint32_t i = i0; i < n_view; i += gridDim.x * 1024u) view_dst[i] = view_src[i];
 }
@@ -2005,8 +2006,8 @@ __global__ __launch_bounds__(256) void k_shadow_occlusion(ZrPass P, const ZrObje
 // (2.5 on average in the camera pass) and walks the survivors in whatever mix of sizes the queue hands a wave.
 // Here a meshlet is processed ONCE: k_geom transforms its vertices, applies the exact per-triangle tests (facing, degenerate, no
 // pixel centre, Hi-Z in round 2) and emits one 32-byte record per (triangle, owned tile) - vertices relative to the tile, three depths,
-// the primitive id - plus its tile id; k_scan_tri lays the tiles' ranges out, k_index MOVES the records into tile order, and k_tile's
-// lanes stream them and do nothing but edge setup + walk on live triangles.  Same arithmetic, same keys as the meshlet-binned path
+// the primitive id - plus its tile id; k_scan_tri lays the tiles' ranges out, k_index writes the records' positions in tile order (an
+// index list), and k_tile's lanes gather them and do nothing but edge setup + walk on live triangles.  Same arithmetic, same keys as the meshlet-binned path
 // (kept in -DZR_DIAG builds for A/B): the frame is the same bit for bit.
 
 // Which meshlet-instances does this round draw?  (The split of the two-pass occlusion culling, as k_bin_count makes it.)
@@ -2367,8 +2368,8 @@ __global__ __launch_bounds__(1024) void k_scan_tri(const uint32_t* __restrict__ 
     }
 }
 
-// Every record -> its place in its tile's stretch of the sorted record array, and the record itself is MOVED there, so that k_tile
-// streams its work unit instead of gathering it.  A cursor per tile is advanced once per (wave, distinct tile) - the 64 records of a wave
+// Every record -> its place in its tile's stretch of the tile-ordered INDEX LIST sidx[] (4 bytes per record: the record stays where k_geom
+// wrote it and k_tile gathers it).  A cursor per tile is advanced once per (wave, distinct tile) - the 64 records of a wave
 // come meshlet by meshlet, so they name a handful of tiles - because atomics on one address run at about 10 ns apiece on this part and
 // there are half a million records: the lanes first sort themselves into tile groups (scalar work, no memory), then every group's first
 // lane issues its add in ONE instruction.  One wave per record chunk.
@@ -2385,9 +2386,6 @@ __global__ __launch_bounds__(256) void k_index(ZrTriBins B, const ZrDevStats* __
     for (uint32_t ch = blockIdx.x * 4u + wv; ch < used; ch += gridDim.x * 4u) {
         const uint32_t n = B.chunk_fill[ch], r0 = ch * ZR_TPOOL_CHUNK;
         bool have[NB]; uint32_t tile[NB], off[NB], rank[NB], cnt[NB], b[NB]; int first[NB];
-#if !ZR_INDEX_LIST
-        uint4 qa[NB], qb[NB];
-#endif
 #pragma unroll
         for (uint32_t k = 0; k < NB; ++k) {
             const uint32_t j = k * 64u + lane;
@@ -2397,10 +2395,6 @@ __global__ __launch_bounds__(256) void k_index(ZrTriBins B, const ZrDevStats* __
 #pragma unroll
         for (uint32_t k = 0; k < NB; ++k) {
             const uint32_t j = k * 64u + lane;
-#if !ZR_INDEX_LIST
-            qa[k] = make_uint4(0, 0, 0, 0); qb[k] = qa[k];
-            if (have[k]) { qa[k] = B.recA[r0 + j]; qb[k] = B.recB[r0 + j]; }
-#endif
             off[k] = have[k] ? tile_offset[tile[k]] : 0u;
         }
 #pragma unroll
@@ -2421,17 +2415,13 @@ __global__ __launch_bounds__(256) void k_index(ZrTriBins B, const ZrDevStats* __
         for (uint32_t k = 0; k < NB; ++k) {
             const uint32_t bb = (uint32_t)__shfl((int)b[k], first[k]);
             const uint32_t dst = off[k] + bb + rank[k];
-#if ZR_INDEX_LIST
             if (have[k] && dst < B.sorted_cap) B.sidx[dst] = r0 + k * 64u + lane;
-#else
-            if (have[k] && dst < B.sorted_cap) { B.srtA[dst] = qa[k]; B.srtB[dst] = qb[k]; }
-#endif
         }
     }
 }
 
-// Persistent workgroups pull work units: <= ZR_TCHUNK records of one tile, contiguous in the sorted array; lane per triangle: edge setup
-// + walk into the tile's LDS keys; touched keys are merged into the frame key buffer.  Nothing else: no vertices, no tests, no gather.
+// Persistent workgroups pull work units: <= ZR_TCHUNK records of one tile, contiguous in the index list; lane per triangle: gather, edge
+// setup + walk into the tile's LDS keys; touched keys are merged into the frame key buffer.  Nothing else: no vertices, no tests.
 // The kernel also leaves the per-tile counters and the record pool as the next round's k_geom wants them (zero).
 // Sorted walk.  The 64 lanes of a wave walk their triangles' boxes in lock step: a row loop as long as the tallest box, a column loop per
 // row as long as the widest box still alive there - with a unit's records in arrival order 35 % of the lanes' iterations were live
@@ -2478,12 +2468,8 @@ void k_tile(ZrPass P, const uint4* __restrict__ chunk_tab, ZrTriBins B, uint32_t
             const uint32_t j = tid + (uint32_t)k * 256u;
             key[k] = 0u; rank[k] = 0u;
             if (j < n) {
-#if ZR_INDEX_LIST
                 const uint32_t src = B.sidx[rbeg + j];      // (a tile's records come in runs of one meshlet's: the gather reads whole cache lines mostly)
                 qa[k] = B.recA[src]; qb[k] = B.recB[src];
-#else
-                qa[k] = B.srtA[rbeg + j]; qb[k] = B.srtB[rbeg + j];
-#endif
                 const int X0 = (int)(short)(qa[k].x & 0xFFFFu), Y0 = (int)qa[k].x >> 16, X1 = (int)(short)(qa[k].z & 0xFFFFu), Y1 = (int)qa[k].z >> 16;
                 const int X2 = (int)(short)(qb[k].x & 0xFFFFu), Y2 = (int)qb[k].x >> 16;
                 const int x0 = max((imin3(X0, X1, X2) - 128 + 255) >> 8, 0), x1 = min((imax3(X0, X1, X2) - 128) >> 8, wx1);
@@ -2545,7 +2531,7 @@ void k_tile(ZrPass P, const uint4* __restrict__ chunk_tab, ZrTriBins B, uint32_t
             uint32_t nc = 0;
             for (uint32_t i = blockIdx.x * 256u + tid; i < B.n_waves; i += gridDim.x * 256u) nc += B.wave_culled[i];
             nc = (uint32_t)wave_sum((int)nc);
-            if (lane == 0u && nc) { atomicAdd(&stats->hiz_culled, nc); atomicSub(&stats->survivors[2], nc); }
+            if (lane == 0u && nc) { atomicAdd(&stats->hiz_culled, nc); atomicAdd(&stats->hiz_culled_geom, nc); atomicSub(&stats->survivors[2], nc); }
         }
         const uint32_t half_cap = B.slow_cap / 2u;
         const uint32_t n_a = min(stats->n_slow[1], half_cap), n_b = slot == 2 ? min(stats->n_slow[2], half_cap) : 0u;
@@ -2609,7 +2595,7 @@ __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __r
         uint32_t nc = 0;
         for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_waves; i += gridDim.x * 256u) nc += wave_culled[i];
         nc = (uint32_t)wave_sum((int)nc);
-        if ((threadIdx.x & 63u) == 0u && nc) { atomicAdd(&stats->hiz_culled, nc); atomicSub(&stats->survivors[2], nc); }
+        if ((threadIdx.x & 63u) == 0u && nc) { atomicAdd(&stats->hiz_culled, nc); atomicAdd(&stats->hiz_culled_geom, nc); atomicSub(&stats->survivors[2], nc); }
     }
     if (n_a + n_b == 0u) return;
     const uint32_t tid = threadIdx.x;
@@ -3371,11 +3357,11 @@ void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* w
     hipLaunchKernelGGL(k_bin_fill, dim3((P.n_work + 1023) / 1024), dim3(1024), n_tiles * sizeof(uint32_t), s, P, objs, work, rects,
                        tile_offset, tile_cursor, bins, Z, stats, slot);
 }
-void zr_launch_frame_begin(ZrDevStats* stats, ZrDevStats* shadow_stats, const XkView* view_src_pinned, XkView* view_dst, uint32_t rebuild_lists, hipStream_t s)
+void zr_launch_frame_begin(ZrDevStats* stats, const XkView* view_src_pinned, XkView* view_dst, uint32_t rebuild_lists, hipStream_t s)
 {
     static_assert(sizeof(XkView) % 4 == 0 && offsetof(ZrDevStats, overflow_sticky) % 4 == 0, "dword copies");
     hipLaunchKernelGGL(k_frame_begin, dim3(view_src_pinned ? 4 : 1), dim3(1024), 0, s, (uint32_t*)stats, (uint32_t)(offsetof(ZrDevStats, overflow_sticky) / 4),
-                       (const uint32_t*)view_src_pinned, (uint32_t*)view_dst, (uint32_t)(sizeof(XkView) / 4), &shadow_stats->n_vis_work[0], &stats->n_vis_work[1], rebuild_lists);
+                       (const uint32_t*)view_src_pinned, (uint32_t*)view_dst, (uint32_t)(sizeof(XkView) / 4), &stats->n_vis_work[1], rebuild_lists);
 }
 void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s)
 {

@@ -138,6 +138,8 @@ struct ZrDevStats {
     uint32_t shadow_occluded;        // shadow pass: meshlet-instances left out because the map's depths already hide them (host copy: the sum of
                                      //   the 32 partial sums k_shadow_occlusion keeps in the shadow pipeline's covered_part)
     uint32_t shadow_late;            //   ... and drawn in the late launch (not drawn last frame, not hidden this frame)
+    uint32_t hiz_culled_geom;        // of hiz_culled: rejected by k_geom (exact vertex box / every triangle hidden), i.e. AFTER a wave transformed
+                                     //   the meshlet's vertices; the rest fell to k_select's bounds before any vertex work
     uint32_t overflow_sticky;        // from here on: NOT cleared at frame begin.  Set with `overflow`, cleared by zr_finish when it reports it
     uint32_t n_vis_work[2];          // meshlet-instances on the pass's work list (k_cull_instances); the list and its length stand while the
                                      // pass's matrices and the scene do - k_frame_begin zeroes a slot when the host is about to rebuild it
@@ -204,15 +206,11 @@ struct ZrTriBins {
     uint32_t* chunk_fill;            //   records in each chunk
     uint32_t  n_waves;               // waves of the k_geom grid
     uint32_t* wave_culled;           // per wave: meshlets it dropped behind the Hi-Z pyramid (round 2)
-    uint4*    srtA; uint4* srtB;     // ZR_INDEX_LIST 0: the drawn records moved into tile order by k_index: k_tile streams them
-    uint32_t* sidx;                  // ZR_INDEX_LIST 1: the records' positions in tile order (k_index writes 4 B per record, k_tile gathers 2 x 16 B)
+    uint32_t* sidx;                  // the records' positions in tile order (k_index writes 4 B per record, k_tile gathers 2 x 16 B)
     uint32_t  sorted_cap;
     uint4*    slow; uint32_t slow_cap;      // 4 x uint4 per slow triangle: three clip-space vertices, (prim, 0, 0, 0)
 };
 #define ZR_TPOOL_CHUNK 256u          // records per chunk of the record pool
-#ifndef ZR_INDEX_LIST
-#define ZR_INDEX_LIST 1              // k_index writes an index list instead of moving the records (see k_index)
-#endif
 #ifndef ZR_TSTRIDE
 #define ZR_TSTRIDE 4u                 // words between the per-tile record counters (and cursors) of neighbouring tiles
 #endif
@@ -233,7 +231,7 @@ void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, u
                         int slot, hipStream_t s, ZrBinEntry* sel = nullptr, const uint8_t* vis_prev = nullptr, bool reuse_list = false);      // sel: round 1's list (camera)
 void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
                         uint32_t* tile_cursor, ZrBinEntry* bins, const ZrHiz& Z, ZrDevStats* stats, int slot, hipStream_t s);
-void zr_launch_frame_begin(ZrDevStats* stats, ZrDevStats* shadow_stats, const XkView* view_src_pinned, XkView* view_dst, uint32_t rebuild_lists, hipStream_t s);
+void zr_launch_frame_begin(ZrDevStats* stats, const XkView* view_src_pinned, XkView* view_dst, uint32_t rebuild_lists, hipStream_t s);
 void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s);
 void zr_launch_fill64(unsigned long long* p, unsigned long long v, size_t n, hipStream_t s);
 // shadow pass with occlusion culling: after the rasteriser has drawn the meshlet-instances flagged in `flags`, test every survivor of the

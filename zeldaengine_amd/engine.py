@@ -70,10 +70,11 @@ def lib():
         "zr_set_timing_interval": [vp, u32],
         "zr_get_frame_latencies": [vp, u32, vp],
         "zr_get_frame_periods": [vp, u32, vp],
-        "zr_get_stats": [vp, C.POINTER(abi.Stats)],
+        "zr_get_stats": [vp, C.POINTER(abi.Stats), sz],
         "zr_read_color": [vp, vp, sz],
         "zr_read_gbuffer": [vp, C.c_int, vp, sz],
         "zr_read_shadowmap": [vp, vp, sz],
+        "zr_copy_frame_async": [vp, vp, vp],
         "zr_tiles_device_buffer": [vp, C.POINTER(vp), C.POINTER(sz)],
         "zr_composite": [vp, vp],
         "zr_read_tiles": [vp, vp, sz],
@@ -109,6 +110,11 @@ def lib():
         f = getattr(L, name)
         f.argtypes = args
         f.restype = C.c_int
+    L.zr_abi_version.argtypes = []
+    L.zr_abi_version.restype = u32
+    if L.zr_abi_version() != abi.ABI_VERSION:
+        raise ImportError("libzelda_render.so speaks ABI version %d, this binding %d: rebuild (python -m zeldaengine_amd.build --force)"
+                          % (L.zr_abi_version(), abi.ABI_VERSION))
     L.zr_tile_owner.argtypes = [u32, u32, u32]
     L.zr_tile_owner.restype = u32
     L.zr_destroy.argtypes = [vp]
@@ -414,10 +420,10 @@ class Renderer:
 
     def stats(self):
         s = abi.Stats()
-        self._chk(self.L.zr_get_stats(self.h, C.byref(s)))
+        self._chk(self.L.zr_get_stats(self.h, C.byref(s), C.sizeof(s)))
         return {"work_items": list(s.work_items), "survivors": list(s.survivors), "bin_entries": list(s.bin_entries),
                 "covered_pixels": int(s.covered_pixels), "covered_shadow_texels": int(s.covered_shadow_texels), "overflow": int(s.overflow),
-                "hiz_culled": int(s.hiz_culled), "round1_survivors": int(s.round1_survivors),
+                "hiz_culled": int(s.hiz_culled), "hiz_culled_geom": int(s.hiz_culled_geom), "round1_survivors": int(s.round1_survivors),
                 "shadow_occluded": int(s.shadow_occluded), "shadow_late": int(s.shadow_late)}
 
     # ---- read-back
@@ -435,6 +441,10 @@ class Renderer:
         out = np.zeros((self.SD, self.SD), dtype=np.float32)
         self._chk(self.L.zr_read_shadowmap(self.h, _ptr(out), out.nbytes))
         return out
+
+    def copy_frame_async(self, color_dev=None, shadow_dev=None):
+        """The frame enqueued last -> caller-owned device buffers (addresses), in stream order, no host synchronisation."""
+        self._chk(self.L.zr_copy_frame_async(self.h, C.c_void_p(color_dev) if color_dev else None, C.c_void_p(shadow_dev) if shadow_dev else None))
 
     # ---- multi-GPU
     def tiles_device_buffer(self):
