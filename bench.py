@@ -133,6 +133,10 @@ def main():
                     help="N > 1: every rank rasterises 1/N of the casters and the maps are MIN all-reduced (4 MiB, on the shadow -> lighting "
                          "dependency of every frame).  NOT the default: no N > 1 run on hardware has compared the two modes yet "
                          "(profiles/r04_scaling_projection.json is a one-GPU projection), and the north star names one collective")
+    ap.add_argument("--shadow-tiles", action="store_true",
+                    help="N > 1: the shadow MAP is owned by light-space super-tiles like the frame (a rank draws the casters that reach its tiles; "
+                         "one more all-gather, of the packed shadow tiles: 4 MiB in total, nothing reduced).  NOT the default either, for the "
+                         "same reason")
     ap.add_argument("--replicated-shadow", action="store_true",
                     help="(the default for N > 1, kept so that older command lines still parse) every rank renders the whole 1024^2 shadow "
                          "map; the all-gather of the composite is the only collective")
@@ -185,6 +189,7 @@ def main():
             dist.all_reduce(torch.zeros(1, dtype=torch.int32))      # a CPU tensor: gloo
 
     args.split_shadow = world > 1 and args.split_shadow and not args.replicated_shadow
+    args.shadow_mode = "replicated" if (world == 1 or args.replicated_shadow) else "tiles" if args.shadow_tiles else "split" if args.split_shadow else "replicated"
     n_point = 256 if args.config == 5 else 16
     if args.config == 3:
         cfg = scenes.config3(args.instances, cube_dim=args.cube_dim, textured=args.textured)
@@ -196,7 +201,7 @@ def main():
     def make_renderer(cfg_, flags=0):
         native = world > 1 and not args.python_dist and not rehearsal
         dr_ = zdist.make_distributed(W, H, 1024, device_index=local_rank, rank=rank, world=world, flags=flags,
-                                     split_shadow=args.split_shadow, native=native)
+                                     split_shadow=args.shadow_mode, native=native)
         engine.load_scene(dr_.r, cfg_)
         return dr_
 
@@ -411,7 +416,8 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "resolution": [W, H], "lib_sha16": sha,
-                       "parallelism": ("screen super-tiles over %d ranks, %s, %s" % (world, "shadow casters i%%%d + MIN all-reduce" % world if args.split_shadow
+                       "parallelism": ("screen super-tiles over %d ranks, %s, %s" % (world, "shadow casters i%%%d + MIN all-reduce" % world if args.shadow_mode == "split"
+                                       else "shadow map owned by light-space super-tiles + all-gather of the packed shadow tiles" if args.shadow_mode == "tiles"
                                        else "shadow map replicated (all-gather of the composite is the only collective)",
                                        "torch.distributed loop" if (args.python_dist or rehearsal) else
                                        ("torch.distributed loop (the native RCCL host could not be brought up: %s)" % fallback if fallback

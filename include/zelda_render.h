@@ -225,6 +225,17 @@ int  zr_tile_partition(uint32_t width, uint32_t height, uint32_t world, uint32_t
 /* Shadow pass split: this context draws instances i % world == rank into its shadow map; the caller min-reduces the maps
  * (depth test LESS_OR_EQUAL = min) between zr_render_shadow and zr_render_lighting.  Default 0 / 1 = everything. */
 int  zr_set_shadow_partition(zr_ctx* ctx, uint32_t rank, uint32_t world);
+/* Shadow pass split, second form: the MAP is owned by light-space super-tiles (zr_tile_owner on the map's 32 x 32-texel tiles) the way
+ * the frame is owned by screen super-tiles.  This context then draws only the casters whose texel box can reach a tile it owns - whole,
+ * so its owned tiles equal the single-GPU map's bit for bit; the ranks exchange tiles with ONE all-gather and nothing is reduced:
+ *   zr_render_geometry | zr_shadow_pack -> all-gather of world x zr_shadow_tiles_bytes -> zr_shadow_unpack | zr_render_lighting
+ * (zr_tile_partition(shadow_dim, shadow_dim, world, rank, ...) lists the owned tiles = the slots of the packed buffer; unused slots hold
+ * depth 1.0.)  Replaces nothing in the reference (one device, ZE:2241); the pass it shards is ZE:3239-3393.  Default 0 / 1 = the whole map.
+ * hip_stream NULL = the render stream. */
+int  zr_set_shadow_tiles(zr_ctx* ctx, uint32_t rank, uint32_t world);
+int  zr_shadow_tiles_bytes(zr_ctx* ctx, size_t* bytes_per_rank);
+int  zr_shadow_pack(zr_ctx* ctx, void* packed_dev, void* hip_stream);
+int  zr_shadow_unpack(zr_ctx* ctx, const void* gathered_dev, void* hip_stream);
 /* Caller-owned shadow map, float[shadow_dim^2] device memory (NULL = internal). */
 int  zr_set_shadow_buffer(zr_ctx* ctx, void* dev_ptr);
 /* Packed tile-major RGBA8 of the tiles this rank owns (device pointer, stable until zr_destroy). */
@@ -247,6 +258,9 @@ int  zr_color_device_ptr(zr_ctx* ctx, void** dev_ptr);
  * casters i % world == rank and the 1024^2 maps are reduced with ncclAllReduce(min) next to the camera passes.
  * zr_finish / the read-back entry points wait for the collective stream too.  librccl is loaded on first use (dlopen). */
 #define ZR_DIST_SPLIT_SHADOW 1u
+/* ... or ZR_DIST_SHADOW_TILES: the shadow MAP is owned by light-space super-tiles (zr_set_shadow_tiles) and the second collective is an
+ * ncclAllGather of the packed shadow tiles (4 MiB in total for a 1024^2 map, no reduction), between the shadow pass and the lighting pass. */
+#define ZR_DIST_SHADOW_TILES 2u
 int  zr_dist_unique_id(void* id, size_t bytes);                       /* bytes must be 128 */
 int  zr_dist_init(zr_ctx* ctx, const void* id, size_t bytes, uint32_t rank, uint32_t world, uint32_t dist_flags);
 /* The same bring-up in two steps, for hosts that can agree between them: zr_dist_prepare is LOCAL (librccl, collective stream, packed /

@@ -18,6 +18,8 @@ def main():
     dist.init_process_group("gloo")
     cfg = scenes.config3(300, 416, 250)
     split = os.environ.get("ZR_TEST_SPLIT_SHADOW") == "1"     # default: all-gather of the composite is the only collective
+    if os.environ.get("ZR_TEST_SPLIT_SHADOW") == "tiles":      # the map owned by light-space super-tiles + an all-gather of the packed tiles
+        split = "tiles"
     if os.environ.get("ZR_TEST_NATIVE") == "1":
         # the native RCCL host cannot come up with every rank on one GPU (RCCL wants a device per rank): all ranks must notice, agree
         # and fall back to the torch.distributed loop together

@@ -1,4 +1,5 @@
-"""Multi-GPU path on CPU: the screen-tile partition + all-gather + untile logic with world_size 2 over gloo.
+"""Multi-GPU path on CPU: the screen-tile partition + all-gather + untile logic with world_size 2 over gloo, and both ways of sharing the
+shadow pass (casters split by instance + MIN all-reduce; the map owned by light-space super-tiles + all-gather of the packed tiles).
 
 Each rank stands in for a GPU: it takes the frame the oracle rendered, keeps only the tiles it owns (pack_tiles = the
 layout k_lighting writes), all-gathers the packed buffers and untiles (= k_untile).  The result must be the full frame on
@@ -82,6 +83,35 @@ def _rank_main(rank, world, port, W, H, q):
     sh = torch.from_numpy(part.shadowmap().reshape(-1).copy())
     dist.all_reduce(sh, op=dist.ReduceOp.MIN)
     shadow_ok = bool(np.array_equal(sh.numpy().view(np.uint32), o.shadowmap().reshape(-1).view(np.uint32)))
+    # shadow MAP owned by light-space super-tiles (zr_set_shadow_tiles): this rank draws the casters whose texel footprint can reach a tile
+    # it owns, packs the owned tiles (zr_shadow_pack), the tiles are all-gathered and scattered (zr_shadow_unpack): no reduction
+    SD = 256                            # 2 x 2 super-tiles of 128 texels: both ranks own some
+    whole = pyoracle.Oracle(W, H, SD)
+    pyoracle.load_scene(whole, cfg)
+    whole.render(0, 1)
+    full_map = whole.shadowmap()
+    slay = zdist.tile_layout(SD, SD, world)
+    mine_tiles = set(zdist.owned_tiles(rank, world, slay["tiles_x"], slay["tiles_y"]))
+    inst = cfg["objects"][0]["instances"]
+    keep = []
+    for i in range(len(inst)):          # a caster is this rank's when it changes a texel of an owned tile (found with the oracle itself)
+        one = pyoracle.Oracle(W, H, SD)
+        ocfg = dict(cfg); ocfg["objects"] = [{"mesh": cfg["objects"][0]["mesh"], "instances": inst[i:i + 1]}]
+        pyoracle.load_scene(one, ocfg)
+        one.render(0, 1)
+        ys, xs = np.nonzero(one.shadowmap() < 1.0)
+        if any(((y // 32) * slay["tiles_x"] + x // 32) in mine_tiles for y, x in zip(ys, xs)):
+            keep.append(i)
+        one.close()
+    share = pyoracle.Oracle(W, H, SD)
+    scfg = dict(cfg); scfg["objects"] = [{"mesh": cfg["objects"][0]["mesh"], "instances": inst[keep]}]
+    pyoracle.load_scene(share, scfg)
+    share.render(0, 1)
+    spacked = torch.from_numpy(zdist.pack_tiles(share.shadowmap(), rank, world, pad=1.0).reshape(-1).copy())
+    sgathered = torch.empty(spacked.numel() * world, dtype=torch.float32)
+    dist.all_gather_into_tensor(sgathered, spacked)
+    smap = zdist.untile(sgathered.numpy().reshape(world, slay["slots_per_rank"], 32, 32), SD, SD)
+    shadow_ok = shadow_ok and bool(np.array_equal(smap.view(np.uint32), full_map.view(np.uint32))) and 0 < len(keep) < len(inst)
     q.put((rank, bool(np.array_equal(frame, full)) and shadow_ok, int(mine.numel())))
     dist.barrier()
     dist.destroy_process_group()

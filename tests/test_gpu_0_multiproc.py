@@ -9,15 +9,16 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("world,split", [(2, 0), (3, 1)])
+@pytest.mark.parametrize("world,split", [(2, 0), (3, 1), (2, "tiles")])
 def test_ranks_composite_the_single_gpu_frame(world, split):
-    """Every rank renders its tiles (split = 1: and its share of the shadow casters, min-all-reduced), all-gathers the packed
-    tiles and composites: every rank must end up with the frame (and shadow map) one context renders alone."""
+    """Every rank renders its tiles (split = 1: and its share of the shadow casters, min-all-reduced; "tiles": and the casters that
+    reach its tiles of the shadow MAP, the packed map tiles all-gathered), all-gathers the packed frame tiles and composites: every
+    rank must end up with the frame (and shadow map) one context renders alone."""
     env = dict(os.environ)
     env["MASTER_ADDR"] = "127.0.0.1"
     env["ZR_TEST_SPLIT_SHADOW"] = str(split)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(29540 + world), os.path.join(HERE, "mp_dist_worker.py")]
+           "--master-port", str(29540 + world + (4 if split == "tiles" else 0)), os.path.join(HERE, "mp_dist_worker.py")]
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     text = out.stdout.decode(errors="replace")
     assert out.returncode == 0 and "MP_DIST_OK" in text, text[-3000:]

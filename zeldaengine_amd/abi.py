@@ -109,3 +109,21 @@ def make_material(images=None):
             keep.append(a)
             m.tex[i] = Image(a.ctypes.data, a.shape[1], a.shape[0])
     return m, keep
+
+
+DIST_SPLIT_SHADOW = 1      # ZR_DIST_SPLIT_SHADOW: casters i % world == rank + ncclAllReduce(min) of the maps
+DIST_SHADOW_TILES = 2      # ZR_DIST_SHADOW_TILES: the map owned by light-space super-tiles + ncclAllGather of the packed tiles
+SHADOW_MODES = ("replicated", "split", "tiles")
+
+
+def shadow_mode(split_shadow=False, mode=None):
+    """The multi-GPU shadow mode from the two ways hosts name it: mode in SHADOW_MODES, or the older split_shadow flag."""
+    if mode is None:
+        mode = "split" if split_shadow is True else (split_shadow if isinstance(split_shadow, str) else "replicated")
+    if mode not in SHADOW_MODES:
+        raise ValueError("shadow mode %r: one of %r" % (mode, SHADOW_MODES))
+    return mode
+
+
+def dist_flags(mode):
+    return {"replicated": 0, "split": DIST_SPLIT_SHADOW, "tiles": DIST_SHADOW_TILES}[mode]

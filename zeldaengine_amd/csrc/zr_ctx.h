@@ -86,6 +86,10 @@ struct zr_ctx {
     float* d_shadow = nullptr; uint32_t* d_color = nullptr; uint32_t* d_tiles = nullptr;
     float* d_shadow_ext = nullptr;       // caller-owned shadow map (zr_set_shadow_buffer), or null
     uint32_t shadow_rank = 0, shadow_world = 1; int stage = 0;   // stage: 0 idle, 1 shadow done, 2 gbuffer done
+    // The shadow MAP owned by light-space super-tiles (zr_set_shadow_tiles): this context draws the casters that can reach a tile of the map
+    // it owns; its owned tiles are exact, the others hold leftovers until zr_shadow_unpack scatters every rank's tiles in.
+    uint32_t stile_rank = 0, stile_world = 1, s_slots_per_rank = 0, n_sowned_rank = 0;
+    uint32_t *d_sowned_rank = nullptr, *d_stile_map = nullptr;
     uint32_t* d_tiles_ext = nullptr;     // caller-owned packed tile buffer for the next frames (zr_set_tiles_buffer), or null
 
     // cull / bin scratch, one set per geometry pass (0 shadow, 1 camera) so that the two pipelines can run on two streams

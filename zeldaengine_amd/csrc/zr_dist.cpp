@@ -3,8 +3,10 @@
 // The reference has no multi-GPU path (one VkDevice, one queue, ZE:2241); this is the MI355X-native addition of SURVEY 5 / 8(e): the
 // frame is partitioned by screen super-tiles (zr_tile_owner), every rank holds the whole scene and renders its tiles into a packed,
 // tile-major RGBA8 buffer, and ONE ncclAllGather over xGMI per frame (4 bytes per pixel of the frame in total) + an untile kernel
-// gives every rank the composite.  Optionally (ZR_DIST_SPLIT_SHADOW) the shadow casters are split i % world and the 1024^2 maps are
-// reduced with ncclAllReduce(min): the depth test LESS_OR_EQUAL is a min and the bias is per triangle, so the split is exact.
+// gives every rank the composite.  Optionally the shadow pass shrinks with N too: ZR_DIST_SHADOW_TILES owns the MAP by light-space
+// super-tiles (a rank draws the casters that reach its tiles; a second ncclAllGather of the packed tiles, 4 MiB in total, no reduction),
+// or ZR_DIST_SPLIT_SHADOW splits the casters i % world and reduces the 1024^2 maps with ncclAllReduce(min) (the depth test LESS_OR_EQUAL
+// is a min and the bias is per triangle); both are exact.
 //
 // Streams: the render stream + the camera lane produce frame k + 1 while the collective stream gathers and composites frame k; the
 // packed / gathered buffers are double-buffered and ordered by events, so the xGMI latency hides behind rendering and the host only
@@ -17,6 +19,7 @@
 
 #include <cstring>
 #include <new>
+#include <vector>
 
 struct ZrDist {
     void* lib = nullptr;
@@ -28,7 +31,8 @@ struct ZrDist {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     ncclComm_t comm = nullptr;
     hipStream_t comm_s = nullptr;
-    uint32_t rank = 0, world = 1; bool split_shadow = false;
+    uint32_t rank = 0, world = 1; bool split_shadow = false, shadow_tiles = false;
+    size_t stile_bytes = 0; uint32_t* spacked = nullptr; uint32_t* sgathered = nullptr; hipEvent_t shadow_packed = nullptr;
     size_t tile_bytes = 0;
     uint32_t* tiles[2] = { nullptr, nullptr }; uint32_t* gathered[2] = { nullptr, nullptr };
     hipEvent_t rendered[2] = { nullptr, nullptr }, consumed[2] = { nullptr, nullptr }, shadow_reduced = nullptr;
@@ -85,6 +89,10 @@ void zr_dist_destroy(zr_ctx* c)
         if (c->d_shadow_ext == d->shadow) { c->d_shadow_ext = nullptr; c->shadow_rank = 0; c->shadow_world = 1; }      // back to the whole map
         (void)hipFree(d->shadow);
     }
+    if (d->shadow_tiles && c->stile_world > 1) (void)zr_set_shadow_tiles(c, 0, 1);      // back to the whole map
+    if (d->spacked) (void)hipFree(d->spacked);
+    if (d->sgathered) (void)hipFree(d->sgathered);
+    if (d->shadow_packed) (void)hipEventDestroy(d->shadow_packed);
     if (d->shadow_reduced) (void)hipEventDestroy(d->shadow_reduced);
     if (d->comm_s) (void)hipStreamDestroy(d->comm_s);
     if (c->d_tiles_ext == d->tiles[0] || c->d_tiles_ext == d->tiles[1]) c->d_tiles_ext = nullptr;
@@ -112,7 +120,9 @@ extern "C" int zr_dist_prepare(zr_ctx* c, uint32_t rank, uint32_t world, uint32_
     c->dist = d;
     std::string err;
     if (!load_rccl(d, &err)) { zr_dist_destroy(c); return zr_fail(c, ZR_ERR_UNSUPPORTED, err); }
+    if ((dist_flags & ZR_DIST_SPLIT_SHADOW) && (dist_flags & ZR_DIST_SHADOW_TILES)) { zr_dist_destroy(c); return zr_fail(c, ZR_ERR_ARG, "zr_dist_prepare: SPLIT_SHADOW and SHADOW_TILES exclude each other"); }
     d->rank = rank; d->world = world; d->split_shadow = (dist_flags & ZR_DIST_SPLIT_SHADOW) != 0 && world > 1;
+    d->shadow_tiles = (dist_flags & ZR_DIST_SHADOW_TILES) != 0 && world > 1;
     d->tile_bytes = (size_t)c->slots_per_rank * ZR_TILE * ZR_TILE * 4;
     auto bail = [&](int code, const std::string& m) { zr_dist_destroy(c); return zr_fail(c, code, m); };
     int least = 0, greatest = 0;
@@ -127,6 +137,19 @@ extern "C" int zr_dist_prepare(zr_ctx* c, uint32_t rank, uint32_t world, uint32_
     if (d->split_shadow) {
         if (hipMalloc((void**)&d->shadow, (size_t)c->SD * c->SD * 4) != hipSuccess ||
             hipEventCreateWithFlags(&d->shadow_reduced, hipEventDisableTiming) != hipSuccess) return bail(ZR_ERR_DEVICE, "zr_dist_prepare: shadow buffer");
+    }
+    if (d->shadow_tiles) {
+        // the map's tile partition for `world` ranks: sizes only (the context keeps drawing the whole map until the communicator stands)
+        uint32_t n_owned = 0, spr = 0;
+        if (zr_tile_partition(c->SD, c->SD, world, rank, nullptr, &n_owned, &spr) != ZR_OK) return bail(ZR_ERR_ARG, "zr_dist_prepare: shadow tile partition");
+        d->stile_bytes = (size_t)spr * ZR_TILE * ZR_TILE * 4;
+        if (hipMalloc((void**)&d->spacked, d->stile_bytes) != hipSuccess || hipMalloc((void**)&d->sgathered, d->stile_bytes * world) != hipSuccess ||
+            hipEventCreateWithFlags(&d->shadow_packed, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&d->shadow_reduced, hipEventDisableTiming) != hipSuccess) return bail(ZR_ERR_DEVICE, "zr_dist_prepare: shadow tile buffers");
+        {   // unused slots of a rank with fewer tiles than slots_per_rank are gathered too: depth 1.0, once
+            std::vector<uint32_t> ones(d->stile_bytes / 4, 0x3F800000u);
+            if (hipMemcpy(d->spacked, ones.data(), d->stile_bytes, hipMemcpyHostToDevice) != hipSuccess) return bail(ZR_ERR_DEVICE, "zr_dist_prepare: shadow tile buffers");
+        }
     }
     return ZR_OK;
 }
@@ -150,6 +173,7 @@ extern "C" int zr_dist_connect(zr_ctx* c, const void* id, size_t bytes)
     // only a connected context draws a share of the shadow casters: a host that keeps using a context whose bring-up failed through
     // plain zr_render must get the whole map
     if (d->split_shadow) { c->d_shadow_ext = d->shadow; c->shadow_rank = d->rank; c->shadow_world = d->world; }
+    if (d->shadow_tiles) { const int rc = zr_set_shadow_tiles(c, d->rank, d->world); if (rc != ZR_OK) return rc; }
     return ZR_OK;
 }
 
@@ -182,6 +206,22 @@ extern "C" int zr_dist_frame(zr_ctx* c)
         NCCLCHK(c, d, d->AllReduce(d->shadow, d->shadow, (size_t)c->SD * c->SD, ncclFloat32, ncclMin, d->comm, d->comm_s));
         HIPCHK(c, hipEventRecord(d->shadow_reduced, d->comm_s));
         HIPCHK(c, hipStreamWaitEvent(c->stream, d->shadow_reduced, 0));
+        rc = zr_render_lighting(c);
+    } else if (d->shadow_tiles) {
+        // this rank's share of the MAP on the render stream (camera passes on the lane); its owned tiles packed behind the pass, gathered on
+        // the collective stream, scattered back into the map on the render stream ahead of the lighting pass.  One buffer pair does: the next
+        // frame's pack follows this frame's unpack in render-stream order.
+        rc = zr_render_geometry(c);
+        if (rc) return rc;
+        rc = zr_shadow_pack(c, d->spacked, nullptr);
+        if (rc) return rc;
+        HIPCHK(c, hipEventRecord(d->shadow_packed, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(d->comm_s, d->shadow_packed, 0));
+        NCCLCHK(c, d, d->AllGather(d->spacked, d->sgathered, d->stile_bytes, ncclUint8, d->comm, d->comm_s));
+        HIPCHK(c, hipEventRecord(d->shadow_reduced, d->comm_s));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, d->shadow_reduced, 0));
+        rc = zr_shadow_unpack(c, d->sgathered, nullptr);
+        if (rc) return rc;
         rc = zr_render_lighting(c);
     } else rc = zr_render(c);
     if (rc) return rc;

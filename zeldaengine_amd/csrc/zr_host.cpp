@@ -297,7 +297,7 @@ extern "C" void zr_destroy(zr_ctx* c)
         dev_free(c->d_shadow_b[b]); dev_free(c->d_view_b[b]); dev_free(c->d_empty_b[b]);
     }
     dev_free(c->d_color); dev_free(c->d_stats); dev_free(c->d_sstats); dev_free(c->d_lut); dev_free(c->d_unorm_lut); dev_free(c->d_sky_keys);
-    dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles); dev_free(c->d_tile_map);
+    dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles); dev_free(c->d_tile_map); dev_free(c->d_sowned_rank); dev_free(c->d_stile_map);
     for (auto& sc : c->sc) {
         dev_free(sc.tile_count); dev_free(sc.tile_offset); dev_free(sc.tile_cursor); dev_free(sc.chunk_offset);
         dev_free(sc.rects); dev_free(sc.bins); dev_free(sc.work); dev_free(sc.chunk_tab);
@@ -1066,7 +1066,7 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
     P->W = mode == ZR_MODE_SHADOW ? c->SD : c->W; P->H = mode == ZR_MODE_SHADOW ? c->SD : c->H;
     P->hw = 0.5f * (float)P->W; P->hh = 0.5f * (float)P->H;
     P->tiles_x = mode == ZR_MODE_SHADOW ? c->stiles_x : c->tiles_x; P->tiles_y = mode == ZR_MODE_SHADOW ? c->stiles_y : c->tiles_y;
-    P->tile_rank = mode == ZR_MODE_SHADOW ? 0 : c->cfg.tile_rank; P->tile_world = mode == ZR_MODE_SHADOW ? 1 : c->cfg.tile_world;
+    P->tile_rank = mode == ZR_MODE_SHADOW ? c->stile_rank : c->cfg.tile_rank; P->tile_world = mode == ZR_MODE_SHADOW ? c->stile_world : c->cfg.tile_world;
     P->inst_rank = mode == ZR_MODE_SHADOW ? c->shadow_rank : 0; P->inst_world = mode == ZR_MODE_SHADOW ? c->shadow_world : 1;
     P->images = !c->any_images ? 0u : c->mixed_images ? 2u : 1u;     // 1: every material with images has the packed form
     P->n_objects = c->n_objs; P->n_work = c->n_work; P->n_inst_total = c->n_inst_total; P->bin_capacity = c->bin_capacity;
@@ -1085,7 +1085,8 @@ static bool build_pass(const zr_ctx* c, const XkUniformBufferMVP& u, int mode, Z
         P->p00 = pr[0]; P->p11 = pr[5];
         P->pz_a = -pr[10]; P->pz_b = pr[14];       // z_view = -d: (p10 * -d + p14) / d
         P->sphere_ok = (centred && rigid3(u.Model) && rigid3(u.View) && finite16(P->VM)) ? 1u : 0u;
-        P->rect_cull = (mode == ZR_MODE_GBUFFER && P->sphere_ok && c->cfg.tile_world > 1 && !(c->cfg.flags & ZR_FLAG_NO_RECT_CULL)) ? 1u : 0u;
+        // (both passes: the camera pass against the frame's tiles, the shadow pass against the map's when the map is owned by tiles)
+        P->rect_cull = (P->sphere_ok && P->tile_world > 1 && !(c->cfg.flags & ZR_FLAG_NO_RECT_CULL)) ? 1u : 0u;
         if (P->rect_cull) P->use_worklist = 1u;
     }
     {
@@ -1507,7 +1508,76 @@ extern "C" int zr_set_shadow_partition(zr_ctx* c, uint32_t rank, uint32_t world)
 {
     if (!c) return ZR_ERR_ARG;
     ARGCHK(c, world >= 1 && rank < world);
+    if (world > 1 && c->stile_world > 1) return zr_fail(c, ZR_ERR_STATE, "zr_set_shadow_partition: the map is already owned by tiles (zr_set_shadow_tiles)");
     c->shadow_rank = rank; c->shadow_world = world;
+    return ZR_OK;
+}
+
+// Multi-GPU shadow pass, second form: the MAP is owned by light-space super-tiles exactly as the frame is owned by screen super-tiles
+// (zr_tile_owner on the map's 32 x 32-texel tiles).  This context then draws only the casters whose texel box can reach a tile it owns
+// (rank-local work list, instance- and meshlet-level rejects before any vertex work) - drawn whole, so its owned tiles are bit for
+// bit the single-GPU map's - and the ranks exchange their tiles with ONE all-gather: zr_shadow_pack -> all-gather -> zr_shadow_unpack.
+// No reduction: every texel has one owner.  rank 0 / world 1 = the whole map (default).
+static int zr_set_shadow_tiles_impl(zr_ctx* c, uint32_t rank, uint32_t world)
+{
+    if (!c) return ZR_ERR_ARG;
+    ARGCHK(c, world >= 1 && rank < world);
+    if (c->stage != 0) return zr_fail(c, ZR_ERR_STATE, "zr_set_shadow_tiles between the stages of a frame");
+    if (world > 1 && c->shadow_world > 1) return zr_fail(c, ZR_ERR_STATE, "zr_set_shadow_tiles: the casters are already split by instance (zr_set_shadow_partition)");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, zr_sync_all(c));
+    dev_free(c->d_sowned_rank); dev_free(c->d_stile_map);
+    c->stile_rank = 0; c->stile_world = 1; c->s_slots_per_rank = c->sn_tiles; c->n_sowned_rank = 0;
+    c->list_valid[0] = false;
+    if (world == 1) return ZR_OK;
+    std::vector<uint32_t> owned, map(c->sn_tiles), counts(world, 0u);
+    for (uint32_t t = 0; t < c->sn_tiles; ++t) {
+        const uint32_t o = zr_tile_owner(t % c->stiles_x, t / c->stiles_x, world);
+        map[t] = counts[o]++;
+        if (o == rank) owned.push_back(t);
+    }
+    uint32_t spr = 0;
+    for (uint32_t n : counts) spr = std::max(spr, n);
+    for (uint32_t t = 0; t < c->sn_tiles; ++t) map[t] += zr_tile_owner(t % c->stiles_x, t / c->stiles_x, world) * spr;
+    HIPCHK(c, upload(&c->d_sowned_rank, owned)); HIPCHK(c, upload(&c->d_stile_map, map));
+    c->stile_rank = rank; c->stile_world = world; c->s_slots_per_rank = spr; c->n_sowned_rank = (uint32_t)owned.size();
+    return ZR_OK;
+}
+extern "C" int zr_set_shadow_tiles(zr_ctx* c, uint32_t rank, uint32_t world)
+{
+    return zr_guard(c, [&]() { return zr_set_shadow_tiles_impl(c, rank, world); });
+}
+// bytes of one rank's packed share (slots_per_rank tiles of 32 x 32 floats; the all-gathered buffer holds world times that)
+extern "C" int zr_shadow_tiles_bytes(zr_ctx* c, size_t* bytes_per_rank)
+{
+    if (!c || !bytes_per_rank) return ZR_ERR_ARG;
+    *bytes_per_rank = (size_t)(c->stile_world > 1 ? c->s_slots_per_rank : c->sn_tiles) * ZR_TILE * ZR_TILE * 4;
+    return ZR_OK;
+}
+// The owned tiles of the map just rasterised -> packed_dev (slot k = the k-th owned tile, unused slots keep depth 1.0), on `hip_stream`
+// (NULL = the render stream, behind the shadow pass).
+extern "C" int zr_shadow_pack(zr_ctx* c, void* packed_dev, void* hip_stream)
+{
+    if (!c) return ZR_ERR_ARG;
+    ARGCHK(c, packed_dev != nullptr);
+    if (c->stile_world <= 1) return zr_fail(c, ZR_ERR_STATE, "zr_shadow_pack: the shadow map is not owned by tiles (zr_set_shadow_tiles)");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    zr_launch_pack_tiles((const uint32_t*)shadow_buf(c), c->d_sowned_rank, c->n_sowned_rank, (uint32_t*)packed_dev, c->SD, c->SD, c->stiles_x, 0x3F800000u, s);
+    HIPCHK(c, hipGetLastError());
+    return ZR_OK;
+}
+// The all-gathered buffer (world x bytes_per_rank, rank-major) -> this frame's shadow map, every tile from its owner, on `hip_stream`
+// (NULL = the render stream: call it before zr_render_lighting).
+extern "C" int zr_shadow_unpack(zr_ctx* c, const void* gathered_dev, void* hip_stream)
+{
+    if (!c) return ZR_ERR_ARG;
+    ARGCHK(c, gathered_dev != nullptr);
+    if (c->stile_world <= 1) return zr_fail(c, ZR_ERR_STATE, "zr_shadow_unpack: the shadow map is not owned by tiles (zr_set_shadow_tiles)");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    zr_launch_untile((const uint32_t*)gathered_dev, c->d_stile_map, (uint32_t*)shadow_buf(c), c->SD, c->SD, c->stiles_x, c->sn_tiles, s);
+    HIPCHK(c, hipGetLastError());
     return ZR_OK;
 }
 

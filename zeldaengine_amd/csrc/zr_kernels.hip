@@ -311,7 +311,8 @@ __device__ __forceinline__ bool instance_test(const ZrPass& P, const ZrObject* _
                             __builtin_fmaf(P.planes[k][2], cw4.z, P.planes[k][3])));
             if (d < -rw) vis = false;
         }
-        if (vis && MODE == ZR_MODE_GBUFFER && P.rect_cull && !sphere_reaches_owned_tile(P, co, radius)) vis = false;
+        // (shadow pass with the MAP owned by light-space super-tiles, zr_set_shadow_tiles: the same reject against the map's tiles)
+        if (vis && P.rect_cull && !sphere_reaches_owned_tile(P, co, radius)) vis = false;
         // a whole instance between the pixel (texel) centres: a million instances under a 1024^2 shadow map are mostly that
         if (vis && P.sphere_ok && P.frustum_ok && sphere_holds_no_centre(P, co, radius)) vis = false;
     }
@@ -433,7 +434,7 @@ __device__ __forceinline__ bool cull_stage_a(const ZrPass& P, const ZrObject* __
             if (zr_dot(d, aw) >= __builtin_fmaf(cn.w + 0.02f, L, rw)) alive = false;
         }
         // multi-GPU: nothing of this meshlet can land on a tile this rank owns -> no vertex of it is transformed here
-        if (alive && MODE == ZR_MODE_GBUFFER && P.rect_cull &&
+        if (alive && P.rect_cull &&
             !sphere_reaches_owned_tile(P, co, bs.w * (instanced ? __builtin_fabsf(I.s) : 1.0f))) alive = false;
     }
     return alive;
@@ -638,6 +639,17 @@ __global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __re
                     if (px0 <= px1 && py0 <= py1) {
                         r = pack_tile_rect<MODE>(px0, py0, px1, py1);
                         pr = make_uint2((uint32_t)px0 | (uint32_t)py0 << 16, (uint32_t)px1 | (uint32_t)py1 << 16);
+                        // Shadow map owned by light-space super-tiles (zr_set_shadow_tiles): a meshlet is this rank's work when its texel box
+                        // - the box itself, not the apron-shrunk rectangle it is LISTED under - reaches a tile the rank owns.  It is then drawn
+                        // whole, in every window it is listed for (the listing tile of a meshlet that straddles a border may be the
+                        // neighbour's): the owned tiles end up exact, whatever lands on the others is not sent anywhere.
+                        if (MODE == ZR_MODE_SHADOW && P.tile_world > 1u) {
+                            bool mine = false;
+                            for (int ty = py0 / TILE; ty <= py1 / TILE; ++ty)
+                                for (int tx = px0 / TILE; tx <= px1 / TILE; ++tx)
+                                    mine = mine || tile_owner((uint32_t)tx, (uint32_t)ty, P.tile_world) == P.tile_rank;
+                            if (!mine) r = ZR_RECT_CULLED;
+                        }
                     }
                 } else r = r_all;
             }
@@ -773,6 +785,8 @@ __global__ __launch_bounds__(1024) void k_bin_count(ZrPass P, const uint32_t* __
     const int vslot = slot > 1 ? 1 : slot;               // camera rounds 1 and 2 share the cull results of slot 1
     const uint32_t n_vis = P.use_worklist ? stats->n_vis_work[vslot] : P.n_work;
     if (blockIdx.x * 1024u >= n_vis) return;            // the grid is sized for every meshlet-instance of the scene
+    // (shadow pass: ownership of the map's tiles was decided per meshlet by k_cull_box - an accepted meshlet is listed in every tile of its rect)
+    const bool shadow = P.mode == ZR_MODE_SHADOW;
     for (uint32_t i = threadIdx.x; i < n_tiles; i += 1024u) hist[i] = 0;
     __syncthreads();
     const uint32_t w = blockIdx.x * 1024u + threadIdx.x;
@@ -791,7 +805,7 @@ __global__ __launch_bounds__(1024) void k_bin_count(ZrPass P, const uint32_t* __
             for (uint32_t ty = ty0; ty <= ty1; ++ty)
                 for (uint32_t tx = tx0; tx <= tx1; ++tx) {
                     const uint32_t t = ty * P.tiles_x + tx;
-                    if (tile_owner(tx, ty, P.tile_world) == P.tile_rank && !tile_hides(Z, zt, t)) atomicAdd(&hist[t], 1u);
+                    if ((shadow || tile_owner(tx, ty, P.tile_world) == P.tile_rank) && !tile_hides(Z, zt, t)) atomicAdd(&hist[t], 1u);
                 }
         }
     }
@@ -881,6 +895,7 @@ __global__ __launch_bounds__(1024) void k_bin_fill(ZrPass P, const ZrObject* __r
     const int vslot = slot > 1 ? 1 : slot;
     const uint32_t n_vis = P.use_worklist ? stats->n_vis_work[vslot] : P.n_work;
     if (blockIdx.x * 1024u >= n_vis) return;
+    const bool shadow = P.mode == ZR_MODE_SHADOW;       // (as in k_bin_count)
     for (uint32_t i = threadIdx.x; i < n_tiles; i += 1024u) hist[i] = 0;
     if (threadIdx.x == 0) tot = 0;
     __syncthreads();
@@ -899,7 +914,7 @@ __global__ __launch_bounds__(1024) void k_bin_fill(ZrPass P, const ZrObject* __r
         for (uint32_t ty = ty0; ty <= ty1; ++ty)
             for (uint32_t tx = tx0; tx <= tx1; ++tx) {
                 const uint32_t t = ty * P.tiles_x + tx;
-                if (tile_owner(tx, ty, P.tile_world) == P.tile_rank && !tile_hides(Z, zt, t)) atomicAdd(&hist[t], 1u);
+                if ((shadow || tile_owner(tx, ty, P.tile_world) == P.tile_rank) && !tile_hides(Z, zt, t)) atomicAdd(&hist[t], 1u);
             }
     }
     __syncthreads();
@@ -922,7 +937,7 @@ __global__ __launch_bounds__(1024) void k_bin_fill(ZrPass P, const ZrObject* __r
         for (uint32_t ty = ty0; ty <= ty1; ++ty)
             for (uint32_t tx = tx0; tx <= tx1; ++tx) {
                 const uint32_t t = ty * P.tiles_x + tx;
-                if (tile_owner(tx, ty, P.tile_world) != P.tile_rank || tile_hides(Z, zt, t)) continue;
+                if ((!shadow && tile_owner(tx, ty, P.tile_world) != P.tile_rank) || tile_hides(Z, zt, t)) continue;
                 const uint32_t pos = atomicAdd(&hist[t], 1u);
                 if (pos < P.bin_capacity) bins[pos] = be;
             }
@@ -1981,7 +1996,6 @@ __global__ __launch_bounds__(256) void k_shadow_occlusion(ZrPass P, const ZrObje
             const uint32_t tx0 = r & 255u, ty0 = (r >> 8) & 255u, tx1 = (r >> 16) & 255u, ty1 = r >> 24;
             for (uint32_t ty = ty0; ty <= ty1; ++ty)
                 for (uint32_t tx = tx0; tx <= tx1; ++tx) {
-                    if (tile_owner(tx, ty, P.tile_world) != P.tile_rank) continue;
                     const uint32_t pos = atomicAdd(&stats->n_chunks[1], 1u);      // (late entries are few; a light that jumps pays ~10 ns apiece here)
                     be.prim_base = ty * P.tiles_x + tx;
                     if (pos < room) bins[P.bin_capacity - 1u - pos] = be;
@@ -2393,10 +2407,7 @@ __global__ __launch_bounds__(256) void k_index(ZrTriBins B, const ZrDevStats* __
             tile[k] = have[k] ? B.rtile[r0 + j] : 0u;
         }
 #pragma unroll
-        for (uint32_t k = 0; k < NB; ++k) {
-            const uint32_t j = k * 64u + lane;
-            off[k] = have[k] ? tile_offset[tile[k]] : 0u;
-        }
+        for (uint32_t k = 0; k < NB; ++k) off[k] = have[k] ? tile_offset[tile[k]] : 0u;
 #pragma unroll
         for (uint32_t k = 0; k < NB; ++k) {
             rank[k] = 0; cnt[k] = 0; first[k] = (int)lane;
@@ -3286,6 +3297,20 @@ __global__ __launch_bounds__(256) void k_untile(const uint32_t* __restrict__ gat
     }
 }
 
+// The other direction, for a plane that is NOT written tile-major by its producer (the shadow map): plane -> packed[slot][TILE_PIX] for
+// the tiles in `tiles` (slot = place in the list); texels beyond the plane's edge are filled with `pad`.
+__global__ __launch_bounds__(256) void k_pack_tiles(const uint32_t* __restrict__ plane, const uint32_t* __restrict__ tiles, uint32_t* __restrict__ packed,
+                                                    uint32_t W, uint32_t H, uint32_t tiles_x, uint32_t pad)
+{
+    const uint32_t tile = tiles[blockIdx.x];
+    uint32_t* dst = packed + (size_t)blockIdx.x * TILE_PIX;
+    const uint32_t tx0 = (tile % tiles_x) * TILE, ty0 = (tile / tiles_x) * TILE;
+    for (uint32_t i = threadIdx.x; i < TILE_PIX; i += 256u) {
+        const uint32_t px = tx0 + (i & (TILE - 1)), py = ty0 + i / TILE;
+        dst[i] = (px < W && py < H) ? plane[(size_t)py * W + px] : pad;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ launchers (C++ linkage, used by zr_host.cpp)
 
 void zr_launch_instance_prep(const XkInstanceData* in, ZrInstance* out, uint32_t n, uint32_t instanced, hipStream_t s)
@@ -3473,4 +3498,9 @@ void zr_launch_untile(const uint32_t* gathered, const uint32_t* tile_map, uint32
                       uint32_t n_tiles, hipStream_t s)
 {
     hipLaunchKernelGGL(k_untile, dim3(n_tiles), dim3(256), 0, s, gathered, tile_map, frame, W, H, tiles_x, n_tiles);
+}
+void zr_launch_pack_tiles(const uint32_t* plane, const uint32_t* tiles, uint32_t n_tiles, uint32_t* packed, uint32_t W, uint32_t H, uint32_t tiles_x,
+                          uint32_t pad, hipStream_t s)
+{
+    if (n_tiles) hipLaunchKernelGGL(k_pack_tiles, dim3(n_tiles), dim3(256), 0, s, plane, tiles, packed, W, H, tiles_x, pad);
 }

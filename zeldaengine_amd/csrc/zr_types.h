@@ -256,3 +256,5 @@ void zr_launch_gbuffer_vis(const ZrLightParams& L, const XkView* view, const GBu
                            const float* lut, uint32_t* out, hipStream_t s);
 void zr_launch_untile(const uint32_t* gathered, const uint32_t* tile_map, uint32_t* frame, uint32_t W, uint32_t H, uint32_t tiles_x,
                       uint32_t n_tiles, hipStream_t s);
+void zr_launch_pack_tiles(const uint32_t* plane, const uint32_t* tiles, uint32_t n_tiles, uint32_t* packed, uint32_t W, uint32_t H, uint32_t tiles_x,
+                          uint32_t pad, hipStream_t s);

@@ -7,8 +7,10 @@ into a packed, tile-major RGBA8 buffer.  Collectives over xGMI per frame:
 
 * composite: an all-gather of the packed tiles (4 B/pixel in total) followed by an untile kernel gives every rank the frame.  By
   default this is the ONLY collective (every rank renders the whole 1024^2 shadow map);
-* `split_shadow=True` adds one: rank r rasterises instances i % world == r into its own map and the maps are all-reduced with MIN
-  (4 MB; the depth test LESS_OR_EQUAL is a min, so the split is exact), on the collective stream next to the camera passes.
+* `split_shadow="tiles"` adds one: the shadow MAP is owned by light-space super-tiles the way the frame is owned by screen super-tiles; a rank
+  draws the casters that reach its tiles and the packed tiles are all-gathered (4 MB in total, nothing reduced: every texel has one owner);
+* `split_shadow=True` ("split") adds another kind: rank r rasterises instances i % world == r into its own map and the maps are all-reduced
+  with MIN (4 MB; the depth test LESS_OR_EQUAL is a min, so the split is exact), on the collective stream next to the camera passes.
 
 `NativeDistributedRenderer` runs that loop inside the library (zr_dist_frame: RCCL called from C++, nothing of Python or torch in the
 frame); `DistributedRenderer` is the same loop spelled with torch.distributed (any backend: the gloo tests use it).
@@ -44,11 +46,12 @@ def tile_layout(width, height, world):
             "slots_per_rank": max(len(owned_tiles(r, world, tx, ty)) for r in range(world))}
 
 
-def pack_tiles(frame, rank, world):
-    """frame (H, W, 4) uint8 -> (slots_per_rank, 32, 32, 4): slot k holds the rank's k-th owned tile, zero padded."""
+def pack_tiles(frame, rank, world, pad=0):
+    """frame (H, W, 4) uint8 -> (slots_per_rank, 32, 32, 4): slot k holds the rank's k-th owned tile, padded with `pad`.
+    Any plane does: a (D, D) float32 shadow map -> (slots_per_rank, 32, 32) with pad = 1.0 (zr_shadow_pack)."""
     H, W = frame.shape[:2]
     lay = tile_layout(W, H, world)
-    out = np.zeros((lay["slots_per_rank"], TILE, TILE, 4), dtype=np.uint8)
+    out = np.full((lay["slots_per_rank"], TILE, TILE) + frame.shape[2:], pad, dtype=frame.dtype)
     for k, t in enumerate(owned_tiles(rank, world, lay["tiles_x"], lay["tiles_y"])):
         x0, y0 = (t % lay["tiles_x"]) * TILE, (t // lay["tiles_x"]) * TILE
         blk = frame[y0:y0 + TILE, x0:x0 + TILE]
@@ -57,10 +60,10 @@ def pack_tiles(frame, rank, world):
 
 
 def untile(gathered, width, height):
-    """gathered (world, slots_per_rank, 32, 32, 4) -> (H, W, 4)."""
+    """gathered (world, slots_per_rank, 32, 32, 4) -> (H, W, 4)  (or (world, slots, 32, 32) -> (H, W): zr_shadow_unpack)."""
     world = gathered.shape[0]
     lay = tile_layout(width, height, world)
-    frame = np.zeros((height, width, 4), dtype=np.uint8)
+    frame = np.zeros((height, width) + gathered.shape[4:], dtype=gathered.dtype)
     for r in range(world):
         for k, t in enumerate(owned_tiles(r, world, lay["tiles_x"], lay["tiles_y"])):
             x0, y0 = (t % lay["tiles_x"]) * TILE, (t // lay["tiles_x"]) * TILE
@@ -97,12 +100,20 @@ class DistributedRenderer:
             self.consumed = [torch.cuda.Event() for _ in range(2)]      # tiles[b] has been gathered (may be overwritten)
             for ev in self.consumed:
                 ev.record(self.comm_stream)
-            self.split_shadow = bool(split_shadow)
+            from . import abi
+            self.shadow_mode = abi.shadow_mode(split_shadow)
+            self.split_shadow = self.shadow_mode == "split"
             if self.split_shadow:
                 self.shadow = torch.ones(shadow_dim * shadow_dim, dtype=torch.float32, device=self.device)
                 self.r.set_shadow_buffer(self.shadow.data_ptr())
                 self.r.set_shadow_partition(rank, world)
                 self.shadow_done, self.shadow_reduced = torch.cuda.Event(), torch.cuda.Event()
+            elif self.shadow_mode == "tiles":
+                self.r.set_shadow_tiles(rank, world)
+                nb = self.r.shadow_tiles_bytes()
+                self.spacked = torch.ones(nb // 4, dtype=torch.float32, device=self.device)      # (unused slots: depth 1.0)
+                self.sgathered = torch.empty(nb // 4 * world, dtype=torch.float32, device=self.device)
+                self.shadow_reduced = torch.cuda.Event()
 
     def frame(self):
         """Enqueue one full frame; returns immediately."""
@@ -126,6 +137,18 @@ class DistributedRenderer:
                     dist.all_reduce(self.shadow, op=dist.ReduceOp.MIN)
                     self.shadow_reduced.record(self.comm_stream)
                 self.render_stream.wait_event(self.shadow_reduced)
+                self.r.render_lighting()
+            elif self.shadow_mode == "tiles":
+                # this rank's share of the MAP, its owned tiles packed behind the pass (render stream), gathered on the collective stream,
+                # scattered back into the map ahead of the lighting pass
+                self.r.render_geometry()
+                self.r.shadow_pack(self.spacked.data_ptr())
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_stream(self.render_stream)             # behind the pack
+                    dist.all_gather_into_tensor(self.sgathered, self.spacked)
+                    self.shadow_reduced.record(self.comm_stream)
+                self.render_stream.wait_event(self.shadow_reduced)
+                self.r.shadow_unpack(self.sgathered.data_ptr())
                 self.r.render_lighting()
             else:
                 self.r.render()

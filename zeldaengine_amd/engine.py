@@ -64,6 +64,8 @@ def lib():
         "zr_render_shadow": [vp], "zr_render_gbuffer": [vp], "zr_render_lighting": [vp],
         "zr_render_geometry": [vp], "zr_stream_wait_shadow": [vp, vp],
         "zr_set_shadow_partition": [vp, u32, u32], "zr_set_shadow_buffer": [vp, vp],
+        "zr_set_shadow_tiles": [vp, u32, u32], "zr_shadow_tiles_bytes": [vp, C.POINTER(sz)],
+        "zr_shadow_pack": [vp, vp, vp], "zr_shadow_unpack": [vp, vp, vp],
         "zr_finish": [vp],
         "zr_get_pass_times": [vp, vp],
         "zr_get_pass_times_avg": [vp, u32, vp],
@@ -386,6 +388,21 @@ class Renderer:
     def set_shadow_partition(self, rank, world):
         self._chk(self.L.zr_set_shadow_partition(self.h, rank, world))
 
+    def set_shadow_tiles(self, rank, world):
+        """The shadow MAP owned by light-space super-tiles: this context draws the casters that reach its tiles (exact there)."""
+        self._chk(self.L.zr_set_shadow_tiles(self.h, rank, world))
+
+    def shadow_tiles_bytes(self):
+        n = C.c_size_t()
+        self._chk(self.L.zr_shadow_tiles_bytes(self.h, C.byref(n)))
+        return n.value
+
+    def shadow_pack(self, packed_dev, hip_stream=None):
+        self._chk(self.L.zr_shadow_pack(self.h, C.c_void_p(packed_dev), C.c_void_p(hip_stream) if hip_stream else None))
+
+    def shadow_unpack(self, gathered_dev, hip_stream=None):
+        self._chk(self.L.zr_shadow_unpack(self.h, C.c_void_p(gathered_dev), C.c_void_p(hip_stream) if hip_stream else None))
+
     def set_shadow_buffer(self, dev_ptr):
         self._chk(self.L.zr_set_shadow_buffer(self.h, C.c_void_p(dev_ptr) if dev_ptr else None))
 
@@ -470,13 +487,14 @@ class Renderer:
         return p.value
 
     def dist_init(self, unique_id, rank, world, split_shadow=False):
-        """Native multi-GPU host: the library calls RCCL itself (zr_dist_frame = render + all-gather + composite)."""
+        """Native multi-GPU host: the library calls RCCL itself (zr_dist_frame = render + all-gather + composite).
+        split_shadow: False / "replicated", True / "split", or "tiles" (abi.SHADOW_MODES)."""
         self._dist_id = bytes(unique_id)
-        self._chk(self.L.zr_dist_init(self.h, self._dist_id, len(self._dist_id), rank, world, 1 if split_shadow else 0))
+        self._chk(self.L.zr_dist_init(self.h, self._dist_id, len(self._dist_id), rank, world, abi.dist_flags(abi.shadow_mode(split_shadow))))
 
     def dist_prepare(self, rank, world, split_shadow=False):
         """The local half of dist_init (librccl, collective stream, buffers): safe to fail on one rank alone."""
-        self._chk(self.L.zr_dist_prepare(self.h, rank, world, 1 if split_shadow else 0))
+        self._chk(self.L.zr_dist_prepare(self.h, rank, world, abi.dist_flags(abi.shadow_mode(split_shadow))))
 
     def dist_connect(self, unique_id):
         """ncclCommInitRank: a collective - call it only when every rank's dist_prepare succeeded."""
