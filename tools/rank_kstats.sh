@@ -1,7 +1,7 @@
-# usage (GPU box): bash tools/rank_kstats.sh <world> <rank> <config>   -> one-stream per-kernel averages of one rank's context of an N-rank job
+# usage (GPU box): bash tools/rank_kstats.sh <world> <rank> <config> [replicated|tiles|split]   -> one-stream per-kernel averages of one rank's context of an N-rank job
 cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_rk
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_rk -o s -- python3 $GRAFT_REPO_ROOT/tools/rank_passes.py $1 $2 $3 serial > /dev/null 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_rk -o s -- python3 $GRAFT_REPO_ROOT/tools/rank_passes.py $1 $2 $3 serial ${4:-split} > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT; python - <<PY
 import csv, glob
 f = glob.glob("gpurun_out/prof_rk/**/*kernel_stats.csv", recursive=True)[0]

@@ -17,7 +17,7 @@
 //   k_select          round 2: the meshlet-instances the Hi-Z pyramid does not hide -> 32-byte records
 //   k_geom<HIZ>       wave per meshlet-instance: vertices once, exact per-triangle tests (round 2: + the pyramid per meshlet and per triangle),
 //                     one 32-byte record per (triangle, tile) + its tile id
-//   k_scan_tri / k_index   per-tile offsets and work units; records MOVED into tile order
+//   k_scan_tri / k_index   per-tile offsets and work units; the records' positions in tile order (an index list)
 //   k_tile / k_tile_slow   lane per record, streamed: edge set-up + walk into the tile's LDS keys; clipped triangles through raster_clipped
 //   k_hiz_build       max-depth pyramid of the key buffer after round 1 (two-pass occlusion culling of the camera pass)
 //   k_sky_tiles       the skydome's triangles into a key plane of their own (drawn after lighting, depth-tested, colour only)
@@ -639,11 +639,13 @@ __global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __re
                     if (px0 <= px1 && py0 <= py1) {
                         r = pack_tile_rect<MODE>(px0, py0, px1, py1);
                         pr = make_uint2((uint32_t)px0 | (uint32_t)py0 << 16, (uint32_t)px1 | (uint32_t)py1 << 16);
-                        // Shadow map owned by light-space super-tiles (zr_set_shadow_tiles): a meshlet is this rank's work when its texel box
-                        // - the box itself, not the apron-shrunk rectangle it is LISTED under - reaches a tile the rank owns.  It is then drawn
-                        // whole, in every window it is listed for (the listing tile of a meshlet that straddles a border may be the
-                        // neighbour's): the owned tiles end up exact, whatever lands on the others is not sent anywhere.
-                        if (MODE == ZR_MODE_SHADOW && P.tile_world > 1u) {
+                        // A target owned by super-tiles (the frame: zr_config.tile_world; the shadow map: zr_set_shadow_tiles): a meshlet is this
+                        // rank's work when its pixel box reaches a tile the rank owns - a much tighter bound than the sphere stage A tested
+                        // (a rank of eight met 1.7 x its share of round 2's candidates through the spheres alone).  Shadow pass: the box
+                        // itself, not the apron-shrunk rectangle the meshlet is LISTED under; it is then drawn whole, in every window it is
+                        // listed for (the listing tile of a meshlet that straddles a border may be the neighbour's): the owned tiles end up
+                        // exact, whatever lands on the others is not sent anywhere.  Camera pass: k_geom emits records for owned tiles only.
+                        if (P.tile_world > 1u && (MODE == ZR_MODE_SHADOW || P.rect_cull)) {      // (ZR_FLAG_NO_RECT_CULL: the camera pass's A/B)
                             bool mine = false;
                             for (int ty = py0 / TILE; ty <= py1 / TILE; ++ty)
                                 for (int tx = px0 / TILE; tx <= px1 / TILE; ++tx)
@@ -2431,8 +2433,8 @@ __global__ __launch_bounds__(256) void k_index(ZrTriBins B, const ZrDevStats* __
     }
 }
 
-// Persistent workgroups pull work units: <= ZR_TCHUNK records of one tile, contiguous in the index list; lane per triangle: gather, edge
-// setup + walk into the tile's LDS keys; touched keys are merged into the frame key buffer.  Nothing else: no vertices, no tests.
+// Persistent workgroups pull work units: <= ZR_TBATCHES batches of <= ZR_TCHUNK records of one tile, contiguous in the index list; lane per
+// triangle: gather, edge setup + walk into the tile's LDS keys; a unit's keys are merged into the frame key buffer once.  Nothing else.
 // The kernel also leaves the per-tile counters and the record pool as the next round's k_geom wants them (zero).
 // Sorted walk.  The 64 lanes of a wave walk their triangles' boxes in lock step: a row loop as long as the tallest box, a column loop per
 // row as long as the widest box still alive there - with a unit's records in arrival order 35 % of the lanes' iterations were live
@@ -2464,14 +2466,17 @@ void k_tile(ZrPass P, const uint4* __restrict__ chunk_tab, ZrTriBins B, uint32_t
     for (;;) {
         if (unit >= n_units) break;
         for (uint32_t i = tid; i < TILE_PIX; i += 256u) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
-        hist[tid] = 0u;
-        __syncthreads();
         const uint4 ct = chunk_tab[unit];
-        const uint32_t tile = ct.x, rbeg = ct.y, n = min(ct.z, B.sorted_cap) - min(ct.y, B.sorted_cap);      // <= ZR_TCHUNK
+        const uint32_t tile = ct.x, n_unit = min(ct.z, B.sorted_cap) - min(ct.y, B.sorted_cap);      // <= ZR_TCHUNK * ZR_TBATCHES
         const int tpx0 = (int)(tile % P.tiles_x) * TILE, tpy0 = (int)(tile / P.tiles_x) * TILE;
         TileCtx T;
         T.px0 = 0; T.py0 = 0; T.W = (int)P.W - tpx0; T.H = (int)P.H - tpy0;
         const int wx1 = min(TILE - 1, T.W - 1), wy1 = min(TILE - 1, T.H - 1);
+      // a unit's batches of <= ZR_TCHUNK records go into the same keys: one clear and one merge per unit, not per batch
+      for (uint32_t b0 = 0; b0 < n_unit; b0 += ZR_TCHUNK) {
+        const uint32_t rbeg = ct.y + b0, n = min(n_unit - b0, ZR_TCHUNK);
+        hist[tid] = 0u;
+        __syncthreads();
         // ---- count: the thread's two records, their clipped boxes (raster_sub's own expressions), the rank among equal keys
         uint4 qa[2], qb[2]; uint32_t key[2], rank[2];
 #pragma unroll
@@ -2522,7 +2527,8 @@ void k_tile(ZrPass P, const uint4* __restrict__ chunk_tab, ZrTriBins B, uint32_t
                 raster_sub<MODE, true, true>(t.a, t.b, t.c, t.prim, T, keys64, nullptr, b4.w);
             }
         }
-        __syncthreads();
+        __syncthreads();      // (the next batch rewrites hist / srec; the merge below reads the keys)
+      }
         for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
             const int px = tpx0 + (int)(i & (TILE - 1)), py = tpy0 + (int)(i / TILE);
             if (px >= (int)P.W || py >= (int)P.H) continue;
@@ -3446,7 +3452,7 @@ void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, uint32_
 void zr_launch_scan_tri(const uint32_t* tile_count, uint32_t* tile_offset, uint4* chunk_tab, uint32_t chunk_cap, uint32_t n_tiles, const ZrTriBins& B,
                         ZrDevStats* stats, int slot, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scan_tri, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, chunk_tab, chunk_cap, n_tiles, B.sorted_cap, stats, slot, ZR_TCHUNK);
+    hipLaunchKernelGGL(k_scan_tri, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, chunk_tab, chunk_cap, n_tiles, B.sorted_cap, stats, slot, ZR_TCHUNK * ZR_TBATCHES);
 }
 void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* tile_cursor, const ZrDevStats* stats, int slot, hipStream_t s)
 {

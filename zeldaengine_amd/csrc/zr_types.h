@@ -217,8 +217,11 @@ struct ZrTriBins {
 #ifdef ZR_TCHUNK_AB
 #define ZR_TCHUNK ZR_TCHUNK_AB
 #else
-#define ZR_TCHUNK 512u               // triangle records per work unit of the tile kernel
+#define ZR_TCHUNK 512u               // triangle records per BATCH of the tile kernel (gathered, sorted and walked together)
 #endif
+#ifndef ZR_TBATCHES
+#define ZR_TBATCHES 4u               // batches per work unit: a unit is <= ZR_TCHUNK * ZR_TBATCHES records of ONE tile, walked into the same LDS keys,
+#endif                               // which are cleared and merged into the key buffer once per unit (1 / 2 / 4 / 8: 5 399 / 5 414 / 5 455 / 5 442 Mpixel/s)
 void zr_launch_select(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats,
                       int slot, hipStream_t s);
 void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, uint32_t* tile_count, ZrDevStats* stats, int slot, unsigned long long* vis64, hipStream_t s);
