@@ -46,7 +46,9 @@ extern "C" {
 /* Multi-GPU screen partition: tiles are owned in super-tiles of (1 << ZR_SUPERTILE_SHIFT)^2 tiles (128 x 128 pixels), dealt to the
  * ranks round-robin along x with a skew per super-tile row, so that a meshlet (tens of pixels) nearly always falls to ONE rank and
  * that rank alone transforms it, while neighbouring super-tiles still go to different ranks. */
+#ifndef ZR_SUPERTILE_SHIFT
 #define ZR_SUPERTILE_SHIFT 2
+#endif
 #define ZR_SUPERTILE_SKEW  3
 
 typedef struct zr_ctx zr_ctx;
