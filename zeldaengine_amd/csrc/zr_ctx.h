@@ -139,6 +139,8 @@ struct zr_ctx {
     uint2* d_spxrect = nullptr; float* d_szmin = nullptr; uint8_t* d_sflag = nullptr;
     bool sflag_history = false;          // the flags come from a frame of this scene (else: all set, and the first test takes every item)
     float* d_hiz = nullptr; ZrHiz hiz = {}; int vis_cur = 0; bool vis_history = false, last_two_round = false;
+    uint32_t vis_mark_prev = 0;          // the stamp the resolve wrote into last frame's visibility marks (ZrHiz::vis_stamp)
+    uint32_t* d_hiz_regions = nullptr; uint32_t n_hiz_regions = 0;      // the 64 x 64 pixel regions over owned tiles (k_hiz_build)
     ZrDevStats* d_stats = nullptr; ZrDevStats h_stats = {};
     // The shadow pipeline's statistics / work counters (slot 0) live in a block of their own: the pipeline resets what it counts itself
     // (k_scan), so it does not wait for the camera lane's k_frame_begin, and the camera lane does not wait for it.

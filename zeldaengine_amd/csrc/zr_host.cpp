@@ -239,6 +239,15 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         c->hiz.fw = (c->W + 3u) / 4u; c->hiz.fh = (c->H + 3u) / 4u;
         tot += (size_t)c->hiz.fw * c->hiz.fh;
         ok &= dev_alloc(&c->d_hiz, tot) == hipSuccess;
+        if (ok) ok &= hipMemset(c->d_hiz, 0, tot * sizeof(float)) == hipSuccess;      // texels over other ranks' regions stay 0 ("hidden")
+        static_assert(ZR_TILE == 32 && ZR_SUPERTILE_SHIFT >= 1, "a 64 x 64 region of the pyramid must lie inside one super-tile");
+        std::vector<uint32_t> regions;
+        for (uint32_t ry = 0; ry < (c->H + 63u) / 64u; ++ry)
+            for (uint32_t rx = 0; rx < (c->W + 63u) / 64u; ++rx)
+                if (zr_tile_owner(rx * 2u, ry * 2u, c->cfg.tile_world) == c->cfg.tile_rank) regions.push_back(rx | ry << 16);
+        c->n_hiz_regions = (uint32_t)regions.size();
+        ok &= dev_alloc(&c->d_hiz_regions, regions.size()) == hipSuccess;
+        if (ok && !regions.empty()) ok &= hipMemcpy(c->d_hiz_regions, regions.data(), regions.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
         float* p = c->d_hiz;
         for (int l = 0; l < 4; ++l) { c->hiz.lvl[l] = p; p += (size_t)c->hiz.hw[l] * c->hiz.hh[l]; }
         c->hiz.fine = p;
@@ -309,7 +318,7 @@ extern "C" void zr_destroy(zr_ctx* c)
     if (c->ev_cam) (void)hipEventDestroy(c->ev_cam);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     dev_free(c->d_vis); dev_free(c->d_slow0);
-    dev_free(c->d_pxrect); dev_free(c->d_zmin); dev_free(c->d_visflag[0]); dev_free(c->d_visflag[1]); dev_free(c->d_hiz);
+    dev_free(c->d_pxrect); dev_free(c->d_zmin); dev_free(c->d_visflag[0]); dev_free(c->d_visflag[1]); dev_free(c->d_hiz); dev_free(c->d_hiz_regions);
     dev_free(c->d_spxrect); dev_free(c->d_szmin); dev_free(c->d_sflag);
     free_tri_bins(c);
     for (auto& fr : c->evr) for (auto& e : fr) if (e) (void)hipEventDestroy(e);
@@ -809,6 +818,7 @@ static int finalize_scene(zr_ctx* c)
         for (auto& sc : c->sc) { dev_free(sc.chunk_tab); HIPCHK(c, dev_alloc(&sc.chunk_tab, c->chunk_capacity)); }
         HIPCHK(c, dev_alloc(&c->d_pxrect, cap_w)); HIPCHK(c, dev_alloc(&c->d_zmin, cap_w));
         HIPCHK(c, dev_alloc(&c->d_visflag[0], cap_w)); HIPCHK(c, dev_alloc(&c->d_visflag[1], cap_w));
+        HIPCHK(c, hipMemset(c->d_visflag[0], 0, cap_w)); HIPCHK(c, hipMemset(c->d_visflag[1], 0, cap_w));      // (no frame's stamp is 0)
         HIPCHK(c, dev_alloc(&c->d_spxrect, cap_w)); HIPCHK(c, dev_alloc(&c->d_szmin, cap_w)); HIPCHK(c, dev_alloc(&c->d_sflag, cap_w));
         c->work_capacity = cap_w;              // every buffer is there
     }
@@ -1155,7 +1165,7 @@ static void tri_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hip
     const zr_ctx::Scratch& sc = c->sc[1];
     if (P.n_work == 0) return;          // nothing to draw: the pass is its clear
     zr_launch_geom(P, Z, c->tb, sc.tile_count, c->d_stats, slot, c->d_vis, s);
-    zr_launch_scan_tri(sc.tile_count, sc.tile_offset, sc.chunk_tab, c->chunk_capacity, c->n_tiles, c->tb, c->d_stats, slot, s);
+    zr_launch_scan_tri(sc.tile_count, sc.tile_offset, sc.chunk_tab, c->chunk_capacity, c->d_owned, c->n_owned, c->tb, c->d_stats, slot, s);
     zr_launch_index(c->tb, sc.tile_offset, sc.tile_cursor, c->d_stats, slot, s);
     // (the frame's last round also draws the slow triangles of both rounds: k_tile<LAST>)
     zr_launch_tile(P, sc.chunk_tab, c->tb, sc.tile_count, sc.tile_cursor, c->n_tiles, c->d_stats, slot, c->d_vis, c->raster_blocks, s, last, c->d_owned, c->n_owned);
@@ -1253,7 +1263,7 @@ static int shadow_pass(zr_ctx* c, hipStream_t s)
     else
 #endif
     {
-        if (occl) { Z.pxrect = c->d_spxrect; Z.zmin = c->d_szmin; Z.vis_prev = c->d_sflag; Z.phase = 1u; }
+        if (occl) { Z.pxrect = c->d_spxrect; Z.zmin = c->d_szmin; Z.vis_prev = c->d_sflag; Z.vis_stamp = 1u; Z.phase = 1u; }      // (the pass's own flags are 0 / 1)
         // a rebuilt work list starts from length 0 - zeroed HERE, in stream order behind the previous frame's shadow pipeline (k_cull_instances
         // grows it, every later kernel of the pipeline reads it)
         if (c->list_rebuild_mask & 1u) zr_launch_fill32(&c->d_sstats->n_vis_work[0], 0u, 1, s);
@@ -1289,6 +1299,9 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
     Z.tiles_x = c->tiles_x; Z.tile_rank = c->cfg.tile_rank; Z.tile_world = c->cfg.tile_world;
     Z.pxrect = hiz_on ? c->d_pxrect : nullptr; Z.zmin = hiz_on ? c->d_zmin : nullptr;
     Z.vis_prev = c->d_visflag[c->vis_cur ^ 1]; Z.vis_now = hiz_on ? c->d_visflag[c->vis_cur] : nullptr;
+    // visibility marks are frame stamps (1 .. 255): the resolve writes this frame's, the culls compare with last frame's - nothing is cleared
+    const uint32_t vis_mark = 1u + (uint32_t)(c->frame_no % 255u);
+    Z.vis_stamp = c->vis_mark_prev;
     Z.phase = 0;
 #ifdef ZR_DIAG
     const bool tri_bins = !(c->cfg.flags & ZR_FLAG_MESHLET_BINS) && ZR_TILE == 32;      // A/B: the meshlet-binned rasteriser for the camera pass too
@@ -1306,7 +1319,6 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
         zr_launch_cull_box(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->d_stats, 1, s, c->tb.sel, c->last_two_round ? Z.vis_prev : nullptr, c->list_reuse[1]);
         if (c->list_rebuild_mask & 2u) c->list_valid[1] = true;
     }
-    if (hiz_on && P.use_worklist) HIPCHK(c, hipMemsetAsync(c->d_visflag[c->vis_cur], 0, c->n_work, s));     // else k_cull clears them
     const bool two = c->last_two_round;
     auto bin = [&](int slot) { if (!tri_bins) bin_and_raster(c, P, Z, slot, c->n_tiles, s); else if (slot == 2) tri_select(c, P, Z, slot, s); };
     auto rast = [&](int slot) { if (tri_bins) tri_raster(c, P, Z, slot, s, slot == 2 || !two); else raster(c, P, Z, slot, s); };
@@ -1316,7 +1328,7 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
         if (ev) HIPCHK(c, hipEventRecord(ev[3], s));
         rast(1);
         if (ev) HIPCHK(c, hipEventRecord(ev[4], s));
-        zr_launch_hiz_build(c->d_vis, c->W, c->H, Z, s);
+        zr_launch_hiz_build(c->d_vis, c->W, c->H, Z, c->d_hiz_regions, c->n_hiz_regions, s);
         Z.phase = 2;
         bin(2);
         if (ev) HIPCHK(c, hipEventRecord(ev[5], s));
@@ -1336,7 +1348,8 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
         if (sky && c->d_sky_keys) { zr_launch_sky_tiles(P, c->d_objs, c->d_owned, c->n_owned, c->d_sky_keys, s); P.sky_keys = c->d_sky_keys; }
     }
     if (ev) HIPCHK(c, hipEventRecord(ev[6], s));
-    zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_lut, c->d_unorm_lut, Z.vis_now, c->d_stats, s);
+    zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_lut, c->d_unorm_lut, Z.vis_now, c->d_stats, s, vis_mark);
+    c->vis_mark_prev = vis_mark;
     if (ev) HIPCHK(c, hipEventRecord(ev[7], s));
     if (hiz_on) { c->vis_history = true; c->vis_cur ^= 1; } else c->vis_history = false;
     HIPCHK(c, hipGetLastError());

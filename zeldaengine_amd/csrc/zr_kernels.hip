@@ -390,7 +390,7 @@ __device__ __forceinline__ bool cull_stage_a(const ZrPass& P, const ZrObject* __
 {
     bool alive = true;
     const uint32_t w = WORKLIST ? work[k] : k;
-    if (!WORKLIST && vis_clear) vis_clear[w] = 0;        // this frame's visibility marks start from zero (saves a fill launch)
+    (void)vis_clear;                                     // (visibility marks are frame stamps: nothing to clear, see ZrHiz::vis_stamp)
     const ZrObject* __restrict__ O = objs + find_object_work(objs, (int)P.n_objects, w);
     const uint32_t local = w - O->work_base, nm = O->n_meshlets;
     const uint32_t inst_i = local / nm, m = local - inst_i * nm;
@@ -550,7 +550,7 @@ template <int MODE, bool WORKLIST>
 __global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
                                                   uint32_t* __restrict__ rects, uint2* __restrict__ pxrect, float* __restrict__ zmin,
                                                   uint8_t* __restrict__ vis_clear, ZrDevStats* __restrict__ stats, int slot,
-                                                  ZrBinEntry* __restrict__ sel, const uint8_t* __restrict__ vis_prev)
+                                                  ZrBinEntry* __restrict__ sel, const uint8_t* __restrict__ vis_prev, uint32_t vis_stamp)
 {
     // sel != nullptr (camera pass): the survivors that round 1 draws - all of them, or with vis_prev those that owned a pixel last
     // frame - are compacted into sel[] right here (what k_select does for round 2), one global atomic per 256 work items
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __re
         }
         if (MODE == ZR_MODE_GBUFFER && sel) {
             const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-            const bool take = r != ZR_RECT_CULLED && (vis_prev == nullptr || vis_prev[it.w] != 0);
+            const bool take = r != ZR_RECT_CULLED && (vis_prev == nullptr || vis_prev[it.w] == (uint8_t)vis_stamp);
             const unsigned long long m = __ballot(take);
             if (lane == 0) wcount[wv] = (uint32_t)__popcll(m);
             __syncthreads();
@@ -687,10 +687,12 @@ __global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __re
 
 // Hi-Z pyramid of the key buffer: level 0 = max depth per 8x8 pixel block (1.0 where a pixel is still empty), each further
 // level the max over 2x2 blocks of the previous one.  One workgroup per 64x64 pixel region builds all four levels in LDS.
-__global__ __launch_bounds__(256) void k_hiz_build(const unsigned long long* __restrict__ vis64, uint32_t W, uint32_t H, ZrHiz Z)
+// regions[]: the 64 x 64 regions that hold tiles this context owns (x | y << 16): a super-tile is whole regions, and the pyramid's texels
+// over other ranks' regions stay 0 from zr_create on ("hidden": nothing is drawn there) - a rank of eight builds an eighth.
+__global__ __launch_bounds__(256) void k_hiz_build(const unsigned long long* __restrict__ vis64, uint32_t W, uint32_t H, ZrHiz Z, const uint32_t* __restrict__ regions)
 {
     __shared__ float l0[8][8];
-    const uint32_t rx = blockIdx.x, ry = blockIdx.y, tid = threadIdx.x;
+    const uint32_t rx = regions[blockIdx.x] & 0xFFFFu, ry = regions[blockIdx.x] >> 16, tid = threadIdx.x;
     // 256 threads: thread t handles pixel-block (t & 7, (t >> 3) & 7) quarter (t >> 6): 4 threads per 8x8 block, a 4x4 sub-block each
     const uint32_t bx = tid & 7u, by = (tid >> 3) & 7u, q = tid >> 6;
     float m = 0.0f;
@@ -796,7 +798,7 @@ __global__ __launch_bounds__(1024) void k_bin_count(ZrPass P, const uint32_t* __
     if (w < n_vis) {
         uint32_t r = rects[w];
         if (r != ZR_RECT_CULLED && Z.phase) {            // two-pass occlusion culling: who is drawn in this round?
-            const bool was_visible = Z.vis_prev[P.use_worklist ? work[w] : w] != 0;
+            const bool was_visible = Z.vis_prev[P.use_worklist ? work[w] : w] == (uint8_t)Z.vis_stamp;
             if (Z.phase == 1u) { if (!was_visible) r = ZR_RECT_CULLED; }
             else if (was_visible) r = ZR_RECT_CULLED;     // drawn in round 1
             else if (hiz_occluded(Z, Z.pxrect[w], Z.zmin[w])) { r = ZR_RECT_CULLED; rects[w] = r; occluded = 1; }
@@ -906,7 +908,7 @@ __global__ __launch_bounds__(1024) void k_bin_fill(ZrPass P, const ZrObject* __r
     if (k < n_vis) {
         r = rects[k]; w = P.use_worklist ? work[k] : k;
         if (r != ZR_RECT_CULLED && Z.phase) {            // same split as k_bin_count (round 2's occluded items were marked CULLED there)
-            const bool was_visible = Z.vis_prev[w] != 0;
+            const bool was_visible = Z.vis_prev[w] == (uint8_t)Z.vis_stamp;
             if ((Z.phase == 1u) != was_visible) r = ZR_RECT_CULLED;
         }
     }
@@ -1539,7 +1541,7 @@ __device__ __forceinline__ zf3 model_point(const ZrPass& P, zf3 p)
 template <int IMAGES>
 __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* __restrict__ objs, uint32_t prim, float depth,
                                               int px, int py, const GBufferPtrs& G, const float* __restrict__ lut,
-                                              uint8_t* __restrict__ vis_now)
+                                              uint8_t* __restrict__ vis_now, uint32_t vis_mark = 1u)
 {
     const size_t p = (size_t)py * P.W + (size_t)px;
     if (prim == ZR_EMPTY_PRIM) {   // clears, ZE:3427-3433
@@ -1554,7 +1556,7 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
     const bool instanced = O->instanced != 0;
     const ZrInstance I = O->inst[inst_i];
     // visibility history for next frame's round 1: this meshlet-instance owns a pixel
-    if (vis_now) vis_now[O->work_base + inst_i * O->n_meshlets + O->tri_meshlet[tri]] = 1;
+    if (vis_now) vis_now[O->work_base + inst_i * O->n_meshlets + O->tri_meshlet[tri]] = (uint8_t)vis_mark;
     zf4 clip[3]; zf3 WP[3], WN[3]; float U[3], V[3]; uint32_t fl[3];
     for (int k = 0; k < 3; ++k) {
         const float4* __restrict__ rv = (const float4*)(O->rverts + O->indices[3u * tri + (uint32_t)k]);
@@ -2051,7 +2053,7 @@ __global__ __launch_bounds__(256) void k_select(ZrPass P, const ZrObject* __rest
             w[j] = P.use_worklist ? work[k] : k;
             take[j] = rects[k] != ZR_RECT_CULLED;
             if (take[j] && Z.phase) {
-                const bool was_visible = Z.vis_prev[w[j]] != 0;
+                const bool was_visible = Z.vis_prev[w[j]] == (uint8_t)Z.vis_stamp;
                 if (Z.phase == 1u) take[j] = was_visible;
                 else if (was_visible) take[j] = false;
                 else if (hiz_occluded(Z, Z.pxrect[k], Z.zmin[k])) { take[j] = false; occluded = true; }
@@ -2348,15 +2350,16 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
 // the camera pipeline's critical path) and is as fast at 1080p but four times slower at 3840 x 2160 (8 160 tiles per scan, 32 KB of LDS
 // per workgroup: k_index 1.1 ms instead of 0.3).
 __global__ __launch_bounds__(1024) void k_scan_tri(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
-                                                   uint4* __restrict__ chunk_tab, uint32_t chunk_cap, uint32_t n_tiles, uint32_t sorted_cap,
-                                                   ZrDevStats* __restrict__ stats, int slot, uint32_t unit)
+                                                   uint4* __restrict__ chunk_tab, uint32_t chunk_cap, const uint32_t* __restrict__ owned_tiles, uint32_t n_tiles,
+                                                   uint32_t sorted_cap, ZrDevStats* __restrict__ stats, int slot, uint32_t unit)
 {
+    // (n_tiles = the tiles this context owns, owned_tiles their indices: only they can hold records - a rank of eight scans an eighth)
     __shared__ uint32_t wtot[16], cwtot[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t per = (n_tiles + 1023u) / 1024u;
     const uint32_t b = min(n_tiles, tid * per), e = min(n_tiles, b + per);
     uint32_t s = 0, cs = 0;
-    for (uint32_t i = b; i < e; ++i) { const uint32_t t = tile_count[i * ZR_TSTRIDE]; s += t; cs += (t + unit - 1u) / unit; }
+    for (uint32_t j = b; j < e; ++j) { const uint32_t t = tile_count[owned_tiles[j] * ZR_TSTRIDE]; s += t; cs += (t + unit - 1u) / unit; }
     // scan: inside the wave by shuffles, across the 16 waves through LDS - one barrier (this kernel is one workgroup on the critical path)
     uint32_t incl = s, cincl = cs;
     for (int o = 1; o < 64; o <<= 1) {
@@ -2368,7 +2371,8 @@ __global__ __launch_bounds__(1024) void k_scan_tri(const uint32_t* __restrict__ 
     uint32_t wpre = 0, cwpre = 0, tot = 0, ctot = 0;
     for (uint32_t i = 0; i < 16u; ++i) { if (i < wv) { wpre += wtot[i]; cwpre += cwtot[i]; } tot += wtot[i]; ctot += cwtot[i]; }
     uint32_t run = wpre + incl - s, crun = cwpre + cincl - cs;
-    for (uint32_t i = b; i < e; ++i) {
+    for (uint32_t j = b; j < e; ++j) {
+        const uint32_t i = owned_tiles[j];
         const uint32_t t = tile_count[i * ZR_TSTRIDE], nu = (t + unit - 1u) / unit;
         tile_offset[i] = run;
         for (uint32_t k = 0; k < nu; ++k)          // k_tile's work units: (tile, first record, end) - one load there, not a search
@@ -2705,7 +2709,7 @@ __global__ __launch_bounds__(TB, TB == 64 ? ZR_RESOLVE_IMG_WAVES : 1) void k_res
                                                         const uint32_t* __restrict__ owned_tiles,
                                                         unsigned long long* __restrict__ vis64, GBufferPtrs G,
                                                         const float* __restrict__ srgb_lut, const float* __restrict__ unorm_lut,
-                                                        uint8_t* __restrict__ vis_now, ZrDevStats* __restrict__ stats)
+                                                        uint8_t* __restrict__ vis_now, ZrDevStats* __restrict__ stats, uint32_t vis_mark)
 {
     __shared__ uint32_t covered_s;
     __shared__ float tlut[IMAGES ? 512 : 1];       // texel decode tables of the sampler (see tex_decode)
@@ -2738,7 +2742,7 @@ __global__ __launch_bounds__(TB, TB == 64 ? ZR_RESOLVE_IMG_WAVES : 1) void k_res
         const int px = tx0 + (int)(i & (TILE - 1)), py = ty0 + (int)(i / TILE);
         if (px >= (int)P.W || py >= (int)P.H) continue;
         const unsigned long long k = keys[q];
-        ncov += resolve_pixel<IMAGES>(P, objs, (uint32_t)k, zr_u2f((uint32_t)(k >> 32)), px, py, G, dlut, vis_now) ? 1u : 0u;
+        ncov += resolve_pixel<IMAGES>(P, objs, (uint32_t)k, zr_u2f((uint32_t)(k >> 32)), px, py, G, dlut, vis_now, vis_mark) ? 1u : 0u;
         if (IMAGES != 0 && P.sky_keys != nullptr) {
             // The skydome (ZE:3681-3691: drawn last, depth test LESS against the scene's depth, colour only).  Its triangles were
             // resolved among themselves into a key plane of their own; the dome shows where that depth is less than the scene's.
@@ -3348,19 +3352,20 @@ void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint3
 void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, const ZrHiz& Z, ZrDevStats* stats,
                         int slot, hipStream_t s, ZrBinEntry* sel, const uint8_t* vis_prev, bool reuse_list)
 {
+    const uint32_t vis_stamp = Z.vis_stamp;
     if (P.n_work == 0) return;
     const dim3 gi((P.n_inst_total + ZR_CI_THREADS * ZR_CI_PER - 1u) / (ZR_CI_THREADS * ZR_CI_PER)), bi(ZR_CI_THREADS), b(256);
     const dim3 g(std::min<uint32_t>((P.n_work + 255u) / 256u, 8192u));
     if (P.mode == ZR_MODE_GBUFFER) {
         if (P.use_worklist) {
             if (!reuse_list) hipLaunchKernelGGL(k_cull_instances<ZR_MODE_GBUFFER>, gi, bi, 0, s, P, objs, work, stats, slot);
-            hipLaunchKernelGGL((k_cull_box<ZR_MODE_GBUFFER, true>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot, sel, vis_prev);
-        } else hipLaunchKernelGGL((k_cull_box<ZR_MODE_GBUFFER, false>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot, sel, vis_prev);
+            hipLaunchKernelGGL((k_cull_box<ZR_MODE_GBUFFER, true>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot, sel, vis_prev, vis_stamp);
+        } else hipLaunchKernelGGL((k_cull_box<ZR_MODE_GBUFFER, false>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, Z.vis_now, stats, slot, sel, vis_prev, vis_stamp);
     } else {
         if (P.use_worklist) {
             if (!reuse_list) hipLaunchKernelGGL(k_cull_instances<ZR_MODE_SHADOW>, gi, bi, 0, s, P, objs, work, stats, slot);
-            hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, true>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, (uint8_t*)nullptr, stats, slot, (ZrBinEntry*)nullptr, (const uint8_t*)nullptr);
-        } else hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, false>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, (uint8_t*)nullptr, stats, slot, (ZrBinEntry*)nullptr, (const uint8_t*)nullptr);
+            hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, true>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, (uint8_t*)nullptr, stats, slot, (ZrBinEntry*)nullptr, (const uint8_t*)nullptr, vis_stamp);
+        } else hipLaunchKernelGGL((k_cull_box<ZR_MODE_SHADOW, false>), g, b, 0, s, P, objs, work, rects, Z.pxrect, Z.zmin, (uint8_t*)nullptr, stats, slot, (ZrBinEntry*)nullptr, (const uint8_t*)nullptr, vis_stamp);
     }
 }
 void zr_launch_bin_count(const ZrPass& P, const uint32_t* work, uint32_t* rects, uint32_t* tile_count, const ZrHiz& Z, ZrDevStats* stats,
@@ -3370,9 +3375,9 @@ void zr_launch_bin_count(const ZrPass& P, const uint32_t* work, uint32_t* rects,
     const uint32_t n_tiles = P.tiles_x * P.tiles_y;
     hipLaunchKernelGGL(k_bin_count, dim3((P.n_work + 1023) / 1024), dim3(1024), n_tiles * sizeof(uint32_t), s, P, work, rects, tile_count, Z, stats, slot);
 }
-void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H, const ZrHiz& Z, hipStream_t s)
+void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H, const ZrHiz& Z, const uint32_t* regions, uint32_t n_regions, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_hiz_build, dim3((W + 63) / 64, (H + 63) / 64), dim3(256), 0, s, vis64, W, H, Z);
+    if (n_regions) hipLaunchKernelGGL(k_hiz_build, dim3(n_regions), dim3(256), 0, s, vis64, W, H, Z, regions);
 }
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint4* chunk_tab,
                     uint32_t chunk_cap, uint32_t n, uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s,
@@ -3449,10 +3454,10 @@ void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, uint32_
     if (Z.phase == 2u) hipLaunchKernelGGL(k_geom<true>, g, b, 0, s, P, B.sel, Z, B, tile_count, stats, slot, vis64);
     else hipLaunchKernelGGL(k_geom<false>, g, b, 0, s, P, B.sel, Z, B, tile_count, stats, slot, vis64);
 }
-void zr_launch_scan_tri(const uint32_t* tile_count, uint32_t* tile_offset, uint4* chunk_tab, uint32_t chunk_cap, uint32_t n_tiles, const ZrTriBins& B,
-                        ZrDevStats* stats, int slot, hipStream_t s)
+void zr_launch_scan_tri(const uint32_t* tile_count, uint32_t* tile_offset, uint4* chunk_tab, uint32_t chunk_cap, const uint32_t* owned_tiles, uint32_t n_owned,
+                        const ZrTriBins& B, ZrDevStats* stats, int slot, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scan_tri, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, chunk_tab, chunk_cap, n_tiles, B.sorted_cap, stats, slot, ZR_TCHUNK * ZR_TBATCHES);
+    hipLaunchKernelGGL(k_scan_tri, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, chunk_tab, chunk_cap, owned_tiles, n_owned, B.sorted_cap, stats, slot, ZR_TCHUNK * ZR_TBATCHES);
 }
 void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* tile_cursor, const ZrDevStats* stats, int slot, hipStream_t s)
 {
@@ -3466,11 +3471,11 @@ void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B,
 }
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, const float* unorm_lut, uint8_t* vis_now,
-                               ZrDevStats* stats, hipStream_t s)
+                               ZrDevStats* stats, hipStream_t s, uint32_t vis_mark)
 {
     if (n_owned == 0) return;
     // one pixel per thread (ZR_PIXELS_PER_THREAD): see the note above k_lighting
-#define ZR_LAUNCH_RESOLVE(IM, TB, PPT) hipLaunchKernelGGL((k_resolve_gbuffer<IM, TB, PPT>), dim3(n_owned * (TILE_PIX / (PPT) / (TB))), dim3(TB), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats)
+#define ZR_LAUNCH_RESOLVE(IM, TB, PPT) hipLaunchKernelGGL((k_resolve_gbuffer<IM, TB, PPT>), dim3(n_owned * (TILE_PIX / (PPT) / (TB))), dim3(TB), 0, s, P, objs, owned_tiles, vis64, G, srgb_lut, unorm_lut, vis_now, stats, vis_mark)
     if (P.images == 1u) ZR_LAUNCH_RESOLVE(1, 64, ZR_PIXELS_PER_THREAD);
     else if (P.images) ZR_LAUNCH_RESOLVE(2, 64, ZR_PIXELS_PER_THREAD);
     else ZR_LAUNCH_RESOLVE(0, ZR_RESOLVE_TB, ZR_PIXELS_PER_THREAD);

@@ -153,8 +153,9 @@ struct ZrHiz {
     float*    fine; uint32_t fw, fh; // one level below: max depth per 4 x 4 pixel block (small meshlets and single triangles are tested here)
     uint2*    pxrect;                // per work item: snapped pixel bbox (x0 | y0 << 16, x1 | y1 << 16)
     float*    zmin;                  // per work item: least NDC depth of the meshlet's vertices, < 0: do not occlusion-test
-    const uint8_t* vis_prev;         // per meshlet-instance: owned a pixel of the previous frame
-    uint8_t*  vis_now;               // marked by the resolve
+    const uint8_t* vis_prev;         // per meshlet-instance: == vis_stamp: owned a pixel of the previous frame
+    uint8_t*  vis_now;               // marked by the resolve with THIS frame's stamp (1 + frame % 255: the marks of older frames need no clearing;
+    uint32_t  vis_stamp;             //   one 510 frames old reads as "visible" once, which only moves a meshlet between the rounds)
     uint32_t  phase;                 // 0: no Hi-Z (one round); 1: round 1 = last frame's visible set; 2: round 2 = the rest, Hi-Z tested
     uint32_t  tiles_x, tile_rank, tile_world;   // pyramid texels over another rank's tiles read 0 ("hidden"): nothing is drawn there
 };
@@ -192,7 +193,7 @@ void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint3
                     int slot, uint32_t n_waves, hipStream_t s);
 void zr_launch_bin_count(const ZrPass& P, const uint32_t* work, uint32_t* rects, uint32_t* tile_count, const ZrHiz& Z, ZrDevStats* stats,
                          int slot, hipStream_t s);
-void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H, const ZrHiz& Z, hipStream_t s);
+void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H, const ZrHiz& Z, const uint32_t* regions, uint32_t n_regions, hipStream_t s);
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint4* chunk_tab,
                     uint32_t chunk_cap, uint32_t n, uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s,
                     uint32_t chunk = ZR_CHUNK);
@@ -225,8 +226,8 @@ struct ZrTriBins {
 void zr_launch_select(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats,
                       int slot, hipStream_t s);
 void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, uint32_t* tile_count, ZrDevStats* stats, int slot, unsigned long long* vis64, hipStream_t s);
-void zr_launch_scan_tri(const uint32_t* tile_count, uint32_t* tile_offset, uint4* chunk_tab, uint32_t chunk_cap, uint32_t n_tiles, const ZrTriBins& B,
-                        ZrDevStats* stats, int slot, hipStream_t s);
+void zr_launch_scan_tri(const uint32_t* tile_count, uint32_t* tile_offset, uint4* chunk_tab, uint32_t chunk_cap, const uint32_t* owned_tiles, uint32_t n_owned,
+                        const ZrTriBins& B, ZrDevStats* stats, int slot, hipStream_t s);
 void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* tile_cursor, const ZrDevStats* stats, int slot, hipStream_t s);
 void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B, uint32_t* tile_count, uint32_t* tile_cursor, uint32_t n_tiles,
                     ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s, bool last, const uint32_t* owned_tiles, uint32_t n_owned);
@@ -249,7 +250,7 @@ void zr_launch_raster_chunks(const ZrPass& P, const ZrObject* objs, const uint4*
                                                                         // stage 1: the flagged share only (k_tile_slow waits); 2: the late list, then k_tile_slow
 void zr_launch_resolve_gbuffer(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
                                unsigned long long* vis64, const GBufferPtrs& G, const float* srgb_lut, const float* unorm_lut, uint8_t* vis_now,
-                               ZrDevStats* stats, hipStream_t s);
+                               ZrDevStats* stats, hipStream_t s, uint32_t vis_mark = 1u);
 void zr_launch_sky_tiles(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned, unsigned long long* sky64, hipStream_t s);
 void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, hipStream_t s);
 void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32_t* owned_tiles, uint32_t n_owned,
