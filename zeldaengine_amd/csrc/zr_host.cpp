@@ -1147,7 +1147,11 @@ static void bin_and_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot,
     const zr_ctx::Scratch& sc = c->sc[slot ? 1 : 0];
     ZrDevStats* st = slot ? c->d_stats : c->d_sstats;        // the shadow pipeline (slot 0) has a block of its own
     zr_launch_bin_count(P, sc.work, sc.rects, sc.tile_count, Z, st, slot, s);
-    zr_launch_scan(sc.tile_count, sc.tile_offset, sc.tile_cursor, sc.chunk_offset, sc.chunk_tab, c->chunk_capacity, n_tiles, c->bin_capacity, st, slot, s);
+    // A rank that owns a share of the shadow MAP (zr_set_shadow_tiles, four ranks or more) has a small pass beside a camera lane that is as
+    // busy as ever: units of 128 entries on half the persistent grid leave that lane more of the machine (a rank of eight at config 4:
+    // 0.779 -> 0.752 ms; 32 / 16 entries: 0.88 / 1.05 ms; 256: 0.754).  Units only get bigger here: the chunk table's capacity holds.
+    const uint32_t chunk = (slot == 0 && c->stile_world >= 4u) ? 2u * ZR_CHUNK : ZR_CHUNK;
+    zr_launch_scan(sc.tile_count, sc.tile_offset, sc.tile_cursor, sc.chunk_offset, sc.chunk_tab, c->chunk_capacity, n_tiles, c->bin_capacity, st, slot, s, chunk);
     zr_launch_bin_fill(P, c->d_objs, sc.work, sc.rects, sc.tile_offset, sc.tile_cursor, sc.bins, Z, st, slot, s);
 }
 // One round of the triangle-binned camera pass: which meshlet-instances (k_select: timed with the cull), then their triangles as
@@ -1176,7 +1180,8 @@ static void raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStre
     const zr_ctx::Scratch& sc = c->sc[shadow ? 0 : 1];
     const bool defer = shadow && c->env_shadow_defer && c->d_slow0 != nullptr;
     zr_launch_raster_chunks(P, c->d_objs, sc.chunk_tab, sc.bins, shadow ? c->d_sstats : c->d_stats, slot, c->d_vis,
-                            (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow), shadow ? c->shadow_blocks : c->raster_blocks, Z, s,
+                            (uint32_t*)(c->d_shadow_ext ? c->d_shadow_ext : c->d_shadow),
+                            shadow ? (c->stile_world >= 4u ? c->shadow_blocks / 2u : c->shadow_blocks) : c->raster_blocks, Z, s,
                             defer ? c->d_slow0 : nullptr, c->slow0_cap, c->d_sowned, c->sn_tiles, stage);
 }
 

@@ -639,13 +639,13 @@ __global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __re
                     if (px0 <= px1 && py0 <= py1) {
                         r = pack_tile_rect<MODE>(px0, py0, px1, py1);
                         pr = make_uint2((uint32_t)px0 | (uint32_t)py0 << 16, (uint32_t)px1 | (uint32_t)py1 << 16);
-                        // A target owned by super-tiles (the frame: zr_config.tile_world; the shadow map: zr_set_shadow_tiles): a meshlet is this
-                        // rank's work when its pixel box reaches a tile the rank owns - a much tighter bound than the sphere stage A tested
-                        // (a rank of eight met 1.7 x its share of round 2's candidates through the spheres alone).  Shadow pass: the box
-                        // itself, not the apron-shrunk rectangle the meshlet is LISTED under; it is then drawn whole, in every window it is
-                        // listed for (the listing tile of a meshlet that straddles a border may be the neighbour's): the owned tiles end up
-                        // exact, whatever lands on the others is not sent anywhere.  Camera pass: k_geom emits records for owned tiles only.
-                        if (P.tile_world > 1u && (MODE == ZR_MODE_SHADOW || P.rect_cull)) {      // (ZR_FLAG_NO_RECT_CULL: the camera pass's A/B)
+                        // Shadow map owned by light-space super-tiles (zr_set_shadow_tiles): a meshlet is this rank's work when its texel box
+                        // - the box itself, not the apron-shrunk rectangle it is LISTED under - reaches a tile the rank owns.  It is then drawn
+                        // whole, in every window it is listed for (the listing tile of a meshlet that straddles a border may be the
+                        // neighbour's): the owned tiles end up exact, whatever lands on the others is not sent anywhere.
+                        // (The camera pass goes without: what the box test would drop there falls to k_select's Hi-Z test at the same price -
+                        // a rank of eight: k_cull_box + 8 us, k_select unchanged - and k_geom emits records for owned tiles only.)
+                        if (MODE == ZR_MODE_SHADOW && P.tile_world > 1u) {
                             bool mine = false;
                             for (int ty = py0 / TILE; ty <= py1 / TILE; ++ty)
                                 for (int tx = px0 / TILE; tx <= px1 / TILE; ++tx)
