@@ -62,3 +62,35 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in text.replace("CPU oracle", "").replace("the oracle", "") or f == "build.py", (dirpath, f)
+
+
+def test_abi_version_is_one_number_everywhere():
+    """include/zelda_render.h, the ctypes binding and the built library must name the same ZR_ABI_VERSION (no GPU needed); zr_stats
+    is passed with the caller's size, so its ctypes mirror must be the header's struct."""
+    from zeldaengine_amd import abi, engine
+    hdr = open(os.path.join(ROOT, "include", "zelda_render.h")).read()
+    ver = int(re.search(r"#define ZR_ABI_VERSION (\d+)u", hdr).group(1))
+    assert ver == abi.ABI_VERSION
+    L = engine.lib()
+    assert L.zr_abi_version() == ver
+    assert C.sizeof(abi.Stats) == 96                          # ABI version 5 (zr_stats::struct_bytes)
+    src = os.path.join(ROOT, "tests", "_stats_size.c")
+    try:
+        open(src, "w").write('#include "zelda_render.h"\n#include <stdio.h>\nint main(void){printf("%zu", sizeof(zr_stats));return 0;}\n')
+        exe = src[:-2]
+        subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        assert int(subprocess.check_output([exe]).decode()) == C.sizeof(abi.Stats)
+    finally:
+        for f in (src, src[:-2]):
+            if os.path.exists(f):
+                os.remove(f)
+
+
+def test_shadow_mode_names_map_to_the_dist_flags():
+    from zeldaengine_amd import abi
+    assert [abi.dist_flags(abi.shadow_mode(m)) for m in (False, True, "replicated", "split", "tiles")] == [0, 1, 0, 1, 2]
+    assert abi.shadow_mode(False, "tiles") == "tiles"
+    with pytest.raises(ValueError):
+        abi.shadow_mode("bands")
+    hdr = open(os.path.join(ROOT, "include", "zelda_render.h")).read()
+    assert "#define ZR_DIST_SPLIT_SHADOW 1u" in hdr and "#define ZR_DIST_SHADOW_TILES 2u" in hdr
