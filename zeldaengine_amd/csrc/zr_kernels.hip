@@ -89,6 +89,34 @@ __device__ __forceinline__ int find_object_prim(const ZrObject* __restrict__ obj
     return lo;
 }
 
+// Loads through pointers that were themselves read from memory (ZrObject's fields, a bin record's three addresses).  The compiler cannot
+// know what such a pointer points into and emits FLAT loads for it: those count on BOTH wait counters (every LDS access then waits for
+// them and they for it), keep their 64-bit addresses in vector registers and can never be scalar.  All of these point into device memory
+// that no kernel of the frame writes while it is read - scene data, or records an earlier kernel laid down - so the loads are spelled in
+// the global address space (an SGPR base + a 32-bit lane offset) or, for a record every lane reads, in the constant one (scalar loads).
+#define ZR_AS_GLOBAL __attribute__((address_space(1)))
+#define ZR_AS_CONST __attribute__((address_space(4)))
+typedef float zr_f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t zr_u2v __attribute__((ext_vector_type(2)));
+typedef uint32_t zr_u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_global(const float4* p) { const zr_f4v v = *(const ZR_AS_GLOBAL zr_f4v*)p; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint2 ld_global(const uint2* p) { const zr_u2v v = *(const ZR_AS_GLOBAL zr_u2v*)p; return make_uint2(v.x, v.y); }
+__device__ __forceinline__ uint4 ld_global(const uint4* p) { const zr_u4v v = *(const ZR_AS_GLOBAL zr_u4v*)p; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint32_t ld_global(const uint32_t* p) { return *(const ZR_AS_GLOBAL uint32_t*)p; }
+__device__ __forceinline__ float ld_global(const float* p) { return *(const ZR_AS_GLOBAL float*)p; }
+__device__ __forceinline__ uint8_t ld_global(const uint8_t* p) { return *(const ZR_AS_GLOBAL uint8_t*)p; }
+// a whole record (dwords): scalar loads when the address is wave-uniform, vector loads when it is not
+template <class T> __device__ __forceinline__ T ld_record(const T* p)
+{
+    static_assert(sizeof(T) % 4 == 0, "dwords");
+    T v;
+    uint32_t* d = (uint32_t*)&v;
+    const ZR_AS_CONST uint32_t* q = (const ZR_AS_CONST uint32_t*)p;
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(T) / 4; ++i) d[i] = q[i];
+    return v;
+}
+
 // Base.vert:26 / BaseInstanced.vert:70 / Shadowmap*.vert: object-space position fed to PVM
 __device__ __forceinline__ zf3 vs_position(zf3 p, const ZrInstance& I, bool instanced)
 {
@@ -299,7 +327,7 @@ __device__ __forceinline__ bool instance_test(const ZrPass& P, const ZrObject* _
     // the shadow map and the copies are min-reduced (depth test LESS_OR_EQUAL is a min, so the split is exact)
     if (MODE == ZR_MODE_SHADOW && ((O->flags & ZR_OBJ_SKY) || inst_i % P.inst_world != P.inst_rank)) vis = false;
     if (vis && (P.frustum_ok | P.rect_cull | P.sphere_ok)) {
-        const ZrInstance I = O->inst[inst_i];
+        const ZrInstance I = ld_record(O->inst + inst_i);
         const bool instanced = O->instanced != 0;
         co = vs_position(zr3(O->mesh_center[0], O->mesh_center[1], O->mesh_center[2]), I, instanced);
         radius = O->mesh_radius * (instanced ? __builtin_fabsf(I.s) : 1.0f);
@@ -397,11 +425,11 @@ __device__ __forceinline__ bool cull_stage_a(const ZrPass& P, const ZrObject* __
     const XkMeshlet* __restrict__ mlp = O->meshlets + m;
     // the 64-byte record as aligned 16-byte words: [16] centre.xyz radius  [32] apex.xyz axis.x  [48] axis.yz cutoff
     const float4* __restrict__ mq = (const float4*)mlp;
-    const float4 bs = mq[1], q2 = mq[2], q3 = mq[3];
+    const float4 q0 = ld_global(mq), bs = ld_global(mq + 1), q2 = ld_global(mq + 2), q3 = ld_global(mq + 3);
     const float4 cn = make_float4(q2.w, q3.x, q3.y, q3.z);      // axis.xyz, cutoff
     it.O = O; it.m = m; it.inst_i = inst_i; it.w = w;
-    it.mposv = O->mpos + mlp->VertexOffset; it.vcount = mlp->VertexCount; it.tcount = mlp->TriangleCount; it.tri_base = mlp->BindlessContext;
-    it.I = O->inst[inst_i];
+    it.mposv = O->mpos + zr_f2u(q0.x); it.vcount = zr_f2u(q0.y); it.tcount = zr_f2u(q0.w); it.tri_base = zr_f2u(q3.w);      // VertexOffset, VertexCount, TriangleCount, BindlessContext
+    it.I = ld_record(O->inst + inst_i);
     const ZrInstance& I = it.I;
     const uint32_t instanced = O->instanced != 0 ? 1u : 0u;
     it.instanced = instanced;
@@ -567,7 +595,7 @@ __global__ __launch_bounds__(256) void k_cull_box(ZrPass P, const ZrObject* __re
         uint32_t r = ZR_RECT_CULLED; uint2 pr = make_uint2(0u, 0u); float zm = -1.0f;
         const uint32_t r_all = (P.tiles_x - 1u) << 16 | (P.tiles_y - 1u) << 24;          // every tile: extents unknown
         if (k < n && cull_stage_a<MODE, WORKLIST>(P, objs, work, vis_clear, k, it)) {
-            const float4 lo = it.O->mbox[2u * it.m], hi = it.O->mbox[2u * it.m + 1u];
+            const float4 lo = ld_global(it.O->mbox + 2u * it.m), hi = ld_global(it.O->mbox + 2u * it.m + 1u);
             const float FM = 3.402823466e38f, U = 9.5367431640625e-7f;           // 8 ulps
             bool fin = true, clip = false;
             float mag = 0.0f, mx = 0.0f, my = 0.0f, mz = 0.0f, mw = 0.0f, wmin = FM;
@@ -934,8 +962,9 @@ __global__ __launch_bounds__(1024) void k_bin_fill(ZrPass P, const ZrObject* __r
         const uint32_t inst_i = local / O->n_meshlets, m = local - inst_i * O->n_meshlets;
         const XkMeshlet* __restrict__ ml = O->meshlets + m;
         ZrBinEntry be;
-        be.mpos = O->mpos + ml->VertexOffset; be.mtri = O->mtri + ml->BindlessContext; be.inst = O->inst + inst_i;
-        be.counts = ml->VertexCount | ml->TriangleCount << 8 | (O->instanced ? 1u << 16 : 0u);
+        const uint4 mh = ld_global((const uint4*)ml);            // VertexOffset, VertexCount, TriangleOffset, TriangleCount
+        be.mpos = O->mpos + mh.x; be.mtri = O->mtri + ld_global(&ml->BindlessContext); be.inst = O->inst + inst_i;
+        be.counts = mh.y | mh.w << 8 | (O->instanced ? 1u << 16 : 0u);
         be.prim_base = O->prim_base + inst_i * O->n_tris;
         const float zt = tile_test_depth(Z, k);
         for (uint32_t ty = ty0; ty <= ty1; ++ty)
@@ -1252,7 +1281,7 @@ __device__ __forceinline__ zf4 tex_finish(zf4 r, bool srgb)
 }
 __device__ __forceinline__ zf4 tex_fetch(const uint8_t* __restrict__ lvl, uint32_t w, int x, int y, bool srgb, const float* __restrict__ lut)
 {
-    const uint32_t t = *(const uint32_t*)(lvl + ((size_t)y * w + (size_t)x) * 4);
+    const uint32_t t = ld_global((const uint32_t*)(lvl + ((size_t)y * w + (size_t)x) * 4));
     zf4 r;
     r.x = tex_decode(t & 255u, srgb, lut); r.y = tex_decode((t >> 8) & 255u, srgb, lut);
     r.z = tex_decode((t >> 16) & 255u, srgb, lut); r.w = tex_decode(t >> 24, false, lut);
@@ -1378,8 +1407,8 @@ __device__ __forceinline__ zf4 tex_decode4(uint32_t t, bool srgb, const float* _
 }
 __device__ __forceinline__ zf4 tex_bilinear_geo(const uint8_t* __restrict__ base, const TexGeo& g, bool srgb, const float* __restrict__ lut)
 {
-    const uint32_t u00 = *(const uint32_t*)(base + g.o00), u10 = *(const uint32_t*)(base + g.o10);
-    const uint32_t u01 = *(const uint32_t*)(base + g.o01), u11 = *(const uint32_t*)(base + g.o11);
+    const uint32_t u00 = ld_global((const uint32_t*)(base + g.o00)), u10 = ld_global((const uint32_t*)(base + g.o10));
+    const uint32_t u01 = ld_global((const uint32_t*)(base + g.o01)), u11 = ld_global((const uint32_t*)(base + g.o11));
     const zf4 t00 = tex_decode4(u00, srgb, lut), t10 = tex_decode4(u10, srgb, lut), t01 = tex_decode4(u01, srgb, lut), t11 = tex_decode4(u11, srgb, lut);
     const float a = g.a, b = g.b;
     zf4 r;
@@ -1427,10 +1456,10 @@ __device__ __forceinline__ void tex_sample_packed(const ZrTex& T, const float* _
             uu = __builtin_fmaf(F.du, off, u); vv = __builtin_fmaf(F.dv, off, v);
         }
         const TexGeo g0 = tex_geo(F.w, F.h, l0, uu, vv), g1 = tex_geo(F.w, F.h, l1, uu, vv);     // offsets for 4-byte texels: x 4 here
-        const uint4 a00 = *(const uint4*)(base + (size_t)g0.o00 * 4u), a10 = *(const uint4*)(base + (size_t)g0.o10 * 4u);
-        const uint4 a01 = *(const uint4*)(base + (size_t)g0.o01 * 4u), a11 = *(const uint4*)(base + (size_t)g0.o11 * 4u);
-        const uint4 b00 = *(const uint4*)(base + (size_t)g1.o00 * 4u), b10 = *(const uint4*)(base + (size_t)g1.o10 * 4u);
-        const uint4 b01 = *(const uint4*)(base + (size_t)g1.o01 * 4u), b11 = *(const uint4*)(base + (size_t)g1.o11 * 4u);
+        const uint4 a00 = ld_global((const uint4*)(base + (size_t)g0.o00 * 4u)), a10 = ld_global((const uint4*)(base + (size_t)g0.o10 * 4u));
+        const uint4 a01 = ld_global((const uint4*)(base + (size_t)g0.o01 * 4u)), a11 = ld_global((const uint4*)(base + (size_t)g0.o11 * 4u));
+        const uint4 b00 = ld_global((const uint4*)(base + (size_t)g1.o00 * 4u)), b10 = ld_global((const uint4*)(base + (size_t)g1.o10 * 4u));
+        const uint4 b01 = ld_global((const uint4*)(base + (size_t)g1.o01 * 4u)), b11 = ld_global((const uint4*)(base + (size_t)g1.o11 * 4u));
         const zr_f2 a0 = { g0.a, g0.a }, b0 = { g0.b, g0.b }, a1 = { g1.a, g1.a }, b1 = { g1.b, g1.b };
 #pragma unroll
         for (int j = 0; j < PAIRS; ++j) {                  // per channel: tex_bilinear's and tex_trilinear's expressions, in their order
@@ -1554,13 +1583,13 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
     const uint32_t local = prim - O->prim_base;
     const uint32_t inst_i = local / O->n_tris, tri = local - inst_i * O->n_tris;
     const bool instanced = O->instanced != 0;
-    const ZrInstance I = O->inst[inst_i];
+    const ZrInstance I = ld_record(O->inst + inst_i);
     // visibility history for next frame's round 1: this meshlet-instance owns a pixel
-    if (vis_now) vis_now[O->work_base + inst_i * O->n_meshlets + O->tri_meshlet[tri]] = (uint8_t)vis_mark;
+    if (vis_now) vis_now[O->work_base + inst_i * O->n_meshlets + ld_global(O->tri_meshlet + tri)] = (uint8_t)vis_mark;
     zf4 clip[3]; zf3 WP[3], WN[3]; float U[3], V[3]; uint32_t fl[3];
     for (int k = 0; k < 3; ++k) {
-        const float4* __restrict__ rv = (const float4*)(O->rverts + O->indices[3u * tri + (uint32_t)k]);
-        const float4 q0 = rv[0], q1 = rv[1];       // position.xyz u | normalize(normal).xyz v
+        const float4* __restrict__ rv = (const float4*)(O->rverts + ld_global(O->indices + 3u * tri + (uint32_t)k));
+        const float4 q0 = ld_global(rv), q1 = ld_global(rv + 1);       // position.xyz u | normalize(normal).xyz v
         const zf3 pos = vs_position(zr3(q0.x, q0.y, q0.z), I, instanced);
         clip[k] = zr_mat4_point(P.PVM, pos);
         WP[k] = model_point(P, pos);
@@ -1759,10 +1788,10 @@ void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* _
 
             // both rounds' triangle words and the vertex are requested together, before anything waits
             uint2 tri_w[2];
-            tri_w[0] = lane < tcount ? tw[lane] : make_uint2(0u, 0u);
-            tri_w[1] = lane + WAVE < tcount ? tw[lane + WAVE] : make_uint2(0u, 0u);
-            const float4 pp = lane < vcount ? mp[lane] : make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-            const ZrInstance I = *ip;
+            tri_w[0] = lane < tcount ? ld_global(tw + lane) : make_uint2(0u, 0u);
+            tri_w[1] = lane + WAVE < tcount ? ld_global(tw + lane + WAVE) : make_uint2(0u, 0u);
+            const float4 pp = lane < vcount ? ld_global(mp + lane) : make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+            const ZrInstance I = ld_record(ip);
 
             lds_fence();   // this wave's previous readers are done with its staging area
             // Almost every meshlet has no vertex outside the frustum at all: that is one wave-wide vote over ten comparisons (each a
@@ -1810,7 +1839,7 @@ void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* _
                         zf4 cc[3];
                         const uint32_t li[3] = { i0, i1, i2 };
                         for (int k = 0; k < 3; ++k) {
-                            const float4 pk = mp[li[k]];
+                            const float4 pk = ld_global(mp + li[k]);
                             cc[k] = zr_mat4_point(P.PVM, vs_position(zr3(pk.x, pk.y, pk.z), I, instanced));
                         }
                         if (DEFER) {
@@ -1994,8 +2023,9 @@ __global__ __launch_bounds__(256) void k_shadow_occlusion(ZrPass P, const ZrObje
             const uint32_t inst_i = local / O->n_meshlets, m = local - inst_i * O->n_meshlets;
             const XkMeshlet* __restrict__ ml = O->meshlets + m;
             ZrBinEntry be;
-            be.mpos = O->mpos + ml->VertexOffset; be.mtri = O->mtri + ml->BindlessContext; be.inst = O->inst + inst_i;
-            be.counts = ml->VertexCount | ml->TriangleCount << 8 | (O->instanced ? 1u << 16 : 0u);
+            const uint4 mh = ld_global((const uint4*)ml);            // VertexOffset, VertexCount, TriangleOffset, TriangleCount
+            be.mpos = O->mpos + mh.x; be.mtri = O->mtri + ld_global(&ml->BindlessContext); be.inst = O->inst + inst_i;
+            be.counts = mh.y | mh.w << 8 | (O->instanced ? 1u << 16 : 0u);
             const uint32_t room = P.bin_capacity - min(stats->bin_entries[0], P.bin_capacity);      // above the first launch's entries
             const uint32_t tx0 = r & 255u, ty0 = (r >> 8) & 255u, tx1 = (r >> 16) & 255u, ty1 = r >> 24;
             for (uint32_t ty = ty0; ty <= ty1; ++ty)
@@ -2081,8 +2111,9 @@ __global__ __launch_bounds__(256) void k_select(ZrPass P, const ZrObject* __rest
         const uint32_t inst_i = local / O->n_meshlets, mi = local - inst_i * O->n_meshlets;
         const XkMeshlet* __restrict__ ml = O->meshlets + mi;
         ZrBinEntry be;
-        be.mpos = O->mpos + ml->VertexOffset; be.mtri = O->mtri + ml->BindlessContext; be.inst = O->inst + inst_i;
-        be.counts = ml->VertexCount | ml->TriangleCount << 8 | (O->instanced ? 1u << 16 : 0u);
+        const uint4 mh = ld_global((const uint4*)ml);            // VertexOffset, VertexCount, TriangleOffset, TriangleCount
+        be.mpos = O->mpos + mh.x; be.mtri = O->mtri + ld_global(&ml->BindlessContext); be.inst = O->inst + inst_i;
+        be.counts = mh.y | mh.w << 8 | (O->instanced ? 1u << 16 : 0u);
         be.prim_base = O->prim_base + inst_i * O->n_tris;
         sel[wbase[j * 4 + (int)wv] + (uint32_t)__popcll(m[j] & ((1ull << lane) - 1ull))] = be;
     }
@@ -2177,10 +2208,10 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
         const uint32_t vcount = counts & 255u, tcount = (counts >> 8) & 255u;
         const bool instanced = (counts >> 16) & 1u;
         uint2 tri_w[2];
-        tri_w[0] = lane < tcount ? tw[lane] : make_uint2(0u, 0u);
-        tri_w[1] = lane + WAVE < tcount ? tw[lane + WAVE] : make_uint2(0u, 0u);
-        const float4 pp = lane < vcount ? mp[lane] : make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-        const ZrInstance I = *ip;
+        tri_w[0] = lane < tcount ? ld_global(tw + lane) : make_uint2(0u, 0u);
+        tri_w[1] = lane + WAVE < tcount ? ld_global(tw + lane + WAVE) : make_uint2(0u, 0u);
+        const float4 pp = lane < vcount ? ld_global(mp + lane) : make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        const ZrInstance I = ld_record(ip);
 
         lds_fence();   // this wave's previous readers are done with its staging area
         bool flagged;
@@ -2288,7 +2319,7 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
                     if (pos_r < B.slow_cap / 2u) {
                         const uint32_t li[3] = { i0, i1, i2 };
                         for (int k = 0; k < 3; ++k) {
-                            const float4 pk = mp[li[k]];
+                            const float4 pk = ld_global(mp + li[k]);
                             const zf4 cc = zr_mat4_point(P.PVM, vs_position(zr3(pk.x, pk.y, pk.z), I, instanced));
                             B.slow[4u * pos + (uint32_t)k] = make_uint4(zr_f2u(cc.x), zr_f2u(cc.y), zr_f2u(cc.z), zr_f2u(cc.w));
                         }
@@ -2681,7 +2712,7 @@ __global__ __launch_bounds__(256) void k_sky_tiles(ZrPass P, const ZrObject* __r
     for (uint32_t t = tid; t < O->n_tris; t += 256u) {
         zf4 c[3];
         for (int k = 0; k < 3; ++k) {
-            const float4 q0 = *(const float4*)(O->rverts + O->indices[3u * t + (uint32_t)k]);
+            const float4 q0 = ld_global((const float4*)(O->rverts + ld_global(O->indices + 3u * t + (uint32_t)k)));
             c[k] = zr_mat4_point(P.PVM, vs_position(zr3(q0.x, q0.y, q0.z), I, false));
         }
         if (classify(vertex_flags(c[0]), vertex_flags(c[1]), vertex_flags(c[2])) == 0) continue;
