@@ -907,7 +907,7 @@ static int zr_set_cubemap_impl(zr_ctx* c, const uint8_t* const faces[6], uint32_
     if (!c) return ZR_ERR_ARG;
     static const uint8_t grey[4] = { 127, 127, 127, 255 };
     if (!faces) dim = 1;
-    ARGCHK(c, dim > 0 && dim <= 8192);          // (the whole chain in one allocation addressed with 32-bit byte offsets: 2.1 GB at 8192)
+    ARGCHK(c, dim > 0 && dim <= 16384);
     if (faces) for (int f = 0; f < 6; ++f) ARGCHK(c, faces[f] != nullptr);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, zr_sync_all(c));
@@ -941,17 +941,10 @@ static int zr_set_cubemap_impl(zr_ctx* c, const uint8_t* const faces[6], uint32_
         d = nd;
     }
     memset(&c->cube, 0, sizeof c->cube);
-    {   // one allocation, level after level
-        std::vector<uint8_t> all;
-        std::vector<uint32_t> offs(16, 0u);
-        for (uint32_t l = 0; l < levels; ++l) { offs[l] = (uint32_t)all.size(); c->cube.off[l] = offs[l]; all.insert(all.end(), lv[l].begin(), lv[l].end()); lv[l] = std::vector<uint8_t>(); }
-        if (all.size() > 0xFFFFFFF0ull) return zr_fail(c, ZR_ERR_ARG, "cubemap too large");
-        uint8_t* p = nullptr; uint32_t* po = nullptr;
-        HIPCHK(c, upload(&p, all));
-        c->d_cube.push_back(p);
-        HIPCHK(c, upload(&po, offs));
-        c->d_cube.push_back((uint8_t*)po);
-        c->cube.base = p; c->cube.off_dev = po;
+    for (uint32_t l = 0; l < levels; ++l) {
+        uint8_t* p = nullptr;
+        HIPCHK(c, upload(&p, lv[l]));
+        c->d_cube.push_back(p); c->cube.levels[l] = p;
     }
     c->cube_dim = dim; c->cube_levels = levels;
     c->view.LightsCount[3] = (int32_t)levels;       // CubemapMaxMips, ZE:4308

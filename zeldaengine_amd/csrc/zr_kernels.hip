@@ -117,28 +117,6 @@ template <class T> __device__ __forceinline__ T ld_record(const T* p)
     return v;
 }
 
-// Element `idx` of an array whose base is a kernel argument (wave-uniform: an SGPR pair) and whose byte offsets fit 32 bits (render targets
-// are at most 8160 x 8160 pixels of 8 bytes, shadow maps 16384^2 floats): the lane's address is ONE register holding the byte offset -
-// no sign extension, no 64-bit shift-and-add per access.
-template <class T> __device__ __forceinline__ T ld_at(const T* base, uint32_t idx)
-{
-    return *(const ZR_AS_GLOBAL T*)((const ZR_AS_GLOBAL uint8_t*)base + (size_t)(idx * (uint32_t)sizeof(T)));
-}
-__device__ __forceinline__ uint2 ld_at(const uint2* base, uint32_t idx)
-{
-    const zr_u2v v = *(const ZR_AS_GLOBAL zr_u2v*)((const ZR_AS_GLOBAL uint8_t*)base + (size_t)(idx * 8u));
-    return make_uint2(v.x, v.y);
-}
-template <class T> __device__ __forceinline__ void st_at(T* base, uint32_t idx, T v)
-{
-    *(ZR_AS_GLOBAL T*)((ZR_AS_GLOBAL uint8_t*)base + (size_t)(idx * (uint32_t)sizeof(T))) = v;
-}
-__device__ __forceinline__ void st_at(uint2* base, uint32_t idx, uint2 v)
-{
-    zr_u2v w; w.x = v.x; w.y = v.y;
-    *(ZR_AS_GLOBAL zr_u2v*)((ZR_AS_GLOBAL uint8_t*)base + (size_t)(idx * 8u)) = w;
-}
-
 // Base.vert:26 / BaseInstanced.vert:70 / Shadowmap*.vert: object-space position fed to PVM
 __device__ __forceinline__ zf3 vs_position(zf3 p, const ZrInstance& I, bool instanced)
 {
@@ -1594,11 +1572,11 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
                                               int px, int py, const GBufferPtrs& G, const float* __restrict__ lut,
                                               uint8_t* __restrict__ vis_now, uint32_t vis_mark = 1u)
 {
-    const uint32_t p = (uint32_t)py * P.W + (uint32_t)px;
+    const size_t p = (size_t)py * P.W + (size_t)px;
     if (prim == ZR_EMPTY_PRIM) {   // clears, ZE:3427-3433
-        st_at(G.depth, p, 1.0f); st_at(G.scene_color, p, 0xFF000000u); st_at(G.gA, p, 0u); st_at(G.gB, p, 0xFF000000u); st_at(G.gC, p, 0xFF000000u);
-        st_at(G.gD, p, make_uint2(0u, 0x3C000000u));
-        if (P.write_overlay) st_at(G.overlay, p, 0u);
+        G.depth[p] = 1.0f; G.scene_color[p] = 0xFF000000u; G.gA[p] = 0u; G.gB[p] = 0xFF000000u; G.gC[p] = 0xFF000000u;
+        G.gD[p] = make_uint2(0u, 0x3C000000u);
+        if (P.write_overlay) G.overlay[p] = 0u;
         return false;
     }
     const ZrObject* __restrict__ O = objs + find_object_prim(objs, (int)P.n_objects, prim);
@@ -1648,11 +1626,11 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
     if (O->flags & ZR_OBJ_SKY) {    // Skydome.frag: texture(skydomeSampler, uv).rgb, gamma - colour only, into the overlay plane: the pass
         // is drawn after the lighting quad (ZE:3681-3691) and no GBuffer attachment is written by it
         const zf4 sk = tex_sample<IMAGES>(O->tex[0], O->texc[0], true, lut, u0, v0, s1, t1, s2, t2);
-        st_at(G.overlay, p, zr_unorm(zr_pow(sk.x, 0.4545f), 255.0f) | zr_unorm(zr_pow(sk.y, 0.4545f), 255.0f) << 8 |
-                            zr_unorm(zr_pow(sk.z, 0.4545f), 255.0f) << 16 | 255u << 24);
+        G.overlay[p] = zr_unorm(zr_pow(sk.x, 0.4545f), 255.0f) | zr_unorm(zr_pow(sk.y, 0.4545f), 255.0f) << 8 |
+                       zr_unorm(zr_pow(sk.z, 0.4545f), 255.0f) << 16 | 255u << 24;
         return false;
     }
-    if (P.write_overlay) st_at(G.overlay, p, 0u);
+    if (P.write_overlay) G.overlay[p] = 0u;
     // texture(samplerN, fragTexCoord), BaseScene.frag:30-36; slot 0 (base colour) is R8G8B8A8_SRGB (ZE:5878).  Targets whose slots are
     // all constant were packed on the host (same zr_unorm), and so was the tangent-space normal of a constant normal map.
     uint32_t w_sc, w_gB, w_gC;
@@ -1692,12 +1670,12 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
     const zf3 Nw = compute_normal(pos_dx, pos_dy, s1, t1, s2, t2, N0, ts);
     const zf3 Nn = zr_normalize(Nw);
     const zf3 NP = zr3((Nn.x + 1.0f) / 2.0f, (Nn.y + 1.0f) / 2.0f, (Nn.z + 1.0f) / 2.0f);
-    st_at(G.depth, p, depth);
-    st_at(G.scene_color, p, w_sc);
-    st_at(G.gA, p, zr_unorm(NP.z, 1023.0f) | zr_unorm(NP.y, 1023.0f) << 10 | zr_unorm(NP.x, 1023.0f) << 20 | 3u << 30);
-    st_at(G.gB, p, w_gB);
-    st_at(G.gC, p, w_gC);
-    st_at(G.gD, p, make_uint2(f32_to_f16_hw(P0.x) | f32_to_f16_hw(P0.y) << 16, f32_to_f16_hw(P0.z) | 0x3C000000u));
+    G.depth[p] = depth;
+    G.scene_color[p] = w_sc;
+    G.gA[p] = zr_unorm(NP.z, 1023.0f) | zr_unorm(NP.y, 1023.0f) << 10 | zr_unorm(NP.x, 1023.0f) << 20 | 3u << 30;
+    G.gB[p] = w_gB;
+    G.gC[p] = w_gC;
+    G.gD[p] = make_uint2(f32_to_f16_hw(P0.x) | f32_to_f16_hw(P0.y) << 16, f32_to_f16_hw(P0.z) | 0x3C000000u);
     return true;
 }
 
@@ -2784,9 +2762,9 @@ __global__ __launch_bounds__(TB, TB == 64 ? ZR_RESOLVE_IMG_WAVES : 1) void k_res
         const int px = tx0 + (int)(i & (TILE - 1)), py = ty0 + (int)(i / TILE);
         keys[q] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
         if (px < (int)P.W && py < (int)P.H) {
-            const uint32_t p = (uint32_t)py * P.W + (uint32_t)px;
-            keys[q] = ld_at(vis64, p);
-            st_at(vis64, p, (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM);
+            const size_t p = (size_t)py * P.W + (size_t)px;
+            keys[q] = vis64[p];
+            vis64[p] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
         }
     }
 #pragma unroll
@@ -2824,20 +2802,18 @@ __global__ void k_count_shadow(const uint32_t* __restrict__ bits, size_t n, ZrDe
 
 __device__ __forceinline__ int idx_clamp(float f, int hi) { f = __builtin_fminf(__builtin_fmaxf(f, 0.0f), (float)hi); return (int)f; }
 
-// coff: CubeDesc::off where the kernel can index it per lane (LDS), or the descriptor's own array when the level is known at compile time
-__device__ __forceinline__ zf3 cube_fetch(const CubeDesc& C, const uint32_t* __restrict__ coff, const float* __restrict__ lut, uint32_t dim0, int level, int face, int x, int y)
+__device__ __forceinline__ zf3 cube_fetch(const CubeDesc& C, const float* __restrict__ lut, uint32_t dim0, int level, int face, int x, int y)
 {
     uint32_t d = dim0 >> level; if (d == 0) d = 1;
-    // one uniform base + a 32-bit byte offset per lane (zr_set_cubemap keeps the chain under 4 GB)
-    const uint32_t byte = coff[level] + ((d * d * (uint32_t)face + (uint32_t)y * d + (uint32_t)x) << 2);
-    const uint32_t t = *(const ZR_AS_GLOBAL uint32_t*)((const ZR_AS_GLOBAL uint8_t*)C.base + (size_t)byte);
+    const uint8_t* p = C.levels[level] + ((size_t)d * d * (size_t)face + (size_t)y * d + (size_t)x) * 4;
+    const uint32_t t = *(const uint32_t*)p;
     return zr3(lut[t & 255u], lut[(t >> 8) & 255u], lut[(t >> 16) & 255u]);
 }
 __device__ __forceinline__ zf3 lerp3(float a, zf3 x, zf3 y)
 {
     return zr3(__builtin_fmaf(a, y.x - x.x, x.x), __builtin_fmaf(a, y.y - x.y, x.y), __builtin_fmaf(a, y.z - x.z, x.z));
 }
-__device__ __forceinline__ zf3 cube_bilinear(const CubeDesc& C, const uint32_t* __restrict__ coff, const float* __restrict__ lut, uint32_t dim0, int level, int face, float s, float t)
+__device__ __forceinline__ zf3 cube_bilinear(const CubeDesc& C, const float* __restrict__ lut, uint32_t dim0, int level, int face, float s, float t)
 {
     uint32_t d = dim0 >> level; if (d == 0) d = 1;
     const float u = __builtin_fmaf(s, (float)d, -0.5f), v = __builtin_fmaf(t, (float)d, -0.5f);
@@ -2845,12 +2821,12 @@ __device__ __forceinline__ zf3 cube_bilinear(const CubeDesc& C, const uint32_t* 
     const float a = u - fu, b = v - fv;
     const int x0 = idx_clamp(fu, (int)d - 1), x1 = idx_clamp(fu + 1.0f, (int)d - 1);
     const int y0 = idx_clamp(fv, (int)d - 1), y1 = idx_clamp(fv + 1.0f, (int)d - 1);
-    const zf3 top = lerp3(a, cube_fetch(C, coff, lut, dim0, level, face, x0, y0), cube_fetch(C, coff, lut, dim0, level, face, x1, y0));
-    const zf3 bot = lerp3(a, cube_fetch(C, coff, lut, dim0, level, face, x0, y1), cube_fetch(C, coff, lut, dim0, level, face, x1, y1));
+    const zf3 top = lerp3(a, cube_fetch(C, lut, dim0, level, face, x0, y0), cube_fetch(C, lut, dim0, level, face, x1, y0));
+    const zf3 bot = lerp3(a, cube_fetch(C, lut, dim0, level, face, x0, y1), cube_fetch(C, lut, dim0, level, face, x1, y1));
     return lerp3(b, top, bot);
 }
 // textureLod(samplerCube, R, lod): Vulkan face selection (z wins ties over y over x), trilinear, faces clamp-to-edge
-__device__ __forceinline__ zf3 cube_sample(const CubeDesc& C, const uint32_t* __restrict__ coff, const float* __restrict__ lut, uint32_t dim0, int nlevels, zf3 R, float lod)
+__device__ __forceinline__ zf3 cube_sample(const CubeDesc& C, const float* __restrict__ lut, uint32_t dim0, int nlevels, zf3 R, float lod)
 {
     const float ax = __builtin_fabsf(R.x), ay = __builtin_fabsf(R.y), az = __builtin_fabsf(R.z);
     int face; float sc, tc, ma;
@@ -2862,7 +2838,7 @@ __device__ __forceinline__ zf3 cube_sample(const CubeDesc& C, const uint32_t* __
     const float l = __builtin_fminf(__builtin_fmaxf(lod, 0.0f), (float)(nlevels - 1));
     const float fl = __builtin_floorf(l);
     const int l0 = (int)fl, l1 = min(l0 + 1, nlevels - 1);
-    return lerp3(l - fl, cube_bilinear(C, coff, lut, dim0, l0, face, s, t), cube_bilinear(C, coff, lut, dim0, l1, face, s, t));
+    return lerp3(l - fl, cube_bilinear(C, lut, dim0, l0, face, s, t), cube_bilinear(C, lut, dim0, l1, face, s, t));
 }
 
 __device__ __forceinline__ float F_Schlick(float f0, float f90, float u) { return __builtin_fmaf(f90 - f0, zr_pow5(1.0f - u), f0); }   // SH/Common.glsl:134
@@ -2931,10 +2907,7 @@ static_assert(TILE_PIX / ZR_PIXELS_PER_THREAD >= ZR_LIGHT_TB && TILE_PIX / ZR_PI
 template <bool LIGHT_LIST, bool BACKGROUND, int TB, int PPT>      // PPT: pixels per thread, 4 or 1 (as in k_resolve_gbuffer)
 // (compiled for exactly 4 waves per SIMD: left to itself the allocator takes 127 VGPRs, told so it makes do with 97 - the same four
 // waves, but 120 registers per SIMD left for the other lane's kernels; 5 or 6 waves (95 / 80 VGPRs) are faster alone, not beside)
-#ifndef ZR_LIGHT_VGPRS
-#define ZR_LIGHT_VGPRS 128
-#endif
-__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(ZR_LIGHT_WAVES, ZR_LIGHT_WAVES), amdgpu_num_vgpr(ZR_LIGHT_VGPRS))) void k_lighting(ZrLightParams L, const XkView* __restrict__ view,
+__global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(ZR_LIGHT_WAVES, ZR_LIGHT_WAVES))) void k_lighting(ZrLightParams L, const XkView* __restrict__ view,
                                                   const uint32_t* __restrict__ owned_tiles, GBufferPtrs G,
                                                   const float* __restrict__ shadowmap, CubeDesc C,
                                                   const float* __restrict__ srgb_lut, const float* __restrict__ unorm_lut,
@@ -2949,8 +2922,6 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(ZR_LIGHT_WAV
     const uint32_t tile_slot = blockIdx.x / PARTS;
     for (uint32_t i = threadIdx.x; i < 256u; i += (uint32_t)TB) { u8[i] = unorm_lut[i]; slut[i] = srgb_lut[i]; }
     for (uint32_t i = threadIdx.x; i < 1024u; i += (uint32_t)TB) u10[i] = unorm_lut[256u + i];
-    __shared__ uint32_t coff[16];        // CubeDesc::off (the reflection picks its two mip levels per pixel)
-    if (threadIdx.x < 16u) coff[threadIdx.x] = C.off_dev[threadIdx.x];
     __syncthreads();
     if (L.clear_next) {      // the clear of the next frame's shadow pass (depth 1.0, ZE:3248), a slice per workgroup: saves a launch
         const uint32_t per = (L.clear_n + gridDim.x - 1u) / gridDim.x, b = blockIdx.x * per;
@@ -2976,9 +2947,9 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(ZR_LIGHT_WAV
         for (uint32_t i = tid; i < TILE_PIX; i += T) {
             const int px = tx0 + (int)(i & (TILE - 1)), py = ty0 + (int)(i / TILE);
             if (px >= (int)L.W || py >= (int)L.H) continue;
-            const uint32_t p = (uint32_t)py * L.W + (uint32_t)px;
-            if ((ld_at(G.scene_color, p) >> 24) == 0u) continue;
-            const uint2 D = ld_at(G.gD, p);
+            const size_t p = (size_t)py * L.W + (size_t)px;
+            if ((G.scene_color[p] >> 24) == 0u) continue;
+            const uint2 D = G.gD[p];
             const float q[3] = { f16_to_f32_hw(D.x & 0xFFFFu), f16_to_f32_hw(D.x >> 16), f16_to_f32_hw(D.y & 0xFFFFu) };
             for (int a = 0; a < 3; ++a) {
                 if (!(__builtin_fabsf(q[a]) <= 3.402823466e38f)) odd = true;
@@ -3020,15 +2991,15 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(ZR_LIGHT_WAV
     for (uint32_t i = tid; i < TILE_PIX; i += T) {
         const int px = tx0 + (int)(i & (TILE - 1)), py = ty0 + (int)(i / TILE);
         if (px >= (int)L.W || py >= (int)L.H) continue;
-        const uint32_t p = (uint32_t)py * L.W + (uint32_t)px;
-        const uint32_t sc = ld_at(G.scene_color, p), A = ld_at(G.gA, p), B = ld_at(G.gB, p), Cc = ld_at(G.gC, p);
-        const uint2 D = ld_at(G.gD, p);
+        const size_t p = (size_t)py * L.W + (size_t)px;
+        const uint32_t sc = G.scene_color[p], A = G.gA[p], B = G.gB[p], Cc = G.gC[p];
+        const uint2 D = G.gD[p];
         // what every path ends with: the skydome / background drawn over the lit quad in view 0 (ZE:3681-3699), then the store
         auto emit = [&](uint32_t rgba) {
             if (L.debug_view == 0u) {
-                const uint32_t ov = L.has_overlay ? ld_at(G.overlay, p) : 0u;
+                const uint32_t ov = L.has_overlay ? G.overlay[p] : 0u;
                 if (ov) rgba = ov;
-                else if (BACKGROUND && L.bg_enabled && 1.0f <= ld_at(G.depth, p)) {
+                else if (BACKGROUND && L.bg_enabled && 1.0f <= G.depth[p]) {
                     const float u = ((float)px + 0.5f) / (float)L.W, v = ((float)py + 0.5f) / (float)L.H;
                     const float one4[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
                     const zf4 bgc = tex_sample<2>(L.bg, one4, true, tl, u, v, 1.0f / (float)L.W, 0.0f, 0.0f, 1.0f / (float)L.H);
@@ -3036,7 +3007,8 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(ZR_LIGHT_WAV
                            zr_unorm(zr_pow(bgc.z, 0.4545f), 255.0f) << 16 | 255u << 24;
                 }
             }
-            st_at(out, L.packed_out ? tile_slot * TILE_PIX + i : p, rgba);
+            if (L.packed_out) out[(size_t)tile_slot * TILE_PIX + i] = rgba;
+            else out[p] = rgba;
         };
         // A pixel nothing was drawn to holds the clear values of every target (ZE:3427-3433), so the shader computes the same
         // colour for all of them: it was computed once (zr_launch_lighting's one-pixel pre-launch of this very kernel).
@@ -3090,10 +3062,8 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(ZR_LIGHT_WAV
                 uint32_t lit = 0u;
 #pragma unroll
                 for (int y = 0; y < 5; ++y) {
-                    const ZR_AS_GLOBAL uint8_t* sm = (const ZR_AS_GLOBAL uint8_t*)shadowmap;      // (uniform base + 32-bit byte offset, see ld_at)
-                    const uint32_t o0 = (uint32_t)(ry0[y] + cb) << 2, o1 = (uint32_t)(ry1[y] + cb) << 2;
-                    const float4_u a0 = *(const ZR_AS_GLOBAL float4_u*)(sm + (size_t)o0), a1 = *(const ZR_AS_GLOBAL float4_u*)(sm + (size_t)(o0 + 16u));
-                    const float4_u b0 = *(const ZR_AS_GLOBAL float4_u*)(sm + (size_t)o1), b1 = *(const ZR_AS_GLOBAL float4_u*)(sm + (size_t)(o1 + 16u));
+                    const float4_u a0 = *(const float4_u*)(shadowmap + ry0[y] + cb), a1 = *(const float4_u*)(shadowmap + ry0[y] + cb + 4);
+                    const float4_u b0 = *(const float4_u*)(shadowmap + ry1[y] + cb), b1 = *(const float4_u*)(shadowmap + ry1[y] + cb + 4);
                     const float t00[5] = { a0.x, p1 ? a0.z : a0.y, a0.w, p3 ? a1.y : a1.x, a1.z };
                     const float t10[5] = { a0.y, p1 ? a0.w : a0.z, a1.x, p3 ? a1.z : a1.y, a1.w };
                     const float t01[5] = { b0.x, p1 ? b0.z : b0.y, b0.w, p3 ? b1.y : b1.x, b1.z };
@@ -3114,8 +3084,8 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(ZR_LIGHT_WAV
                 for (int x = 0; x < 5; ++x)
 #pragma unroll
                     for (int y = 0; y < 5; ++y) {
-                        const float t00 = ld_at(shadowmap, (uint32_t)(ry0[y] + cx0[x])), t10 = ld_at(shadowmap, (uint32_t)(ry0[y] + cx1[x]));
-                        const float t01 = ld_at(shadowmap, (uint32_t)(ry1[y] + cx0[x])), t11 = ld_at(shadowmap, (uint32_t)(ry1[y] + cx1[x]));
+                        const float t00 = shadowmap[ry0[y] + cx0[x]], t10 = shadowmap[ry0[y] + cx1[x]];
+                        const float t01 = shadowmap[ry1[y] + cx0[x]], t11 = shadowmap[ry1[y] + cx1[x]];
                         const float top = __builtin_fmaf(wa[x], t10 - t00, t00), bot = __builtin_fmaf(wa[x], t11 - t01, t01);
                         const float dist = __builtin_fmaf(wb[y], bot - top, top);
                         sum += (sw > 0.0f && dist < sz) ? 0.1f : 1.0f;
@@ -3216,7 +3186,7 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(ZR_LIGHT_WAV
         }
         // ComputeReflectionMipFromRoughness, SH/Common.glsl:191-198
         const float MIPS = (maxmips - 1.0f) - __builtin_fmaf(-1.2f, zr_log2(__builtin_fmaxf(Roughness, 0.001f)), 1.0f);
-        const zf3 RL = (ZR_DIAG_SKIP(L.debug_skip) & 4u) ? zr3(0.0f, 0.0f, 0.0f) : cube_sample(C, coff, slut, L.cube_dim, (int)L.cube_levels, R, MIPS) * 10.0f;
+        const zf3 RL = (ZR_DIAG_SKIP(L.debug_skip) & 4u) ? zr3(0.0f, 0.0f, 0.0f) : cube_sample(C, slut, L.cube_dim, (int)L.cube_levels, R, MIPS) * 10.0f;
         const float RV = zr_saturate((zr_pow(NdotV + AO, Roughness * Roughness) - 1.0f) + AO);   // GetSpecularOcclusion :226
         const zf3 RefC = zr3((RL.x * RV) * RBRDF.x, (RL.y * RV) * RBRDF.y, (RL.z * RV) * RBRDF.z);
 
@@ -3334,7 +3304,7 @@ __global__ __launch_bounds__(256) void k_gbuffer_vis(ZrLightParams L, const XkVi
                 const float q = __builtin_fmaf(eta, dNI, __builtin_sqrtf(kk));
                 R = zr3(__builtin_fmaf(eta, Vv.x, -(q * Nn.x)), __builtin_fmaf(eta, Vv.y, -(q * Nn.y)), __builtin_fmaf(eta, Vv.z, -(q * Nn.z)));
             }
-            o = cube_sample(C, C.off, srgb_lut, L.cube_dim, (int)L.cube_levels, R, 0.0f) * 10.0f;
+            o = cube_sample(C, srgb_lut, L.cube_dim, (int)L.cube_levels, R, 0.0f) * 10.0f;
             break;
         }
         default: {

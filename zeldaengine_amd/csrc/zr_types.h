@@ -185,9 +185,7 @@ struct GBufferPtrs {
     uint32_t* overlay;               // RGBA8 of the skydome pass (0 = nothing drawn); not a GBuffer attachment
 };
 // Cubemap mip chain, level l = 6 faces of (dim >> l)^2 RGBA8 sRGB texels, face-major.
-// The cubemap's mip chain in ONE allocation (level l's six faces start off[l] bytes in; at most 8192^2 faces: 2.1 GB, 32-bit offsets);
-// off_dev: the same offsets in device memory (a kernel's LDS copy is filled from there: a level is picked per pixel)
-struct CubeDesc { const uint8_t* base; const uint32_t* off_dev; uint32_t off[16]; };
+struct CubeDesc { const uint8_t* levels[16]; };
 
 // launchers defined in zr_kernels.hip
 void zr_launch_instance_prep(const XkInstanceData* in, ZrInstance* out, uint32_t n, uint32_t instanced, hipStream_t s);
