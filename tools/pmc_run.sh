@@ -3,7 +3,7 @@ tag=$1; ctrs=$2
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc_$tag
-timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d $R/gpurun_out/pmc_$tag -o p -- python3 $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pmc_$tag.err || { tail -5 $R/gpurun_out/pmc_$tag.err; exit 1; }
+timeout -k 5 ${PMC_TIMEOUT:-300} rocprofv3 --pmc $ctrs --output-format csv -d $R/gpurun_out/pmc_$tag -o p -- python3 $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pmc_$tag.err || { tail -5 $R/gpurun_out/pmc_$tag.err; exit 1; }
 cd $R && python - "$tag" <<'PY'
 import csv, glob, sys
 from collections import defaultdict
