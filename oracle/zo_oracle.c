@@ -1054,12 +1054,9 @@ static void zo_gbuffer_sample(const zo_ctx* c, float u, float v, zo_gtexel* out)
 static float zo_pcf(const zo_ctx* c, const float* SB, zo_v3 P, float dxy)
 {
     zo_v4 s4 = zo_mat4_point(SB, P);
-#ifdef ZO_LITERAL
+    /* shadowCoord / shadowCoord.w (SH/Common.glsl:296): a correctly rounded division per component in BOTH builds since round 6 - as
+       reciprocal-multiply it moved z by an ulp and with it the PCF comparison's ties (oracle/CONTRACT.md, the struck part of row 3) */
     float sx = s4.x / s4.w, sy = s4.y / s4.w, sz = s4.z / s4.w, sw = s4.w / s4.w;
-#else
-    float rsw = 1.0f / s4.w;                                /* shadowCoord / shadowCoord.w */
-    float sx = s4.x * rsw, sy = s4.y * rsw, sz = s4.z * rsw, sw = s4.w * rsw;
-#endif
     float sum = 0.0f;
     for (int x = -2; x <= 2; ++x) for (int y = -2; y <= 2; ++y)               /* ComputePCF r=2, :323-342 */
         sum += zo_shadow_tap(c, sx, sy, sz, sw, dxy * (float)x, dxy * (float)y);

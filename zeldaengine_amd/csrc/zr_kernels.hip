@@ -3030,8 +3030,9 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(ZR_LIGHT_WAV
         const float NdotV = zr_saturate(zr_dot(N, Vv));
 
         const zf4 s4 = zr_mat4_point(L.SB, Pw);
-        const float rsw = 1.0f / s4.w;                 // shadowCoord / shadowCoord.w: one IEEE reciprocal, four multiplies
-        const float sx = s4.x * rsw, sy = s4.y * rsw, sz = s4.z * rsw, sw = s4.w * rsw;
+        // shadowCoord / shadowCoord.w (SH/Common.glsl:296): IEEE divisions - the PCF comparison below is the shader's one discontinuity,
+        // and a reciprocal-multiply moved its ties (oracle/CONTRACT.md)
+        const float sx = s4.x / s4.w, sy = s4.y / s4.w, sz = s4.z / s4.w, sw = s4.w / s4.w;
         // ComputePCF r = 2 (SH/Common.glsl:323-342): 25 taps of ShadowDepthProject.  A tap's texel column / row and bilinear
         // weight depend only on its x / y offset, so they are formed once per axis (5 + 5) instead of once per tap (25 + 25);
         // every tap still evaluates fma(sx + ox, dim, -0.5) etc. with the same operands, i.e. the same bits.
@@ -3309,8 +3310,7 @@ __global__ __launch_bounds__(256) void k_gbuffer_vis(ZrLightParams L, const XkVi
         }
         default: {
             const zf4 s4 = zr_mat4_point(L.SB, Pw);
-            const float rsw = 1.0f / s4.w;
-            const float sx = s4.x * rsw, sy = s4.y * rsw, sz = s4.z * rsw, sw = s4.w * rsw;
+            const float sx = s4.x / s4.w, sy = s4.y / s4.w, sz = s4.z / s4.w, sw = s4.w / s4.w;
             const float dxy = 1.5f * 1.0f / (float)L.SD;
             float sum = 0.0f;
             for (int xo = -2; xo <= 2; ++xo)
