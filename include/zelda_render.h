@@ -37,7 +37,7 @@ extern "C" {
 
 /* Version of this header's structs and entry points.  A host checks zr_abi_version() == ZR_ABI_VERSION after loading the library
  * (INTEGRATION.md); structs that may grow (zr_stats) are passed with their size as the caller knows it and only ever grow at the end. */
-#define ZR_ABI_VERSION 5u
+#define ZR_ABI_VERSION 6u
 
 #ifndef ZR_TILE
 #define ZR_TILE 32            /* screen tile edge in pixels (raster + multi-GPU partition unit); 32 or 64 */
@@ -177,6 +177,14 @@ int  zr_update_uniforms(zr_ctx* ctx, const zr_camera* cam,
 int  zr_set_frame(zr_ctx* ctx, const XkUniformBufferMVP* camera, const XkUniformBufferMVP* shadow, const XkView* view);
 int  zr_get_frame(zr_ctx* ctx, XkUniformBufferMVP* camera, XkUniformBufferMVP* shadow, XkView* view);
 int  zr_set_debug_view(zr_ctx* ctx, uint32_t spec_constants);
+/* Which of the engine's two scene pipelines shades the frame (ZE:93 ENABLE_DEFERRED_SHADING picks one at compile time):
+ *   ZR_SHADING_DEFERRED (default)  BaseScene.frag -> GBuffer -> BaseLighting.frag (ZE:2803-2997, 3417-3480, 3531-3540);
+ *   ZR_SHADING_FORWARD             Base.frag:46-144 straight into the frame (pipelines ZE:2749-2801, draws ZE:3544-3680): unquantised
+ *                                  inputs, no Mask, FinalColor * ShadowFactor, Base.frag's own debug table (:123-143; view 9 = view 0).
+ * Takes effect with the next frame; between the stages of a frame: ZR_ERR_STATE.  The GBuffer targets are still written (zr_read_gbuffer). */
+#define ZR_SHADING_DEFERRED 0u
+#define ZR_SHADING_FORWARD  1u
+int  zr_set_shading(zr_ctx* ctx, uint32_t mode);
 
 /* --- the frame (replaces RecordCommandBuffer ZE:3160-3744 + vkQueueSubmit ZE:2014) ---
  * cull -> shadow -> cull -> gbuffer -> lighting [-> composite].  Asynchronous: the call only enqueues.  The shadow pipeline and

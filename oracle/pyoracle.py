@@ -48,6 +48,7 @@ def lib(literal=False):
         L.zo_set_frame.argtypes = [C.c_void_p] * 4
         L.zo_get_frame.argtypes = [C.c_void_p] * 4
         L.zo_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.zo_set_shading.argtypes = [C.c_void_p, C.c_int]
         for n in ("zo_color", "zo_shadowmap", "zo_visibility"):
             getattr(L, n).restype = C.c_void_p
             getattr(L, n).argtypes = [C.c_void_p]
@@ -168,6 +169,10 @@ class Oracle:
 
     def set_frame(self, cam, sh, view):
         self.L.zo_set_frame(self.h, cam.ctypes.data, sh.ctypes.data, view.ctypes.data)
+
+    def set_shading(self, forward):
+        """False: the deferred frame; True: the forward variant (SH/Base.frag)."""
+        self.L.zo_set_shading(self.h, int(bool(forward)))
 
     def render(self, debug_view=0, passes=7):
         self.L.zo_render(self.h, debug_view, passes)

@@ -51,7 +51,11 @@ struct zo_ctx {
     /* skydome + background passes (ZE:2657-2744, 3681-3699) */
     zo_mesh sky_mesh; zo_tex sky_tex; int sky_set, sky_enabled; zo_tex bg_tex; int bg_set, bg_enabled;
     uint32_t* overlay; float* main_depth; uint32_t* sky_vis;
+    /* forward variant (SH/Base.frag; the engine built with ENABLE_DEFERRED_SHADING false, ZE:93): the fragment's unquantised inputs */
+    int forward; struct zo_fsurf* fwd;
 };
+/* what Base.frag:48-60 holds before it lights the fragment: nothing has been through a render-target format */
+typedef struct zo_fsurf { zo_v3 BaseColor; float Metallic, Roughness; zo_v3 Normal, AmbientOcclution, P, VertexColor; } zo_fsurf;
 
 static int zo_idx_clamp(float f, int hi);
 static uint8_t zo_srgb_encode(float l);
@@ -126,7 +130,7 @@ void zo_destroy(zo_ctx* c)
     if (!c) return;
     zo_scene_clear(c); zo_free_cube(c);
     free(c->depth); free(c->scene_color); free(c->gA); free(c->gB); free(c->gC); free(c->gD);
-    free(c->vis); free(c->color); free(c->shadowmap); free(c->overlay); free(c->main_depth); free(c->sky_vis);
+    free(c->vis); free(c->color); free(c->shadowmap); free(c->overlay); free(c->main_depth); free(c->sky_vis); free(c->fwd);
     zo_set_skydome(c, NULL, 0, NULL, 0, NULL); zo_set_background(c, NULL);
     free(c);
 }
@@ -936,6 +940,19 @@ static void zo_resolve_gbuffer(zo_ctx* c, const float* PVM)
 
         zo_v3 Nw = zo_compute_normal(pos_dx, pos_dy, s1, t1, s2, t2, f0.N, zo_v3make(nm[0], nm[1], nm[2]));
         float Rough = fmaxf(0.01f, ro[0]);
+        if (c->forward) {      /* Base.frag:48-60: the same fetches and ComputeNormal, kept as floats; fragColor interpolated like the rest */
+            zo_fsurf* F = &c->fwd[p];
+            const XkVertex* v0 = &m->v[m->idx[3 * tri]]; const XkVertex* v1 = &m->v[m->idx[3 * tri + 1u]]; const XkVertex* v2 = &m->v[m->idx[3 * tri + 2u]];
+            F->BaseColor = zo_v3make(bc[0], bc[1], bc[2]);
+            F->Metallic = zo_saturate(me[0]);
+            F->Roughness = fmaxf(0.01f, zo_saturate(ro[0]));
+            F->Normal = Nw;
+            F->AmbientOcclution = zo_v3make(ao[0], ao[1], ao[2]);
+            F->P = f0.P;
+            F->VertexColor = zo_v3make(fmaf(b0[2], v2->Color[0], fmaf(b0[1], v1->Color[0], b0[0] * v0->Color[0])),
+                                       fmaf(b0[2], v2->Color[1], fmaf(b0[1], v1->Color[1], b0[0] * v0->Color[1])),
+                                       fmaf(b0[2], v2->Color[2], fmaf(b0[1], v1->Color[2], b0[0] * v0->Color[2])));
+        }
         zo_v3 Nn = zo_normalize(Nw);
         zo_v3 NP = zo_v3make((Nn.x + 1.0f) / 2.0f, (Nn.y + 1.0f) / 2.0f, (Nn.z + 1.0f) / 2.0f);
         c->scene_color[p] = zo_unorm(em[0], 255.0f) | zo_unorm(em[1], 255.0f) << 8 | zo_unorm(em[2], 255.0f) << 16 | zo_unorm(ms[0], 255.0f) << 24;
@@ -1111,6 +1128,83 @@ static zo_v3 zo_gbuffer_vis(const zo_ctx* c, uint32_t px, uint32_t py, zo_v3 Fin
     }
 }
 
+/* What BaseLighting.frag:174-221 and Base.frag:62-112 have in common, word for word: the PCF factor, (1) direct lighting over the
+ * directional then the point lights, (2) the lambert indirect term, (3) the image-based reflection.  Inputs as the shader holds them at
+ * that point (N: `normalize(Normal)` of the unpacked GBufferA in the deferred shader, ComputeNormal()'s result in the forward one). */
+typedef struct { zo_v3 Direct, Indirect, RefC; float ShadowFactor; } zo_lit;
+static zo_lit zo_shade(const zo_ctx* c, const float* SB, zo_v3 cam, float dxy, zo_v3 BaseColor, float Metallic, float Roughness,
+                       zo_v3 N, float AO, zo_v3 P)
+{
+    const XkView* V = &c->view;
+    uint32_t nDir = (uint32_t)V->LightsCount[0], nPoint = (uint32_t)V->LightsCount[1];
+    float maxmips = (float)(uint32_t)V->LightsCount[3];
+    zo_v3 Vv = zo_normalize(zo_sub(cam, P));
+    float NdotV = zo_saturate(zo_dot(N, Vv));
+
+    float ShadowFactor = zo_pcf(c, SB, P, dxy);
+
+    zo_v3 Direct = zo_v3make(0, 0, 0);
+    zo_v3 Nn = zo_normalize(N);                  /* Apply*Light and refract() re-normalise N */
+    zo_v3 DiffuseColor = zo_scale(BaseColor, 1.0f - Metallic);
+    for (uint32_t i = 0; i < nDir + nPoint; ++i) {
+        int isdir = i < nDir;
+        const XkLight* Lt = isdir ? &V->DirectionalLights[i] : &V->PointLights[i - nDir];
+        zo_v3 lp = zo_v3make(Lt->Position[0], Lt->Position[1], Lt->Position[2]);
+        /* point light: distance() and normalize() of light_pos - position share one inversesqrt: length = d2 * inversesqrt(d2) */
+        zo_v3 dl = zo_sub(lp, P);
+        float d2 = zo_dot(dl, dl), rd = zo_shader_rsqrt(d2);
+        zo_v3 L = isdir ? zo_normalize(zo_v3make(Lt->Direction[0], Lt->Direction[1], Lt->Direction[2])) : zo_scale(dl, rd);
+        zo_v3 Hh = zo_normalize(zo_add(Vv, L));
+        float LdotH = zo_saturate(zo_dot(L, Hh)), NdotH = zo_saturate(zo_dot(N, Hh)), NdotL = zo_saturate(zo_dot(N, L));
+        /* DefaultLitBxDF, Common.glsl:259-282: F0 = 0.04, F90 = saturate(50*0.04) = 1 */
+        float F = zo_F_Schlick(0.04f, zo_saturate(50.0f * 0.04f), LdotH);
+        float Vis = zo_V_SmithGGXCorrelated(NdotV, NdotL, Roughness);
+        float Dg = zo_D_GGX(NdotH, Roughness);
+        float Fr = (F * Dg) * Vis;
+        float Fd = zo_Fr_DisneyDiffuse(NdotV, NdotL, LdotH, Roughness);
+        zo_v3 bx = zo_v3make(fmaf(DiffuseColor.x * (1.0f - F), Fd, Fr), fmaf(DiffuseColor.y * (1.0f - F), Fd, Fr),
+                             fmaf(DiffuseColor.z * (1.0f - F), Fd, Fr));
+        /* Apply*Light, Common.glsl:364-372 / 399-416 */
+        float ndotl = zo_clampf(zo_dot(Nn, L), 0.0f, 1.0f);
+        float k = ndotl * Lt->Color[3];
+        zo_v3 rad = zo_v3make(k * Lt->Color[0], k * Lt->Color[1], k * Lt->Color[2]);
+        if (isdir) {
+            Direct = zo_v3make(fmaf(rad.x * bx.x, ShadowFactor, Direct.x), fmaf(rad.y * bx.y, ShadowFactor, Direct.y),
+                               fmaf(rad.z * bx.z, ShadowFactor, Direct.z));
+        } else {
+            float dist = ZO_IS_LITERAL ? sqrtf(d2) : (d2 > 0.0f ? d2 * rd : 0.0f);      /* distance(): literal = its own sqrt */
+            float falloff = Lt->Direction[3];
+            float att = 1.0f - zo_clampf(dist, 0.0f, falloff) / falloff;   /* remap(dist,0,falloff,0,1), :43-47 */
+            rad = zo_scale(rad, att);
+            Direct = zo_v3make(fmaf(rad.x, bx.x, Direct.x), fmaf(rad.y, bx.y, Direct.y), fmaf(rad.z, bx.z, Direct.z));
+        }
+    }
+    /* (2) indirect, :210 */
+    zo_v3 Indirect = zo_v3make(((zo_div_pi(DiffuseColor.x) * AO) * 0.3f) * ShadowFactor,
+                               ((zo_div_pi(DiffuseColor.y) * AO) * 0.3f) * ShadowFactor,
+                               ((zo_div_pi(DiffuseColor.z) * AO) * 0.3f) * ShadowFactor);
+    /* (3) reflection, :213-221 */
+    zo_v3 bcl = zo_v3make(zo_clampf(BaseColor.x, 0.04f, 1.0f), zo_clampf(BaseColor.y, 0.04f, 1.0f), zo_clampf(BaseColor.z, 0.04f, 1.0f));
+    float dsf0 = (0.04f * 2.0f) * 0.5f;
+    zo_v3 RSpec = zo_v3make(fmaf(Metallic, bcl.x, (1.0f - Metallic) * dsf0), fmaf(Metallic, bcl.y, (1.0f - Metallic) * dsf0),
+                            fmaf(Metallic, bcl.z, (1.0f - Metallic) * dsf0));
+    float AB[2]; zo_EnvBRDFApproxLazarov(Roughness, NdotV, AB);
+    float F90 = zo_saturate(50.0f * RSpec.y);
+    zo_v3 RBRDF = zo_v3make(fmaf(RSpec.x, AB[0], F90 * AB[1]), fmaf(RSpec.y, AB[0], F90 * AB[1]), fmaf(RSpec.z, AB[0], F90 * AB[1]));
+    float eta = 1.00f / 1.52f;
+    float dNI = zo_dot(Nn, Vv);
+    float kk = fmaf(-(eta * eta), fmaf(-dNI, dNI, 1.0f), 1.0f);
+    zo_v3 R;
+    if (kk < 0.0f) R = zo_v3make(0, 0, 0);
+    else { float q = fmaf(eta, dNI, sqrtf(kk)); R = zo_v3make(fmaf(eta, Vv.x, -(q * Nn.x)), fmaf(eta, Vv.y, -(q * Nn.y)), fmaf(eta, Vv.z, -(q * Nn.z))); }
+    float MIPS = zo_ReflectionMip(Roughness, maxmips);
+    zo_v3 RL = zo_scale(zo_cube_sample(c, R, MIPS), 10.0f);
+    float RV = zo_saturate((zo_powf(NdotV + AO, Roughness * Roughness) - 1.0f) + AO);
+    zo_v3 RefC = zo_v3make((RL.x * RV) * RBRDF.x, (RL.y * RV) * RBRDF.y, (RL.z * RV) * RBRDF.z);
+    zo_lit r = { Direct, Indirect, RefC, ShadowFactor };
+    return r;
+}
+
 static void zo_lighting(zo_ctx* c, uint32_t debug_view)
 {
     const XkView* V = &c->view;
@@ -1118,8 +1212,6 @@ static void zo_lighting(zo_ctx* c, uint32_t debug_view)
     static const float Bias[16] = {0.5f,0,0,0, 0,0.5f,0,0, 0,0,1,0, 0.5f,0.5f,0,1};
     float SB[16]; zo_mat4_mul(Bias, V->ShadowmapSpace, SB);
     zo_v3 cam = zo_v3make(V->CameraInfo[0], V->CameraInfo[1], V->CameraInfo[2]);
-    uint32_t nDir = (uint32_t)V->LightsCount[0], nPoint = (uint32_t)V->LightsCount[1];
-    float maxmips = (float)(uint32_t)V->LightsCount[3];
     float dxy = 1.5f * 1.0f / (float)c->SD;
 #pragma omp parallel for schedule(dynamic, 4) num_threads(c->threads)
     for (uint32_t py = 0; py < c->H; ++py) for (uint32_t px = 0; px < c->W; ++px) {
@@ -1137,69 +1229,8 @@ static void zo_lighting(zo_ctx* c, uint32_t debug_view)
         float AO = zo_saturate(AOc);
         zo_v3 N = zo_normalize(Normal);
         zo_v3 P = zo_v3make(zo_f16_to_f32((uint16_t)D), zo_f16_to_f32((uint16_t)(D >> 16)), zo_f16_to_f32((uint16_t)(D >> 32)));
-        zo_v3 Vv = zo_normalize(zo_sub(cam, P));
-        float NdotV = zo_saturate(zo_dot(N, Vv));
-
-        float ShadowFactor = zo_pcf(c, SB, P, dxy);
-
-        zo_v3 Direct = zo_v3make(0, 0, 0);
-        zo_v3 Nn = zo_normalize(N);                  /* Apply*Light and refract() re-normalise N */
-        zo_v3 DiffuseColor = zo_scale(BaseColor, 1.0f - Metallic);
-        for (uint32_t i = 0; i < nDir + nPoint; ++i) {
-            int isdir = i < nDir;
-            const XkLight* Lt = isdir ? &V->DirectionalLights[i] : &V->PointLights[i - nDir];
-            zo_v3 lp = zo_v3make(Lt->Position[0], Lt->Position[1], Lt->Position[2]);
-            /* point light: distance() and normalize() of light_pos - position share one inversesqrt: length = d2 * inversesqrt(d2) */
-            zo_v3 dl = zo_sub(lp, P);
-            float d2 = zo_dot(dl, dl), rd = zo_shader_rsqrt(d2);
-            zo_v3 L = isdir ? zo_normalize(zo_v3make(Lt->Direction[0], Lt->Direction[1], Lt->Direction[2])) : zo_scale(dl, rd);
-            zo_v3 Hh = zo_normalize(zo_add(Vv, L));
-            float LdotH = zo_saturate(zo_dot(L, Hh)), NdotH = zo_saturate(zo_dot(N, Hh)), NdotL = zo_saturate(zo_dot(N, L));
-            /* DefaultLitBxDF, Common.glsl:259-282: F0 = 0.04, F90 = saturate(50*0.04) = 1 */
-            float F = zo_F_Schlick(0.04f, zo_saturate(50.0f * 0.04f), LdotH);
-            float Vis = zo_V_SmithGGXCorrelated(NdotV, NdotL, Roughness);
-            float Dg = zo_D_GGX(NdotH, Roughness);
-            float Fr = (F * Dg) * Vis;
-            float Fd = zo_Fr_DisneyDiffuse(NdotV, NdotL, LdotH, Roughness);
-            zo_v3 bx = zo_v3make(fmaf(DiffuseColor.x * (1.0f - F), Fd, Fr), fmaf(DiffuseColor.y * (1.0f - F), Fd, Fr),
-                                 fmaf(DiffuseColor.z * (1.0f - F), Fd, Fr));
-            /* Apply*Light, Common.glsl:364-372 / 399-416 */
-            float ndotl = zo_clampf(zo_dot(Nn, L), 0.0f, 1.0f);
-            float k = ndotl * Lt->Color[3];
-            zo_v3 rad = zo_v3make(k * Lt->Color[0], k * Lt->Color[1], k * Lt->Color[2]);
-            if (isdir) {
-                Direct = zo_v3make(fmaf(rad.x * bx.x, ShadowFactor, Direct.x), fmaf(rad.y * bx.y, ShadowFactor, Direct.y),
-                                   fmaf(rad.z * bx.z, ShadowFactor, Direct.z));
-            } else {
-                float dist = ZO_IS_LITERAL ? sqrtf(d2) : (d2 > 0.0f ? d2 * rd : 0.0f);      /* distance(): literal = its own sqrt */
-                float falloff = Lt->Direction[3];
-                float att = 1.0f - zo_clampf(dist, 0.0f, falloff) / falloff;   /* remap(dist,0,falloff,0,1), :43-47 */
-                rad = zo_scale(rad, att);
-                Direct = zo_v3make(fmaf(rad.x, bx.x, Direct.x), fmaf(rad.y, bx.y, Direct.y), fmaf(rad.z, bx.z, Direct.z));
-            }
-        }
-        /* (2) indirect, :210 */
-        zo_v3 Indirect = zo_v3make(((zo_div_pi(DiffuseColor.x) * AO) * 0.3f) * ShadowFactor,
-                                   ((zo_div_pi(DiffuseColor.y) * AO) * 0.3f) * ShadowFactor,
-                                   ((zo_div_pi(DiffuseColor.z) * AO) * 0.3f) * ShadowFactor);
-        /* (3) reflection, :213-221 */
-        zo_v3 bcl = zo_v3make(zo_clampf(BaseColor.x, 0.04f, 1.0f), zo_clampf(BaseColor.y, 0.04f, 1.0f), zo_clampf(BaseColor.z, 0.04f, 1.0f));
-        float dsf0 = (0.04f * 2.0f) * 0.5f;
-        zo_v3 RSpec = zo_v3make(fmaf(Metallic, bcl.x, (1.0f - Metallic) * dsf0), fmaf(Metallic, bcl.y, (1.0f - Metallic) * dsf0),
-                                fmaf(Metallic, bcl.z, (1.0f - Metallic) * dsf0));
-        float AB[2]; zo_EnvBRDFApproxLazarov(Roughness, NdotV, AB);
-        float F90 = zo_saturate(50.0f * RSpec.y);
-        zo_v3 RBRDF = zo_v3make(fmaf(RSpec.x, AB[0], F90 * AB[1]), fmaf(RSpec.y, AB[0], F90 * AB[1]), fmaf(RSpec.z, AB[0], F90 * AB[1]));
-        float eta = 1.00f / 1.52f;
-        float dNI = zo_dot(Nn, Vv);
-        float kk = fmaf(-(eta * eta), fmaf(-dNI, dNI, 1.0f), 1.0f);
-        zo_v3 R;
-        if (kk < 0.0f) R = zo_v3make(0, 0, 0);
-        else { float q = fmaf(eta, dNI, sqrtf(kk)); R = zo_v3make(fmaf(eta, Vv.x, -(q * Nn.x)), fmaf(eta, Vv.y, -(q * Nn.y)), fmaf(eta, Vv.z, -(q * Nn.z))); }
-        float MIPS = zo_ReflectionMip(Roughness, maxmips);
-        zo_v3 RL = zo_scale(zo_cube_sample(c, R, MIPS), 10.0f);
-        float RV = zo_saturate((zo_powf(NdotV + AO, Roughness * Roughness) - 1.0f) + AO);
-        zo_v3 RefC = zo_v3make((RL.x * RV) * RBRDF.x, (RL.y * RV) * RBRDF.y, (RL.z * RV) * RBRDF.z);
+        zo_lit lit = zo_shade(c, SB, cam, dxy, BaseColor, Metallic, Roughness, N, AO, P);
+        zo_v3 Direct = lit.Direct, Indirect = lit.Indirect, RefC = lit.RefC; float ShadowFactor = lit.ShadowFactor;
 
         zo_v3 Final = zo_add(zo_add(Direct, Indirect), RefC);
         Final = zo_scale(Final, Mask);
@@ -1226,6 +1257,55 @@ static void zo_lighting(zo_ctx* c, uint32_t debug_view)
         o[0] = (uint8_t)zo_unorm(out.x, 255.0f); o[1] = (uint8_t)zo_unorm(out.y, 255.0f);
         o[2] = (uint8_t)zo_unorm(out.z, 255.0f); o[3] = 255;
         if (debug_view == 0 && c->overlay[p]) memcpy(o, &c->overlay[p], 4);   /* skydome / background drawn over the lit quad */
+    }
+}
+
+/* ------------------------------------------------------------------ forward variant (SH/Base.frag:46-144) */
+/* The engine built with ENABLE_DEFERRED_SHADING false (ZE:93): the main render pass clears colour (0,0,0,1) and depth 1.0 (ZE:3517-3519,
+ * 2366-2373) and Base.frag shades every fragment that passes LESS straight into the swapchain image (pipelines ZE:2749-2801, draws
+ * ZE:3544-3680).  Against the deferred path: the inputs never pass through a render-target format, N is ComputeNormal()'s result as it
+ * is, AO is not saturated, there is no Mask, case 0 shows FinalColor * ShadowFactor (gamma first, :114-121), and the debug table is
+ * Base.frag's own (:123-143: base colour without gamma, AmbientOcclution.rgb, the interpolated vertex colour, no GBufferVis).  The
+ * skydome and background follow in the same pass (view 0 only, ZE:3681-3699), depth-tested as in the deferred frame. */
+void zo_set_shading(zo_ctx* c, int forward)
+{
+    c->forward = forward != 0;
+    if (c->forward && !c->fwd) c->fwd = (zo_fsurf*)calloc((size_t)c->W * c->H, sizeof(zo_fsurf));
+}
+
+static void zo_forward_shading(zo_ctx* c, uint32_t debug_view)
+{
+    const XkView* V = &c->view;
+    static const float Bias[16] = {0.5f,0,0,0, 0,0.5f,0,0, 0,0,1,0, 0.5f,0.5f,0,1};
+    float SB[16]; zo_mat4_mul(Bias, V->ShadowmapSpace, SB);
+    zo_v3 cam = zo_v3make(V->CameraInfo[0], V->CameraInfo[1], V->CameraInfo[2]);
+    float dxy = 1.5f * 1.0f / (float)c->SD;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(c->threads)
+    for (uint32_t py = 0; py < c->H; ++py) for (uint32_t px = 0; px < c->W; ++px) {
+        size_t p = (size_t)py * c->W + px;
+        uint8_t* o = c->color + p * 4;
+        o[0] = o[1] = o[2] = 0; o[3] = 255;                              /* clearValues[0].color, ZE:3517 */
+        if (c->vis[p] != ZO_EMPTY) {
+            const zo_fsurf* F = &c->fwd[p];
+            float AO = F->AmbientOcclution.x;                            /* Base.frag:57: not saturated */
+            zo_lit lit = zo_shade(c, SB, cam, dxy, F->BaseColor, F->Metallic, F->Roughness, F->Normal, AO, F->P);
+            zo_v3 Final = zo_add(zo_add(lit.Direct, lit.Indirect), lit.RefC);
+            Final = zo_v3make(zo_powf(Final.x, 0.4545f), zo_powf(Final.y, 0.4545f), zo_powf(Final.z, 0.4545f));
+            zo_v3 out;
+            switch (debug_view) {
+            case 1: out = F->BaseColor; break;
+            case 2: out = zo_v3make(F->Metallic, F->Metallic, F->Metallic); break;
+            case 3: out = zo_v3make(F->Roughness, F->Roughness, F->Roughness); break;
+            case 4: out = F->Normal; break;
+            case 5: out = F->AmbientOcclution; break;
+            case 6: out = F->VertexColor; break;
+            case 7: out = lit.RefC; break;
+            case 8: out = zo_v3make(lit.ShadowFactor, lit.ShadowFactor, lit.ShadowFactor); break;
+            default: out = zo_scale(Final, lit.ShadowFactor); break;    /* cases 0, 9 and default */
+            }
+            o[0] = (uint8_t)zo_unorm(out.x, 255.0f); o[1] = (uint8_t)zo_unorm(out.y, 255.0f); o[2] = (uint8_t)zo_unorm(out.z, 255.0f);
+        }
+        if (debug_view == 0 && c->overlay[p]) memcpy(o, &c->overlay[p], 4);
     }
 }
 
@@ -1341,7 +1421,7 @@ void zo_render(zo_ctx* c, uint32_t debug_view, uint32_t passes)
         zo_resolve_gbuffer(c, PVM);
         zo_sky_background(c, PVM);
     }
-    if (passes & 4u) zo_lighting(c, debug_view);             /* lighting quad, ZE:3531-3540 */
+    if (passes & 4u) { if (c->forward) zo_forward_shading(c, debug_view); else zo_lighting(c, debug_view); }   /* lighting quad, ZE:3531-3540 */
 }
 
 const uint8_t* zo_color(zo_ctx* c) { return c->color; }

@@ -37,6 +37,8 @@ void    zo_update_uniforms(zo_ctx*, const zo_camera* cam, const XkLight* dir, ui
                            float roll_stage, float roll_light, float time);
 void    zo_set_frame(zo_ctx*, const XkUniformBufferMVP* camera, const XkUniformBufferMVP* shadow, const XkView* view);
 void    zo_get_frame(zo_ctx*, XkUniformBufferMVP* camera, XkUniformBufferMVP* shadow, XkView* view);
+/* 0 (default): the deferred frame (BaseScene.frag + BaseLighting.frag); 1: the forward variant (Base.frag:46-144) - set before zo_render */
+void    zo_set_shading(zo_ctx*, int forward);
 /* passes bitmask: 1 shadow, 2 gbuffer, 4 lighting */
 void    zo_render(zo_ctx*, uint32_t debug_view, uint32_t passes);
 const uint8_t*  zo_color(zo_ctx*);              /* W*H RGBA8 */

@@ -58,7 +58,7 @@ class Stats(C.Structure):
                 ("hiz_culled_geom", C.c_uint32), ("struct_bytes", C.c_uint32)]
 
 
-ABI_VERSION = 5      # ZR_ABI_VERSION of include/zelda_render.h
+ABI_VERSION = 6      # ZR_ABI_VERSION of include/zelda_render.h
 
 
 PASS_NAMES = ["cull_shadow", "shadow", "cull_camera", "gbuffer", "hiz", "gbuffer2", "resolve", "lighting", "composite", "total"]

@@ -75,6 +75,7 @@ struct zr_ctx {
 
     XkUniformBufferMVP cam, shadow; XkView view; XkView* d_view = nullptr; bool frame_valid = false;
     uint32_t debug_view = 0;
+    uint32_t shading = 0;                           // ZR_SHADING_*: which scene pipeline shades the frame (zr_set_shading)
 
     uint32_t W = 0, H = 0, SD = 0;
     uint32_t tiles_x = 0, tiles_y = 0, n_tiles = 0, n_owned = 0, slots_per_rank = 0;
@@ -124,6 +125,7 @@ struct zr_ctx {
     // it reuses the double-buffered copies, and consecutive ones give the per-frame GPU period (zr_get_frame_periods) for free.
     static constexpr int END_RING = 512;
     hipEvent_t ev_end[END_RING] = {};
+    uint32_t* d_prim_b[2] = { nullptr, nullptr };   // forward variant: winner ids per GBuffer copy (zr_set_shading)
     GBufferPtrs Gb[2] = {}; float* d_shadow_b[2] = { nullptr, nullptr }; XkView* d_view_b[2] = { nullptr, nullptr };
     uint32_t* d_empty_b[2] = { nullptr, nullptr };
     bool overlay_dirty[2] = { false, false };       // Gb[i].overlay may hold skydome pixels of an earlier frame

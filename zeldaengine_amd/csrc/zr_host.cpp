@@ -303,7 +303,7 @@ extern "C" void zr_destroy(zr_ctx* c)
     for (int b = 0; b < 2; ++b) {
         GBufferPtrs& G = c->Gb[b];
         dev_free(G.depth); dev_free(G.scene_color); dev_free(G.gA); dev_free(G.gB); dev_free(G.gC); dev_free(G.gD); dev_free(G.overlay);
-        dev_free(c->d_shadow_b[b]); dev_free(c->d_view_b[b]); dev_free(c->d_empty_b[b]);
+        dev_free(c->d_shadow_b[b]); dev_free(c->d_view_b[b]); dev_free(c->d_empty_b[b]); dev_free(c->d_prim_b[b]);
     }
     dev_free(c->d_color); dev_free(c->d_stats); dev_free(c->d_sstats); dev_free(c->d_lut); dev_free(c->d_unorm_lut); dev_free(c->d_sky_keys);
     dev_free(c->d_owned); dev_free(c->d_sowned); dev_free(c->d_tiles); dev_free(c->d_tile_map); dev_free(c->d_sowned_rank); dev_free(c->d_stile_map);
@@ -1052,6 +1052,34 @@ extern "C" int zr_get_frame(zr_ctx* c, XkUniformBufferMVP* cam, XkUniformBufferM
 }
 extern "C" int zr_set_debug_view(zr_ctx* c, uint32_t s) { if (!c) return ZR_ERR_ARG; c->debug_view = s; return ZR_OK; }
 
+// Forward variant (SH/Base.frag): the resolve additionally keeps each pixel's winning primitive id (one more plane per GBuffer copy,
+// allocated on first use), and the lighting step runs k_forward on those instead of k_lighting on the GBuffer.
+static int zr_set_shading_impl(zr_ctx* c, uint32_t mode)
+{
+    if (!c) return ZR_ERR_ARG;
+    if (mode != ZR_SHADING_DEFERRED && mode != ZR_SHADING_FORWARD) return zr_fail(c, ZR_ERR_ARG, "zr_set_shading: unknown mode");
+    if (c->stage != 0) return zr_fail(c, ZR_ERR_STATE, "zr_set_shading between the stages of a frame");
+    if (mode == c->shading) return ZR_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    // frames in flight read / write the planes this call swaps in or out
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->cam_s) HIPCHK(c, hipStreamSynchronize(c->cam_s));
+    const size_t n = (size_t)c->W * c->H;
+    for (int b = 0; b < 2; ++b) {
+        if (mode == ZR_SHADING_FORWARD && !c->d_prim_b[b]) {
+            if (dev_alloc(&c->d_prim_b[b], n) != hipSuccess) return zr_fail(c, ZR_ERR_DEVICE, "zr_set_shading: out of device memory");
+            HIPCHK(c, hipMemset(c->d_prim_b[b], 0xFF, n * 4));
+        }
+        c->Gb[b].prim = mode == ZR_SHADING_FORWARD ? c->d_prim_b[b] : nullptr;
+    }
+    c->shading = mode;
+    return ZR_OK;
+}
+extern "C" int zr_set_shading(zr_ctx* c, uint32_t mode)
+{
+    return zr_guard(c, [&]() { return zr_set_shading_impl(c, mode); });
+}
+
 static bool finite16(const float* m) { for (int i = 0; i < 16; ++i) if (!std::isfinite(m[i])) return false; return true; }
 static bool rigid3(const float* m)     // upper 3x3 orthonormal, det > 0, last row 0 0 0 1
 {
@@ -1455,7 +1483,7 @@ static void light_params(const zr_ctx* c, ZrLightParams* Lp)
 static int empty_pixel_pass(zr_ctx* c, hipStream_t s)
 {
     c->empty_ready = false;
-    if (c->debug_view == 6u || c->env_no_empty_px) return ZR_OK;
+    if (c->debug_view == 6u || c->env_no_empty_px || c->shading == ZR_SHADING_FORWARD) return ZR_OK;      // (forward: an empty pixel is the clear colour)
     ZrLightParams L; light_params(c, &L);
     L.W = 1; L.H = 1; L.tiles_x = 1; L.packed_out = 0; L.bg_enabled = 0;
     zr_launch_lighting(L, c->d_view, c->d_sowned, 1, c->Gclear, shadow_buf(c), c->cube, c->d_lut, c->d_unorm_lut, c->d_empty_rgba, s);
@@ -1473,10 +1501,16 @@ static int lighting_pass(zr_ctx* c, hipStream_t s)
     // writes while this pass runs: clear it here.
     const int npar = (int)((c->frame_no + 1u) & 1u);
     if (c->n_owned && s == c->stream) { L.clear_next = (uint32_t*)c->d_shadow_b[npar]; L.clear_n = c->SD * c->SD; c->shadow_cleared[npar] = true; }
-    zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, shadow_buf(c), c->cube, c->d_lut, c->d_unorm_lut,
-                       L.packed_out ? (c->d_tiles_ext ? c->d_tiles_ext : c->d_tiles) : c->d_color, s);
-    if (c->debug_view == 9u)        // GBufferVis mosaic over the lit frame (needs the whole GBuffer: single-rank contexts only)
-        zr_launch_gbuffer_vis(L, c->d_view, c->G, shadow_buf(c), c->cube, c->d_lut, c->d_color, s);
+    uint32_t* const frame_out = L.packed_out ? (c->d_tiles_ext ? c->d_tiles_ext : c->d_tiles) : c->d_color;
+    if (c->shading == ZR_SHADING_FORWARD) {
+        // Base.frag over the winners the resolve recorded, with this frame's camera block (frame_begin built it; the overlay fields play no part)
+        if (L.clear_next) { zr_launch_fill32(L.clear_next, 0x3F800000u, L.clear_n, s); L.clear_next = nullptr; }
+        zr_launch_forward(c->pass[1], L, c->d_view, c->d_objs, c->d_owned, c->n_owned, c->G, shadow_buf(c), c->cube, c->d_lut, c->d_unorm_lut, frame_out, s);
+    } else {
+        zr_launch_lighting(L, c->d_view, c->d_owned, c->n_owned, c->G, shadow_buf(c), c->cube, c->d_lut, c->d_unorm_lut, frame_out, s);
+        if (c->debug_view == 9u)        // GBufferVis mosaic over the lit frame (needs the whole GBuffer: single-rank contexts only)
+            zr_launch_gbuffer_vis(L, c->d_view, c->G, shadow_buf(c), c->cube, c->d_lut, c->d_color, s);
+    }
     if (ev) HIPCHK(c, hipEventRecord(ev[8], s));
     HIPCHK(c, hipEventRecord(c->ev_end[c->frame_no % zr_ctx::END_RING], s));      // this frame's GBuffer / shadow map / uniforms copies are free again
     HIPCHK(c, hipGetLastError());

@@ -1565,25 +1565,24 @@ __device__ __forceinline__ zf3 model_point(const ZrPass& P, zf3 p)
     return zr3(w.x, w.y, w.z);
 }
 
-// BaseScene.frag:26-48 for the pixel (px, py) whose winning primitive is `prim`
-// returns true when the pixel holds scene geometry (not empty, not sky)
-template <int IMAGES>
-__device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* __restrict__ objs, uint32_t prim, float depth,
-                                              int px, int py, const GBufferPtrs& G, const float* __restrict__ lut,
-                                              uint8_t* __restrict__ vis_now, uint32_t vis_mark = 1u)
+// The fragment of primitive `prim` at pixel (px, py): what the rasteriser and the vertex stage hand a fragment shader (Base.vert /
+// BaseInstanced.vert outputs interpolated perspective-correctly, and their fine derivatives over the pixel's 2 x 2 quad).
+struct PixGeom {
+    const ZrObject* O; uint32_t tri, inst_i;
+    zf3 P0, N0, pos_dx, pos_dy;            // fragPosition, fragNormal, dFdx / dFdy(fragPosition)
+    float u0, v0, s1, t1, s2, t2;          // fragTexCoord, dFdx(uv) = (s1, t1), dFdy(uv) = (s2, t2)
+    Bary b0;                               // the pixel's own barycentrics (for whatever else is interpolated)
+};
+__device__ __forceinline__ PixGeom pixel_geom(const ZrPass& P, const ZrObject* __restrict__ objs, uint32_t prim, int px, int py,
+                                              uint8_t* __restrict__ vis_now = nullptr, uint32_t vis_mark = 1u)
 {
-    const size_t p = (size_t)py * P.W + (size_t)px;
-    if (prim == ZR_EMPTY_PRIM) {   // clears, ZE:3427-3433
-        G.depth[p] = 1.0f; G.scene_color[p] = 0xFF000000u; G.gA[p] = 0u; G.gB[p] = 0xFF000000u; G.gC[p] = 0xFF000000u;
-        G.gD[p] = make_uint2(0u, 0x3C000000u);
-        if (P.write_overlay) G.overlay[p] = 0u;
-        return false;
-    }
+    PixGeom g;
     const ZrObject* __restrict__ O = objs + find_object_prim(objs, (int)P.n_objects, prim);
     const uint32_t local = prim - O->prim_base;
     const uint32_t inst_i = local / O->n_tris, tri = local - inst_i * O->n_tris;
     const bool instanced = O->instanced != 0;
     const ZrInstance I = ld_record(O->inst + inst_i);
+    g.O = O; g.tri = tri; g.inst_i = inst_i;
     // visibility history for next frame's round 1: this meshlet-instance owns a pixel
     if (vis_now) vis_now[O->work_base + inst_i * O->n_meshlets + ld_global(O->tri_meshlet + tri)] = (uint8_t)vis_mark;
     zf4 clip[3]; zf3 WP[3], WN[3]; float U[3], V[3]; uint32_t fl[3];
@@ -1616,12 +1615,35 @@ __device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* _
         b0 = bary_homog(clip, P.hw, P.hh, px, py); bh = bary_homog(clip, P.hw, P.hh, qx, py); bv = bary_homog(clip, P.hw, P.hh, px, qy);
     }
     const zf3 P0 = interp3(b0, WP[0], WP[1], WP[2]), Ph = interp3(bh, WP[0], WP[1], WP[2]), Pv = interp3(bv, WP[0], WP[1], WP[2]);
-    const zf3 N0 = interp3(b0, WN[0], WN[1], WN[2]);
+    g.P0 = P0; g.b0 = b0;
+    g.N0 = interp3(b0, WN[0], WN[1], WN[2]);
     const float u0 = interp1(b0, U[0], U[1], U[2]), uh = interp1(bh, U[0], U[1], U[2]), uv_ = interp1(bv, U[0], U[1], U[2]);
     const float v0 = interp1(b0, V[0], V[1], V[2]), vh = interp1(bh, V[0], V[1], V[2]), vv = interp1(bv, V[0], V[1], V[2]);
     const float sx = (px & 1) ? 1.0f : -1.0f, sy = (py & 1) ? 1.0f : -1.0f;
-    const zf3 pos_dx = (P0 - Ph) * sx, pos_dy = (P0 - Pv) * sy;
-    const float s1 = (u0 - uh) * sx, t1 = (v0 - vh) * sx, s2 = (u0 - uv_) * sy, t2 = (v0 - vv) * sy;
+    g.pos_dx = (P0 - Ph) * sx; g.pos_dy = (P0 - Pv) * sy;
+    g.u0 = u0; g.v0 = v0;
+    g.s1 = (u0 - uh) * sx; g.t1 = (v0 - vh) * sx; g.s2 = (u0 - uv_) * sy; g.t2 = (v0 - vv) * sy;
+    return g;
+}
+
+// BaseScene.frag:26-48 for the pixel (px, py) whose winning primitive is `prim`
+// returns true when the pixel holds scene geometry (not empty, not sky)
+template <int IMAGES>
+__device__ __forceinline__ bool resolve_pixel(const ZrPass& P, const ZrObject* __restrict__ objs, uint32_t prim, float depth,
+                                              int px, int py, const GBufferPtrs& G, const float* __restrict__ lut,
+                                              uint8_t* __restrict__ vis_now, uint32_t vis_mark = 1u)
+{
+    const size_t p = (size_t)py * P.W + (size_t)px;
+    if (prim == ZR_EMPTY_PRIM) {   // clears, ZE:3427-3433
+        G.depth[p] = 1.0f; G.scene_color[p] = 0xFF000000u; G.gA[p] = 0u; G.gB[p] = 0xFF000000u; G.gC[p] = 0xFF000000u;
+        G.gD[p] = make_uint2(0u, 0x3C000000u);
+        if (P.write_overlay) G.overlay[p] = 0u;
+        return false;
+    }
+    const PixGeom g = pixel_geom(P, objs, prim, px, py, vis_now, vis_mark);
+    const ZrObject* __restrict__ O = g.O;
+    const zf3 P0 = g.P0, N0 = g.N0, pos_dx = g.pos_dx, pos_dy = g.pos_dy;
+    const float u0 = g.u0, v0 = g.v0, s1 = g.s1, t1 = g.t1, s2 = g.s2, t2 = g.t2;
 
     if (O->flags & ZR_OBJ_SKY) {    // Skydome.frag: texture(skydomeSampler, uv).rgb, gamma - colour only, into the overlay plane: the pass
         // is drawn after the lighting quad (ZE:3681-3691) and no GBuffer attachment is written by it
@@ -2774,6 +2796,7 @@ __global__ __launch_bounds__(TB, TB == 64 ? ZR_RESOLVE_IMG_WAVES : 1) void k_res
         if (px >= (int)P.W || py >= (int)P.H) continue;
         const unsigned long long k = keys[q];
         ncov += resolve_pixel<IMAGES>(P, objs, (uint32_t)k, zr_u2f((uint32_t)(k >> 32)), px, py, G, dlut, vis_now, vis_mark) ? 1u : 0u;
+        if (G.prim) G.prim[(size_t)py * P.W + (size_t)px] = (uint32_t)k;      // forward variant (k_forward): the depth test's winner
         if (IMAGES != 0 && P.sky_keys != nullptr) {
             // The skydome (ZE:3681-3691: drawn last, depth test LESS against the scene's depth, colour only).  Its triangles were
             // resolved among themselves into a key plane of their own; the dome shows where that depth is less than the scene's.
@@ -2883,6 +2906,183 @@ __device__ __forceinline__ float shadow_tap(const float* __restrict__ S, int SD,
         if (sw > 0.0f && dist < sz) f = 0.1f;
     }
     return f;
+}
+
+// What BaseLighting.frag:174-221 and Base.frag:62-112 have in common, word for word: the PCF factor, (1) direct lighting over the
+// directional then the point lights, (2) the lambert indirect term, (3) the image-based reflection.  Inputs as the shader holds them at that
+// point (N: normalize(Normal) of the unpacked GBufferA in the deferred shader, ComputeNormal()'s result in the forward one).
+// USE_MASK: the point lights are the set bits of lmask (the tile's light list, k_lighting), walked in ascending order.
+template <bool USE_MASK>
+__device__ __forceinline__ void shade_surface(const ZrLightParams& L, const XkView* __restrict__ view, const float* __restrict__ shadowmap,
+                                              const CubeDesc& C, const float* __restrict__ slut, const uint32_t* lmask,
+                                              uint32_t nDir, uint32_t nPoint, float maxmips, float dxy, zf3 cam,
+                                              zf3 BaseColor, float Metallic, float Roughness, zf3 N, float AO, zf3 Pw,
+                                              zf3& Direct, zf3& Indirect, zf3& RefC, float& ShadowFactor)
+{
+    const zf3 Vv = zr_normalize(cam - Pw);
+    const float NdotV = zr_saturate(zr_dot(N, Vv));
+
+    const zf4 s4 = zr_mat4_point(L.SB, Pw);
+    // shadowCoord / shadowCoord.w (SH/Common.glsl:296): IEEE divisions - the PCF comparison below is the shader's one discontinuity,
+    // and a reciprocal-multiply moved its ties
+    const float sx = s4.x / s4.w, sy = s4.y / s4.w, sz = s4.z / s4.w, sw = s4.w / s4.w;
+    // ComputePCF r = 2 (SH/Common.glsl:323-342): 25 taps of ShadowDepthProject.  A tap's texel column / row and bilinear
+    // weight depend only on its x / y offset, so they are formed once per axis (5 + 5) instead of once per tap (25 + 25);
+    // every tap still evaluates fma(sx + ox, dim, -0.5) etc. with the same operands, i.e. the same bits.
+    float sum = 0.0f;
+    if (sz > -1.0f && sz < 1.0f && !(ZR_DIAG_SKIP(L.debug_skip) & 1u)) {
+        const int SDi = (int)L.SD;
+        const float dim = (float)SDi;
+        int cx0[5], cx1[5], ry0[5], ry1[5]; float wa[5], wb[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float off = dxy * (float)(k - 2);
+            const float u = __builtin_fmaf(sx + off, dim, -0.5f), v = __builtin_fmaf(sy + off, dim, -0.5f);
+            const float fu = __builtin_floorf(u), fv = __builtin_floorf(v);
+            wa[k] = u - fu; wb[k] = v - fv;
+            cx0[k] = idx_clamp(fu, SDi - 1); cx1[k] = idx_clamp(fu + 1.0f, SDi - 1);
+            ry0[k] = idx_clamp(fv, SDi - 1) * SDi; ry1[k] = idx_clamp(fv + 1.0f, SDi - 1) * SDi;
+        }
+        // Column pattern of the five x offsets (-3, -1.5, 0, 1.5, 3 texels) when nothing is clamped: pairs start at
+        // cb, cb+1|cb+2, cb+3, cb+4|cb+5, cb+6 - all inside an 8-texel span.  Then each tap row is TWO 16-byte loads per lane
+        // instead of ten 4-byte ones (the texture path processes ~4 lane addresses per clock whatever their width), and the
+        // taps pick their texels from registers.  Any deviation (map edge, a rounding oddity) takes the per-texel path.
+        const int cb = cx0[0];
+        const bool p1 = cx0[1] == cb + 2, p3 = cx0[3] == cb + 5;
+        const bool pattern = cx1[0] == cb + 1 && (cx0[1] == cb + 1 || p1) && cx1[1] == cx0[1] + 1 && cx0[2] == cb + 3 && cx1[2] == cb + 4 &&
+                             (cx0[3] == cb + 4 || p3) && cx1[3] == cx0[3] + 1 && cx0[4] == cb + 6 && cx1[4] == cb + 7;
+        if (pattern) {
+            // taps accumulate in the reference's order (x outer, y inner): keep the 25 outcomes (one bit each), add afterwards
+            uint32_t lit = 0u;
+#pragma unroll
+            for (int y = 0; y < 5; ++y) {
+                const float4_u a0 = *(const float4_u*)(shadowmap + ry0[y] + cb), a1 = *(const float4_u*)(shadowmap + ry0[y] + cb + 4);
+                const float4_u b0 = *(const float4_u*)(shadowmap + ry1[y] + cb), b1 = *(const float4_u*)(shadowmap + ry1[y] + cb + 4);
+                const float t00[5] = { a0.x, p1 ? a0.z : a0.y, a0.w, p3 ? a1.y : a1.x, a1.z };
+                const float t10[5] = { a0.y, p1 ? a0.w : a0.z, a1.x, p3 ? a1.z : a1.y, a1.w };
+                const float t01[5] = { b0.x, p1 ? b0.z : b0.y, b0.w, p3 ? b1.y : b1.x, b1.z };
+                const float t11[5] = { b0.y, p1 ? b0.w : b0.z, b1.x, p3 ? b1.z : b1.y, b1.w };
+#pragma unroll
+                for (int x = 0; x < 5; ++x) {
+                    const float top = __builtin_fmaf(wa[x], t10[x] - t00[x], t00[x]), bot = __builtin_fmaf(wa[x], t11[x] - t01[x], t01[x]);
+                    const float dist = __builtin_fmaf(wb[y], bot - top, top);
+                    if (sw > 0.0f && dist < sz) lit |= 1u << (x * 5 + y);
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < 5; ++x)
+#pragma unroll
+                for (int y = 0; y < 5; ++y) sum += ((lit >> (x * 5 + y)) & 1u) ? 0.1f : 1.0f;
+        } else {
+#pragma unroll
+            for (int x = 0; x < 5; ++x)
+#pragma unroll
+                for (int y = 0; y < 5; ++y) {
+                    const float t00 = shadowmap[ry0[y] + cx0[x]], t10 = shadowmap[ry0[y] + cx1[x]];
+                    const float t01 = shadowmap[ry1[y] + cx0[x]], t11 = shadowmap[ry1[y] + cx1[x]];
+                    const float top = __builtin_fmaf(wa[x], t10 - t00, t00), bot = __builtin_fmaf(wa[x], t11 - t01, t01);
+                    const float dist = __builtin_fmaf(wb[y], bot - top, top);
+                    sum += (sw > 0.0f && dist < sz) ? 0.1f : 1.0f;
+                }
+        }
+    } else sum = 25.0f;      // every tap returns 1.0: 25 exact additions
+    ShadowFactor = sum * 0.04f;       // ShadowFactor / Count (25 taps)
+
+    Direct = zr3(0.0f, 0.0f, 0.0f);
+    const zf3 Nn = zr_normalize(N);                      // Apply*Light and refract() re-normalise N
+    const zf3 DiffuseColor = BaseColor * (1.0f - Metallic);
+    // lights in the shader's order: directional, then point (with a tile list: only its set bits, ascending)
+    const uint32_t n_lights = (ZR_DIAG_SKIP(L.debug_skip) & 2u) ? 0u : nDir + nPoint;
+    uint32_t mword = 0u, mnext = 0u;       // remaining bits of the current mask word, index of the next word
+    for (uint32_t li = 0; li < n_lights; ++li) {
+        if (USE_MASK && li >= nDir) {
+            while (mword == 0u && mnext * 32u < nPoint) mword = lmask[mnext++];
+            if (mword == 0u) break;
+            const uint32_t b = (uint32_t)__builtin_ctz(mword);
+            mword &= mword - 1u;
+            li = nDir + (mnext - 1u) * 32u + b;
+            if (li >= n_lights) break;
+        }
+        const bool isdir = li < nDir;
+        const XkLight* __restrict__ Lt = isdir ? &view->DirectionalLights[li] : &view->PointLights[li - nDir];
+        const zf3 lp = zr3(Lt->Position[0], Lt->Position[1], Lt->Position[2]);
+        // A light whose radiance factor is exactly 0 adds fma(0, bxdf, Direct) = Direct: skip its BxDF.  That is the
+        // case beyond a point light's radius (attenuation 1 - clamp(d, 0, r) / r = 0) and for N.L <= 0.  The skip
+        // needs finite colour * intensity (0 * finite = 0); the test is wave-uniform per light.
+        const bool lfinite = __builtin_fabsf(Lt->Color[0]) <= 3.402823466e38f && __builtin_fabsf(Lt->Color[1]) <= 3.402823466e38f &&
+                             __builtin_fabsf(Lt->Color[2]) <= 3.402823466e38f && __builtin_fabsf(Lt->Color[3]) <= 3.402823466e38f;
+        float att = 1.0f;
+        zf3 Lv;
+        if (!isdir) {
+            const float falloff = Lt->Direction[3];
+            // far outside the radius (1e-6 relative margin on the squared distance covers every rounding in dist): the exact
+            // test below would give att == 0, so the distance and the quotient need not be formed
+            const zf3 dl = lp - Pw;
+            const float d2 = zr_dot(dl, dl);
+            if (lfinite && falloff > 0.0f && d2 > (falloff * falloff) * 1.000001f) continue;
+            // distance(light_pos, position) and normalize(light_pos - position) share ONE inversesqrt: length = d2 * inversesqrt(d2)
+            // (0 for d2 = 0; GLSL derives sqrt's precision from inversesqrt's), direction = dl * inversesqrt(d2)
+            const float rd = zr_rsqrt(d2);
+            const float dist = d2 > 0.0f ? d2 * rd : 0.0f;
+            // remap(dist, 0, falloff, 0, 1), SH/Common.glsl:43-47.  The quotient stays an IEEE division: falloff / falloff must be
+            // exactly 1 beyond the radius (the tile light lists and the skips around here rest on att == 0 there)
+            att = 1.0f - zr_clamp(dist, 0.0f, falloff) / falloff;
+            if (lfinite && att == 0.0f) continue;
+            Lv = dl * rd;
+        } else Lv = zr_normalize(zr3(Lt->Direction[0], Lt->Direction[1], Lt->Direction[2]));
+        // ApplyDirectionalLight / ApplyPointLight (SH/Common.glsl:364-372, 399-416)
+        const float ndotl = zr_clamp(zr_dot(Nn, Lv), 0.0f, 1.0f);
+        if (lfinite && ndotl == 0.0f) continue;
+        const zf3 Hh = zr_normalize(Vv + Lv);
+        const float LdotH = zr_saturate(zr_dot(Lv, Hh)), NdotH = zr_saturate(zr_dot(N, Hh)), NdotL = zr_saturate(zr_dot(N, Lv));
+        // DefaultLitBxDF (SH/Common.glsl:259-282): F0 = 0.04, F90 = saturate(50 * 0.04)
+        const float F = F_Schlick(0.04f, zr_saturate(50.0f * 0.04f), LdotH);
+        const float Vis = V_SmithGGXCorrelated(NdotV, NdotL, Roughness);
+        const float Dg = D_GGX(NdotH, Roughness);
+        const float Fr = (F * Dg) * Vis;
+        const float Fd = Fr_DisneyDiffuse(NdotV, NdotL, LdotH, Roughness);
+        const zf3 bx = zr3(__builtin_fmaf(DiffuseColor.x * (1.0f - F), Fd, Fr), __builtin_fmaf(DiffuseColor.y * (1.0f - F), Fd, Fr),
+                           __builtin_fmaf(DiffuseColor.z * (1.0f - F), Fd, Fr));
+        const float k = ndotl * Lt->Color[3];
+        zf3 rad = zr3(k * Lt->Color[0], k * Lt->Color[1], k * Lt->Color[2]);
+        if (isdir) {
+            Direct = zr3(__builtin_fmaf(rad.x * bx.x, ShadowFactor, Direct.x), __builtin_fmaf(rad.y * bx.y, ShadowFactor, Direct.y),
+                         __builtin_fmaf(rad.z * bx.z, ShadowFactor, Direct.z));
+        } else {
+            rad = rad * att;
+            Direct = zr3(__builtin_fmaf(rad.x, bx.x, Direct.x), __builtin_fmaf(rad.y, bx.y, Direct.y), __builtin_fmaf(rad.z, bx.z, Direct.z));
+        }
+    }
+    // (2) indirect, BaseLighting.frag:210
+    Indirect = zr3((((DiffuseColor.x * ZR_INV_PI) * AO) * 0.3f) * ShadowFactor,
+                             (((DiffuseColor.y * ZR_INV_PI) * AO) * 0.3f) * ShadowFactor,
+                             (((DiffuseColor.z * ZR_INV_PI) * AO) * 0.3f) * ShadowFactor);
+    // (3) reflection, :213-221
+    const zf3 bcl = zr3(zr_clamp(BaseColor.x, 0.04f, 1.0f), zr_clamp(BaseColor.y, 0.04f, 1.0f), zr_clamp(BaseColor.z, 0.04f, 1.0f));
+    const float dsf0 = (0.04f * 2.0f) * 0.5f;
+    const zf3 RSpec = zr3(__builtin_fmaf(Metallic, bcl.x, (1.0f - Metallic) * dsf0), __builtin_fmaf(Metallic, bcl.y, (1.0f - Metallic) * dsf0),
+                          __builtin_fmaf(Metallic, bcl.z, (1.0f - Metallic) * dsf0));
+    // EnvBRDFApproxLazarov, SH/Common.glsl:201-211
+    const float rx = __builtin_fmaf(Roughness, -1.0f, 1.0f), ry = __builtin_fmaf(Roughness, -0.0275f, 0.0425f);
+    const float rz = __builtin_fmaf(Roughness, -0.572f, 1.04f), rw = __builtin_fmaf(Roughness, 0.022f, -0.04f);
+    const float a004 = __builtin_fmaf(__builtin_fminf(rx * rx, zr_exp2(-9.28f * NdotV)), rx, ry);
+    const float ABx = __builtin_fmaf(-1.04f, a004, rz), ABy = __builtin_fmaf(1.04f, a004, rw);
+    const float F90 = zr_saturate(50.0f * RSpec.y);
+    const zf3 RBRDF = zr3(__builtin_fmaf(RSpec.x, ABx, F90 * ABy), __builtin_fmaf(RSpec.y, ABx, F90 * ABy), __builtin_fmaf(RSpec.z, ABx, F90 * ABy));
+    const float eta = 1.00f / 1.52f;
+    const float dNI = zr_dot(Nn, Vv);
+    const float kk = __builtin_fmaf(-(eta * eta), __builtin_fmaf(-dNI, dNI, 1.0f), 1.0f);
+    zf3 R;
+    if (kk < 0.0f) R = zr3(0.0f, 0.0f, 0.0f);
+    else {
+        const float q = __builtin_fmaf(eta, dNI, __builtin_sqrtf(kk));
+        R = zr3(__builtin_fmaf(eta, Vv.x, -(q * Nn.x)), __builtin_fmaf(eta, Vv.y, -(q * Nn.y)), __builtin_fmaf(eta, Vv.z, -(q * Nn.z)));
+    }
+    // ComputeReflectionMipFromRoughness, SH/Common.glsl:191-198
+    const float MIPS = (maxmips - 1.0f) - __builtin_fmaf(-1.2f, zr_log2(__builtin_fmaxf(Roughness, 0.001f)), 1.0f);
+    const zf3 RL = (ZR_DIAG_SKIP(L.debug_skip) & 4u) ? zr3(0.0f, 0.0f, 0.0f) : cube_sample(C, slut, L.cube_dim, (int)L.cube_levels, R, MIPS) * 10.0f;
+    const float RV = zr_saturate((zr_pow(NdotV + AO, Roughness * Roughness) - 1.0f) + AO);   // GetSpecularOcclusion :226
+    RefC = zr3((RL.x * RV) * RBRDF.x, (RL.y * RV) * RBRDF.y, (RL.z * RV) * RBRDF.z);
 }
 
 // BaseLighting.frag:147-254 for every pixel of the owned tiles (the full-screen quad of ZE:3531-3540)
@@ -3026,170 +3226,9 @@ __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(ZR_LIGHT_WAV
         Roughness = __builtin_fmaxf(0.01f, Roughness);
         const zf3 N = zr_normalize(Normal);
         const zf3 Pw = zr3(f16_to_f32_hw(D.x & 0xFFFFu), f16_to_f32_hw(D.x >> 16), f16_to_f32_hw(D.y & 0xFFFFu));
-        const zf3 Vv = zr_normalize(cam - Pw);
-        const float NdotV = zr_saturate(zr_dot(N, Vv));
-
-        const zf4 s4 = zr_mat4_point(L.SB, Pw);
-        // shadowCoord / shadowCoord.w (SH/Common.glsl:296): IEEE divisions - the PCF comparison below is the shader's one discontinuity,
-        // and a reciprocal-multiply moved its ties (oracle/CONTRACT.md)
-        const float sx = s4.x / s4.w, sy = s4.y / s4.w, sz = s4.z / s4.w, sw = s4.w / s4.w;
-        // ComputePCF r = 2 (SH/Common.glsl:323-342): 25 taps of ShadowDepthProject.  A tap's texel column / row and bilinear
-        // weight depend only on its x / y offset, so they are formed once per axis (5 + 5) instead of once per tap (25 + 25);
-        // every tap still evaluates fma(sx + ox, dim, -0.5) etc. with the same operands, i.e. the same bits.
-        float sum = 0.0f;
-        if (sz > -1.0f && sz < 1.0f && !(ZR_DIAG_SKIP(L.debug_skip) & 1u)) {
-            const int SDi = (int)L.SD;
-            const float dim = (float)SDi;
-            int cx0[5], cx1[5], ry0[5], ry1[5]; float wa[5], wb[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const float off = dxy * (float)(k - 2);
-                const float u = __builtin_fmaf(sx + off, dim, -0.5f), v = __builtin_fmaf(sy + off, dim, -0.5f);
-                const float fu = __builtin_floorf(u), fv = __builtin_floorf(v);
-                wa[k] = u - fu; wb[k] = v - fv;
-                cx0[k] = idx_clamp(fu, SDi - 1); cx1[k] = idx_clamp(fu + 1.0f, SDi - 1);
-                ry0[k] = idx_clamp(fv, SDi - 1) * SDi; ry1[k] = idx_clamp(fv + 1.0f, SDi - 1) * SDi;
-            }
-            // Column pattern of the five x offsets (-3, -1.5, 0, 1.5, 3 texels) when nothing is clamped: pairs start at
-            // cb, cb+1|cb+2, cb+3, cb+4|cb+5, cb+6 - all inside an 8-texel span.  Then each tap row is TWO 16-byte loads per lane
-            // instead of ten 4-byte ones (the texture path processes ~4 lane addresses per clock whatever their width), and the
-            // taps pick their texels from registers.  Any deviation (map edge, a rounding oddity) takes the per-texel path.
-            const int cb = cx0[0];
-            const bool p1 = cx0[1] == cb + 2, p3 = cx0[3] == cb + 5;
-            const bool pattern = cx1[0] == cb + 1 && (cx0[1] == cb + 1 || p1) && cx1[1] == cx0[1] + 1 && cx0[2] == cb + 3 && cx1[2] == cb + 4 &&
-                                 (cx0[3] == cb + 4 || p3) && cx1[3] == cx0[3] + 1 && cx0[4] == cb + 6 && cx1[4] == cb + 7;
-            if (pattern) {
-                // taps accumulate in the reference's order (x outer, y inner): keep the 25 outcomes (one bit each), add afterwards
-                uint32_t lit = 0u;
-#pragma unroll
-                for (int y = 0; y < 5; ++y) {
-                    const float4_u a0 = *(const float4_u*)(shadowmap + ry0[y] + cb), a1 = *(const float4_u*)(shadowmap + ry0[y] + cb + 4);
-                    const float4_u b0 = *(const float4_u*)(shadowmap + ry1[y] + cb), b1 = *(const float4_u*)(shadowmap + ry1[y] + cb + 4);
-                    const float t00[5] = { a0.x, p1 ? a0.z : a0.y, a0.w, p3 ? a1.y : a1.x, a1.z };
-                    const float t10[5] = { a0.y, p1 ? a0.w : a0.z, a1.x, p3 ? a1.z : a1.y, a1.w };
-                    const float t01[5] = { b0.x, p1 ? b0.z : b0.y, b0.w, p3 ? b1.y : b1.x, b1.z };
-                    const float t11[5] = { b0.y, p1 ? b0.w : b0.z, b1.x, p3 ? b1.z : b1.y, b1.w };
-#pragma unroll
-                    for (int x = 0; x < 5; ++x) {
-                        const float top = __builtin_fmaf(wa[x], t10[x] - t00[x], t00[x]), bot = __builtin_fmaf(wa[x], t11[x] - t01[x], t01[x]);
-                        const float dist = __builtin_fmaf(wb[y], bot - top, top);
-                        if (sw > 0.0f && dist < sz) lit |= 1u << (x * 5 + y);
-                    }
-                }
-#pragma unroll
-                for (int x = 0; x < 5; ++x)
-#pragma unroll
-                    for (int y = 0; y < 5; ++y) sum += ((lit >> (x * 5 + y)) & 1u) ? 0.1f : 1.0f;
-            } else {
-#pragma unroll
-                for (int x = 0; x < 5; ++x)
-#pragma unroll
-                    for (int y = 0; y < 5; ++y) {
-                        const float t00 = shadowmap[ry0[y] + cx0[x]], t10 = shadowmap[ry0[y] + cx1[x]];
-                        const float t01 = shadowmap[ry1[y] + cx0[x]], t11 = shadowmap[ry1[y] + cx1[x]];
-                        const float top = __builtin_fmaf(wa[x], t10 - t00, t00), bot = __builtin_fmaf(wa[x], t11 - t01, t01);
-                        const float dist = __builtin_fmaf(wb[y], bot - top, top);
-                        sum += (sw > 0.0f && dist < sz) ? 0.1f : 1.0f;
-                    }
-            }
-        } else sum = 25.0f;      // every tap returns 1.0: 25 exact additions
-        const float ShadowFactor = sum * 0.04f;       // ShadowFactor / Count (25 taps)
-
-        zf3 Direct = zr3(0.0f, 0.0f, 0.0f);
-        const zf3 Nn = zr_normalize(N);                      // Apply*Light and refract() re-normalise N
-        const zf3 DiffuseColor = BaseColor * (1.0f - Metallic);
-        // lights in the shader's order: directional, then point (with a tile list: only its set bits, ascending)
-        const uint32_t n_lights = (ZR_DIAG_SKIP(L.debug_skip) & 2u) ? 0u : nDir + nPoint;
-        uint32_t mword = 0u, mnext = 0u;       // remaining bits of the current mask word, index of the next word
-        for (uint32_t li = 0; li < n_lights; ++li) {
-            if (use_mask && li >= nDir) {
-                while (mword == 0u && mnext * 32u < nPoint) mword = lmask[mnext++];
-                if (mword == 0u) break;
-                const uint32_t b = (uint32_t)__builtin_ctz(mword);
-                mword &= mword - 1u;
-                li = nDir + (mnext - 1u) * 32u + b;
-                if (li >= n_lights) break;
-            }
-            const bool isdir = li < nDir;
-            const XkLight* __restrict__ Lt = isdir ? &view->DirectionalLights[li] : &view->PointLights[li - nDir];
-            const zf3 lp = zr3(Lt->Position[0], Lt->Position[1], Lt->Position[2]);
-            // A light whose radiance factor is exactly 0 adds fma(0, bxdf, Direct) = Direct: skip its BxDF.  That is the
-            // case beyond a point light's radius (attenuation 1 - clamp(d, 0, r) / r = 0) and for N.L <= 0.  The skip
-            // needs finite colour * intensity (0 * finite = 0); the test is wave-uniform per light.
-            const bool lfinite = __builtin_fabsf(Lt->Color[0]) <= 3.402823466e38f && __builtin_fabsf(Lt->Color[1]) <= 3.402823466e38f &&
-                                 __builtin_fabsf(Lt->Color[2]) <= 3.402823466e38f && __builtin_fabsf(Lt->Color[3]) <= 3.402823466e38f;
-            float att = 1.0f;
-            zf3 Lv;
-            if (!isdir) {
-                const float falloff = Lt->Direction[3];
-                // far outside the radius (1e-6 relative margin on the squared distance covers every rounding in dist): the exact
-                // test below would give att == 0, so the distance and the quotient need not be formed
-                const zf3 dl = lp - Pw;
-                const float d2 = zr_dot(dl, dl);
-                if (lfinite && falloff > 0.0f && d2 > (falloff * falloff) * 1.000001f) continue;
-                // distance(light_pos, position) and normalize(light_pos - position) share ONE inversesqrt: length = d2 * inversesqrt(d2)
-                // (0 for d2 = 0; GLSL derives sqrt's precision from inversesqrt's), direction = dl * inversesqrt(d2)
-                const float rd = zr_rsqrt(d2);
-                const float dist = d2 > 0.0f ? d2 * rd : 0.0f;
-                // remap(dist, 0, falloff, 0, 1), SH/Common.glsl:43-47.  The quotient stays an IEEE division: falloff / falloff must be
-                // exactly 1 beyond the radius (the tile light lists and the skips around here rest on att == 0 there)
-                att = 1.0f - zr_clamp(dist, 0.0f, falloff) / falloff;
-                if (lfinite && att == 0.0f) continue;
-                Lv = dl * rd;
-            } else Lv = zr_normalize(zr3(Lt->Direction[0], Lt->Direction[1], Lt->Direction[2]));
-            // ApplyDirectionalLight / ApplyPointLight (SH/Common.glsl:364-372, 399-416)
-            const float ndotl = zr_clamp(zr_dot(Nn, Lv), 0.0f, 1.0f);
-            if (lfinite && ndotl == 0.0f) continue;
-            const zf3 Hh = zr_normalize(Vv + Lv);
-            const float LdotH = zr_saturate(zr_dot(Lv, Hh)), NdotH = zr_saturate(zr_dot(N, Hh)), NdotL = zr_saturate(zr_dot(N, Lv));
-            // DefaultLitBxDF (SH/Common.glsl:259-282): F0 = 0.04, F90 = saturate(50 * 0.04)
-            const float F = F_Schlick(0.04f, zr_saturate(50.0f * 0.04f), LdotH);
-            const float Vis = V_SmithGGXCorrelated(NdotV, NdotL, Roughness);
-            const float Dg = D_GGX(NdotH, Roughness);
-            const float Fr = (F * Dg) * Vis;
-            const float Fd = Fr_DisneyDiffuse(NdotV, NdotL, LdotH, Roughness);
-            const zf3 bx = zr3(__builtin_fmaf(DiffuseColor.x * (1.0f - F), Fd, Fr), __builtin_fmaf(DiffuseColor.y * (1.0f - F), Fd, Fr),
-                               __builtin_fmaf(DiffuseColor.z * (1.0f - F), Fd, Fr));
-            const float k = ndotl * Lt->Color[3];
-            zf3 rad = zr3(k * Lt->Color[0], k * Lt->Color[1], k * Lt->Color[2]);
-            if (isdir) {
-                Direct = zr3(__builtin_fmaf(rad.x * bx.x, ShadowFactor, Direct.x), __builtin_fmaf(rad.y * bx.y, ShadowFactor, Direct.y),
-                             __builtin_fmaf(rad.z * bx.z, ShadowFactor, Direct.z));
-            } else {
-                rad = rad * att;
-                Direct = zr3(__builtin_fmaf(rad.x, bx.x, Direct.x), __builtin_fmaf(rad.y, bx.y, Direct.y), __builtin_fmaf(rad.z, bx.z, Direct.z));
-            }
-        }
-        // (2) indirect, BaseLighting.frag:210
-        const zf3 Indirect = zr3((((DiffuseColor.x * ZR_INV_PI) * AO) * 0.3f) * ShadowFactor,
-                                 (((DiffuseColor.y * ZR_INV_PI) * AO) * 0.3f) * ShadowFactor,
-                                 (((DiffuseColor.z * ZR_INV_PI) * AO) * 0.3f) * ShadowFactor);
-        // (3) reflection, :213-221
-        const zf3 bcl = zr3(zr_clamp(BaseColor.x, 0.04f, 1.0f), zr_clamp(BaseColor.y, 0.04f, 1.0f), zr_clamp(BaseColor.z, 0.04f, 1.0f));
-        const float dsf0 = (0.04f * 2.0f) * 0.5f;
-        const zf3 RSpec = zr3(__builtin_fmaf(Metallic, bcl.x, (1.0f - Metallic) * dsf0), __builtin_fmaf(Metallic, bcl.y, (1.0f - Metallic) * dsf0),
-                              __builtin_fmaf(Metallic, bcl.z, (1.0f - Metallic) * dsf0));
-        // EnvBRDFApproxLazarov, SH/Common.glsl:201-211
-        const float rx = __builtin_fmaf(Roughness, -1.0f, 1.0f), ry = __builtin_fmaf(Roughness, -0.0275f, 0.0425f);
-        const float rz = __builtin_fmaf(Roughness, -0.572f, 1.04f), rw = __builtin_fmaf(Roughness, 0.022f, -0.04f);
-        const float a004 = __builtin_fmaf(__builtin_fminf(rx * rx, zr_exp2(-9.28f * NdotV)), rx, ry);
-        const float ABx = __builtin_fmaf(-1.04f, a004, rz), ABy = __builtin_fmaf(1.04f, a004, rw);
-        const float F90 = zr_saturate(50.0f * RSpec.y);
-        const zf3 RBRDF = zr3(__builtin_fmaf(RSpec.x, ABx, F90 * ABy), __builtin_fmaf(RSpec.y, ABx, F90 * ABy), __builtin_fmaf(RSpec.z, ABx, F90 * ABy));
-        const float eta = 1.00f / 1.52f;
-        const float dNI = zr_dot(Nn, Vv);
-        const float kk = __builtin_fmaf(-(eta * eta), __builtin_fmaf(-dNI, dNI, 1.0f), 1.0f);
-        zf3 R;
-        if (kk < 0.0f) R = zr3(0.0f, 0.0f, 0.0f);
-        else {
-            const float q = __builtin_fmaf(eta, dNI, __builtin_sqrtf(kk));
-            R = zr3(__builtin_fmaf(eta, Vv.x, -(q * Nn.x)), __builtin_fmaf(eta, Vv.y, -(q * Nn.y)), __builtin_fmaf(eta, Vv.z, -(q * Nn.z)));
-        }
-        // ComputeReflectionMipFromRoughness, SH/Common.glsl:191-198
-        const float MIPS = (maxmips - 1.0f) - __builtin_fmaf(-1.2f, zr_log2(__builtin_fmaxf(Roughness, 0.001f)), 1.0f);
-        const zf3 RL = (ZR_DIAG_SKIP(L.debug_skip) & 4u) ? zr3(0.0f, 0.0f, 0.0f) : cube_sample(C, slut, L.cube_dim, (int)L.cube_levels, R, MIPS) * 10.0f;
-        const float RV = zr_saturate((zr_pow(NdotV + AO, Roughness * Roughness) - 1.0f) + AO);   // GetSpecularOcclusion :226
-        const zf3 RefC = zr3((RL.x * RV) * RBRDF.x, (RL.y * RV) * RBRDF.y, (RL.z * RV) * RBRDF.z);
+        zf3 Direct, Indirect, RefC; float ShadowFactor;
+        shade_surface<use_mask>(L, view, shadowmap, C, slut, lmask, nDir, nPoint, maxmips, dxy, cam, BaseColor, Metallic, Roughness, N, AO, Pw,
+                                Direct, Indirect, RefC, ShadowFactor);
 
         zf3 Final = ((Direct + Indirect) + RefC) * Mask;
         Final = zr3(zr_pow(Final.x, 0.4545f), zr_pow(Final.y, 0.4545f), zr_pow(Final.z, 0.4545f));
@@ -3322,6 +3361,86 @@ __global__ __launch_bounds__(256) void k_gbuffer_vis(ZrLightParams L, const XkVi
         }
     }
     out[(size_t)py * L.W + px] = zr_unorm(o.x, 255.0f) | zr_unorm(o.y, 255.0f) << 8 | zr_unorm(o.z, 255.0f) << 16 | 255u << 24;
+}
+
+// ------------------------------------------------------------------------------------------------ forward variant
+// Base.frag:46-144 - the engine built with ENABLE_DEFERRED_SHADING false (ZE:93): the main render pass clears colour (0,0,0,1) and depth
+// (ZE:3517-3519, 2366-2373) and Base.frag shades every fragment that passes LESS straight into the swapchain image (pipelines
+// ZE:2749-2801, draws ZE:3544-3680).  Here the winner of the depth test is already known per pixel (the resolve keeps its primitive id in
+// G.prim when the context shades forward), so the shader runs once per covered pixel, as with an early depth test and no overdraw.
+// Against the deferred pair: the fetched material and ComputeNormal()'s result are used as floats (no render-target format in between),
+// AO is not saturated, there is no Mask, every view multiplies FinalColor by ShadowFactor AFTER the gamma (:114-121), and the debug table
+// is Base.frag's own (:123-143: base colour without gamma, AmbientOcclution.rgb, the interpolated vertex colour, no GBufferVis).
+// The skydome and the background follow in the same render pass (view 0 only, ZE:3681-3699) exactly as in the deferred frame.
+template <bool IMAGES>
+__global__ __launch_bounds__(256) void k_forward(ZrPass P, ZrLightParams L, const XkView* __restrict__ view, const ZrObject* __restrict__ objs,
+                                                 const uint32_t* __restrict__ owned_tiles, GBufferPtrs G, const float* __restrict__ shadowmap,
+                                                 CubeDesc C, const float* __restrict__ srgb_lut, const float* __restrict__ unorm_lut,
+                                                 uint32_t* __restrict__ out)
+{
+    __shared__ float tl[512];            // [0, 256) sRGB decode, [256, 512) c / 255: tex_decode's layout
+    for (uint32_t i = threadIdx.x; i < 256u; i += 256u) { tl[i] = srgb_lut[i]; tl[256u + i] = unorm_lut[i]; }
+    __syncthreads();
+    const uint32_t tile_slot = blockIdx.x / (TILE_PIX / 256u), i = threadIdx.x + (blockIdx.x % (TILE_PIX / 256u)) * 256u;
+    const uint32_t tile = owned_tiles[tile_slot];
+    const int px = (int)(tile % L.tiles_x) * TILE + (int)(i & (TILE - 1)), py = (int)(tile / L.tiles_x) * TILE + (int)(i / TILE);
+    if (px >= (int)L.W || py >= (int)L.H) return;
+    const size_t p = (size_t)py * L.W + (size_t)px;
+    const uint32_t prim = G.prim[p];
+    uint32_t rgba = 0xFF000000u;         // clearValues[0].color, ZE:3517
+    if (prim != ZR_EMPTY_PRIM) {
+        const PixGeom g = pixel_geom(P, objs, prim, px, py);
+        const ZrObject* __restrict__ O = g.O;
+        // texture(samplerN, fragTexCoord), Base.frag:50-54 (emissive and mask are bound but not fetched)
+        zf4 ms[ZR_MATERIAL_SLOTS];
+        if (IMAGES) tex_sample_material(O, tl, g.u0, g.v0, g.s1, g.t1, g.s2, g.t2, ms);
+        else for (int k = 0; k < ZR_MATERIAL_SLOTS; ++k) { ms[k].x = O->texc[k][0]; ms[k].y = O->texc[k][1]; ms[k].z = O->texc[k][2]; ms[k].w = O->texc[k][3]; }
+        const zf3 BaseColor = zr3(ms[0].x, ms[0].y, ms[0].z);
+        const float Metallic = zr_saturate(ms[1].x);
+        const float Roughness = __builtin_fmaxf(0.01f, zr_saturate(ms[2].x));
+        const zf3 ts = (O->const_slots & 8u) ? zr3(O->ts_const[0], O->ts_const[1], O->ts_const[2]) : zr_tangent_space_normal(zr3(ms[3].x, ms[3].y, ms[3].z));
+        const zf3 Normal = compute_normal(g.pos_dx, g.pos_dy, g.s1, g.t1, g.s2, g.t2, g.N0, ts);
+        const zf3 AmbientOcclution = zr3(ms[4].x, ms[4].y, ms[4].z);
+        const zf3 cam = zr3(view->CameraInfo[0], view->CameraInfo[1], view->CameraInfo[2]);
+        zf3 Direct, Indirect, RefC; float ShadowFactor;
+        shade_surface<false>(L, view, shadowmap, C, tl, nullptr, (uint32_t)view->LightsCount[0], (uint32_t)view->LightsCount[1],
+                             (float)(uint32_t)view->LightsCount[3], 1.5f * 1.0f / (float)L.SD, cam,
+                             BaseColor, Metallic, Roughness, Normal, AmbientOcclution.x, g.P0, Direct, Indirect, RefC, ShadowFactor);
+        zf3 Final = (Direct + Indirect) + RefC;
+        Final = zr3(zr_pow(Final.x, 0.4545f), zr_pow(Final.y, 0.4545f), zr_pow(Final.z, 0.4545f));
+        zf3 o;
+        switch (L.debug_view) {
+        case 1: o = BaseColor; break;
+        case 2: o = zr3(Metallic, Metallic, Metallic); break;
+        case 3: o = zr3(Roughness, Roughness, Roughness); break;
+        case 4: o = Normal; break;
+        case 5: o = AmbientOcclution; break;
+        case 6: {   // fragColor = inColor (Base.vert:28), interpolated like every other varying
+            const uint32_t* __restrict__ ix = O->indices + 3u * g.tri;
+            const XkVertex* __restrict__ v0 = O->verts + ld_global(ix), * __restrict__ v1 = O->verts + ld_global(ix + 1), * __restrict__ v2 = O->verts + ld_global(ix + 2);
+            o = interp3(g.b0, zr3(v0->Color[0], v0->Color[1], v0->Color[2]), zr3(v1->Color[0], v1->Color[1], v1->Color[2]),
+                        zr3(v2->Color[0], v2->Color[1], v2->Color[2]));
+            break;
+        }
+        case 7: o = RefC; break;
+        case 8: o = zr3(ShadowFactor, ShadowFactor, ShadowFactor); break;
+        default: o = Final * ShadowFactor; break;      // cases 0, 9 and default
+        }
+        rgba = zr_unorm(o.x, 255.0f) | zr_unorm(o.y, 255.0f) << 8 | zr_unorm(o.z, 255.0f) << 16 | 255u << 24;
+    }
+    if (L.debug_view == 0u) {            // skydome, then the background quad at depth 1 (ZE:3681-3699)
+        const uint32_t ov = L.has_overlay ? G.overlay[p] : 0u;
+        if (ov) rgba = ov;
+        else if (L.bg_enabled && 1.0f <= G.depth[p]) {
+            const float u = ((float)px + 0.5f) / (float)L.W, v = ((float)py + 0.5f) / (float)L.H;
+            const float one4[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
+            const zf4 bgc = tex_sample<2>(L.bg, one4, true, tl, u, v, 1.0f / (float)L.W, 0.0f, 0.0f, 1.0f / (float)L.H);
+            rgba = zr_unorm(zr_pow(bgc.x, 0.4545f), 255.0f) | zr_unorm(zr_pow(bgc.y, 0.4545f), 255.0f) << 8 |
+                   zr_unorm(zr_pow(bgc.z, 0.4545f), 255.0f) << 16 | 255u << 24;
+        }
+    }
+    if (L.packed_out) out[(size_t)tile_slot * TILE_PIX + i] = rgba;
+    else out[p] = rgba;
 }
 
 // Multi-GPU composite: gathered[rank][slot][TILE_PIX] -> frame; tile_map[t] = owner * slots_per_rank + slot of tile t
@@ -3530,6 +3649,13 @@ void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32
     if (L.light_list) { if (L.bg_enabled) ZR_LAUNCH_LIGHTING(true, true); else ZR_LAUNCH_LIGHTING(true, false); }
     else { if (L.bg_enabled) ZR_LAUNCH_LIGHTING(false, true); else ZR_LAUNCH_LIGHTING(false, false); }
 #undef ZR_LAUNCH_LIGHTING
+}
+void zr_launch_forward(const ZrPass& P, const ZrLightParams& L, const XkView* view, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
+                       const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C, const float* lut, const float* unorm_lut, uint32_t* out, hipStream_t s)
+{
+    if (n_owned == 0) return;
+    if (P.images) hipLaunchKernelGGL((k_forward<true>), dim3(n_owned * (TILE_PIX / 256u)), dim3(256), 0, s, P, L, view, objs, owned_tiles, G, shadowmap, C, lut, unorm_lut, out);
+    else hipLaunchKernelGGL((k_forward<false>), dim3(n_owned * (TILE_PIX / 256u)), dim3(256), 0, s, P, L, view, objs, owned_tiles, G, shadowmap, C, lut, unorm_lut, out);
 }
 void zr_launch_gbuffer_vis(const ZrLightParams& L, const XkView* view, const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C,
                            const float* lut, uint32_t* out, hipStream_t s)

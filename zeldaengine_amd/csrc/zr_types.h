@@ -183,6 +183,7 @@ struct ZrLightParams {
 struct GBufferPtrs {
     float* depth; uint32_t* scene_color; uint32_t* gA; uint32_t* gB; uint32_t* gC; uint2* gD;
     uint32_t* overlay;               // RGBA8 of the skydome pass (0 = nothing drawn); not a GBuffer attachment
+    uint32_t* prim;                  // forward variant only (else nullptr): the primitive id that won the pixel, ZR_EMPTY_PRIM where nothing was drawn
 };
 // Cubemap mip chain, level l = 6 faces of (dim >> l)^2 RGBA8 sRGB texels, face-major.
 struct CubeDesc { const uint8_t* levels[16]; };
@@ -256,6 +257,9 @@ void zr_launch_count_shadow(const uint32_t* bits, size_t n, ZrDevStats* stats, h
 void zr_launch_lighting(const ZrLightParams& L, const XkView* view, const uint32_t* owned_tiles, uint32_t n_owned,
                         const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C, const float* lut, const float* unorm_lut,
                         uint32_t* out, hipStream_t s);
+// forward variant (SH/Base.frag): shades the winners recorded in G.prim with the camera pass's own parameter block
+void zr_launch_forward(const ZrPass& P, const ZrLightParams& L, const XkView* view, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned,
+                       const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C, const float* lut, const float* unorm_lut, uint32_t* out, hipStream_t s);
 void zr_launch_gbuffer_vis(const ZrLightParams& L, const XkView* view, const GBufferPtrs& G, const float* shadowmap, const CubeDesc& C,
                            const float* lut, uint32_t* out, hipStream_t s);
 void zr_launch_untile(const uint32_t* gathered, const uint32_t* tile_map, uint32_t* frame, uint32_t W, uint32_t H, uint32_t tiles_x,

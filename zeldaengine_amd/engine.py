@@ -60,6 +60,7 @@ def lib():
         "zr_set_frame": [vp, vp, vp, vp],
         "zr_get_frame": [vp, vp, vp, vp],
         "zr_set_debug_view": [vp, u32],
+        "zr_set_shading": [vp, u32],
         "zr_render": [vp],
         "zr_render_shadow": [vp], "zr_render_gbuffer": [vp], "zr_render_lighting": [vp],
         "zr_render_geometry": [vp], "zr_stream_wait_shadow": [vp, vp],
@@ -361,6 +362,10 @@ class Renderer:
 
     def set_debug_view(self, v):
         self._chk(self.L.zr_set_debug_view(self.h, v))
+
+    def set_shading(self, forward):
+        """False: the deferred frame (default); True: the forward variant, SH/Base.frag (zr_set_shading)."""
+        self._chk(self.L.zr_set_shading(self.h, 1 if forward else 0))
 
     # ---- frame
     def render(self, debug_view=None, passes=None):
