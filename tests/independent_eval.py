@@ -95,7 +95,7 @@ def base_scene(draws, cam, prim_ids, W, H):
     """
     model, view, proj = mat(cam["Model"]), mat(cam["View"]), mat(cam["Proj"])
     ys, xs = np.nonzero(prim_ids != 0xFFFFFFFF)
-    out = {k: np.zeros((len(ys), n)) for k, n in (("scene_color", 4), ("a", 4), ("b", 4), ("c", 4), ("d", 4), ("d_per_pixel", 3))}
+    out = {k: np.zeros((len(ys), n)) for k, n in (("scene_color", 4), ("a", 4), ("b", 4), ("c", 4), ("d", 4), ("d_per_pixel", 3), ("normal", 3))}
     pid = prim_ids[ys, xs].astype(np.int64)
     for d in draws:
         n_tris = len(d["idx"]) // 3
@@ -141,6 +141,7 @@ def base_scene(draws, cam, prim_ids, W, H):
             k = len(m)
             out["scene_color"][m] = np.hstack([np.broadcast_to(emissive, (k, 3)), np.full((k, 1), mask)])
             out["a"][m] = np.hstack([packed, np.ones((k, 1))])
+            out["normal"][m] = normal                                       # ComputeNormal()'s result as Base.frag uses it (forward variant)
             out["b"][m] = np.broadcast_to([metallic, 1.0, max(0.01, rough), 1.0], (k, 4))
             out["c"][m] = np.hstack([np.broadcast_to(base_color, (k, 3)), np.full((k, 1), ao)])
             out["d"][m] = np.hstack([P0, np.ones((k, 1))])
@@ -233,8 +234,10 @@ def bxdf(diffuse_color, roughness, LoH, NoV, NoL, NoH):
     return diffuse_color * (1.0 - F)[..., None] * Fd[..., None] + Fr[..., None]
 
 
-def lighting(gb, shadow_map, view, cube_face_colors, W, H, pcf_eps=0.0):
+def lighting(gb, shadow_map, view, cube_face_colors, W, H, pcf_eps=0.0, forward=False):
     """BaseLighting.frag:147-227 + case 0 of the switch for every pixel of the W x H quad.
+    forward=True: Base.frag:46-123 instead - the same text except that N is used as ComputeNormal() returned it, AO is not saturated,
+    there is no Mask, and case 0 shows FinalColor * ShadowFactor (after the gamma); gb then holds the fragment's unquantised inputs.
 
     gb: dict scene_color / a / b / c (float RGBA as texture() returns them) and d (fp16 values), each (H, W, 4); view: XkView record
     pcf_eps: added to the reference depth of the 25 shadow comparisons - the shader's one discontinuity: a caller that wants to know
@@ -246,9 +249,9 @@ def lighting(gb, shadow_map, view, cube_face_colors, W, H, pcf_eps=0.0):
     metallic = saturate(gb["b"][..., 0])
     roughness = np.maximum(0.01, saturate(gb["b"][..., 2]))
     normal = gb["a"][..., :3] * 2.0 - 1.0
-    ao = saturate(gb["c"][..., 3])
+    ao = gb["c"][..., 3] if forward else saturate(gb["c"][..., 3])
     mask = gb["scene_color"][..., 3]
-    N = normalize(normal)
+    N = normal if forward else normalize(normal)
     P = gb["d"][..., :3]
     cam = np.asarray(view["CameraInfo"], dtype=F64)[:3]
     V = normalize(cam - P)
@@ -317,6 +320,9 @@ def lighting(gb, shadow_map, view, cube_face_colors, W, H, pcf_eps=0.0):
         refl_v = saturate(np.power(NdotV + ao, roughness * roughness) - 1.0 + ao)
         refl = refl_l * refl_v[..., None] * refl_brdf
 
-        final = (direct + indirect + refl) * mask[..., None]
-        final = np.power(final, 0.4545)
+        if forward:
+            final = np.power(direct + indirect + refl, 0.4545) * shadow[..., None]
+        else:
+            final = (direct + indirect + refl) * mask[..., None]
+            final = np.power(final, 0.4545)
     return final

@@ -182,6 +182,40 @@ def test_oracle_agrees_with_an_independent_float64_evaluation(oracle_lib, name):
     assert len(np.unique(have.reshape(-1, 4), axis=0)) > 200        # a real picture: lights, shadow, reflection all vary
 
 
+@pytest.mark.parametrize("name", ["mixed", "single_sphere_no_sun", "rolled_and_clipped", "random_01", "random_04", "random_08"])
+def test_oracle_forward_variant_agrees_with_an_independent_float64_evaluation(oracle_lib, name):
+    """The forward variant (SH/Base.frag:46-123, zo_set_shading) against the same float64 statement of the GLSL: here nothing separates the
+    stages (no GBuffer to read back), so the evaluator shades its OWN interpolants - from unsnapped vertices, where the oracle interpolates
+    from vertices on the 1/256-pixel grid - and the agreement is that of the whole fragment shader."""
+    W, H, SD = 192, 128, 256
+    scene, cam, (d, p, sp), roll = SCENES[name]()
+    o = oracle_lib.Oracle(W, H, SD)
+    scene.load(o)
+    o.update_uniforms(cam, d, p, sp, roll, 0.0, 0.0)
+    o.set_shading(True)
+    o.render(0)
+    mvp, _sh, view = o.get_frame()
+    prim = o.visibility()
+    mine = ie.base_scene(scene.draws(), mvp, prim, W, H)
+    ys, xs = mine["yx"]
+    gb = {k: np.zeros((H, W, 4)) for k in ("scene_color", "a", "b", "c", "d")}
+    gb["scene_color"][ys, xs] = mine["scene_color"]; gb["b"][ys, xs] = mine["b"]; gb["c"][ys, xs] = mine["c"]; gb["d"][ys, xs] = mine["d"]
+    gb["a"][ys, xs, :3] = (mine["normal"] + 1.0) / 2.0          # lighting() undoes exactly this
+    have = o.color().astype(np.int64)
+    covered = prim != 0xFFFFFFFF
+    assert (have[~covered] == (0, 0, 0, 255)).all(), "an empty pixel is the render pass's clear colour (ZE:3517)"
+    shade = lambda eps: ie.unorm(ie.lighting(gb, o.shadowmap(), view, FACES, W, H, pcf_eps=eps, forward=True), 8)      # noqa: E731
+    want, lo_hi = shade(0.0), [shade(-4e-7), shade(4e-7)]       # (the PCF comparison's ties, as in the deferred test above)
+    ok = _within_one(have[..., :3], want)
+    lo, hi = np.minimum(np.minimum(lo_hi[0], lo_hi[1]), want) - 1, np.maximum(np.maximum(lo_hi[0], lo_hi[1]), want) + 1
+    on_edge = (lo_hi[0] != lo_hi[1]).any(axis=-1)
+    ok = ok | (on_edge & np.all((have[..., :3] >= lo) & (have[..., :3] <= hi), axis=-1))
+    frac = ok[covered].mean()
+    print(name, "forward: within one LSB on %.5f of %d covered pixels, worst %d" % (frac, covered.sum(), np.abs(have[..., :3] - want)[covered].max()))
+    assert frac >= 0.999, "forward colour: only %.4f of the covered pixels within one LSB" % frac
+    assert (have[..., 3] == 255).all()
+
+
 def test_rotation_matrix_convention_against_the_oracle(oracle_lib):
     """MakeRotMatrix + `v * mat3(rotMat)` (SH/BaseInstanced.vert:38-70): the naming trap (mx turns about Y ...) and the row-vector
     product, checked numerically against the oracle's KAT entry point for a few Euler triples."""
