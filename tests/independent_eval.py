@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE.  Written from the reference's GLSL text alone (SH = Engine/ZeldaEngine/Shaders): SH/Base.vert:23-32,
 SH/BaseInstanced.vert:38-76, SH/BaseScene.frag:26-48, SH/BaseLighting.frag:147-254 and the functions of SH/Common.glsl they call
-— NOT from oracle/zo_oracle.c or csrc/zr_kernels.hip, whose author might have misread a shader line identically in both.  It
+— NOT from oracle/zo_oracle.c or the HIP kernels under csrc/, whose author might have misread a shader line identically in both.  It
 shares no code with them: different language, different precision (float64), different transcendentals (libm), naive evaluation
 order, exact sRGB / UNORM / fp16 conversions by definition instead of by table.
 

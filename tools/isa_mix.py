@@ -1,5 +1,5 @@
 """Static instruction mix of one kernel from the -S output of hipcc (a rough guide to where the VALU work is).
-    hipcc ... --cuda-device-only -S -o /tmp/zr_kernels.s csrc/zr_kernels.hip;  python tools/isa_mix.py /tmp/zr_kernels.s <mangled-prefix> [start-line end-line]"""
+    hipcc ... --cuda-device-only -S -o /tmp/zr_camera.s csrc/zr_camera.hip;  python tools/isa_mix.py /tmp/zr_camera.s <mangled-prefix> [start-line end-line]"""
 import collections, sys
 lines = open(sys.argv[1]).read().split('\n')
 prefix = sys.argv[2]

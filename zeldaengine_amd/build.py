@@ -11,10 +11,26 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libzelda_render.so")
-SOURCES = ["zr_kernels.hip", "zr_host.cpp", "zr_world.cpp", "zr_meshlet.cpp", "zr_assets.cpp", "zr_dist.cpp"]
-HEADERS = ["zr_math.h", "zr_types.h", "zr_ctx.h", "zr_meshlet.h", "../../include/zelda_abi.h", "../../include/zelda_render.h"]
+KERNELS = ["zr_cull.hip", "zr_shadow.hip", "zr_camera.hip", "zr_resolve.hip", "zr_lighting.hip", "zr_forward.hip", "zr_frame.hip"]      # one per pass
+SOURCES = KERNELS + ["zr_host.cpp", "zr_world.cpp", "zr_meshlet.cpp", "zr_assets.cpp", "zr_dist.cpp"]
+HEADERS = ["zr_math.h", "zr_types.h", "zr_ctx.h", "zr_meshlet.h", "zr_dev.h", "zr_raster.h", "zr_texture.h", "zr_surface.h", "zr_shade.h",
+           "../../include/zelda_abi.h", "../../include/zelda_render.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-D__HIP_PLATFORM_AMD__"]
+
+
+def _deps(path, seen=None):
+    """path and every file it #includes with quotes, transitively"""
+    seen = set() if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    for line in open(path, errors="replace"):
+        line = line.strip()
+        if line.startswith('#include "'):
+            _deps(os.path.join(os.path.dirname(path), line.split('"')[1]), seen)
+    return seen
 
 
 def needs_build():
@@ -35,17 +51,26 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
     bdir = os.path.join(HERE, "build" if out is None else "build_" + os.path.basename(out))
     os.makedirs(bdir, exist_ok=True)
     procs = []
+    flagkey = " ".join(FLAGS + list(extra_flags))
     for src in SOURCES:
         obj = os.path.join(bdir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        # a source is compiled again only when it, something it includes, or the flags changed: an A/B edit of one pass's kernels costs
+        # that one file's compile time (each .hip is a translation unit of its own, -fno-gpu-rdc)
+        deps = _deps(os.path.join(CSRC, src))
+        stamp = obj + ".flags"
+        if (not force and os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == flagkey
+                and os.path.getmtime(obj) >= max(os.path.getmtime(d) for d in deps)):
+            continue
         cmd = [hipcc, "-x", "hip"] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-        objs.append(obj)
-    for src, p in procs:
+        procs.append((src, stamp, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, stamp, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
+        open(stamp, "w").write(flagkey)
         if verbose and out:
             print(out.decode(errors="replace"))
     # ONE HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7, like /opt/rocm's).

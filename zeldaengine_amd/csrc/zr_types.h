@@ -188,7 +188,7 @@ struct GBufferPtrs {
 // Cubemap mip chain, level l = 6 faces of (dim >> l)^2 RGBA8 sRGB texels, face-major.
 struct CubeDesc { const uint8_t* levels[16]; };
 
-// launchers defined in zr_kernels.hip
+// launchers: each defined in the .hip of its pass (zr_cull / zr_shadow / zr_camera / zr_resolve / zr_lighting / zr_forward / zr_frame)
 void zr_launch_instance_prep(const XkInstanceData* in, ZrInstance* out, uint32_t n, uint32_t instanced, hipStream_t s);
 void zr_launch_cull(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, const ZrHiz& Z, ZrDevStats* stats,
                     int slot, uint32_t n_waves, hipStream_t s);
@@ -201,7 +201,7 @@ void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_
 // triangle-binned camera pass, per round: [k_select ->] k_geom -> k_scan_tri -> k_index -> k_tile
 struct ZrTriBins {
     ZrBinEntry* sel;                 // meshlet-instances of this round, as self-contained 32-byte records
-    // 32-byte triangle records (see zr_kernels.hip, "triangle records"), in chunks of ZR_TPOOL_CHUNK, structure-of-arrays inside a chunk:
+    // 32-byte triangle records (see zr_camera.hip, "triangle records"), in chunks of ZR_TPOOL_CHUNK, structure-of-arrays inside a chunk:
     uint4*    recA; uint4* recB;     //   (X0|Y0, z0, X1|Y1, z1)  (X2|Y2, z2, prim, 0), tile-relative int16 coordinates
     uint32_t* rtile;                 //   the record's tile
     uint32_t  n_chunks;              //   chunk k < n_waves: where wave k of k_geom starts; the rest is the pool
