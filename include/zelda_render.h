@@ -280,6 +280,10 @@ int  zr_dist_init(zr_ctx* ctx, const void* id, size_t bytes, uint32_t rank, uint
 int  zr_dist_prepare(zr_ctx* ctx, uint32_t rank, uint32_t world, uint32_t dist_flags);
 int  zr_dist_connect(zr_ctx* ctx, const void* id, size_t bytes);
 int  zr_dist_frame(zr_ctx* ctx);
+/* The composite of the frame zr_dist_frame enqueued last, copied into a caller-owned DEVICE buffer (W*H*4 bytes of RGBA8) in the order of
+ * the collective stream: behind that frame's all-gather + untile, ahead of the next frame's - zr_copy_frame_async for a multi-GPU host
+ * that keeps frames in flight (a presenting rank, a test that checks EVERY frame of a pipelined sequence). */
+int  zr_dist_copy_frame_async(zr_ctx* ctx, void* color_dev);
 
 /* --- world JSON + livelink (replaces XkWorld::Load ZE:1051-1147, socket thread ZE:1617-1710) --- */
 /* A Profab is the engine's asset bundle `Profabs/<name>/{models, textures}` (ZE:4922-5000).  Either the caller registers each

@@ -233,3 +233,14 @@ extern "C" int zr_dist_frame(zr_ctx* c)
     HIPCHK(c, hipGetLastError());
     return ZR_OK;
 }
+
+// The composite of the frame enqueued last, copied on the collective stream: in order behind that frame's untile, ahead of the next one's.
+extern "C" int zr_dist_copy_frame_async(zr_ctx* c, void* color_dev)
+{
+    if (!c || !color_dev) return ZR_ERR_ARG;
+    ZrDist* d = c->dist;
+    if (!d || !d->comm || d->k == 0) return zr_fail(c, ZR_ERR_STATE, "zr_dist_copy_frame_async: no frame enqueued by zr_dist_frame");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(color_dev, c->d_color, (size_t)c->W * c->H * 4, hipMemcpyDeviceToDevice, d->comm_s));
+    return ZR_OK;
+}

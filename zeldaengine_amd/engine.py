@@ -90,6 +90,7 @@ def lib():
         "zr_dist_prepare": [vp, u32, u32, u32],
         "zr_dist_connect": [vp, vp, sz],
         "zr_dist_frame": [vp],
+        "zr_dist_copy_frame_async": [vp, vp],
         "zr_profab_register": [vp, C.c_char_p, u32, vp],
         "zr_world_load_json": [vp, C.c_char_p, sz],
         "zr_set_asset_root": [vp, C.c_char_p],
@@ -508,6 +509,10 @@ class Renderer:
 
     def dist_frame(self):
         self._chk(self.L.zr_dist_frame(self.h))
+
+    def dist_copy_frame_async(self, color_dev_ptr):
+        """zr_dist_copy_frame_async: the last enqueued frame's composite into a caller-owned device buffer, in collective-stream order."""
+        self._chk(self.L.zr_dist_copy_frame_async(self.h, C.c_void_p(color_dev_ptr)))
 
     # ---- world / livelink
     def profab_register(self, name, mesh, material=None):
