@@ -317,6 +317,16 @@ def main():
             extras["textured_note"] = "same scene with seven non-constant 512^2 material textures (trilinear + anisotropic sampling in the resolve), %d frames" % k
             dt.r.close()
 
+    # N > 1: the configuration the north star assigns to a node - config 4 (1 M instances, 3840 x 2160) with the shadow map owned by light-space
+    # tiles - timed on the same ranks right after the metric's loop, so that the FIRST run on a node shows the design that is meant to scale and
+    # not only config 3 (0.38 ms of ~ 20 dependent launches per frame, which cannot).  A block of its own: `value` stays config 3.
+    c4_block = None
+    if world > 1 and not args.no_extras and args.config == 3 and not args.textured:
+        try:
+            c4_block = config4_tiles_block(args, world, rank, local_rank, rehearsal, timed_loop, gather_rows=lambda row: gather_json(row, world, dist, torch))
+        except Exception as e:      # noqa: BLE001
+            c4_block = {"error": "%s: %s" % (type(e).__name__, e)}
+
     rank_rows = None
     if world > 1:
         # every rank's own picture (wall time of its loop, GPU frame period, per-pass GPU times, survivors): the first hardware run of
@@ -325,13 +335,7 @@ def main():
                 "frame_gpu_ms_median": round(pct(periods, 0.5), 4) if periods else None,
                 "passes_ms": {k: round(v, 4) for k, v in times.items()},
                 "survivors": stats["survivors"], "covered_pixels": stats["covered_pixels"], "overflow": stats["overflow"]}
-        # (CPU tensors: gloo, like the barrier - nothing here may make torch open an RCCL communicator of its own beside the library's)
-        raw = json.dumps(mine).encode()
-        buf = torch.zeros(8192, dtype=torch.uint8)
-        buf[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
-        outs = [torch.zeros_like(buf) for _ in range(world)]
-        dist.all_gather(outs, buf)
-        rows = [json.loads(bytes(o.tolist()).rstrip(b"\0").decode()) for o in outs]
+        rows = gather_json(mine, world, dist, torch)
         rank_rows = {"slowest": max(rows, key=lambda r: r["frame_gpu_ms_median"] or r["loop_ms_per_step"])["rank"], "per_rank": rows}
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -445,6 +449,8 @@ def main():
                                     "(value-preserving); value_covered_pixels = covered pixels / frame time" % (stats["covered_pixels"], owned_px if world > 1 else W * H))
         if rank_rows is not None:
             line["ranks"] = rank_rows
+        if c4_block is not None:
+            line["config4_tiles"] = c4_block
         line.update(extras)
         if world == 1 and not args.no_cpu_baseline and args.config == 3:     # defined on the metric's workload only
             line["cpu_baseline"] = cpu_baseline(args.instances, args.cube_dim)
@@ -453,6 +459,53 @@ def main():
     if world > 1:
         barrier()
         dist.destroy_process_group()
+
+
+def gather_json(obj, world, dist, torch):
+    """every rank's small JSON object on every rank (CPU tensors: gloo, like the barrier - nothing here may make torch open an RCCL
+    communicator of its own beside the library's)"""
+    raw = json.dumps(obj).encode()
+    buf = torch.zeros(8192, dtype=torch.uint8)
+    buf[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    outs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    return [json.loads(bytes(o.tolist()).rstrip(b"\0").decode()) for o in outs]
+
+
+def config4_tiles_block(args, world, rank, local_rank, rehearsal, timed_loop, gather_rows, steps=40, warmup=8):
+    """BASELINE config 4 on the job's ranks with `--shadow-tiles` semantics: ms per frame (MAX over ranks, barriers as in the main loop)
+    and every rank's own row.  ZR_BENCH_C4_INSTANCES shrinks the scene for rehearsals on one GPU."""
+    from zeldaengine_amd import dist as zdist, engine, scenes
+    n_inst = int(os.environ.get("ZR_BENCH_C4_INSTANCES", "1000000"))
+    cfg = scenes.config4(n_inst, 16, cube_dim=args.cube_dim)
+    W, H = cfg["width"], cfg["height"]
+    native = not args.python_dist and not rehearsal
+    dr = zdist.make_distributed(W, H, 1024, device_index=local_rank, rank=rank, world=world, flags=0, split_shadow="tiles", native=native)
+    try:
+        engine.load_scene(dr.r, cfg)
+        dr.r.set_timing_interval(max(1, steps // 8))
+
+        def uniforms(dr_, i):
+            dr_.r.update_uniforms(cfg["camera"], cfg["dir"], cfg["point"], cfg["spot"], 0.0, 0.002 * i, 0.016 * i)
+        el = timed_loop(dr, steps, warmup, uniforms)
+        per = dr.r.frame_periods(steps - 1)
+        st = dr.r.stats()
+        row = {"rank": rank, "loop_ms_per_frame": round(timed_loop.local / steps * 1e3, 4),
+               "frame_gpu_ms_median": round(pct(per, 0.5), 4) if per else None,
+               "passes_ms": {k: round(v, 4) for k, v in dr.r.pass_times(min(8, steps)).items()},
+               "survivors": st["survivors"], "overflow": st["overflow"]}
+        rows = gather_rows(row)
+        fallback = getattr(dr, "native_fallback", None)
+        return {"workload": "BASELINE config 4: %d instanced 960-triangle spheres (%d meshlet-instances), %dx%d, 1 directional + 16 point lights, 1024^2 shadow map"
+                            % (n_inst, st["work_items"][1], W, H),
+                "shadow_mode": "tiles (the map owned by light-space super-tiles; + one all-gather of the packed shadow tiles)",
+                "host": "torch.distributed loop" if (args.python_dist or rehearsal or fallback) else "native RCCL host (zr_dist_*)",
+                "native_fallback": fallback, "frames": steps, "warmup": warmup,
+                "ms_per_frame": round(el / steps * 1e3, 4), "value_mpixels_s": round(W * H * steps / el / 1e6, 3),
+                "note": "whole-job time per frame (MAX over ranks); never `value` - the metric is quoted on config 3",
+                "per_rank": rows}
+    finally:
+        dr.close()
 
 
 def launch_ranks(n):

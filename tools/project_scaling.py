@@ -73,6 +73,29 @@ class RankContext:
         self.g.close()
 
 
+def verify(ctx, mode, ref_color, ref_shadow, zdist, np):
+    """A rank context's time counts only if it draws what the single context draws: its packed frame tiles (replicated / split: after a
+    whole frame; the split map is a partial one and is not compared) and, with the map owned by tiles, its packed shadow tiles."""
+    g, r, n = ctx.g, ctx.rank, ctx.world
+    keep = ctx.i
+    ctx.i = 1000
+    if mode == "tiles":
+        c = ctx.cfg
+        g.update_uniforms(c["camera"], c["dir"], c["point"], c["spot"], 0.0, 0.002 * ctx.i, 0.016 * ctx.i)
+        g.render_geometry(); g.shadow_pack(ctx.bufs[0].data_ptr()); ctx.torch.cuda.synchronize()
+        lay = zdist.tile_layout(ref_shadow.shape[1], ref_shadow.shape[0], n)
+        got = ctx.bufs[0].cpu().numpy().view(np.uint32).reshape(lay["slots_per_rank"], 32, 32)
+        want = zdist.pack_tiles(ref_shadow, r, n, pad=np.uint32(0x3F800000))
+        assert np.array_equal(got, want), "rank %d of %d: %d texels of its owned shadow tiles differ from the single context's map" % (r, n, int((got != want).sum()))
+        g.shadow_unpack(ctx.bufs[1].data_ptr()); g.render_lighting(); g.finish()      # (an empty map: the lit tiles are not comparable here)
+    else:
+        ctx.frame(); g.finish()
+        if mode == "replicated":
+            got, want = g.read_tiles(), zdist.pack_tiles(ref_color, r, n)
+            assert np.array_equal(got, want), "rank %d of %d: %d pixels of its tiles differ from the single context's frame" % (r, n, int((got != want).any(axis=-1).sum()))
+    ctx.i = keep
+
+
 def time_two_lanes(ctx, frames, warmup=8):
     g = ctx.g
     g.set_timing_interval(0)
@@ -111,9 +134,11 @@ def main():
     ap.add_argument("--frames", type=int, default=30)
     ap.add_argument("--modes", default="replicated,tiles,split")
     args = ap.parse_args()
-    from zeldaengine_amd import abi, engine, scenes
+    import numpy as np
+    from zeldaengine_amd import abi, dist as zdist, engine, scenes
     modes = args.modes.split(",")
     out = {"what": "PROJECTION from rank contexts timed one at a time on ONE MI355X - not a measured scaling curve (see the module docstring)",
+           "verified": "before it is timed, every rank context's packed frame tiles (replicated) / packed shadow tiles (tiles) were compared with the single context's frame / map: identical, or this file would not exist",
            "xgmi_link_gbs": XGMI_LINK_GBS, "assumed_rccl_latency_us_per_step": RCCL_HOP_US, "collectives_priced_as": "ring", "configs": {}}
     for c in [int(x) for x in args.configs.split(",")]:
         n_point = 256 if c == 5 else 16
@@ -122,6 +147,10 @@ def main():
         frames = args.frames if c == 3 else max(8, args.frames // 3)
         one_ctx = RankContext(engine, cfg, 0, 1); one_ctx.set_mode("replicated")
         one, _ = time_two_lanes(one_ctx, frames)
+        # what every rank context below must reproduce on its own tiles before its time counts: the single context's frame and shadow map
+        # at fixed uniforms (frame index 1000: the point lights somewhere along their spiral)
+        one_ctx.i = 1000; one_ctx.frame(); one_ctx.g.finish()
+        ref_color, ref_shadow = one_ctx.g.color(), one_ctx.g.shadowmap().view(np.uint32).copy()
         one_ctx.close()
         entry = {"resolution": [W, H], "n_gpus_1_ms": round(one, 4), "ranks": {}}
         sys.stderr.write("config %d N 1: %.3f ms\n" % (c, one))
@@ -142,6 +171,7 @@ def main():
                 alone = RankContext(engine, cfg, r, n, flags=abi.FLAG_SERIAL_PASSES)
                 for m in modes:
                     two.set_mode(m); alone.set_mode(m)
+                    verify(two, m, ref_color, ref_shadow, zdist, np)
                     ms, st = time_two_lanes(two, frames)
                     lane, _ = time_alone(alone)
                     res[m]["per"].append(round(ms, 4)); res[m]["lane"].append(lane); res[m]["surv"].append(st["survivors"][0])
