@@ -1,5 +1,5 @@
 // zr_camera.hip — the camera pass (deferred-scene pass, ZE:3417-3480) as triangle-level binning: k_hiz_build, k_select, k_geom<HIZ>,
-// k_scan_tri, k_index, k_tile<MODE, LAST>, k_sky_tiles.  See zr_dev.h for the map of the kernel files.
+// k_plan, k_tile<MODE, LAST>, k_sky_tiles.  See zr_dev.h for the map of the kernel files.
 #include "zr_dev.h"
 #include "zr_raster.h"
 
@@ -65,10 +65,10 @@ __global__ __launch_bounds__(256) void k_hiz_build(const unsigned long long* __r
 // A meshlet-binned rasteriser re-transforms a meshlet's vertices and re-tests all of its triangles in every tile the meshlet touches
 // (2.5 on average in the camera pass) and walks the survivors in whatever mix of sizes the queue hands a wave.
 // Here a meshlet is processed ONCE: k_geom transforms its vertices, applies the exact per-triangle tests (facing, degenerate, no
-// pixel centre, Hi-Z in round 2) and emits one 32-byte record per (triangle, owned tile) - vertices relative to the tile, three depths,
-// the primitive id - plus its tile id; k_scan_tri lays the tiles' ranges out, k_index writes the records' positions in tile order (an
-// index list), and k_tile's lanes gather them and do nothing but edge setup + walk on live triangles.  Same arithmetic, same keys as the meshlet-binned path
-// (kept in -DZR_DIAG builds for A/B): the frame is the same bit for bit.
+// pixel centre, Hi-Z in round 2) and appends one 32-byte record per (triangle, owned tile) - vertices relative to the tile, three depths,
+// the primitive id - to that tile's BUCKET of the record arrays (laid out by k_plan from the previous frame's counts: "triangle records"
+// below); k_tile's lanes read a bucket as one run and do nothing but edge setup + walk on live triangles.  Same arithmetic, same keys as the
+// meshlet-binned path (kept in -DZR_DIAG builds for A/B): the frame is the same bit for bit.
 
 // Which meshlet-instances does this round draw?  (The split of the two-pass occlusion culling, as k_bin_count makes it.)
 // Compacted per workgroup: one global atomic per 1024 work items (atomics on one address run at ~10 ns apiece on this part).
@@ -136,31 +136,19 @@ __global__ __launch_bounds__(256) void k_select(ZrPass P, const ZrObject* __rest
 // 32 bytes per (triangle, tile): three snapped vertices RELATIVE TO THE TILE'S ORIGIN as int16 pairs (a small triangle - every edge under
 // 64 px - that reaches the tile has its vertices within [-16384, 24576] sub-pixel units of it) with their depth bits, and the primitive id:
 //   plane A: (X0 | Y0 << 16, z0, X1 | Y1 << 16, z1)      plane B: (X2 | Y2 << 16, z2, prim, 0)
-// plus the tile id in a separate dword stream (k_index reads 4 bytes per record, not the record, to find where it goes).  Records live
-// in chunks of ZR_TPOOL_CHUNK, structure-of-arrays inside a chunk (every store and load of a wave is one contiguous run); chunk_fill[c] =
-// records in chunk c.  Both rounds of a frame use the chunks from 0: round 1's records have been moved and rasterised by then.
+// TILE BUCKETS.  Every tile owns a stretch [tile_base, tile_base + tile_cap) of the record arrays, laid out by k_plan at the end of the
+// PREVIOUS frame from that frame's own per-tile counts (+ 25 % + 32): k_geom appends a meshlet's records for a tile with ONE returning add on
+// the tile's cursor, k_tile reads its tile's stretch as one contiguous run.  No scan and no index list sit between the two kernels (they
+// were k_scan_tri + k_index: two launches, 33 us per frame alone, on the camera lane's critical path, and a 20 MB index list).  What does
+// not fit its bucket - the camera moved, a tile got busier than last frame - goes to ONE overflow region with its tile id beside it, and
+// the tile's first work unit picks its records out of that region: slower, exact, and rare.  A frame without a usable plan (first frame
+// of a scene; the round structure changed) runs k_geom once more ahead of the round, counting only, and plans from that.
 __device__ __forceinline__ uint32_t pack_xy(int X, int Y) { return ((uint32_t)X & 0xFFFFu) | ((uint32_t)Y << 16); }
-struct RecWriter {                 // wave-uniform state of one record stream of a wave
-    uint32_t cur, fill;            // the chunk being filled (>= n_chunks: the pool ran dry) and its fill
-};
-// room for `n` more records (wave-uniform): closes the chunk and takes one from the pool when it would overflow; false: pool dry
-__device__ __forceinline__ bool rec_reserve(RecWriter& W, uint32_t n, uint32_t lane, const ZrTriBins& B, ZrDevStats* __restrict__ stats, int slot)
-{
-    if (W.cur < B.n_chunks && W.fill + n > ZR_TPOOL_CHUNK) {
-        uint32_t nx_c = 0;
-        if (lane == 0) { B.chunk_fill[W.cur] = W.fill; nx_c = B.n_waves + atomicAdd(&stats->pool_next[slot], 1u); }
-        W.cur = min((uint32_t)__builtin_amdgcn_readfirstlane((int)nx_c), B.n_chunks);
-        W.fill = 0;
-    }
-    if (W.cur >= B.n_chunks) { if (lane == 0) { stats->overflow = 1u; stats->overflow_sticky = 1u; } return false; }
-    return true;
-}
-__device__ __forceinline__ void rec_store(const ZrTriBins& B, uint32_t pos, const int4& r0, const int4& r1, const int4& r2, uint32_t prim, uint32_t tile, int tx, int ty)
+__device__ __forceinline__ void rec_store(const ZrTriBins& B, uint32_t pos, const int4& r0, const int4& r1, const int4& r2, uint32_t prim, int tx, int ty)
 {
     const int ox = tx * (TILE * 256), oy = ty * (TILE * 256);
     B.recA[pos] = make_uint4(pack_xy(r0.x - ox, r0.y - oy), (uint32_t)r0.z, pack_xy(r1.x - ox, r1.y - oy), (uint32_t)r1.z);
     B.recB[pos] = make_uint4(pack_xy(r2.x - ox, r2.y - oy), (uint32_t)r2.z, prim, 0u);
-    B.rtile[pos] = tile;
 }
 struct RecTri { SV a, b, c; uint32_t prim; };
 __device__ __forceinline__ RecTri rec_load(const uint4 qa, const uint4 qb)
@@ -171,6 +159,12 @@ __device__ __forceinline__ RecTri rec_load(const uint4 qa, const uint4 qb)
     t.c.X = (int)(short)(qb.x & 0xFFFFu); t.c.Y = (int)qb.x >> 16; t.c.z = zr_u2f(qb.y); t.c.rw = 0.0f;
     t.prim = qb.z;
     return t;
+}
+// the tiles a drawn triangle's clipped pixel box reaches, packed tx0 | ty0 << 8 | tx1 << 16 | ty1 << 24; ZR_NO_TILES: draws nothing
+#define ZR_NO_TILES 0x0000FFFFu          // tx0 = ty0 = 255 > tx1 = ty1 = 0: touches no tile
+__device__ __forceinline__ bool rect_has(uint32_t r, int tx, int ty)
+{
+    return (int)(r & 255u) <= tx && tx <= (int)((r >> 16) & 255u) && (int)((r >> 8) & 255u) <= ty && ty <= (int)(r >> 24);
 }
 
 // Max depth already in the key buffer (per the pyramid Z) over the pixel blocks a snapped box touches: 4 x 4 blocks for a box under 16
@@ -190,14 +184,18 @@ __device__ __forceinline__ float pyramid_max(const ZrHiz& Z, int x0, int y0, int
 
 // One wave per selected meshlet-instance: vertices -> LDS, then a lane per triangle.
 // Triangles that pass the exact tests (facing, a pixel centre of the target inside the snapped box) become records, one per (triangle,
-// owned tile), in the wave's own chunks (wave k starts in chunk k and takes further ones from a pool: one atomic per ZR_TPOOL_CHUNK
-// records; a round is ONE launch whatever the scene's size).
+// owned tile), appended to the tiles' buckets: the wave first counts what every tile of the meshlet's tile rectangle gets (ballots), then
+// the lane of each such tile reserves the run with one returning add on the tile's cursor - ONE round trip per meshlet, whatever its
+// triangles - and the records go out as one contiguous run per tile.
 // ROUND 2 (HIZ = true): a meshlet whose snapped vertex box lies behind this frame's pyramid is dropped after the vertex phase, and every
 // triangle is tested once more by itself against the 4 x 4-pixel level (the meshlet's blocks stay in LDS for that).
-template <bool HIZ>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
-void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, uint32_t* __restrict__ tile_count,
-            ZrDevStats* __restrict__ stats, int slot, unsigned long long* __restrict__ vis64)
+// COUNT: nothing is stored and nothing returned - the per-tile counts of the round for k_plan (a frame without a usable plan).
+#ifndef ZR_GEOM_WAVES
+#define ZR_GEOM_WAVES 8
+#endif
+template <bool HIZ, bool COUNT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ZR_GEOM_WAVES, ZR_GEOM_WAVES)))
+void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, ZrDevStats* __restrict__ stats, int slot)
 {
     __shared__ int4 vstage[4][WAVE];
     __shared__ float hzs[4][WAVE];
@@ -206,17 +204,19 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
     const unsigned long long lt = (1ull << lane) - 1ull;
     const uint32_t wave_id = blockIdx.x * 4u + wv, n_waves = gridDim.x * 4u;
     constexpr bool pyramid = HIZ;
-    if (HIZ && wave_id == 0u && lane == 0u) stats->survivors[slot] = n;      // (k_tile_slow takes the meshlets dropped behind the pyramid off)
-    RecWriter Wd;                                        // the wave's record stream
-    Wd.cur = wave_id; Wd.fill = 0;
+    if (!COUNT && wave_id == 0u && lane == 0u) stats->survivors[slot] = n;      // (round 2: k_tile takes the meshlets dropped behind the pyramid off)
+    uint32_t* __restrict__ const cursor = B.cursor + (size_t)(slot == 2 ? 1u : 0u) * B.n_tiles * ZR_TSTRIDE;
     uint32_t culled = 0;
+    // the wave's next meshlet record is fetched (scalar loads: the address is the wave's) while the current one is worked on: the chain of
+    // dependent round trips per meshlet is vertices -> bucket reservation, not record -> vertices -> reservation
+    ZrBinEntry nx = ld_record(sel + min(wave_id, n ? n - 1u : 0u));
     for (uint32_t i = wave_id; i < n; i += n_waves) {
-        const uint4* __restrict__ rec = (const uint4*)(sel + i);
-        const uint4 e0 = rec[0], e1 = rec[1];
-        const float4* __restrict__ mp = (const float4*)(((unsigned long long)wave_uniform(e0.y) << 32) | wave_uniform(e0.x));
-        const uint2* __restrict__ tw = (const uint2*)(((unsigned long long)wave_uniform(e0.w) << 32) | wave_uniform(e0.z));
-        const ZrInstance* __restrict__ ip = (const ZrInstance*)(((unsigned long long)wave_uniform(e1.y) << 32) | wave_uniform(e1.x));
-        const uint32_t counts = wave_uniform(e1.z), pbase = wave_uniform(e1.w);
+        const ZrBinEntry be = nx;
+        if (i + n_waves < n) nx = ld_record(sel + (i + n_waves));
+        const float4* __restrict__ mp = be.mpos;
+        const uint2* __restrict__ tw = be.mtri;
+        const ZrInstance* __restrict__ ip = be.inst;
+        const uint32_t counts = be.counts, pbase = be.prim_base;
         const uint32_t vcount = counts & 255u, tcount = (counts >> 8) & 255u;
         const bool instanced = (counts >> 16) & 1u;
         uint2 tri_w[2];
@@ -274,6 +274,8 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
         }
         lds_fence();
 
+        // ---- per triangle (two per lane): the exact tests; what is left is the rectangle of tiles its clipped pixel box reaches
+        uint32_t trect[2] = { ZR_NO_TILES, ZR_NO_TILES };
 #pragma unroll
         for (int round = 0; round < 2; ++round) {
             const uint32_t t0 = (uint32_t)round * WAVE;
@@ -321,7 +323,7 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
                 }
             }
             // ---- slow triangles: the three clip-space vertices go to the list every owned tile tries
-            const unsigned long long ms = __ballot(is_slow);
+            const unsigned long long ms = COUNT ? 0ull : __ballot(is_slow);
             if (ms) {
                 uint32_t base = 0;
                 if (lane == (uint32_t)__builtin_ctzll(ms)) base = atomicAdd(&stats->n_slow[slot], (uint32_t)__popcll(ms));
@@ -339,71 +341,134 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
                     } else { stats->overflow = 1u; stats->overflow_sticky = 1u; }
                 }
             }
-            // ---- one record per (triangle, owned tile); ranks within a tile are handed out by k_index
-            const bool draw = alive && !hidden;
-            const int tx0 = x0 / TILE, ty0 = y0 / TILE;
-            const int nx = draw ? x1 / TILE - tx0 + 1 : 0, ny = draw ? y1 / TILE - ty0 + 1 : 0, ntile = nx * ny;
-            for (int step = 0; __ballot(step < ntile) != 0ull; ++step) {
-                bool emit = step < ntile;
-                uint32_t tile = 0;            // the record's tile
-                int rtx = 0, rty = 0;
-                if (emit) {
-                    // (a small triangle spans at most 3 x 3 tiles: the step's row by comparisons, not by a division)
-                    const int sy = (step >= nx) + (step >= 2 * nx), sx = step - sy * nx;
-                    rtx = tx0 + sx; rty = ty0 + sy;
-                    if (P.tile_world > 1u && tile_owner((uint32_t)rtx, (uint32_t)rty, P.tile_world) != P.tile_rank) emit = false;
-                    tile = (uint32_t)rty * P.tiles_x + (uint32_t)rtx;
+            if (alive && !hidden) trect[round] = (uint32_t)(x0 / TILE) | (uint32_t)(y0 / TILE) << 8 | (uint32_t)(x1 / TILE) << 16 | (uint32_t)(y1 / TILE) << 24;
+        }
+        // ---- the meshlet's own rectangle of tiles (a small triangle spans at most 3 x 3; the meshlet's usually 1 .. 4 tiles in all)
+        const unsigned long long any = __ballot(trect[0] != ZR_NO_TILES || trect[1] != ZR_NO_TILES);
+        if (!any) continue;
+        int TX0, TY0, TW, TH;
+        {
+            int lo = 0x7FFF7FFF, hi = (int)0x80008000;
+#pragma unroll
+            for (int round = 0; round < 2; ++round)
+                if (trect[round] != ZR_NO_TILES) {
+                    lo = op_pkmin(lo, (int)((trect[round] & 255u) | ((trect[round] >> 8) & 255u) << 16));
+                    hi = op_pkmax(hi, (int)(((trect[round] >> 16) & 255u) | (trect[round] >> 24) << 16));
                 }
-                const unsigned long long me = __ballot(emit);
-                if (!me) continue;
-                if (!rec_reserve(Wd, (uint32_t)__popcll(me), lane, B, stats, slot)) continue;
-                // count per tile: one add per (wave, tile), all of a step's in one instruction, and nobody waits for them.  The step's records
-                // are laid down tile by tile (a lane's place = its tile group's start + its rank in the group): a tile's records then form
-                // runs of whole cache lines in the chunk, which is what k_tile's gather through the index list reads
-                unsigned long long pend = me;
-                uint32_t cnt = 0, mypos = 0, gbase = 0;
-                while (pend) {
-                    const int leader = __builtin_ctzll(pend);
-                    const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)tile, leader);
-                    const unsigned long long same = __ballot(emit && tile == tl) & pend;
-                    const uint32_t ns = (uint32_t)__popcll(same);
-                    if ((int)lane == leader) cnt = ns;
-                    if (!HIZ && (same >> lane & 1ull)) mypos = gbase + (uint32_t)__popcll(same & lt);
-                    gbase += ns;
-                    pend &= ~same;
+            lo = wave_pkmin16(lo); hi = wave_pkmax16(hi);
+            TX0 = lo & 0xFFFF; TY0 = lo >> 16; TW = (hi & 0xFFFF) - TX0 + 1; TH = (hi >> 16) - TY0 + 1;
+        }
+        const int n_rect = TW * TH;
+        for (int c0 = 0; c0 < n_rect; c0 += WAVE) {          // (one turn, unless the meshlet reaches more than 64 tiles)
+            const int nn = min(WAVE, n_rect - c0);
+            // what every tile of the stretch gets: lane k keeps tile k's numbers
+            uint32_t cnt = 0, cnt0 = 0; int mtx = 0, mty = 0;
+            {
+                int tx = TX0 + c0 % TW, ty = TY0 + c0 / TW;
+                for (int k = 0; k < nn; ++k) {
+                    const uint32_t n0 = (uint32_t)__popcll(__ballot(rect_has(trect[0], tx, ty))), n1 = (uint32_t)__popcll(__ballot(rect_has(trect[1], tx, ty)));
+                    if ((int)lane == k) { cnt0 = n0; cnt = n0 + n1; mtx = tx; mty = ty; }
+                    if (++tx == TX0 + TW) { tx = TX0; ++ty; }
                 }
-                // (round 2 emits a few records per step: laid down in lane order they leave the wave as whole-line stores; grouped, the same
-                // bytes went out as scattered 16-byte writes - 20 MB of write requests for 5.5 MB of records)
-                if (HIZ) mypos = (uint32_t)__popcll(me & lt);
-                if (cnt) atomicAdd(&tile_count[tile * ZR_TSTRIDE], cnt);
-                if (emit) rec_store(B, Wd.cur * ZR_TPOOL_CHUNK + Wd.fill + mypos, r0, r1, r2, prim, tile, rtx, rty);
-                Wd.fill += gbase;
+            }
+            if (P.tile_world > 1u && tile_owner((uint32_t)mtx, (uint32_t)mty, P.tile_world) != P.tile_rank) cnt = 0;      // another rank's tile
+            const uint32_t tile = (uint32_t)mty * P.tiles_x + (uint32_t)mtx;
+            if (COUNT) { if (cnt) atomicAdd(&cursor[tile * ZR_TSTRIDE], cnt); continue; }
+            // one returning add per tile of the meshlet, all of them in one instruction: the run's place in the tile's bucket
+            uint32_t run = 0, tbase = 0, tcap = 0;
+            if (cnt) { run = atomicAdd(&cursor[tile * ZR_TSTRIDE], cnt); tbase = B.tile_base[tile]; tcap = B.tile_cap[tile]; }
+            // what does not fit the bucket (records run .. run + cnt - 1 at places >= tcap) goes to the overflow region: rare
+            uint32_t n_over = (cnt && run + cnt > tcap) ? run + cnt - max(run, tcap) : 0u, obase = 0;
+            if (__ballot(n_over != 0u)) {
+                const uint32_t incl = wave_incl_scan(n_over), tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                uint32_t ob = 0;
+                if (lane == 0u) ob = atomicAdd(&B.over_cursor[slot == 2 ? 1 : 0], tot);
+                obase = (uint32_t)__builtin_amdgcn_readfirstlane((int)ob) + incl - n_over;
+            }
+            // the records, tile by tile (wave-uniform loop): a tile's run is contiguous, round 0's triangles first
+#pragma unroll
+            for (int round = 0; round < 2; ++round) {
+                if ((uint32_t)round * WAVE >= tcount) break;
+                int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0;
+                if (trect[round] != ZR_NO_TILES) {
+                    r0 = vstage[wv][tri_w[round].x & 255u]; r1 = vstage[wv][(tri_w[round].x >> 8) & 255u]; r2 = vstage[wv][(tri_w[round].x >> 16) & 255u];
+                }
+                const uint32_t prim = pbase + tri_w[round].y;
+                for (int k = 0; k < nn; ++k) {
+                    const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)cnt, k);
+                    if (!ck) continue;
+                    const int tx = __builtin_amdgcn_readlane(mtx, k), ty = __builtin_amdgcn_readlane(mty, k);
+                    const bool mine = rect_has(trect[round], tx, ty);
+                    const unsigned long long m = __ballot(mine);
+                    if (!m) continue;
+                    const uint32_t rk = (uint32_t)__builtin_amdgcn_readlane((int)run, k), ca = (uint32_t)__builtin_amdgcn_readlane((int)tcap, k);
+                    if (mine) {
+                        const uint32_t place = rk + (round ? (uint32_t)__builtin_amdgcn_readlane((int)cnt0, k) : 0u) + (uint32_t)__popcll(m & lt);
+                        uint32_t pos;
+                        if (place < ca) pos = (uint32_t)__builtin_amdgcn_readlane((int)tbase, k) + place;
+                        else {
+                            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)obase, k) + (place - max(rk, ca));
+                            pos = o < B.over_cap ? B.over_base + o : 0xFFFFFFFFu;
+                            if (o < B.over_cap) B.over_tile[o] = (uint32_t)ty * P.tiles_x + (uint32_t)tx;
+                            else { stats->overflow = 1u; stats->overflow_sticky = 1u; }      // the record arrays are full: the frame is incomplete, and says so
+                        }
+                        if (pos != 0xFFFFFFFFu) rec_store(B, pos, r0, r1, r2, prim, tx, ty);
+                    }
+                }
             }
         }
     }
-    if (lane == 0) {
-        if (Wd.cur < B.n_chunks) B.chunk_fill[Wd.cur] = Wd.fill;
-        B.wave_culled[wave_id] = HIZ ? culled : 0u;
-    }
+    // (the round's record count is the sum of the tiles' cursors: k_plan books it - 8 192 waves adding to one word here would queue for ~10 ns apiece)
+    if (lane == 0 && !COUNT) B.wave_culled[wave_id] = HIZ ? culled : 0u;
 }
 
-// Exclusive scan of the per-tile record counts into tile_offset and k_tile's work units of <= `unit` records of ONE tile (the counters
-// and cursors of the tiles sit ZR_TSTRIDE words apart: atomics on one cache line queue up behind each other, and neighbouring tiles are
-// hit together); books the round.  ONE workgroup: every workgroup of k_index scanning the counts for itself was tried (a launch less on
-// the camera pipeline's critical path) and is as fast at 1080p but four times slower at 3840 x 2160 (8 160 tiles per scan, 32 KB of LDS
-// per workgroup: k_index 1.1 ms instead of 0.3).
-__global__ __launch_bounds__(1024) void k_scan_tri(const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
-                                                   uint4* __restrict__ chunk_tab, uint32_t chunk_cap, const uint32_t* __restrict__ owned_tiles, uint32_t n_tiles,
-                                                   uint32_t sorted_cap, ZrDevStats* __restrict__ stats, int slot, uint32_t unit)
+#ifndef ZR_BUCKET_SLACK
+#define ZR_BUCKET_SLACK 128u            // records a bucket holds beyond last frame's count + 25 %: a sphere's worth of triangles entering an empty tile
+#endif
+// The plan of the NEXT frame's record arrays, from this frame's per-tile counts (the greater of its rounds'): every owned tile gets a
+// bucket of count + 25 % + ZR_BUCKET_SLACK records (all of them scaled down together should they not fit: the overflow region takes what spills) and
+// ceil(bucket / unit) work units of k_tile; both rounds of a frame use the same buckets and the same units (a unit takes its share of
+// whatever its tile's cursor says).  Also what used to be k_tile's first duty: the cursors are zero again for the next frame.
+// ONE workgroup, after the resolve: the camera lane has nothing to do until the next frame begins, nothing waits for this launch.
+__global__ __launch_bounds__(1024) void k_plan(ZrTriBins B, const uint32_t* __restrict__ owned_tiles, uint32_t n_owned, uint32_t unit, ZrDevStats* __restrict__ stats)
 {
-    // (n_tiles = the tiles this context owns, owned_tiles their indices: only they can hold records - a rank of eight scans an eighth)
     __shared__ uint32_t wtot[16], cwtot[16];
+    __shared__ unsigned long long gsum[16];
+    __shared__ uint32_t nsum[16][2];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const uint32_t per = (n_tiles + 1023u) / 1024u;
-    const uint32_t b = min(n_tiles, tid * per), e = min(n_tiles, b + per);
+    const uint32_t per = (n_owned + 1023u) / 1024u;
+    const uint32_t b = min(n_owned, tid * per), e = min(n_owned, b + per);
+    uint32_t* __restrict__ c0 = B.cursor; uint32_t* __restrict__ c1 = B.cursor + (size_t)B.n_tiles * ZR_TSTRIDE;
+    // pass 1: what the buckets would like in total; and the records each round appended (the frame's statistics)
+    unsigned long long want = 0;
+    uint32_t n0 = 0, n1 = 0;
+    for (uint32_t j = b; j < e; ++j) {
+        const uint32_t t = owned_tiles[j], a0 = c0[t * ZR_TSTRIDE], a1 = c1[t * ZR_TSTRIDE], c = max(a0, a1);
+        want += (unsigned long long)c + (c >> 2) + ZR_BUCKET_SLACK;
+        n0 += a0; n1 += a1;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        want += (unsigned long long)__shfl_xor((long long)want, o);
+        n0 += (uint32_t)__shfl_xor((int)n0, o); n1 += (uint32_t)__shfl_xor((int)n1, o);
+    }
+    if (lane == 0u) { gsum[wv] = want; nsum[wv][0] = n0; nsum[wv][1] = n1; }
+    __syncthreads();
+    unsigned long long all = 0;
+    for (uint32_t i = 0; i < 16u; ++i) all += gsum[i];
+    if (tid == 0 && stats) {
+        uint32_t r0 = 0, r1 = 0;
+        for (uint32_t i = 0; i < 16u; ++i) { r0 += nsum[i][0]; r1 += nsum[i][1]; }
+        stats->bin_entries[1] = r0; stats->bin_entries[2] = r1;
+    }
+    const bool shrink = all > (unsigned long long)B.over_base;
+    // pass 2: buckets and units (one scan of each)
     uint32_t s = 0, cs = 0;
-    for (uint32_t j = b; j < e; ++j) { const uint32_t t = tile_count[owned_tiles[j] * ZR_TSTRIDE]; s += t; cs += (t + unit - 1u) / unit; }
-    // scan: inside the wave by shuffles, across the 16 waves through LDS - one barrier (this kernel is one workgroup on the critical path)
+    for (uint32_t j = b; j < e; ++j) {
+        const uint32_t t = owned_tiles[j], c = max(c0[t * ZR_TSTRIDE], c1[t * ZR_TSTRIDE]);
+        unsigned long long cap = (unsigned long long)c + (c >> 2) + ZR_BUCKET_SLACK;
+        if (shrink) cap = cap * B.over_base / all;
+        s += (uint32_t)cap; cs += max(1u, ((uint32_t)cap + unit - 1u) / unit);
+    }
     uint32_t incl = s, cincl = cs;
     for (int o = 1; o < 64; o <<= 1) {
         const uint32_t v = (uint32_t)__shfl_up((int)incl, o), cv = (uint32_t)__shfl_up((int)cincl, o);
@@ -411,78 +476,31 @@ __global__ __launch_bounds__(1024) void k_scan_tri(const uint32_t* __restrict__ 
     }
     if (lane == 63u) { wtot[wv] = incl; cwtot[wv] = cincl; }
     __syncthreads();
-    uint32_t wpre = 0, cwpre = 0, tot = 0, ctot = 0;
-    for (uint32_t i = 0; i < 16u; ++i) { if (i < wv) { wpre += wtot[i]; cwpre += cwtot[i]; } tot += wtot[i]; ctot += cwtot[i]; }
+    uint32_t wpre = 0, cwpre = 0, ctot = 0;
+    for (uint32_t i = 0; i < 16u; ++i) { if (i < wv) { wpre += wtot[i]; cwpre += cwtot[i]; } ctot += cwtot[i]; }
     uint32_t run = wpre + incl - s, crun = cwpre + cincl - cs;
     for (uint32_t j = b; j < e; ++j) {
-        const uint32_t i = owned_tiles[j];
-        const uint32_t t = tile_count[i * ZR_TSTRIDE], nu = (t + unit - 1u) / unit;
-        tile_offset[i] = run;
-        for (uint32_t k = 0; k < nu; ++k)          // k_tile's work units: (tile, first record, end) - one load there, not a search
-            if (crun + k < chunk_cap) chunk_tab[crun + k] = make_uint4(i, run + k * unit, run + min(t, (k + 1u) * unit), 0u);
-        run += t; crun += nu;
+        const uint32_t t = owned_tiles[j], c = max(c0[t * ZR_TSTRIDE], c1[t * ZR_TSTRIDE]);
+        unsigned long long cap = (unsigned long long)c + (c >> 2) + ZR_BUCKET_SLACK;
+        if (shrink) cap = cap * B.over_base / all;
+        const uint32_t nu = max(1u, ((uint32_t)cap + unit - 1u) / unit);
+        B.tile_base[t] = run; B.tile_cap[t] = (uint32_t)cap;
+        for (uint32_t k = 0; k < nu; ++k)
+            if (crun + k < B.unit_cap) B.unit_tab[crun + k] = make_uint4(t, k, nu, 0u);
+        run += (uint32_t)cap; crun += nu;
+        c0[t * ZR_TSTRIDE] = 0u; c1[t * ZR_TSTRIDE] = 0u;
     }
     if (tid == 0) {
-        stats->bin_entries[slot] = tot;               // triangle records of the round
-        stats->n_chunks[slot] = min(ctot, chunk_cap);
-        stats->chunk_counter[slot] = 0;
-        stats->survivors[slot] = stats->n_sel[slot];
-        if (ctot > chunk_cap || tot > sorted_cap) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
+        *B.n_units = min(ctot, B.unit_cap);
+        B.over_cursor[0] = 0u; B.over_cursor[1] = 0u;
+        if (ctot > B.unit_cap && stats) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
     }
 }
 
-// Every record -> its place in its tile's stretch of the tile-ordered INDEX LIST sidx[] (4 bytes per record: the record stays where k_geom
-// wrote it and k_tile gathers it).  A cursor per tile is advanced once per (wave, distinct tile) - the 64 records of a wave
-// come meshlet by meshlet, so they name a handful of tiles - because atomics on one address run at about 10 ns apiece on this part and
-// there are half a million records: the lanes first sort themselves into tile groups (scalar work, no memory), then every group's first
-// lane issues its add in ONE instruction.  One wave per record chunk.
-__global__ __launch_bounds__(256) void k_index(ZrTriBins B, const ZrDevStats* __restrict__ stats, int slot,
-                                               const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor)
-{
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const uint32_t used = min(B.n_waves + stats->pool_next[slot], B.n_chunks);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    // A chunk's four stretches of 64 records go through the dependent steps TOGETHER (tile ids -> tile offsets -> one cursor add per
-    // (stretch, tile) group -> stores): the kernel waits for memory three times per chunk, not three times per stretch (it spent 74 % of
-    // its wave-cycles waiting: round 3's counters).
-    constexpr uint32_t NB = ZR_TPOOL_CHUNK / 64u;
-    for (uint32_t ch = blockIdx.x * 4u + wv; ch < used; ch += gridDim.x * 4u) {
-        const uint32_t n = B.chunk_fill[ch], r0 = ch * ZR_TPOOL_CHUNK;
-        bool have[NB]; uint32_t tile[NB], off[NB], rank[NB], cnt[NB], b[NB]; int first[NB];
-#pragma unroll
-        for (uint32_t k = 0; k < NB; ++k) {
-            const uint32_t j = k * 64u + lane;
-            have[k] = j < n;
-            tile[k] = have[k] ? B.rtile[r0 + j] : 0u;
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < NB; ++k) off[k] = have[k] ? tile_offset[tile[k]] : 0u;
-#pragma unroll
-        for (uint32_t k = 0; k < NB; ++k) {
-            rank[k] = 0; cnt[k] = 0; first[k] = (int)lane;
-            unsigned long long pend = __ballot(have[k]);
-            while (pend) {
-                const int leader = __builtin_ctzll(pend);
-                const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)tile[k], leader);
-                const unsigned long long same = __ballot(have[k] && tile[k] == tl) & pend;
-                if (same >> lane & 1ull) { first[k] = leader; rank[k] = (uint32_t)__popcll(same & lt); cnt[k] = (uint32_t)__popcll(same); }
-                pend &= ~same;
-            }
-            b[k] = 0;
-            if (have[k] && first[k] == (int)lane) b[k] = atomicAdd(&tile_cursor[tile[k] * ZR_TSTRIDE], cnt[k]);
-        }
-#pragma unroll
-        for (uint32_t k = 0; k < NB; ++k) {
-            const uint32_t bb = (uint32_t)__shfl((int)b[k], first[k]);
-            const uint32_t dst = off[k] + bb + rank[k];
-            if (have[k] && dst < B.sorted_cap) B.sidx[dst] = r0 + k * 64u + lane;
-        }
-    }
-}
-
-// Persistent workgroups pull work units: <= ZR_TBATCHES batches of <= ZR_TCHUNK records of one tile, contiguous in the index list; lane per
-// triangle: gather, edge setup + walk into the tile's LDS keys; a unit's keys are merged into the frame key buffer once.  Nothing else.
-// The kernel also leaves the per-tile counters and the record pool as the next round's k_geom wants them (zero).
+// Persistent workgroups pull work units: a unit is part `part` of `parts` of ONE tile's bucket (k_plan: a tile whose bucket holds more than
+// ZR_TCHUNK * ZR_TBATCHES records is shared by several units), walked in batches of <= ZR_TCHUNK records; lane per triangle: edge setup + walk
+// into the tile's LDS keys; a unit's keys are merged into the frame key buffer once.  A tile's first unit also takes the tile's records out
+// of the overflow region (what did not fit the bucket this frame), if there are any.
 // Sorted walk.  The 64 lanes of a wave walk their triangles' boxes in lock step: a row loop as long as the tallest box, a column loop per
 // row as long as the widest box still alive there - with a unit's records in arrival order 35 % of the lanes' iterations were live
 // (simulated on the benchmark frame, 42.9 column iterations per 64 records for 15.0 of work).  A unit's <= 512
@@ -495,33 +513,68 @@ __global__ __launch_bounds__(256) void k_index(ZrTriBins B, const ZrDevStats* __
 // statistics.  The clipper is inlined under this kernel's own register budget (it spills; the path is rare).
 template <int MODE, bool LAST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
-void k_tile(ZrPass P, const uint4* __restrict__ chunk_tab, ZrTriBins B, uint32_t* __restrict__ tile_count,
-            uint32_t* __restrict__ tile_cursor, uint32_t n_tiles, ZrDevStats* __restrict__ stats, int slot,
+void k_tile(ZrPass P, ZrTriBins B, ZrDevStats* __restrict__ stats, int slot,
             unsigned long long* __restrict__ vis64, const uint32_t* __restrict__ owned_tiles, uint32_t n_owned)
 {
     static_assert(ZR_TCHUNK == 512u && TILE == 32, "two records per thread; box coordinates in 5 bits");
     __shared__ unsigned long long keys64[TILE_PIX];
     __shared__ uint4 srecA[ZR_TCHUNK], srecB[ZR_TCHUNK];
     __shared__ uint32_t hist[ZR_TSORT_BINS], wsum[4];
-    __shared__ uint32_t cur_unit;
+    __shared__ uint32_t cur_unit, uh[4], ocount;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const uint32_t n_units = stats->n_chunks[slot];
-    for (uint32_t i = blockIdx.x * 256u + tid; i < n_tiles; i += gridDim.x * 256u) { tile_count[i * ZR_TSTRIDE] = 0u; tile_cursor[i * ZR_TSTRIDE] = 0u; }
-    if (blockIdx.x == 0 && tid == 0) { stats->pool_used[slot] = stats->pool_next[slot]; }
+    const uint32_t n_units = *B.n_units, ri = slot == 2 ? 1u : 0u;
+    const uint32_t* __restrict__ const cursor = B.cursor + (size_t)ri * B.n_tiles * ZR_TSTRIDE;
+    if (blockIdx.x == 0 && tid == 0) { stats->n_chunks[slot] = n_units; stats->pool_used[slot] = B.over_cursor[ri]; }      // (pool_used: the round's overflow records)
     uint32_t unit = blockIdx.x;
     bool first = true;
     for (;;) {
         if (unit >= n_units) break;
+        // the unit's header, read by ONE thread while the others clear the keys: its tile, its share of the tile's bucket (records [lo, lo + n_own)
+        // of the min(cursor, cap) the bucket holds: equal shares, the last one short) and - a tile's first unit only - how much of the overflow
+        // region it has to sift for records that name its tile
+        if (tid == 0) {
+            const uint4 ct = B.unit_tab[unit];
+            const uint32_t n_all = cursor[ct.x * ZR_TSTRIDE], tcap = B.tile_cap[ct.x], n_in = min(n_all, tcap);
+            const uint32_t len = (n_in + ct.z - 1u) / ct.z, lo = min(n_in, ct.y * len);
+            uh[0] = ct.x; uh[1] = min(n_in - lo, len); uh[2] = B.tile_base[ct.x] + lo;
+            uh[3] = (ct.y == 0u && n_all > tcap) ? min(B.over_cursor[ri], B.over_cap) : 0u;
+        }
         for (uint32_t i = tid; i < TILE_PIX; i += 256u) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
-        const uint4 ct = chunk_tab[unit];
-        const uint32_t tile = ct.x, n_unit = min(ct.z, B.sorted_cap) - min(ct.y, B.sorted_cap);      // <= ZR_TCHUNK * ZR_TBATCHES
+        __syncthreads();
+        const uint32_t tile = wave_uniform(uh[0]), n_own = wave_uniform(uh[1]), rec0 = wave_uniform(uh[2]), n_sift = wave_uniform(uh[3]);
+        const uint32_t n_unit = n_own + n_sift;
+        if (n_unit == 0u) {           // nothing for this unit (an empty tile keeps its one unit): the next one
+            if (first) { first = false; __syncthreads(); unit += gridDim.x; continue; }
+            if (tid == 0) cur_unit = 2u * gridDim.x + atomicAdd(&stats->chunk_counter[slot], 1u);
+            __syncthreads();
+            unit = cur_unit;
+            __syncthreads();
+            continue;
+        }
         const int tpx0 = (int)(tile % P.tiles_x) * TILE, tpy0 = (int)(tile / P.tiles_x) * TILE;
         TileCtx T;
         T.px0 = 0; T.py0 = 0; T.W = (int)P.W - tpx0; T.H = (int)P.H - tpy0;
         const int wx1 = min(TILE - 1, T.W - 1), wy1 = min(TILE - 1, T.H - 1);
+        // A tile that got more than its bucket holds: its first unit sifts the overflow region's tile ids ONCE (256 threads, coalesced) for the
+        // records that name this tile and lists them (in the record staging area, which is idle here).  Up to ZR_TCHUNK of them - the usual
+        // case by far: a few dozen - head the unit's first batch; more than that and the unit walks the whole region in batches instead.
+        uint32_t n_list = 0u;
+        bool listed = true;
+        uint32_t* const olist = (uint32_t*)srecA;          // (ZR_TCHUNK x 16 bytes: room for 4 x ZR_TCHUNK indices)
+        if (n_sift) {
+            if (tid == 0) ocount = 0u;
+            __syncthreads();
+            for (uint32_t o = tid; o < n_sift; o += 256u)
+                if (B.over_tile[o] == tile) { const uint32_t sl = atomicAdd(&ocount, 1u); if (sl < ZR_TCHUNK) olist[sl] = o; }
+            __syncthreads();
+            n_list = wave_uniform(ocount);
+            listed = n_list <= ZR_TCHUNK;
+            if (!listed) n_list = 0u;
+        }
+        const uint32_t n_seq = listed ? n_list + n_own : n_unit;      // the unit's sequence: [listed overflow records] bucket records [the region, batch by batch]
       // a unit's batches of <= ZR_TCHUNK records go into the same keys: one clear and one merge per unit, not per batch
-      for (uint32_t b0 = 0; b0 < n_unit; b0 += ZR_TCHUNK) {
-        const uint32_t rbeg = ct.y + b0, n = min(n_unit - b0, ZR_TCHUNK);
+      for (uint32_t b0 = 0; b0 < n_seq; b0 += ZR_TCHUNK) {
+        const uint32_t n = min(n_seq - b0, ZR_TCHUNK);
         hist[tid] = 0u;
         __syncthreads();
         // ---- count: the thread's two records, their clipped boxes (raster_sub's own expressions), the rank among equal keys
@@ -530,8 +583,16 @@ void k_tile(ZrPass P, const uint4* __restrict__ chunk_tab, ZrTriBins B, uint32_t
         for (int k = 0; k < 2; ++k) {
             const uint32_t j = tid + (uint32_t)k * 256u;
             key[k] = 0u; rank[k] = 0u;
-            if (j < n) {
-                const uint32_t src = B.sidx[rbeg + j];      // (a tile's records come in runs of one meshlet's: the gather reads whole cache lines mostly)
+            // (the bucket is one contiguous run; behind it, for a tile's first unit, the overflow region's records that name this tile)
+            const uint32_t g = b0 + j;
+            bool have = j < n;
+            uint32_t src;
+            if (g < n_list) src = B.over_base + olist[g];              // (only the first batch can hold listed records: read before anything is staged)
+            else {
+                src = rec0 + (g - n_list);
+                if (have && g - n_list >= n_own) { const uint32_t o = g - n_list - n_own; have = B.over_tile[o] == tile; src = B.over_base + o; }
+            }
+            if (have) {
                 qa[k] = B.recA[src]; qb[k] = B.recB[src];
                 const int X0 = (int)(short)(qa[k].x & 0xFFFFu), Y0 = (int)qa[k].x >> 16, X1 = (int)(short)(qa[k].z & 0xFFFFu), Y1 = (int)qa[k].z >> 16;
                 const int X2 = (int)(short)(qb[k].x & 0xFFFFu), Y2 = (int)qb[k].x >> 16;
@@ -548,8 +609,7 @@ void k_tile(ZrPass P, const uint4* __restrict__ chunk_tab, ZrTriBins B, uint32_t
         // ---- exclusive scan of the 256 bins (bin 0 = records that reach no pixel of the tile: none, by k_geom's construction)
         {
             const uint32_t v = tid ? hist[tid] : 0u;
-            uint32_t incl = v;
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, o); if ((int)lane >= o) incl += u; }
+            const uint32_t incl = wave_incl_scan(v);      // (on the DPP network: no lane-index registers held across the unit loop)
             if (lane == 63u) wsum[wv] = incl;
             __syncthreads();
             uint32_t pre = 0;
@@ -589,6 +649,7 @@ void k_tile(ZrPass P, const uint4* __restrict__ chunk_tab, ZrTriBins B, uint32_t
         if (tid == 0) cur_unit = 2u * gridDim.x + atomicAdd(&stats->chunk_counter[slot], 1u);
         __syncthreads();
         unit = cur_unit;
+        __syncthreads();      // (cur_unit is rewritten by the next claim)
     }
     if (LAST) {
         if (slot == 2) {        // the meshlets round 2's k_geom dropped behind the pyramid: per-wave counts, strided over this grid
@@ -678,26 +739,24 @@ void zr_launch_select(const ZrPass& P, const ZrObject* objs, const uint32_t* wor
     if (P.n_work == 0) return;
     hipLaunchKernelGGL(k_select, dim3((P.n_work + 1023) / 1024), dim3(ZR_SELECT_THREADS), 0, s, P, objs, work, rects, Z, B.sel, stats, slot);
 }
-void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, uint32_t* tile_count, ZrDevStats* stats, int slot, unsigned long long* vis64, hipStream_t s)
+void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats, int slot, bool count_only, hipStream_t s)
 {
     const dim3 g(B.n_waves / 4u), b(256);
-    if (Z.phase == 2u) hipLaunchKernelGGL(k_geom<true>, g, b, 0, s, P, B.sel, Z, B, tile_count, stats, slot, vis64);
-    else hipLaunchKernelGGL(k_geom<false>, g, b, 0, s, P, B.sel, Z, B, tile_count, stats, slot, vis64);
+    if (count_only) {
+        if (Z.phase == 2u) hipLaunchKernelGGL((k_geom<true, true>), g, b, 0, s, P, B.sel, Z, B, stats, slot);
+        else hipLaunchKernelGGL((k_geom<false, true>), g, b, 0, s, P, B.sel, Z, B, stats, slot);
+    } else if (Z.phase == 2u) hipLaunchKernelGGL((k_geom<true, false>), g, b, 0, s, P, B.sel, Z, B, stats, slot);
+    else hipLaunchKernelGGL((k_geom<false, false>), g, b, 0, s, P, B.sel, Z, B, stats, slot);
 }
-void zr_launch_scan_tri(const uint32_t* tile_count, uint32_t* tile_offset, uint4* chunk_tab, uint32_t chunk_cap, const uint32_t* owned_tiles, uint32_t n_owned,
-                        const ZrTriBins& B, ZrDevStats* stats, int slot, hipStream_t s)
+void zr_launch_plan(const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned, ZrDevStats* stats, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_scan_tri, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, chunk_tab, chunk_cap, owned_tiles, n_owned, B.sorted_cap, stats, slot, ZR_TCHUNK * ZR_TBATCHES);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, B, owned_tiles, n_owned, ZR_TCHUNK * ZR_TBATCHES, stats);
 }
-void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* tile_cursor, const ZrDevStats* stats, int slot, hipStream_t s)
+void zr_launch_tile(const ZrPass& P, const ZrTriBins& B, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s, bool last,
+                    const uint32_t* owned_tiles, uint32_t n_owned)
 {
-    hipLaunchKernelGGL(k_index, dim3(B.n_waves / 4u), dim3(256), 0, s, B, stats, slot, tile_offset, tile_cursor);
-}
-void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B, uint32_t* tile_count, uint32_t* tile_cursor, uint32_t n_tiles,
-                    ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s, bool last, const uint32_t* owned_tiles, uint32_t n_owned)
-{
-    if (last) hipLaunchKernelGGL((k_tile<ZR_MODE_GBUFFER, true>), dim3(n_blocks), dim3(256), 0, s, P, chunk_tab, B, tile_count, tile_cursor, n_tiles, stats, slot, vis64, owned_tiles, n_owned);
-    else hipLaunchKernelGGL((k_tile<ZR_MODE_GBUFFER, false>), dim3(n_blocks), dim3(256), 0, s, P, chunk_tab, B, tile_count, tile_cursor, n_tiles, stats, slot, vis64, owned_tiles, n_owned);
+    if (last) hipLaunchKernelGGL((k_tile<ZR_MODE_GBUFFER, true>), dim3(n_blocks), dim3(256), 0, s, P, B, stats, slot, vis64, owned_tiles, n_owned);
+    else hipLaunchKernelGGL((k_tile<ZR_MODE_GBUFFER, false>), dim3(n_blocks), dim3(256), 0, s, P, B, stats, slot, vis64, owned_tiles, n_owned);
 }
 void zr_launch_sky_tiles(const ZrPass& P, const ZrObject* objs, const uint32_t* owned_tiles, uint32_t n_owned, unsigned long long* sky64, hipStream_t s)
 {

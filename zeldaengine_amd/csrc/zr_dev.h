@@ -196,6 +196,14 @@ __device__ __forceinline__ int op_fmax(int a, int b) { return (int)zr_f2u(__buil
 __device__ __forceinline__ float wave_fmin(float f) { const int idn = 0x7F800000, v = (int)zr_f2u(f); return zr_u2f((uint32_t)[&]() { ZR_WAVE_REDUCE(op_fmin); }()); }
 __device__ __forceinline__ float wave_fmax(float f) { const int idn = (int)0xFF800000, v = (int)zr_f2u(f); return zr_u2f((uint32_t)[&]() { ZR_WAVE_REDUCE(op_fmax); }()); }
 
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)      // inclusive prefix sum over the wave's lanes (rows on the DPP network, then across)
+{
+    const int idn = 0;
+    int r = (int)v;
+    ZR_DPP_STEP(op_add, 0x111, 0xF); ZR_DPP_STEP(op_add, 0x112, 0xF); ZR_DPP_STEP(op_add, 0x114, 0xF); ZR_DPP_STEP(op_add, 0x118, 0xF);
+    ZR_DPP_STEP(op_add, 0x142, 0xA); ZR_DPP_STEP(op_add, 0x143, 0xC);
+    return (uint32_t)r;
+}
 __device__ __forceinline__ float lane_bcast(float v, uint32_t src) { return zr_u2f((uint32_t)__builtin_amdgcn_readlane((int)zr_f2u(v), (int)src)); }
 __device__ __forceinline__ uint32_t lane_bcast(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
 

@@ -200,7 +200,9 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
     for (auto& e : c->view_ev) ok &= hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     {   // The camera lane must not share a hardware queue with the host's stream (HIP multiplexes streams onto a few of them and
         // two streams on one queue run strictly one after the other).  Streams of different priority come from different queue
-        // pools, so the camera lane - the frame's critical path anyway - is created with the highest priority.
+        // pools.  Which priority: the frame's period is the HOST's lane (lighting -> shadow pipeline), and since the camera lane lost its
+        // two scans and two index passes per frame (round 6: tile buckets) it no longer fills the period - at the highest priority it
+        // took from the host lane what it saved itself (5 300 Mpixel/s), at the lowest the host lane keeps its share (5 540; normal: 5 470).
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
 #ifdef ZR_DIAG
@@ -219,7 +221,7 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         if (mc && make_masked(mc, &c->cam_s)) { }
         else
 #endif
-        ok &= hipStreamCreateWithPriority(&c->cam_s, hipStreamNonBlocking, greatest) == hipSuccess;
+        ok &= hipStreamCreateWithPriority(&c->cam_s, hipStreamNonBlocking, least) == hipSuccess;
     }
     ok &= hipEventCreateWithFlags(&c->ev_cam, hipEventDisableTiming) == hipSuccess;
     ok &= hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
@@ -274,8 +276,10 @@ static void free_mesh_buffers(ZrMesh& m)
 
 static void free_tri_bins(zr_ctx* c)
 {
-    dev_free(c->tb.sel); dev_free(c->tb.recA); dev_free(c->tb.recB); dev_free(c->tb.rtile); dev_free(c->tb.sidx);
-    dev_free(c->tb.slow); dev_free(c->tb.chunk_fill); dev_free(c->tb.wave_culled);
+    dev_free(c->tb.sel); dev_free(c->tb.recA); dev_free(c->tb.recB); dev_free(c->tb.tile_base); dev_free(c->tb.tile_cap); dev_free(c->tb.cursor);
+    dev_free(c->tb.over_tile); dev_free(c->tb.over_cursor); dev_free(c->tb.unit_tab); dev_free(c->tb.n_units);
+    dev_free(c->tb.slow); dev_free(c->tb.wave_culled);
+    c->plan_valid = false;
 }
 
 static void free_scene(zr_ctx* c)
@@ -793,29 +797,32 @@ static int finalize_scene(zr_ctx* c)
             HIPCHK(c, dev_alloc(&sc.bins, c->bin_capacity));
             HIPCHK(c, dev_alloc(&sc.chunk_tab, c->chunk_capacity));
         }
-        // triangle-binned camera pass: triangle records (32 B + a 4-byte tile id) live in chunks of ZR_TPOOL_CHUNK; every wave of k_geom's
-        // fixed grid starts in two chunks of its own (drawn / deferred records) and takes further ones from the pool (a pool that runs dry
-        // is reported like a bin overflow); k_index lists their positions in tile order (4 bytes apiece).  Sized from the scene:
-        // 8 records per meshlet-instance, at least 32 Mi (8192 x 256 on top are the waves' own chunks) - 40 bytes
-        // apiece, 1.6 GB of 288 reserved, touched as far as a frame needs.
+        // triangle-binned camera pass: triangle records (32 B) live in per-tile BUCKETS of two 16-byte planes, laid out every frame by
+        // k_plan from the previous frame's per-tile counts; the last quarter of the planes is the overflow region (what a tile gets beyond its
+        // bucket).  Sized from the scene: 8 records per meshlet-instance, at least 32 Mi - 1 GB of 288 reserved, touched as far as a frame
+        // needs.  Planes that run full are reported like a bin overflow (zr_set_limits sizes them: 256 records per "chunk").
         free_tri_bins(c);
         c->tb.n_waves = 8192; c->tb.slow_cap = 1u << 18;
-        const uint64_t n_rec = std::min<uint64_t>(std::max<uint64_t>(32ull << 20, 8ull * c->n_work) + 1ull * c->tb.n_waves * ZR_TPOOL_CHUNK, 0x3FFFFFFFull);
-        c->tb.n_chunks = (uint32_t)(n_rec / ZR_TPOOL_CHUNK);
-        if (c->limit_record_chunks) c->tb.n_chunks = c->limit_record_chunks;      // zr_set_limits (a host sizing the pool; the overflow tests)
+        uint64_t n_rec = std::min<uint64_t>(std::max<uint64_t>(32ull << 20, 8ull * c->n_work), 0x3FFFFFFFull);
+        if (c->limit_record_chunks) n_rec = 256ull * c->limit_record_chunks;      // zr_set_limits (a host sizing the planes; the overflow tests)
         if (c->limit_slow_triangles) c->tb.slow_cap = std::max(2u, c->limit_slow_triangles);
-        c->tb.sorted_cap = (uint32_t)std::min<uint64_t>((uint64_t)c->tb.n_chunks * ZR_TPOOL_CHUNK, 0x7FFFFFFFull);
+        c->tb.over_base = (uint32_t)(n_rec - n_rec / 4u); c->tb.over_cap = (uint32_t)(n_rec / 4u);
+        c->tb.n_tiles = c->n_tiles;
+        c->tb.unit_cap = c->tb.over_base / (ZR_TCHUNK * ZR_TBATCHES) + 2u * c->n_tiles + 1u;
         HIPCHK(c, dev_alloc(&c->tb.sel, cap_w));
-        HIPCHK(c, dev_alloc(&c->tb.recA, (size_t)c->tb.n_chunks * ZR_TPOOL_CHUNK));
-        HIPCHK(c, dev_alloc(&c->tb.recB, (size_t)c->tb.n_chunks * ZR_TPOOL_CHUNK));
-        HIPCHK(c, dev_alloc(&c->tb.rtile, (size_t)c->tb.n_chunks * ZR_TPOOL_CHUNK));
-        HIPCHK(c, dev_alloc(&c->tb.sidx, c->tb.sorted_cap));
-        HIPCHK(c, dev_alloc(&c->tb.chunk_fill, c->tb.n_chunks));
-        HIPCHK(c, hipMemset(c->tb.chunk_fill, 0, (size_t)c->tb.n_chunks * 4));
+        HIPCHK(c, dev_alloc(&c->tb.recA, (size_t)n_rec));
+        HIPCHK(c, dev_alloc(&c->tb.recB, (size_t)n_rec));
+        HIPCHK(c, dev_alloc(&c->tb.over_tile, std::max<size_t>(1, c->tb.over_cap)));
+        HIPCHK(c, dev_alloc(&c->tb.tile_base, c->n_tiles)); HIPCHK(c, dev_alloc(&c->tb.tile_cap, c->n_tiles));
+        HIPCHK(c, dev_alloc(&c->tb.cursor, (size_t)2 * c->n_tiles * ZR_TSTRIDE));
+        HIPCHK(c, dev_alloc(&c->tb.over_cursor, 2)); HIPCHK(c, dev_alloc(&c->tb.n_units, 1));
+        HIPCHK(c, dev_alloc(&c->tb.unit_tab, c->tb.unit_cap));
+        // (no plan yet: every bucket is empty - the first frame counts before it draws, see gbuffer_pass)
+        HIPCHK(c, hipMemset(c->tb.tile_base, 0, (size_t)c->n_tiles * 4)); HIPCHK(c, hipMemset(c->tb.tile_cap, 0, (size_t)c->n_tiles * 4));
+        HIPCHK(c, hipMemset(c->tb.cursor, 0, (size_t)2 * c->n_tiles * ZR_TSTRIDE * 4));
+        HIPCHK(c, hipMemset(c->tb.over_cursor, 0, 8)); HIPCHK(c, hipMemset(c->tb.n_units, 0, 4));
         HIPCHK(c, dev_alloc(&c->tb.wave_culled, c->tb.n_waves));
         HIPCHK(c, dev_alloc(&c->tb.slow, 4ull * c->tb.slow_cap));
-        c->chunk_capacity = std::max<uint32_t>(c->chunk_capacity, c->tb.sorted_cap / ZR_TCHUNK + 2u * std::max(c->n_tiles, c->sn_tiles) + 1u);
-        for (auto& sc : c->sc) { dev_free(sc.chunk_tab); HIPCHK(c, dev_alloc(&sc.chunk_tab, c->chunk_capacity)); }
         HIPCHK(c, dev_alloc(&c->d_pxrect, cap_w)); HIPCHK(c, dev_alloc(&c->d_zmin, cap_w));
         HIPCHK(c, dev_alloc(&c->d_visflag[0], cap_w)); HIPCHK(c, dev_alloc(&c->d_visflag[1], cap_w));
         HIPCHK(c, hipMemset(c->d_visflag[0], 0, cap_w)); HIPCHK(c, hipMemset(c->d_visflag[1], 0, cap_w));      // (no frame's stamp is 0)
@@ -1189,18 +1196,20 @@ static void tri_select(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hip
 {
     zr_launch_select(P, c->d_objs, c->sc[1].work, c->sc[1].rects, Z, c->tb, c->d_stats, slot, s);
 }
-// One round of the triangle-binned camera pass: triangles -> records (k_geom), offsets (k_scan_tri), records -> tile order (k_index), tile
-// raster (k_tile).  One
-// k_tile_slow after the last round draws the clipped / long triangles of both.
-static void tri_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s, bool last)
+// One round of the triangle-binned camera pass: triangles -> records in their tiles' buckets (k_geom), tile raster (k_tile).  The buckets were
+// laid out by the previous frame's k_plan; `count_first`: there is no usable plan (first frame of a scene, or the last plan was made by a
+// two-round frame and this round draws everything) - k_geom runs once more ahead of the round, counting only, and k_plan lays the buckets
+// out from that.
+static void tri_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s, bool last, bool count_first)
 {
-    const zr_ctx::Scratch& sc = c->sc[1];
     if (P.n_work == 0) return;          // nothing to draw: the pass is its clear
-    zr_launch_geom(P, Z, c->tb, sc.tile_count, c->d_stats, slot, c->d_vis, s);
-    zr_launch_scan_tri(sc.tile_count, sc.tile_offset, sc.chunk_tab, c->chunk_capacity, c->d_owned, c->n_owned, c->tb, c->d_stats, slot, s);
-    zr_launch_index(c->tb, sc.tile_offset, sc.tile_cursor, c->d_stats, slot, s);
+    if (count_first) {
+        zr_launch_geom(P, Z, c->tb, c->d_stats, slot, true, s);
+        zr_launch_plan(c->tb, c->d_owned, c->n_owned, c->d_stats, s);
+    }
+    zr_launch_geom(P, Z, c->tb, c->d_stats, slot, false, s);
     // (the frame's last round also draws the slow triangles of both rounds: k_tile<LAST>)
-    zr_launch_tile(P, sc.chunk_tab, c->tb, sc.tile_count, sc.tile_cursor, c->n_tiles, c->d_stats, slot, c->d_vis, c->raster_blocks, s, last, c->d_owned, c->n_owned);
+    zr_launch_tile(P, c->tb, c->d_stats, slot, c->d_vis, c->raster_blocks, s, last, c->d_owned, c->n_owned);
 }
 static void raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hipStream_t s, int stage = 0)
 {
@@ -1354,7 +1363,9 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
     }
     const bool two = c->last_two_round;
     auto bin = [&](int slot) { if (!tri_bins) bin_and_raster(c, P, Z, slot, c->n_tiles, s); else if (slot == 2) tri_select(c, P, Z, slot, s); };
-    auto rast = [&](int slot) { if (tri_bins) tri_raster(c, P, Z, slot, s, slot == 2 || !two); else raster(c, P, Z, slot, s); };
+    // (the record buckets are planned from the previous frame: see tri_raster)
+    const bool count_first = !c->plan_valid || (!two && c->plan_two_round);
+    auto rast = [&](int slot) { if (tri_bins) tri_raster(c, P, Z, slot, s, slot == 2 || !two, slot == 1 && count_first); else raster(c, P, Z, slot, s); };
     if (c->last_two_round) {
         Z.phase = 1;
         bin(1);
@@ -1384,6 +1395,10 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
     zr_launch_resolve_gbuffer(P, c->d_objs, c->d_owned, c->n_owned, c->d_vis, c->G, c->d_lut, c->d_unorm_lut, Z.vis_now, c->d_stats, s, vis_mark);
     c->vis_mark_prev = vis_mark;
     if (ev) HIPCHK(c, hipEventRecord(ev[7], s));
+    if (tri_bins && P.n_work != 0) {     // the next frame's buckets, from this frame's counts: nothing on this lane waits for it
+        zr_launch_plan(c->tb, c->d_owned, c->n_owned, c->d_stats, s);
+        c->plan_valid = true; c->plan_two_round = two;
+    }
     if (hiz_on) { c->vis_history = true; c->vis_cur ^= 1; } else c->vis_history = false;
     HIPCHK(c, hipGetLastError());
     return ZR_OK;
@@ -1772,9 +1787,9 @@ extern "C" int zr_get_stats(zr_ctx* c, zr_stats* out_user, size_t bytes)
 #ifdef ZR_DIAG
     if (getenv("ZR_DUMP_STATS")) {     // diagnostics: the raw device block
         const ZrDevStats& h = c->h_stats;
-        fprintf(stderr, "zr stats: survivors %u %u %u  bin_entries %u %u %u  n_sel %u %u %u  n_slow %u %u %u  pool_used %u %u %u  hiz_culled %u  n_chunks %u %u %u\n",
+        fprintf(stderr, "zr stats: survivors %u %u %u  bin_entries %u %u %u  n_sel %u %u %u  n_slow %u %u %u  hiz_culled %u  n_chunks %u %u %u  overflow records %u %u\n",
                 h.survivors[0], h.survivors[1], h.survivors[2], h.bin_entries[0], h.bin_entries[1], h.bin_entries[2], h.n_sel[0], h.n_sel[1], h.n_sel[2],
-                h.n_slow[0], h.n_slow[1], h.n_slow[2], h.pool_used[0], h.pool_used[1], h.pool_used[2], h.hiz_culled, h.n_chunks[0], h.n_chunks[1], h.n_chunks[2]);
+                h.n_slow[0], h.n_slow[1], h.n_slow[2], h.hiz_culled, h.n_chunks[0], h.n_chunks[1], h.n_chunks[2], h.pool_used[1], h.pool_used[2]);
     }
 #endif
     memset(out, 0, sizeof *out);

@@ -397,14 +397,6 @@ void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* _
 // spans of 4 texels (the map's rows are 4-byte aligned, nothing more is asked of a global load), masks what lies beyond the box's right
 // edge, and folds its maximum into the item's word in LDS (ds_max).
 struct __attribute__((packed, aligned(4))) ZrTexel4 { uint32_t x, y, z, w; };      // four texels of a map row, from any texel on
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)      // inclusive prefix sum over the wave's lanes (rows on the DPP network, then across)
-{
-    const int idn = 0;
-    int r = (int)v;
-    ZR_DPP_STEP(op_add, 0x111, 0xF); ZR_DPP_STEP(op_add, 0x112, 0xF); ZR_DPP_STEP(op_add, 0x114, 0xF); ZR_DPP_STEP(op_add, 0x118, 0xF);
-    ZR_DPP_STEP(op_add, 0x142, 0xA); ZR_DPP_STEP(op_add, 0x143, 0xC);
-    return (uint32_t)r;
-}
 template <bool WORKLIST>
 __global__ __launch_bounds__(256) void k_shadow_occlusion(ZrPass P, const ZrObject* __restrict__ objs, const uint32_t* __restrict__ work,
                                                           const uint32_t* __restrict__ rects, const uint2* __restrict__ pxrect,

@@ -134,7 +134,7 @@ struct ZrDevStats {
     uint32_t hiz_culled;             // meshlet-instances rejected by the Hi-Z test
     uint32_t n_sel[3];               // triangle-binned camera pass: meshlet-instances selected for a round (slots as above)
     uint32_t n_slow[3];              //   triangles of the round that need the clipper / the 64-bit walk
-    uint32_t pool_next[3], pool_used[3];   // record chunks taken from the pool: running (k_geom) / final
+    uint32_t pool_next[3], pool_used[3];   // pool_used[slot]: records of the round that did not fit their tile's bucket (overflow region); pool_next: unused
     uint32_t shadow_occluded;        // shadow pass: meshlet-instances left out because the map's depths already hide them (host copy: the sum of
                                      //   the 32 partial sums k_shadow_occlusion keeps in the shadow pipeline's covered_part)
     uint32_t shadow_late;            //   ... and drawn in the late launch (not drawn last frame, not hidden this frame)
@@ -198,23 +198,26 @@ void zr_launch_hiz_build(const unsigned long long* vis64, uint32_t W, uint32_t H
 void zr_launch_scan(uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* chunk_offset, uint4* chunk_tab,
                     uint32_t chunk_cap, uint32_t n, uint32_t capacity, ZrDevStats* stats, int slot, hipStream_t s,
                     uint32_t chunk = ZR_CHUNK);
-// triangle-binned camera pass, per round: [k_select ->] k_geom -> k_scan_tri -> k_index -> k_tile
+// triangle-binned camera pass, per round: [k_select ->] k_geom -> k_tile; once per frame, after the resolve: k_plan (the next frame's buckets)
 struct ZrTriBins {
     ZrBinEntry* sel;                 // meshlet-instances of this round, as self-contained 32-byte records
-    // 32-byte triangle records (see zr_camera.hip, "triangle records"), in chunks of ZR_TPOOL_CHUNK, structure-of-arrays inside a chunk:
+    // 32-byte triangle records (see zr_camera.hip, "triangle records") in two 16-byte planes:
     uint4*    recA; uint4* recB;     //   (X0|Y0, z0, X1|Y1, z1)  (X2|Y2, z2, prim, 0), tile-relative int16 coordinates
-    uint32_t* rtile;                 //   the record's tile
-    uint32_t  n_chunks;              //   chunk k < n_waves: where wave k of k_geom starts; the rest is the pool
-    uint32_t* chunk_fill;            //   records in each chunk
+    uint32_t* tile_base;             // per tile: its bucket [tile_base, tile_base + tile_cap) of the planes, planned by k_plan from the previous
+    uint32_t* tile_cap;              //   frame's counts (buckets fill [0, over_base))
+    uint32_t* cursor;                // [2][n_tiles * ZR_TSTRIDE]: records appended to each tile in round 1 / round 2 of the frame (k_geom; zeroed by k_plan)
+    uint32_t  over_base, over_cap;   // the overflow region [over_base, over_base + over_cap): what did not fit its bucket, any tile's
+    uint32_t* over_tile;             //   ... and each such record's tile
+    uint32_t* over_cursor;           // [2]: overflow records of round 1 / round 2
+    uint4*    unit_tab;              // k_tile's work units (tile, part, parts of the tile, 0), planned with the buckets
+    uint32_t  unit_cap; uint32_t* n_units;
+    uint32_t  n_tiles;
     uint32_t  n_waves;               // waves of the k_geom grid
     uint32_t* wave_culled;           // per wave: meshlets it dropped behind the Hi-Z pyramid (round 2)
-    uint32_t* sidx;                  // the records' positions in tile order (k_index writes 4 B per record, k_tile gathers 2 x 16 B)
-    uint32_t  sorted_cap;
-    uint4*    slow; uint32_t slow_cap;      // 4 x uint4 per slow triangle: three clip-space vertices, (prim, 0, 0, 0)
+    uint4*    slow; uint32_t slow_cap;      // 4 x uint4 per slow triangle: three clip-space vertices, (prim, tile rect, 0, 0)
 };
-#define ZR_TPOOL_CHUNK 256u          // records per chunk of the record pool
 #ifndef ZR_TSTRIDE
-#define ZR_TSTRIDE 4u                 // words between the per-tile record counters (and cursors) of neighbouring tiles
+#define ZR_TSTRIDE 4u                 // words between the per-tile record cursors of neighbouring tiles
 #endif
 #ifdef ZR_TCHUNK_AB
 #define ZR_TCHUNK ZR_TCHUNK_AB
@@ -226,12 +229,10 @@ struct ZrTriBins {
 #endif                               // which are cleared and merged into the key buffer once per unit (1 / 2 / 4 / 8: 5 399 / 5 414 / 5 455 / 5 442 Mpixel/s)
 void zr_launch_select(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats,
                       int slot, hipStream_t s);
-void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, uint32_t* tile_count, ZrDevStats* stats, int slot, unsigned long long* vis64, hipStream_t s);
-void zr_launch_scan_tri(const uint32_t* tile_count, uint32_t* tile_offset, uint4* chunk_tab, uint32_t chunk_cap, const uint32_t* owned_tiles, uint32_t n_owned,
-                        const ZrTriBins& B, ZrDevStats* stats, int slot, hipStream_t s);
-void zr_launch_index(const ZrTriBins& B, const uint32_t* tile_offset, uint32_t* tile_cursor, const ZrDevStats* stats, int slot, hipStream_t s);
-void zr_launch_tile(const ZrPass& P, const uint4* chunk_tab, const ZrTriBins& B, uint32_t* tile_count, uint32_t* tile_cursor, uint32_t n_tiles,
-                    ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s, bool last, const uint32_t* owned_tiles, uint32_t n_owned);
+void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats, int slot, bool count_only, hipStream_t s);
+void zr_launch_plan(const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned, ZrDevStats* stats, hipStream_t s);
+void zr_launch_tile(const ZrPass& P, const ZrTriBins& B, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s, bool last,
+                    const uint32_t* owned_tiles, uint32_t n_owned);
 void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, const ZrHiz& Z, ZrDevStats* stats,
                         int slot, hipStream_t s, ZrBinEntry* sel = nullptr, const uint8_t* vis_prev = nullptr, bool reuse_list = false);      // sel: round 1's list (camera)
 void zr_launch_bin_fill(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const uint32_t* tile_offset,
