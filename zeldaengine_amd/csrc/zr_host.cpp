@@ -833,6 +833,7 @@ static int finalize_scene(zr_ctx* c)
     for (const ZrObject& d : tab) for (int t = 0; t < 7; ++t) if (d.tex[t].data) c->any_images = true;
     for (const auto& o : c->objects) if (o.mixed_sizes) c->mixed_images = true;      // (the skydome's one image is sampled by itself)
     c->vis_history = false;         // work item numbering changed: last frame's visibility says nothing about this scene
+    c->plan_valid = false;          // ... and neither do its per-tile record counts: the next frame counts before it draws (tri_raster)
     if (c->n_work) HIPCHK(c, hipMemsetAsync(c->d_sflag, 1, c->n_work, c->stream));      // shadow pass: everything is drawn in the first launch
     c->sflag_history = false;
     c->list_valid[0] = c->list_valid[1] = false;      // ... and neither do the passes' work lists
