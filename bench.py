@@ -10,8 +10,8 @@ A step is one full frame of the hot path on synthetic, HBM-resident input, INCLU
     -> deferred PBR + PCF lighting [-> RCCL all-gather of the packed RGBA8 tiles + untile, N > 1].
 N > 1 partitions the SAME frame by screen tiles, so scaling is "strong".  value = W*H*steps / max-over-ranks(wall time).
 
-roofline: quoted for the pass the north star names, the GBuffer-write pass = the two camera rounds (k_geom + k_scan_tri + k_index +
-k_tile [+ k_tile_slow] each) + k_resolve_gbuffer, against the 8 TB/s HBM peak.  `achieved` = SURVEY 8(d)'s algorithmic bytes of that
+roofline: quoted for the pass the north star names, the GBuffer-write pass = the two camera rounds (k_geom + k_tile each) +
+k_resolve_gbuffer, against the 8 TB/s HBM peak.  `achieved` = SURVEY 8(d)'s algorithmic bytes of that
 pass / the summed mean duration of those kernels, measured live with HIP events on the stream they are launched on (the library's
 camera lane).
 `traffic` = the same kernels' FETCH_SIZE / WRITE_SIZE counter bytes from the committed rocprofv3 summary named in
@@ -40,14 +40,14 @@ VALU_PEAK_PER_S = 256 * 4 * 2.4e9 / 2.0
 PROFILE_INDEX = os.path.join(ROOT, "profiles", "current.json")     # written by tools/make_profile_summary.py
 
 # the kernels of each timed pass (the cull / hiz passes are groups of launch-bound kernels).  A camera round of the triangle-binned
-# pass is k_geom (vertices -> triangle records) + k_scan_tri + k_index (records -> per-tile lists) + k_tile (+ k_tile_slow); k_scan_tri,
-# k_index, k_tile and k_tile_slow run once per round under one name, so their profile rows hold both rounds.
-KERNEL_OF_PASS = {"shadow": ("k_raster<SHADOW>", "k_tile_slow<SHADOW>"), "gbuffer": ("k_geom<false>", "k_scan_tri", "k_index", "k_tile<0>"),
+# pass is k_geom (vertices -> triangle records in their tiles' buckets) + k_tile; k_tile runs once per round under one name, so its
+# profile row holds both rounds.  (k_plan - the next frame's buckets - runs behind the resolve, off the pass's path.)
+KERNEL_OF_PASS = {"shadow": ("k_raster<SHADOW>", "k_tile_slow<SHADOW>"), "gbuffer": ("k_geom<false>", "k_tile<0>"),
                   "gbuffer2": ("k_geom<true>",), "resolve": ("k_resolve_gbuffer",), "lighting": ("k_lighting",)}
 # kernels a pass runs only in some scenes (the shadow pass's occlusion culling: on from one meshlet-instance per five texels of the map)
 KERNEL_OF_PASS_OPTIONAL = {"shadow": ("k_shadow_occlusion", "k_raster<SHADOW,late>")}
 GBUFFER_WRITE_PASS = ("gbuffer", "gbuffer2", "resolve")
-GBUFFER_WRITE_KERNELS = "k_geom + k_scan_tri + k_index + k_tile (x2 rounds; the last one also draws the slow triangles) + k_resolve_gbuffer"
+GBUFFER_WRITE_KERNELS = "k_geom + k_tile (x2 rounds; the last one also draws the slow triangles) + k_resolve_gbuffer"
 
 
 def workload_name(config, n_inst, n_work, W, H, n_point, cube_dim):

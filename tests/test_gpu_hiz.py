@@ -256,7 +256,7 @@ def test_config5_reduced_against_the_oracle_with_a_moving_camera(oracle_lib, gpu
 
 
 def test_camera_pass_against_the_oracle_with_and_without_hiz_rounds(oracle_lib, gpu_engine):
-    """The triangle-binned camera pass (k_cull_box, k_geom, k_index, k_tile) over the history sequence, with and without the Hi-Z rounds:
+    """The triangle-binned camera pass (k_cull_box, k_geom, k_tile) over the history sequence, with and without the Hi-Z rounds:
     both must give the oracle's frame, and the slow-triangle list must be exercised (the ground plane crosses the near plane; the
     wall's triangles are longer than 64 pixels).  (The meshlet-binned A/B rasteriser for the camera pass exists in -DZR_DIAG builds only:
     the product library refuses ZR_FLAG_MESHLET_BINS.)"""
@@ -287,8 +287,8 @@ def test_camera_pass_against_the_oracle_with_and_without_hiz_rounds(oracle_lib, 
 
 def test_record_pool_chunks_beyond_the_first(oracle_lib, gpu_engine):
     """With NO_HIZ every frame is one round over all frustum / cone survivors: at 60 000 instances a wave of k_geom handles ~60
-    meshlet-instances and fills its first record chunk (256 records: ZR_TPOOL_CHUNK) many times over, so the chunks it takes from the pool, their
-    fill counts and k_index's walk over them are exercised.  Checked against the scalar oracle (57.6 M triangles: ~20 s of CPU)."""
+    meshlet-instances and the busiest tiles hold tens of thousands of records - buckets split over many work units of k_tile, planned from a
+    count-only run of k_geom on the first frame.  Checked against the scalar oracle (57.6 M triangles: ~20 s of CPU)."""
     from zeldaengine_amd import engine as eng
     cfg = scenes.config3(60000, 1920, 1080)
     g = gpu_engine.Renderer(cfg["width"], cfg["height"], 1024, flags=abi.FLAG_NO_HIZ)

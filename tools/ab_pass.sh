@@ -25,7 +25,7 @@ out = []
 for n in sorted(rows):
     if n.startswith(("k_geom", "k_scan_tri", "k_index", "k_tile<0", "k_resolve", "k_hiz", "k_select")):
         per = rows[n][0] * rows[n][1] / frames
-        if not n.startswith(("k_hiz", "k_select")): tot += per
+        if not n.startswith(("k_hiz", "k_select")) and not (n.startswith("k_geom") and n.endswith(", true>")): tot += per      # (count-only k_geom: first frame only)
         out.append("%s %.1f" % (n.replace("k_", ""), per))
 print("    alone, us per frame: " + "  ".join(out) + "  | GBuffer-write pass alone %.1f us" % tot)
 PY

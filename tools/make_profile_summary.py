@@ -41,6 +41,8 @@ SHORT = {"k_raster_chunks<0, false>": "k_raster<GBUFFER>", "k_raster_chunks<0, t
          "k_raster_chunks<0, false, false>": "k_raster<GBUFFER>", "k_raster_chunks<0, true, false>": "k_raster<GBUFFER,HiZ>",
          "k_tile_slow<0, false>": "k_tile_slow<GBUFFER>", "k_tile_slow<1, true>": "k_tile_slow<SHADOW>",
          "k_tile<0, false>": "k_tile<0>", "k_tile<0, true>": "k_tile<0>",      # (the frame's last round also draws the slow triangles)
+         "k_geom<false, false>": "k_geom<false>", "k_geom<true, false>": "k_geom<true>",      # (<.., true>: the count-only run of a frame without a bucket plan)
+         "k_geom<false, true>": "k_geom<false,count>", "k_geom<true, true>": "k_geom<true,count>",
          "k_cull_box<0, false>": "k_cull_box<GBUFFER>", "k_cull_box<1, false>": "k_cull_box<SHADOW>",
          "k_cull_box<0, true>": "k_cull_box<GBUFFER,worklist>", "k_cull_box<1, true>": "k_cull_box<SHADOW,worklist>", "k_cull<0, false>": "k_cull<GBUFFER>", "k_cull<1, false>": "k_cull<SHADOW>",
          "k_cull<0, true>": "k_cull<GBUFFER,worklist>", "k_cull<1, true>": "k_cull<SHADOW,worklist>"}
