@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_tile_slow(ZrPass P, const uint32_t* __r
                 if ((uint32_t)k != ZR_EMPTY_PRIM && k < vis64[p]) atomicMin(&vis64[p], k);
             } else {
                 const uint32_t k = keys32[i];
-                if (k < shadow_bits[p]) atomicMin(&shadow_bits[p], k);
+                if (k != 0x3F800000u && k < shadow_bits[p]) atomicMin(&shadow_bits[p], k);
             }
         }
         __syncthreads();      // the keys are cleared again for the next tile
