@@ -253,7 +253,7 @@ __device__ __forceinline__ bool tile_hides(const ZrHiz& Z, float zt, uint32_t ti
 #define ZR_LIGHT_TB 512
 #endif
 #ifndef ZR_LIGHT_WAVES
-#define ZR_LIGHT_WAVES 4             // waves per SIMD k_lighting is compiled for (see the note at the kernel)
+#define ZR_LIGHT_WAVES 5             // waves per SIMD k_lighting is compiled for (see the note at the kernel)
 #endif
 #ifndef ZR_PIXELS_PER_THREAD
 #define ZR_PIXELS_PER_THREAD 1       // of k_resolve_gbuffer and k_lighting: 1, 2 or 4 (a tile is 1 024 pixels; workgroups per tile follow)

@@ -6,8 +6,10 @@
 
 // BaseLighting.frag:147-254 for every pixel of the owned tiles (the full-screen quad of ZE:3531-3540)
 template <bool LIGHT_LIST, bool BACKGROUND, int TB, int PPT>      // PPT: pixels per thread, 4 or 1 (as in k_resolve_gbuffer)
-// (compiled for exactly 4 waves per SIMD: left to itself the allocator takes 127 VGPRs, told so it makes do with 97 - the same four
-// waves, but 120 registers per SIMD left for the other lane's kernels; 5 or 6 waves (95 / 80 VGPRs) are faster alone, not beside)
+// (compiled for exactly ZR_LIGHT_WAVES = 5 waves per SIMD: 96 VGPRs and 24 bytes of scratch.  Left to itself the allocator takes 127 registers.
+// Rounds 4 - 5 ran it at 4 waves (97 VGPRs): beside a camera lane that filled the whole period, a fifth wave cost that lane more than it gave
+// this pass.  Since the camera lane lost its scans and index passes (round 6) the frame's period is THIS lane's, and the fifth wave pays:
+// 4 / 5 / 6 waves: 5 548 / 5 670 / 5 420 Mpixel/s)
 __global__ __launch_bounds__(TB) __attribute__((amdgpu_waves_per_eu(ZR_LIGHT_WAVES, ZR_LIGHT_WAVES))) void k_lighting(ZrLightParams L, const XkView* __restrict__ view,
                                                   const uint32_t* __restrict__ owned_tiles, GBufferPtrs G,
                                                   const float* __restrict__ shadowmap, CubeDesc C,
