@@ -149,10 +149,15 @@ int  zr_mesh_get_meshlets(zr_ctx* ctx, uint32_t mesh_id, XkMeshlet* m, uint32_t*
 /* n_inst == 0: non-instanced draw (Base.vert); n_inst >= 1: instanced draw (BaseInstanced.vert). */
 int  zr_object_add(zr_ctx* ctx, uint32_t mesh_id, const zr_material* mat,
                    const XkInstanceData* inst, uint32_t n_inst);
-/* Capacities of the camera pass's triangle-record pool (in chunks of 256 records of 40 bytes: 32 + a tile id + an index-list entry) and of its clipped-triangle list; 0 =
- * defaults (8 records per meshlet-instance of the scene, at least 32 Mi, plus 8192 chunks the rasteriser's waves start in; 2^18
- * triangles).  A frame that outgrows either reports ZR_ERR_OVERFLOW at zr_finish.  Takes effect at the next frame (the pools are re-made). */
+/* Capacities of the camera pass's triangle-record arrays (record_chunks x 256 records of 32 bytes, + 4 bytes of tile id) and of its
+ * clipped-triangle list; 0 = defaults (8 records per meshlet-instance of the scene, at least 32 Mi; 2^18 triangles).  A frame that
+ * outgrows either reports ZR_ERR_OVERFLOW at zr_finish.  Takes effect at the next frame (the arrays are re-made). */
 int  zr_set_limits(zr_ctx* ctx, uint32_t record_chunks, uint32_t slow_triangles);
+/* The record arrays are laid out per frame as one bucket per screen tile, sized from the previous frame's count (+ 25 % + 128), and
+ * an overflow region behind them for what a tile gets beyond its bucket.  percent (1..100, default 100) plans every bucket at that
+ * share of its size: more of the arrays left to the overflow region, more records taking the slower route through it - same
+ * frame, bit for bit (the overflow tests pin that).  Takes effect with the next plan (the next frame's end). */
+int  zr_set_bucket_share(zr_ctx* ctx, uint32_t percent);
 int  zr_scene_clear(zr_ctx* ctx);                   /* CleanupBasePass, ZE:4142 (also drops meshes and Profabs) */
 int  zr_object_count(zr_ctx* ctx, uint32_t* n);
 /* Copy out the instance array of object `index` (add order); *n = 0 for a non-instanced draw.  dst may be NULL. */

@@ -550,10 +550,10 @@ def test_record_pool_and_slow_list_overflow_are_reported(oracle_lib, gpu_engine,
 
 def test_records_beyond_their_buckets_are_drawn_from_the_overflow_region(oracle_lib, gpu_engine):
     """The camera pass keeps a tile's triangle records in a bucket sized from the PREVIOUS frame's count; what a tile gets beyond it goes to
-    one overflow region that the tile's first work unit sifts.  Record planes sized just above the frame's need (zr_set_limits) shrink every
-    bucket below its tile's count: a fifth of the records then take the overflow route - a few per tile (listed in one pass) with one
-    size, thousands per tile (the unit walks the region batch by batch) with another - and the frame must not change by a bit.  A camera
-    that jumps between frames does the same to the default planes."""
+    the overflow region behind the buckets (64 sections by tile number) that the tile's first work unit sifts.  zr_set_bucket_share plans
+    every bucket at that share of its size: part of every tile's records then takes the overflow route - a few dozen per tile (one
+    sifted batch) with one scene, thousands per tile (several batches, the waves resuming their sift) with the other - and the frame must
+    not change by a bit.  A camera that jumps between frames does the same to the default plan."""
     W, H, SD = 320, 200, 128
 
     def scene(r, n):
@@ -561,22 +561,18 @@ def test_records_beyond_their_buckets_are_drawn_from_the_overflow_region(oracle_
         r.object_add(r.mesh_create(*scenes.uv_sphere()), None, scenes.generate_instances(n, 0.5, 6.0, 0.3, 0.8, seed=3))
         _std_frame()(r)
 
-    for n_inst, factors in ((60, (1.3, 1.6)), (1500, (1.06, 1.3))):      # ~ 250 / ~ 6 400 records per tile
+    for n_inst, pcts in ((60, (70, 30)), (1500, (90, 45, 5))):      # ~ 250 / ~ 6 400 records per tile
         o = oracle_lib.Oracle(W, H, SD); scene(o, n_inst); o.render()
-        g = gpu_engine.Renderer(W, H, SD, flags=abi.FLAG_NO_HIZ); scene(g, n_inst)
-        g.render(); g.finish()
-        need = g.stats()["bin_entries"][1]
-        assert need > 10000
-        g.close()
-        for factor in factors:                         # planes of factor x need records: the buckets get 3/4 of that, the overflow region 1/4
-            # (the small scene's buckets are mostly slack - 128 records apiece - so scaling them down costs its busy tiles more)
+        for pct in pcts:
             g = gpu_engine.Renderer(W, H, SD, flags=abi.FLAG_NO_HIZ)
-            g.set_limits(int(need * factor) // 256 + 1, 0)
+            g.set_bucket_share(pct)
             scene(g, n_inst)
-            for _ in range(3):                         # counted, then planned from its own counts: every frame overflows the same way
+            for k in range(3):                         # counted and planned from its own counts, then planned from the frame before
                 g.render(); g.finish()
-                bad = {k: v for k, v in compare_all(o, g).items() if v}
-                assert not bad, (n_inst, factor, bad)
+                st = g.stats()
+                assert st["overflow"] == 0
+                bad = {k2: v for k2, v in compare_all(o, g).items() if v}
+                assert not bad, (n_inst, pct, k, bad)
             g.close()
     # a camera cut: the plan is last frame's, every tile's count is new
     o = oracle_lib.Oracle(W, H, SD); g = gpu_engine.Renderer(W, H, SD)

@@ -3,6 +3,8 @@
 #include "zr_dev.h"
 #include "zr_raster.h"
 
+#include <type_traits>
+
 // Hi-Z pyramid of the key buffer: level 0 = max depth per 8x8 pixel block (1.0 where a pixel is still empty), each further
 // level the max over 2x2 blocks of the previous one.  One workgroup per 64x64 pixel region builds all four levels in LDS.
 // regions[]: the 64 x 64 regions that hold tiles this context owns (x | y << 16): a super-tile is whole regions, and the pyramid's texels
@@ -140,8 +142,8 @@ __global__ __launch_bounds__(256) void k_select(ZrPass P, const ZrObject* __rest
 // PREVIOUS frame from that frame's own per-tile counts (+ 25 % + 32): k_geom appends a meshlet's records for a tile with ONE returning add on
 // the tile's cursor, k_tile reads its tile's stretch as one contiguous run.  No scan and no index list sit between the two kernels (they
 // were k_scan_tri + k_index: two launches, 33 us per frame alone, on the camera lane's critical path, and a 20 MB index list).  What does
-// not fit its bucket - the camera moved, a tile got busier than last frame - goes to ONE overflow region with its tile id beside it, and
-// the tile's first work unit picks its records out of that region: slower, exact, and rare.  A frame without a usable plan (first frame
+// not fit its bucket - the camera moved, a tile got busier than last frame - goes to ONE overflow region (in ZR_OVER_SECTIONS sections, by
+// tile id modulo) with its tile id beside it, and the tile's first work unit picks its records out of its section: slower, exact, and rare.  A frame without a usable plan (first frame
 // of a scene; the round structure changed) runs k_geom once more ahead of the round, counting only, and plans from that.
 __device__ __forceinline__ uint32_t pack_xy(int X, int Y) { return ((uint32_t)X & 0xFFFFu) | ((uint32_t)Y << 16); }
 __device__ __forceinline__ void rec_store(const ZrTriBins& B, uint32_t pos, const int4& r0, const int4& r1, const int4& r2, uint32_t prim, int tx, int ty)
@@ -207,6 +209,8 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
     if (!COUNT && wave_id == 0u && lane == 0u) stats->survivors[slot] = n;      // (round 2: k_tile takes the meshlets dropped behind the pyramid off)
     uint32_t* __restrict__ const cursor = B.cursor + (size_t)(slot == 2 ? 1u : 0u) * B.n_tiles * ZR_TSTRIDE;
     uint32_t culled = 0;
+    // where the overflow region begins this frame and what each of its sections holds (k_plan: the record arrays behind the last bucket)
+    const uint32_t over_start = COUNT ? 0u : wave_uniform(B.plan[0]), sec_cap = COUNT ? 0u : wave_uniform(B.plan[1]);
     // the wave's next meshlet record is fetched (scalar loads: the address is the wave's) while the current one is worked on: the chain of
     // dependent round trips per meshlet is vertices -> bucket reservation, not record -> vertices -> reservation
     ZrBinEntry nx = ld_record(sel + min(wave_id, n ? n - 1u : 0u));
@@ -378,13 +382,11 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
             uint32_t run = 0, tbase = 0, tcap = 0;
             if (cnt) { run = atomicAdd(&cursor[tile * ZR_TSTRIDE], cnt); tbase = B.tile_base[tile]; tcap = B.tile_cap[tile]; }
             // what does not fit the bucket (records run .. run + cnt - 1 at places >= tcap) goes to the overflow region: rare
-            uint32_t n_over = (cnt && run + cnt > tcap) ? run + cnt - max(run, tcap) : 0u, obase = 0;
-            if (__ballot(n_over != 0u)) {
-                const uint32_t incl = wave_incl_scan(n_over), tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                uint32_t ob = 0;
-                if (lane == 0u) ob = atomicAdd(&B.over_cursor[slot == 2 ? 1 : 0], tot);
-                obase = (uint32_t)__builtin_amdgcn_readfirstlane((int)ob) + incl - n_over;
-            }
+            // (the region has ZR_OVER_SECTIONS sections, a tile's records go to section tile % ZR_OVER_SECTIONS: a tile that spilled sifts one
+            // section, not the region)
+            const uint32_t n_over = (cnt && run + cnt > tcap) ? run + cnt - max(run, tcap) : 0u;
+            uint32_t obase = 0;
+            if (n_over) obase = atomicAdd(&B.over_cursor[(slot == 2 ? ZR_OVER_SECTIONS : 0u) + (tile & (ZR_OVER_SECTIONS - 1u))], n_over);
             // the records, tile by tile (wave-uniform loop): a tile's run is contiguous, round 0's triangles first
 #pragma unroll
             for (int round = 0; round < 2; ++round) {
@@ -407,9 +409,10 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
                         uint32_t pos;
                         if (place < ca) pos = (uint32_t)__builtin_amdgcn_readlane((int)tbase, k) + place;
                         else {
-                            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)obase, k) + (place - max(rk, ca));
-                            pos = o < B.over_cap ? B.over_base + o : 0xFFFFFFFFu;
-                            if (o < B.over_cap) B.over_tile[o] = (uint32_t)ty * P.tiles_x + (uint32_t)tx;
+                            const uint32_t tl = (uint32_t)ty * P.tiles_x + (uint32_t)tx;
+                            const uint32_t ol = (uint32_t)__builtin_amdgcn_readlane((int)obase, k) + (place - max(rk, ca));      // place in the tile's section
+                            pos = ol < sec_cap ? over_start + (tl & (ZR_OVER_SECTIONS - 1u)) * sec_cap + ol : 0xFFFFFFFFu;
+                            if (ol < sec_cap) B.over_tile[pos] = tl;
                             else { stats->overflow = 1u; stats->overflow_sticky = 1u; }      // the record arrays are full: the frame is incomplete, and says so
                         }
                         if (pos != 0xFFFFFFFFu) rec_store(B, pos, r0, r1, r2, prim, tx, ty);
@@ -430,7 +433,9 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
 // ceil(bucket / unit) work units of k_tile; both rounds of a frame use the same buckets and the same units (a unit takes its share of
 // whatever its tile's cursor says).  Also what used to be k_tile's first duty: the cursors are zero again for the next frame.
 // ONE workgroup, after the resolve: the camera lane has nothing to do until the next frame begins, nothing waits for this launch.
-__global__ __launch_bounds__(1024) void k_plan(ZrTriBins B, const uint32_t* __restrict__ owned_tiles, uint32_t n_owned, uint32_t unit, ZrDevStats* __restrict__ stats)
+// `exact`: the counts come from a count-only run of the very round that follows - the buckets are the counts themselves, nothing can spill.
+__global__ __launch_bounds__(1024) void k_plan(ZrTriBins B, const uint32_t* __restrict__ owned_tiles, uint32_t n_owned, uint32_t unit, ZrDevStats* __restrict__ stats,
+                                               uint32_t exact, uint32_t bucket_pct)
 {
     __shared__ uint32_t wtot[16], cwtot[16];
     __shared__ unsigned long long gsum[16];
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(1024) void k_plan(ZrTriBins B, const uint32_t* __re
     uint32_t n0 = 0, n1 = 0;
     for (uint32_t j = b; j < e; ++j) {
         const uint32_t t = owned_tiles[j], a0 = c0[t * ZR_TSTRIDE], a1 = c1[t * ZR_TSTRIDE], c = max(a0, a1);
-        want += (unsigned long long)c + (c >> 2) + ZR_BUCKET_SLACK;
+        want += exact ? (unsigned long long)c : (unsigned long long)c + (c >> 2) + ZR_BUCKET_SLACK;
         n0 += a0; n1 += a1;
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -456,17 +461,20 @@ __global__ __launch_bounds__(1024) void k_plan(ZrTriBins B, const uint32_t* __re
     unsigned long long all = 0;
     for (uint32_t i = 0; i < 16u; ++i) all += gsum[i];
     if (tid == 0 && stats) {
-        uint32_t r0 = 0, r1 = 0;
+        uint32_t r0 = 0, r1 = 0, o0 = 0, o1 = 0;
         for (uint32_t i = 0; i < 16u; ++i) { r0 += nsum[i][0]; r1 += nsum[i][1]; }
+        for (uint32_t i = 0; i < ZR_OVER_SECTIONS; ++i) { o0 += B.over_cursor[i]; o1 += B.over_cursor[ZR_OVER_SECTIONS + i]; }
         stats->bin_entries[1] = r0; stats->bin_entries[2] = r1;
+        stats->pool_used[1] = o0; stats->pool_used[2] = o1;      // (pool_used: the rounds' overflow records)
     }
-    const bool shrink = all > (unsigned long long)B.over_base;
+    const bool shrink = all > (unsigned long long)B.bucket_max;
     // pass 2: buckets and units (one scan of each)
     uint32_t s = 0, cs = 0;
     for (uint32_t j = b; j < e; ++j) {
         const uint32_t t = owned_tiles[j], c = max(c0[t * ZR_TSTRIDE], c1[t * ZR_TSTRIDE]);
-        unsigned long long cap = (unsigned long long)c + (c >> 2) + ZR_BUCKET_SLACK;
-        if (shrink) cap = cap * B.over_base / all;
+        unsigned long long cap = exact ? (unsigned long long)c : (unsigned long long)c + (c >> 2) + ZR_BUCKET_SLACK;
+        if (shrink) cap = cap * B.bucket_max / all;
+        if (bucket_pct != 100u) cap = cap * bucket_pct / 100u;      // (zr_set_bucket_share)
         s += (uint32_t)cap; cs += max(1u, ((uint32_t)cap + unit - 1u) / unit);
     }
     uint32_t incl = s, cincl = cs;
@@ -476,13 +484,14 @@ __global__ __launch_bounds__(1024) void k_plan(ZrTriBins B, const uint32_t* __re
     }
     if (lane == 63u) { wtot[wv] = incl; cwtot[wv] = cincl; }
     __syncthreads();
-    uint32_t wpre = 0, cwpre = 0, ctot = 0;
-    for (uint32_t i = 0; i < 16u; ++i) { if (i < wv) { wpre += wtot[i]; cwpre += cwtot[i]; } ctot += cwtot[i]; }
+    uint32_t wpre = 0, cwpre = 0, ctot = 0, rtot = 0;
+    for (uint32_t i = 0; i < 16u; ++i) { if (i < wv) { wpre += wtot[i]; cwpre += cwtot[i]; } ctot += cwtot[i]; rtot += wtot[i]; }
     uint32_t run = wpre + incl - s, crun = cwpre + cincl - cs;
     for (uint32_t j = b; j < e; ++j) {
         const uint32_t t = owned_tiles[j], c = max(c0[t * ZR_TSTRIDE], c1[t * ZR_TSTRIDE]);
-        unsigned long long cap = (unsigned long long)c + (c >> 2) + ZR_BUCKET_SLACK;
-        if (shrink) cap = cap * B.over_base / all;
+        unsigned long long cap = exact ? (unsigned long long)c : (unsigned long long)c + (c >> 2) + ZR_BUCKET_SLACK;
+        if (shrink) cap = cap * B.bucket_max / all;
+        if (bucket_pct != 100u) cap = cap * bucket_pct / 100u;      // (zr_set_bucket_share)
         const uint32_t nu = max(1u, ((uint32_t)cap + unit - 1u) / unit);
         B.tile_base[t] = run; B.tile_cap[t] = (uint32_t)cap;
         for (uint32_t k = 0; k < nu; ++k)
@@ -492,7 +501,10 @@ __global__ __launch_bounds__(1024) void k_plan(ZrTriBins B, const uint32_t* __re
     }
     if (tid == 0) {
         *B.n_units = min(ctot, B.unit_cap);
-        B.over_cursor[0] = 0u; B.over_cursor[1] = 0u;
+        // everything behind the last bucket is the frame's overflow region, in ZR_OVER_SECTIONS equal sections (a frame after a camera cut
+        // can put most of its records there: round 2 then draws what the stale pyramid hid, far beyond last frame's counts)
+        B.plan[0] = rtot; B.plan[1] = (B.n_rec - rtot) / ZR_OVER_SECTIONS;
+        for (uint32_t i = 0; i < 2u * ZR_OVER_SECTIONS; ++i) B.over_cursor[i] = 0u;
         if (ctot > B.unit_cap && stats) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
     }
 }
@@ -520,11 +532,12 @@ void k_tile(ZrPass P, ZrTriBins B, ZrDevStats* __restrict__ stats, int slot,
     __shared__ unsigned long long keys64[TILE_PIX];
     __shared__ uint4 srecA[ZR_TCHUNK], srecB[ZR_TCHUNK];
     __shared__ uint32_t hist[ZR_TSORT_BINS], wsum[4];
-    __shared__ uint32_t cur_unit, uh[4], ocount;
+    __shared__ uint32_t cur_unit, uh[4], ocnt[4], omore[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t n_units = *B.n_units, ri = slot == 2 ? 1u : 0u;
+    const uint32_t over_start = wave_uniform(B.plan[0]), sec_cap = wave_uniform(B.plan[1]);      // this frame's overflow region (k_plan)
     const uint32_t* __restrict__ const cursor = B.cursor + (size_t)ri * B.n_tiles * ZR_TSTRIDE;
-    if (blockIdx.x == 0 && tid == 0) { stats->n_chunks[slot] = n_units; stats->pool_used[slot] = B.over_cursor[ri]; }      // (pool_used: the round's overflow records)
+    if (blockIdx.x == 0 && tid == 0) stats->n_chunks[slot] = n_units;
     uint32_t unit = blockIdx.x;
     bool first = true;
     for (;;) {
@@ -537,7 +550,7 @@ void k_tile(ZrPass P, ZrTriBins B, ZrDevStats* __restrict__ stats, int slot,
             const uint32_t n_all = cursor[ct.x * ZR_TSTRIDE], tcap = B.tile_cap[ct.x], n_in = min(n_all, tcap);
             const uint32_t len = (n_in + ct.z - 1u) / ct.z, lo = min(n_in, ct.y * len);
             uh[0] = ct.x; uh[1] = min(n_in - lo, len); uh[2] = B.tile_base[ct.x] + lo;
-            uh[3] = (ct.y == 0u && n_all > tcap) ? min(B.over_cursor[ri], B.over_cap) : 0u;
+            uh[3] = (ct.y == 0u && n_all > tcap) ? min(B.over_cursor[ri * ZR_OVER_SECTIONS + (ct.x & (ZR_OVER_SECTIONS - 1u))], sec_cap) : 0u;
         }
         for (uint32_t i = tid; i < TILE_PIX; i += 256u) keys64[i] = (unsigned long long)0x3F800000u << 32 | ZR_EMPTY_PRIM;
         __syncthreads();
@@ -555,26 +568,17 @@ void k_tile(ZrPass P, ZrTriBins B, ZrDevStats* __restrict__ stats, int slot,
         TileCtx T;
         T.px0 = 0; T.py0 = 0; T.W = (int)P.W - tpx0; T.H = (int)P.H - tpy0;
         const int wx1 = min(TILE - 1, T.W - 1), wy1 = min(TILE - 1, T.H - 1);
-        // A tile that got more than its bucket holds: its first unit sifts the overflow region's tile ids ONCE (256 threads, coalesced) for the
-        // records that name this tile and lists them (in the record staging area, which is idle here).  Up to ZR_TCHUNK of them - the usual
-        // case by far: a few dozen - head the unit's first batch; more than that and the unit walks the whole region in batches instead.
-        uint32_t n_list = 0u;
-        bool listed = true;
-        uint32_t* const olist = (uint32_t*)srecA;          // (ZR_TCHUNK x 16 bytes: room for 4 x ZR_TCHUNK indices)
-        if (n_sift) {
-            if (tid == 0) ocount = 0u;
-            __syncthreads();
-            for (uint32_t o = tid; o < n_sift; o += 256u)
-                if (B.over_tile[o] == tile) { const uint32_t sl = atomicAdd(&ocount, 1u); if (sl < ZR_TCHUNK) olist[sl] = o; }
-            __syncthreads();
-            n_list = wave_uniform(ocount);
-            listed = n_list <= ZR_TCHUNK;
-            if (!listed) n_list = 0u;
-        }
-        const uint32_t n_seq = listed ? n_list + n_own : n_unit;      // the unit's sequence: [listed overflow records] bucket records [the region, batch by batch]
-      // a unit's batches of <= ZR_TCHUNK records go into the same keys: one clear and one merge per unit, not per batch
-      for (uint32_t b0 = 0; b0 < n_seq; b0 += ZR_TCHUNK) {
-        const uint32_t n = min(n_seq - b0, ZR_TCHUNK);
+        // The unit's batches of <= ZR_TCHUNK records go into the same keys (one clear and one merge per unit, not per batch): first the unit's
+        // share of the bucket, one contiguous run; then - a tile's first unit, when the tile got more than its bucket holds - the tile's
+        // records in its section of the overflow region.  Each WAVE sifts a quarter of the section's tile ids (64 per step, ballot +
+        // count: no atomics, no barriers) into a list of its own in the record staging area, which is idle here, and stops above 64
+        // entries; the four lists (<= 4 x 128 = ZR_TCHUNK) are one batch; the waves go on from where they stopped until the section is
+        // done.  The usual frame has a few dozen such records for a few hundred tiles: one step, one small batch; a frame after a camera
+        // cut reads each section once per tile of the section.
+        uint32_t* const olist = (uint32_t*)srecA;
+        // one batch: n records - the run [src0, src0 + n) of the arrays, or (LIST) the entries of the four sift lists end to end
+        auto do_batch = [&](const uint32_t n, const uint32_t src0, auto list_tag) {
+        constexpr bool LIST = decltype(list_tag)::value;
         hist[tid] = 0u;
         __syncthreads();
         // ---- count: the thread's two records, their clipped boxes (raster_sub's own expressions), the rank among equal keys
@@ -583,16 +587,13 @@ void k_tile(ZrPass P, ZrTriBins B, ZrDevStats* __restrict__ stats, int slot,
         for (int k = 0; k < 2; ++k) {
             const uint32_t j = tid + (uint32_t)k * 256u;
             key[k] = 0u; rank[k] = 0u;
-            // (the bucket is one contiguous run; behind it, for a tile's first unit, the overflow region's records that name this tile)
-            const uint32_t g = b0 + j;
-            bool have = j < n;
-            uint32_t src;
-            if (g < n_list) src = B.over_base + olist[g];              // (only the first batch can hold listed records: read before anything is staged)
-            else {
-                src = rec0 + (g - n_list);
-                if (have && g - n_list >= n_own) { const uint32_t o = g - n_list - n_own; have = B.over_tile[o] == tile; src = B.over_base + o; }
-            }
-            if (have) {
+            if (j < n) {
+                uint32_t src = src0 + j;
+                if (LIST) {        // (read before anything is staged over the lists)
+                    const uint32_t l1 = ocnt[0], l2 = l1 + ocnt[1], l3 = l2 + ocnt[2];
+                    const uint32_t w = (j >= l1 ? 1u : 0u) + (j >= l2 ? 1u : 0u) + (j >= l3 ? 1u : 0u);
+                    src = olist[w * 128u + (j - (w == 0u ? 0u : w == 1u ? l1 : w == 2u ? l2 : l3))];
+                }
                 qa[k] = B.recA[src]; qb[k] = B.recB[src];
                 const int X0 = (int)(short)(qa[k].x & 0xFFFFu), Y0 = (int)qa[k].x >> 16, X1 = (int)(short)(qa[k].z & 0xFFFFu), Y1 = (int)qa[k].z >> 16;
                 const int X2 = (int)(short)(qb[k].x & 0xFFFFu), Y2 = (int)qb[k].x >> 16;
@@ -635,7 +636,30 @@ void k_tile(ZrPass P, ZrTriBins B, ZrDevStats* __restrict__ stats, int slot,
             }
         }
         __syncthreads();      // (the next batch rewrites hist / srec; the merge below reads the keys)
-      }
+        };
+        for (uint32_t b0 = 0; b0 < n_own; b0 += ZR_TCHUNK) do_batch(min(n_own - b0, ZR_TCHUNK), rec0 + b0, std::false_type());
+        if (n_sift) {
+            const uint32_t sec0 = over_start + (tile & (ZR_OVER_SECTIONS - 1u)) * sec_cap;      // the tile's section (an index into the record arrays)
+            const uint32_t quarter = ((n_sift + 255u) >> 8) << 6;
+            uint32_t spos = wave_uniform(min(n_sift, wv * quarter));      // (wave-uniform, like send and wc)
+            const uint32_t send = wave_uniform(min(n_sift, spos + quarter));
+            for (bool more = true; more;) {
+                uint32_t wc = 0u;
+                while (spos < send && wc <= 64u) {
+                    const uint32_t o = spos + lane;
+                    const bool hit = o < send && B.over_tile[sec0 + o] == tile;
+                    const unsigned long long m = __ballot(hit);
+                    if (hit) olist[wv * 128u + wc + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = sec0 + o;
+                    wc += (uint32_t)__popcll(m); spos += 64u;
+                }
+                if (lane == 0u) { ocnt[wv] = wc; omore[wv] = spos < send ? 1u : 0u; }
+                __syncthreads();
+                const uint32_t n = wave_uniform(ocnt[0] + ocnt[1] + ocnt[2] + ocnt[3]);
+                more = (omore[0] | omore[1] | omore[2] | omore[3]) != 0u;
+                if (n) do_batch(n, 0u, std::true_type());
+                else __syncthreads();      // (this stretch of the section held other tiles' records only; ocnt / omore are rewritten next)
+            }
+        }
         for (uint32_t i = tid; i < TILE_PIX; i += 256u) {
             const int px = tpx0 + (int)(i & (TILE - 1)), py = tpy0 + (int)(i / TILE);
             if (px >= (int)P.W || py >= (int)P.H) continue;
@@ -748,9 +772,9 @@ void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, ZrDevSt
     } else if (Z.phase == 2u) hipLaunchKernelGGL((k_geom<true, false>), g, b, 0, s, P, B.sel, Z, B, stats, slot);
     else hipLaunchKernelGGL((k_geom<false, false>), g, b, 0, s, P, B.sel, Z, B, stats, slot);
 }
-void zr_launch_plan(const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned, ZrDevStats* stats, hipStream_t s)
+void zr_launch_plan(const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned, ZrDevStats* stats, bool exact, uint32_t bucket_pct, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, B, owned_tiles, n_owned, ZR_TCHUNK * ZR_TBATCHES, stats);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(1024), 0, s, B, owned_tiles, n_owned, ZR_TCHUNK * ZR_TBATCHES, stats, exact ? 1u : 0u, bucket_pct);
 }
 void zr_launch_tile(const ZrPass& P, const ZrTriBins& B, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s, bool last,
                     const uint32_t* owned_tiles, uint32_t n_owned)

@@ -96,6 +96,7 @@ struct zr_ctx {
     // cull / bin scratch, one set per geometry pass (0 shadow, 1 camera) so that the two pipelines can run on two streams
     struct Scratch { uint32_t *rects = nullptr, *tile_count = nullptr, *tile_offset = nullptr, *tile_cursor = nullptr, *chunk_offset = nullptr,
                      *work = nullptr; ZrBinEntry* bins = nullptr; uint4* chunk_tab = nullptr; } sc[2];
+    uint32_t bucket_pct = 100;                              // zr_set_bucket_share: every planned bucket at that share of its size
     bool plan_valid = false, plan_two_round = false;      // the record buckets' plan (k_plan): made at all / by a frame that drew two rounds
     ZrTriBins tb = {};                    // triangle-binned camera pass: selection list, records (as emitted / in tile order), slow list
     uint32_t chunk_capacity = 0;         // raster work units the chunk table holds: bin_capacity / ZR_CHUNK + tiles

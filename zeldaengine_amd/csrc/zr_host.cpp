@@ -277,7 +277,7 @@ static void free_mesh_buffers(ZrMesh& m)
 static void free_tri_bins(zr_ctx* c)
 {
     dev_free(c->tb.sel); dev_free(c->tb.recA); dev_free(c->tb.recB); dev_free(c->tb.tile_base); dev_free(c->tb.tile_cap); dev_free(c->tb.cursor);
-    dev_free(c->tb.over_tile); dev_free(c->tb.over_cursor); dev_free(c->tb.unit_tab); dev_free(c->tb.n_units);
+    dev_free(c->tb.over_tile); dev_free(c->tb.plan); dev_free(c->tb.over_cursor); dev_free(c->tb.unit_tab); dev_free(c->tb.n_units);
     dev_free(c->tb.slow); dev_free(c->tb.wave_culled);
     c->plan_valid = false;
 }
@@ -644,14 +644,20 @@ extern "C" int zr_object_add(zr_ctx* c, uint32_t mesh_id, const zr_material* mat
     return zr_guard(c, [&]() { return zr_object_add_impl(c, mesh_id, mat, inst, n_inst); });
 }
 
-// Capacities of the triangle-record pool (chunks of ZR_TPOOL_CHUNK = 256 records, the 8192 chunks the waves of k_geom start in included)
-// and of the clipped-triangle list, for hosts that size them themselves (0 = the default: 8 records per meshlet-instance, at least 32 Mi,
-// plus the waves' own chunks; 2^18 triangles).  Takes effect at the next frame.
+// Capacities of the triangle-record arrays (chunks of 256 records) and of the clipped-triangle list, for hosts that size them themselves
+// (0 = the default: 8 records per meshlet-instance, at least 32 Mi; 2^18 triangles).  Takes effect at the next frame.
 extern "C" int zr_set_limits(zr_ctx* c, uint32_t record_chunks, uint32_t slow_triangles)
 {
     if (!c) return ZR_ERR_ARG;
     c->limit_record_chunks = record_chunks; c->limit_slow_triangles = slow_triangles;
     c->work_capacity = 0; c->scene_dirty = true;          // the pools are re-made by the next frame
+    return ZR_OK;
+}
+
+extern "C" int zr_set_bucket_share(zr_ctx* c, uint32_t percent)
+{
+    if (!c || percent < 1u || percent > 100u) return ZR_ERR_ARG;
+    c->bucket_pct = percent;          // (k_plan's argument from the next plan on; a frame that overflows its buckets is the same frame)
     return ZR_OK;
 }
 
@@ -798,29 +804,29 @@ static int finalize_scene(zr_ctx* c)
             HIPCHK(c, dev_alloc(&sc.chunk_tab, c->chunk_capacity));
         }
         // triangle-binned camera pass: triangle records (32 B) live in per-tile BUCKETS of two 16-byte planes, laid out every frame by
-        // k_plan from the previous frame's per-tile counts; the last quarter of the planes is the overflow region (what a tile gets beyond its
-        // bucket).  Sized from the scene: 8 records per meshlet-instance, at least 32 Mi - 1 GB of 288 reserved, touched as far as a frame
+        // k_plan from the previous frame's per-tile counts; what lies behind the last bucket is the frame's overflow region (what a tile gets
+        // beyond its bucket).  Sized from the scene: 8 records per meshlet-instance, at least 32 Mi - 1 GB of 288 reserved, touched as far as a frame
         // needs.  Planes that run full are reported like a bin overflow (zr_set_limits sizes them: 256 records per "chunk").
         free_tri_bins(c);
         c->tb.n_waves = 8192; c->tb.slow_cap = 1u << 18;
         uint64_t n_rec = std::min<uint64_t>(std::max<uint64_t>(32ull << 20, 8ull * c->n_work), 0x3FFFFFFFull);
         if (c->limit_record_chunks) n_rec = 256ull * c->limit_record_chunks;      // zr_set_limits (a host sizing the planes; the overflow tests)
         if (c->limit_slow_triangles) c->tb.slow_cap = std::max(2u, c->limit_slow_triangles);
-        c->tb.over_base = (uint32_t)(n_rec - n_rec / 4u); c->tb.over_cap = (uint32_t)(n_rec / 4u);
+        c->tb.n_rec = (uint32_t)n_rec; c->tb.bucket_max = (uint32_t)(n_rec - n_rec / 8u);
         c->tb.n_tiles = c->n_tiles;
-        c->tb.unit_cap = c->tb.over_base / (ZR_TCHUNK * ZR_TBATCHES) + 2u * c->n_tiles + 1u;
+        c->tb.unit_cap = c->tb.bucket_max / (ZR_TCHUNK * ZR_TBATCHES) + 2u * c->n_tiles + 1u;
         HIPCHK(c, dev_alloc(&c->tb.sel, cap_w));
         HIPCHK(c, dev_alloc(&c->tb.recA, (size_t)n_rec));
         HIPCHK(c, dev_alloc(&c->tb.recB, (size_t)n_rec));
-        HIPCHK(c, dev_alloc(&c->tb.over_tile, std::max<size_t>(1, c->tb.over_cap)));
+        HIPCHK(c, dev_alloc(&c->tb.over_tile, (size_t)n_rec)); HIPCHK(c, dev_alloc(&c->tb.plan, 2));
         HIPCHK(c, dev_alloc(&c->tb.tile_base, c->n_tiles)); HIPCHK(c, dev_alloc(&c->tb.tile_cap, c->n_tiles));
         HIPCHK(c, dev_alloc(&c->tb.cursor, (size_t)2 * c->n_tiles * ZR_TSTRIDE));
-        HIPCHK(c, dev_alloc(&c->tb.over_cursor, 2)); HIPCHK(c, dev_alloc(&c->tb.n_units, 1));
+        HIPCHK(c, dev_alloc(&c->tb.over_cursor, 2 * ZR_OVER_SECTIONS)); HIPCHK(c, dev_alloc(&c->tb.n_units, 1));
         HIPCHK(c, dev_alloc(&c->tb.unit_tab, c->tb.unit_cap));
         // (no plan yet: every bucket is empty - the first frame counts before it draws, see gbuffer_pass)
         HIPCHK(c, hipMemset(c->tb.tile_base, 0, (size_t)c->n_tiles * 4)); HIPCHK(c, hipMemset(c->tb.tile_cap, 0, (size_t)c->n_tiles * 4));
         HIPCHK(c, hipMemset(c->tb.cursor, 0, (size_t)2 * c->n_tiles * ZR_TSTRIDE * 4));
-        HIPCHK(c, hipMemset(c->tb.over_cursor, 0, 8)); HIPCHK(c, hipMemset(c->tb.n_units, 0, 4));
+        HIPCHK(c, hipMemset(c->tb.over_cursor, 0, 2 * ZR_OVER_SECTIONS * 4)); HIPCHK(c, hipMemset(c->tb.n_units, 0, 4)); HIPCHK(c, hipMemset(c->tb.plan, 0, 8));
         HIPCHK(c, dev_alloc(&c->tb.wave_culled, c->tb.n_waves));
         HIPCHK(c, dev_alloc(&c->tb.slow, 4ull * c->tb.slow_cap));
         HIPCHK(c, dev_alloc(&c->d_pxrect, cap_w)); HIPCHK(c, dev_alloc(&c->d_zmin, cap_w));
@@ -1206,7 +1212,7 @@ static void tri_raster(zr_ctx* c, const ZrPass& P, const ZrHiz& Z, int slot, hip
     if (P.n_work == 0) return;          // nothing to draw: the pass is its clear
     if (count_first) {
         zr_launch_geom(P, Z, c->tb, c->d_stats, slot, true, s);
-        zr_launch_plan(c->tb, c->d_owned, c->n_owned, c->d_stats, s);
+        zr_launch_plan(c->tb, c->d_owned, c->n_owned, c->d_stats, true, c->bucket_pct, s);      // (exact: the round that follows appends what was just counted)
     }
     zr_launch_geom(P, Z, c->tb, c->d_stats, slot, false, s);
     // (the frame's last round also draws the slow triangles of both rounds: k_tile<LAST>)
@@ -1397,7 +1403,7 @@ static int gbuffer_pass(zr_ctx* c, hipStream_t s)
     c->vis_mark_prev = vis_mark;
     if (ev) HIPCHK(c, hipEventRecord(ev[7], s));
     if (tri_bins && P.n_work != 0) {     // the next frame's buckets, from this frame's counts: nothing on this lane waits for it
-        zr_launch_plan(c->tb, c->d_owned, c->n_owned, c->d_stats, s);
+        zr_launch_plan(c->tb, c->d_owned, c->n_owned, c->d_stats, false, c->bucket_pct, s);
         c->plan_valid = true; c->plan_two_round = two;
     }
     if (hiz_on) { c->vis_history = true; c->vis_cur ^= 1; } else c->vis_history = false;

@@ -204,11 +204,12 @@ struct ZrTriBins {
     // 32-byte triangle records (see zr_camera.hip, "triangle records") in two 16-byte planes:
     uint4*    recA; uint4* recB;     //   (X0|Y0, z0, X1|Y1, z1)  (X2|Y2, z2, prim, 0), tile-relative int16 coordinates
     uint32_t* tile_base;             // per tile: its bucket [tile_base, tile_base + tile_cap) of the planes, planned by k_plan from the previous
-    uint32_t* tile_cap;              //   frame's counts (buckets fill [0, over_base))
+    uint32_t* tile_cap;              //   frame's counts (the buckets take at most bucket_max of the planes' n_rec records)
     uint32_t* cursor;                // [2][n_tiles * ZR_TSTRIDE]: records appended to each tile in round 1 / round 2 of the frame (k_geom; zeroed by k_plan)
-    uint32_t  over_base, over_cap;   // the overflow region [over_base, over_base + over_cap): what did not fit its bucket, any tile's
-    uint32_t* over_tile;             //   ... and each such record's tile
-    uint32_t* over_cursor;           // [2]: overflow records of round 1 / round 2
+    uint32_t  n_rec, bucket_max;
+    uint32_t* plan;                  // [2] (k_plan): where this frame's buckets end = where its overflow region begins; records per section of it
+    uint32_t* over_tile;             // [n_rec] the tile of each record of the overflow region (what did not fit its bucket, any tile's)
+    uint32_t* over_cursor;           // [2][ZR_OVER_SECTIONS]: overflow records of round 1 / round 2, per section of the region (section = tile % ZR_OVER_SECTIONS)
     uint4*    unit_tab;              // k_tile's work units (tile, part, parts of the tile, 0), planned with the buckets
     uint32_t  unit_cap; uint32_t* n_units;
     uint32_t  n_tiles;
@@ -216,6 +217,7 @@ struct ZrTriBins {
     uint32_t* wave_culled;           // per wave: meshlets it dropped behind the Hi-Z pyramid (round 2)
     uint4*    slow; uint32_t slow_cap;      // 4 x uint4 per slow triangle: three clip-space vertices, (prim, tile rect, 0, 0)
 };
+#define ZR_OVER_SECTIONS 64u          // sections of the overflow region (a power of two)
 #ifndef ZR_TSTRIDE
 #define ZR_TSTRIDE 4u                 // words between the per-tile record cursors of neighbouring tiles
 #endif
@@ -230,7 +232,7 @@ struct ZrTriBins {
 void zr_launch_select(const ZrPass& P, const ZrObject* objs, const uint32_t* work, const uint32_t* rects, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats,
                       int slot, hipStream_t s);
 void zr_launch_geom(const ZrPass& P, const ZrHiz& Z, const ZrTriBins& B, ZrDevStats* stats, int slot, bool count_only, hipStream_t s);
-void zr_launch_plan(const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned, ZrDevStats* stats, hipStream_t s);
+void zr_launch_plan(const ZrTriBins& B, const uint32_t* owned_tiles, uint32_t n_owned, ZrDevStats* stats, bool exact, uint32_t bucket_pct, hipStream_t s);
 void zr_launch_tile(const ZrPass& P, const ZrTriBins& B, ZrDevStats* stats, int slot, unsigned long long* vis64, uint32_t n_blocks, hipStream_t s, bool last,
                     const uint32_t* owned_tiles, uint32_t n_owned);
 void zr_launch_cull_box(const ZrPass& P, const ZrObject* objs, uint32_t* work, uint32_t* rects, const ZrHiz& Z, ZrDevStats* stats,

@@ -50,6 +50,7 @@ def lib():
         "zr_object_add": [vp, u32, vp, vp, u32],
         "zr_scene_clear": [vp],
         "zr_set_limits": [vp, u32, u32],
+        "zr_set_bucket_share": [vp, u32],
         "zr_object_count": [vp, C.POINTER(u32)],
         "zr_object_get_instances": [vp, u32, C.POINTER(u32), vp, C.POINTER(u32)],
         "zr_set_cubemap": [vp, vp, u32],
@@ -298,8 +299,12 @@ class Renderer:
         self._chk(self.L.zr_scene_clear(self.h))
 
     def set_limits(self, record_chunks=0, slow_triangles=0):
-        """Capacities of the triangle-record pool (chunks of 256 records: ZR_TPOOL_CHUNK, `zr_record_chunk_size()`) and the clipped-triangle list; 0 = defaults."""
+        """Capacities of the triangle-record arrays (chunks of 256 records, `zr_record_chunk_size()`) and the clipped-triangle list; 0 = defaults."""
         self._chk(self.L.zr_set_limits(self.h, record_chunks, slow_triangles))
+
+    def set_bucket_share(self, percent=100):
+        """Plan every per-tile record bucket at `percent` of its size (zr_set_bucket_share): the rest goes the overflow route - same frame."""
+        self._chk(self.L.zr_set_bucket_share(self.h, percent))
 
     def object_count(self):
         n = C.c_uint32()
