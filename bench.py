@@ -15,7 +15,10 @@ k_resolve_gbuffer, against the 8 TB/s HBM peak.  `achieved` = SURVEY 8(d)'s algo
 pass / the summed mean duration of those kernels, measured live with HIP events on the stream they are launched on (the library's
 camera lane).
 `traffic` = the same kernels' FETCH_SIZE / WRITE_SIZE counter bytes from the committed rocprofv3 summary named in
-`traffic_source`, only when that summary was collected on this very workload (else null).  `kernels` lists every kernel the same
+`traffic_source`, only when that summary was collected on this very workload (else null).  `compulsory_bytes` / `compulsory_frac`:
+the bytes any implementation of the pass must move (every pixel's 28 GBuffer bytes once + the scene's unique geometry once) over the same
+time.  `issue_frac`: the pass's SQ_INSTS_VALU (same summary, same build) / the best instruction rate tools/valu_calib reached on this chip
+/ the pass's time - how close the pass runs to the chip's measured vector issue rate.  `kernels` lists every kernel the same
 way; `valu_roofline` states what actually bounds the frame (vector-ALU issue); `frame_hbm` is the whole frame's counter traffic
 over the frame time.  cpu_baseline: the scalar CPU oracle timed on rank 0 on the same workload (N = 1 only).
 """
@@ -392,9 +395,31 @@ def main():
             "timing": "HIP events on the library's camera lane, mean over %d sampled frames; the lane shares the GPU with the shadow pipeline and "
                       "the previous frame's lighting" % n_s,
         }
+        # compulsory bytes: what ANY implementation of the pass must move - every pixel's GBuffer values once (28 B) and the scene's unique
+        # geometry once (the mesh's vertices and indices + one instance record per instance), whatever the number of instances of a meshlet
+        comp = 28 * owned_px + 44 * mesh["n_verts"] + 4 * mesh["n_idx"] + 32 * n_inst
+        roofline["compulsory_bytes"] = int(comp)
+        roofline["compulsory_frac"] = round(comp / (t_gb * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if t_gb > 0 else None
+        # issue_frac: the pass's vector instructions (SQ_INSTS_VALU of its kernels, committed counter summary of THIS build) / the best
+        # rate tools/valu_calib reached on this chip / the pass's time: how close the pass runs to the chip's measured instruction issue
+        pass_valu = None
+        if prof:
+            pv = [ptraffic.get(k, {}).get("SQ_INSTS_VALU") for p_ in GBUFFER_WRITE_PASS for k in pass_kernels(p_)]
+            pl = [ptraffic.get(k, {}).get("launches_per_frame") for p_ in GBUFFER_WRITE_PASS for k in pass_kernels(p_)]
+            if pv and all(x is not None for x in pv) and all(x is not None for x in pl):
+                pass_valu = sum(a * b for a, b in zip(pv, pl))
+        cal = (prof or {}).get("_calib")
+        if pass_valu and cal and t_gb > 0:
+            roofline["valu_wave_insts"] = int(pass_valu)
+            roofline["issue_frac"] = round(pass_valu / cal["best_per_s"] / (t_gb * 1e-3), 4)
+            roofline["issue_peak_per_s"] = cal["best_per_s"]
+        else:
+            roofline["issue_frac"] = None
         if serial:
             t1, b1, g1 = gb_pass(serial["passes_ms"])
             roofline["one_stream"] = {"kernel_ms": round(t1, 4), "achieved": round(g1, 3), "frac": round(g1 / HBM_PEAK_GBS, 6),
+                                      "compulsory_frac": round(comp / (t1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6) if t1 > 0 else None,
+                                      "issue_frac": round(pass_valu / cal["best_per_s"] / (t1 * 1e-3), 4) if (pass_valu and cal and t1 > 0) else None,
                                       "note": "the same kernels alone on the GPU (ZR_FLAG_SERIAL_PASSES run below)"}
         valu = None
         if prof and prof.get("valu_insts_per_frame"):

@@ -146,11 +146,19 @@ __global__ __launch_bounds__(256) void k_select(ZrPass P, const ZrObject* __rest
 // tile id modulo) with its tile id beside it, and the tile's first work unit picks its records out of its section: slower, exact, and rare.  A frame without a usable plan (first frame
 // of a scene; the round structure changed) runs k_geom once more ahead of the round, counting only, and plans from that.
 __device__ __forceinline__ uint32_t pack_xy(int X, int Y) { return ((uint32_t)X & 0xFFFFu) | ((uint32_t)Y << 16); }
-__device__ __forceinline__ void rec_store(const ZrTriBins& B, uint32_t pos, const int4& r0, const int4& r1, const int4& r2, uint32_t prim, int tx, int ty)
+// old with lane `l` replaced by v (both wave-uniform: scalar operands; the lane select goes through M0 - one scalar register per VALU instruction)
+__device__ __forceinline__ int lane_write(int v, int l, int old)
 {
-    const int ox = tx * (TILE * 256), oy = ty * (TILE * 256);
-    B.recA[pos] = make_uint4(pack_xy(r0.x - ox, r0.y - oy), (uint32_t)r0.z, pack_xy(r1.x - ox, r1.y - oy), (uint32_t)r1.z);
-    B.recB[pos] = make_uint4(pack_xy(r2.x - ox, r2.y - oy), (uint32_t)r2.z, prim, 0u);
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(v), "s"(l) : "m0");
+    return old;
+}
+typedef unsigned short zr_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b)      // (a.lo - b.lo) mod 2^16 | (a.hi - b.hi) mod 2^16 << 16: one v_pk_sub_u16
+{
+    zr_us2 x, y; __builtin_memcpy(&x, &a, 4); __builtin_memcpy(&y, &b, 4);
+    const zr_us2 r = x - y;
+    uint32_t o; __builtin_memcpy(&o, &r, 4);
+    return o;
 }
 struct RecTri { SV a, b, c; uint32_t prim; };
 __device__ __forceinline__ RecTri rec_load(const uint4 qa, const uint4 qb)
@@ -342,7 +350,7 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
                             B.slow[4u * pos + (uint32_t)k] = make_uint4(zr_f2u(cc.x), zr_f2u(cc.y), zr_f2u(cc.z), zr_f2u(cc.w));
                         }
                         B.slow[4u * pos + 3u] = make_uint4(prim, slow_rect, 0u, 0u);
-                    } else { stats->overflow = 1u; stats->overflow_sticky = 1u; }
+                    } else { stats->overflow = 1u; stats->overflow_sticky = ZR_OVF_SLOW; }
                 }
             }
             if (alive && !hidden) trect[round] = (uint32_t)(x0 / TILE) | (uint32_t)(y0 / TILE) << 8 | (uint32_t)(x1 / TILE) << 16 | (uint32_t)(y1 / TILE) << 24;
@@ -363,18 +371,48 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
             TX0 = lo & 0xFFFF; TY0 = lo >> 16; TW = (hi & 0xFFFF) - TX0 + 1; TH = (hi >> 16) - TY0 + 1;
         }
         const int n_rect = TW * TH;
-        for (int c0 = 0; c0 < n_rect; c0 += WAVE) {          // (one turn, unless the meshlet reaches more than 64 tiles)
-            const int nn = min(WAVE, n_rect - c0);
-            // what every tile of the stretch gets: lane k keeps tile k's numbers
-            uint32_t cnt = 0, cnt0 = 0; int mtx = 0, mty = 0;
-            {
+        // The cells of the rectangle are taken 32 at a time (one turn, unless the meshlet reaches more than 32 tiles).  Every lane first
+        // forms, per triangle, the MASK of the turn's cells its tile box covers - a row of 1 .. 3 bits, up to three times - so that "is my
+        // triangle in cell k" costs an AND in the loops over the cells below (they were box comparisons: 4 extracts + 4 compares per
+        // triangle per cell, most of the kernel's instructions).
+        for (int c0 = 0; c0 < n_rect; c0 += 32) {
+            const int nn = min(32, n_rect - c0);
+            uint32_t cm[2] = { 0u, 0u };
+            if (n_rect <= 32) {
+#pragma unroll
+                for (int round = 0; round < 2; ++round)
+                    if (trect[round] != ZR_NO_TILES) {
+                        const uint32_t t = trect[round];
+                        const int s0 = ((int)((t >> 8) & 255u) - TY0) * TW + ((int)(t & 255u) - TX0);
+                        const uint32_t w1 = ((t >> 16) & 255u) - (t & 255u), h1 = (t >> 24) - ((t >> 8) & 255u);      // (0 .. 2: a small triangle spans at most 3 tiles)
+                        const uint32_t row = (2u << w1) - 1u;
+                        uint32_t m = row << s0;
+                        if (h1 >= 1u) m |= row << (s0 + TW);
+                        if (h1 >= 2u) m |= row << (s0 + 2 * TW);
+                        cm[round] = m;
+                    }
+            } else {
                 int tx = TX0 + c0 % TW, ty = TY0 + c0 / TW;
                 for (int k = 0; k < nn; ++k) {
-                    const uint32_t n0 = (uint32_t)__popcll(__ballot(rect_has(trect[0], tx, ty))), n1 = (uint32_t)__popcll(__ballot(rect_has(trect[1], tx, ty)));
-                    if ((int)lane == k) { cnt0 = n0; cnt = n0 + n1; mtx = tx; mty = ty; }
+                    if (rect_has(trect[0], tx, ty)) cm[0] |= 1u << k;
+                    if (rect_has(trect[1], tx, ty)) cm[1] |= 1u << k;
                     if (++tx == TX0 + TW) { tx = TX0; ++ty; }
                 }
             }
+            // what every cell of the turn gets: lane k keeps cell k's numbers
+            int cnt_i = 0, cnt0_i = 0, mtx = 0, mty = 0;
+            {
+                int tx = TX0 + c0 % TW, ty = TY0 + c0 / TW;
+                for (int k = 0; k < nn; ++k) {
+                    const uint32_t bit = 1u << k;
+                    const int n0 = __popcll(__ballot((cm[0] & bit) != 0u)), n1 = __popcll(__ballot((cm[1] & bit) != 0u));
+                    cnt0_i = lane_write(n0, k, cnt0_i); cnt_i = lane_write(n0 + n1, k, cnt_i);
+                    mtx = lane_write(tx, k, mtx); mty = lane_write(ty, k, mty);
+                    if (++tx == TX0 + TW) { tx = TX0; ++ty; }
+                }
+            }
+            uint32_t cnt = (uint32_t)cnt_i;
+            const uint32_t cnt0 = (uint32_t)cnt0_i;
             if (P.tile_world > 1u && tile_owner((uint32_t)mtx, (uint32_t)mty, P.tile_world) != P.tile_rank) cnt = 0;      // another rank's tile
             const uint32_t tile = (uint32_t)mty * P.tiles_x + (uint32_t)mtx;
             if (COUNT) { if (cnt) atomicAdd(&cursor[tile * ZR_TSTRIDE], cnt); continue; }
@@ -391,18 +429,21 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
 #pragma unroll
             for (int round = 0; round < 2; ++round) {
                 if ((uint32_t)round * WAVE >= tcount) break;
-                int4 r0 = make_int4(0, 0, 0, 0), r1 = r0, r2 = r0;
-                if (trect[round] != ZR_NO_TILES) {
-                    r0 = vstage[wv][tri_w[round].x & 255u]; r1 = vstage[wv][(tri_w[round].x >> 8) & 255u]; r2 = vstage[wv][(tri_w[round].x >> 16) & 255u];
+                // the triangle's vertices as the record holds them, but for the tile's origin: x | y << 16 (mod 2^16 each) and depth
+                uint32_t q0 = 0u, q1 = 0u, q2 = 0u, z0 = 0u, z1 = 0u, z2 = 0u;
+                if (cm[round]) {
+                    const int4 r0 = vstage[wv][tri_w[round].x & 255u], r1 = vstage[wv][(tri_w[round].x >> 8) & 255u], r2 = vstage[wv][(tri_w[round].x >> 16) & 255u];
+                    q0 = pack_xy(r0.x, r0.y); q1 = pack_xy(r1.x, r1.y); q2 = pack_xy(r2.x, r2.y);
+                    z0 = (uint32_t)r0.z; z1 = (uint32_t)r1.z; z2 = (uint32_t)r2.z;
                 }
                 const uint32_t prim = pbase + tri_w[round].y;
                 for (int k = 0; k < nn; ++k) {
                     const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)cnt, k);
                     if (!ck) continue;
-                    const int tx = __builtin_amdgcn_readlane(mtx, k), ty = __builtin_amdgcn_readlane(mty, k);
-                    const bool mine = rect_has(trect[round], tx, ty);
+                    const bool mine = (cm[round] & (1u << k)) != 0u;
                     const unsigned long long m = __ballot(mine);
                     if (!m) continue;
+                    const int tx = __builtin_amdgcn_readlane(mtx, k), ty = __builtin_amdgcn_readlane(mty, k);
                     const uint32_t rk = (uint32_t)__builtin_amdgcn_readlane((int)run, k), ca = (uint32_t)__builtin_amdgcn_readlane((int)tcap, k);
                     if (mine) {
                         const uint32_t place = rk + (round ? (uint32_t)__builtin_amdgcn_readlane((int)cnt0, k) : 0u) + (uint32_t)__popcll(m & lt);
@@ -413,9 +454,14 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
                             const uint32_t ol = (uint32_t)__builtin_amdgcn_readlane((int)obase, k) + (place - max(rk, ca));      // place in the tile's section
                             pos = ol < sec_cap ? over_start + (tl & (ZR_OVER_SECTIONS - 1u)) * sec_cap + ol : 0xFFFFFFFFu;
                             if (ol < sec_cap) B.over_tile[pos] = tl;
-                            else { stats->overflow = 1u; stats->overflow_sticky = 1u; }      // the record arrays are full: the frame is incomplete, and says so
+                            else { stats->overflow = 1u; stats->overflow_sticky = ZR_OVF_RECORDS; }      // the record arrays are full: the frame is incomplete, and says so
                         }
-                        if (pos != 0xFFFFFFFFu) rec_store(B, pos, r0, r1, r2, prim, tx, ty);
+                        if (pos != 0xFFFFFFFFu) {
+                            // tile-relative coordinates: both halves minus the tile's origin, each modulo 2^16 (= pack_xy of the differences)
+                            const uint32_t o = pack_xy(tx * (TILE * 256), ty * (TILE * 256));
+                            B.recA[pos] = make_uint4(pk_sub16(q0, o), z0, pk_sub16(q1, o), z1);
+                            B.recB[pos] = make_uint4(pk_sub16(q2, o), z2, prim, 0u);
+                        }
                     }
                 }
             }
@@ -505,7 +551,7 @@ __global__ __launch_bounds__(1024) void k_plan(ZrTriBins B, const uint32_t* __re
         // can put most of its records there: round 2 then draws what the stale pyramid hid, far beyond last frame's counts)
         B.plan[0] = rtot; B.plan[1] = (B.n_rec - rtot) / ZR_OVER_SECTIONS;
         for (uint32_t i = 0; i < 2u * ZR_OVER_SECTIONS; ++i) B.over_cursor[i] = 0u;
-        if (ctot > B.unit_cap && stats) { stats->overflow = 1u; stats->overflow_sticky = 1u; }
+        if (ctot > B.unit_cap && stats) { stats->overflow = 1u; stats->overflow_sticky = ZR_OVF_UNITS; }
     }
 }
 

@@ -134,6 +134,7 @@ extern "C" int zr_dist_prepare(zr_ctx* c, uint32_t rank, uint32_t world, uint32_
             hipEventCreateWithFlags(&d->rendered[b], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&d->consumed[b], hipEventDisableTiming) != hipSuccess) return bail(ZR_ERR_DEVICE, "zr_dist_prepare: buffers");
     }
+    if (hipDeviceSynchronize() != hipSuccess) return bail(ZR_ERR_DEVICE, "zr_dist_prepare: fills");      // (null-stream fills; the streams are non-blocking ones)
     if (d->split_shadow) {
         if (hipMalloc((void**)&d->shadow, (size_t)c->SD * c->SD * 4) != hipSuccess ||
             hipEventCreateWithFlags(&d->shadow_reduced, hipEventDisableTiming) != hipSuccess) return bail(ZR_ERR_DEVICE, "zr_dist_prepare: shadow buffer");

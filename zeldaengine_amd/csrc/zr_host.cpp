@@ -260,6 +260,9 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
         for (auto& fr : c->evr) for (auto& e : fr) ok &= hipEventRecord(e, c->stream) == hipSuccess;
         for (auto& e : c->ev_end) ok &= hipEventRecord(e, c->stream) == hipSuccess;
         for (auto& e : c->view_ev) ok &= hipEventRecord(e, c->stream) == hipSuccess;
+        // hipMemset of device memory is ordered on the NULL stream and need not be complete when it returns; the library's streams are
+        // non-blocking ones (no implicit ordering with the null stream): nothing may be enqueued on them before the fills above are through
+        ok &= hipDeviceSynchronize() == hipSuccess;
         ok &= hipStreamSynchronize(c->stream) == hipSuccess;
     }
     if (!ok) { zr_destroy(c); return ZR_ERR_DEVICE; }
@@ -833,6 +836,9 @@ static int finalize_scene(zr_ctx* c)
         HIPCHK(c, dev_alloc(&c->d_visflag[0], cap_w)); HIPCHK(c, dev_alloc(&c->d_visflag[1], cap_w));
         HIPCHK(c, hipMemset(c->d_visflag[0], 0, cap_w)); HIPCHK(c, hipMemset(c->d_visflag[1], 0, cap_w));      // (no frame's stamp is 0)
         HIPCHK(c, dev_alloc(&c->d_spxrect, cap_w)); HIPCHK(c, dev_alloc(&c->d_szmin, cap_w)); HIPCHK(c, dev_alloc(&c->d_sflag, cap_w));
+        // (the fills above sit on the null stream; the frame that follows runs on non-blocking streams: a fill that landed after that
+        // frame's k_plan would wipe the plan - every record then overflows into sections of capacity 0)
+        HIPCHK(c, hipDeviceSynchronize());
         c->work_capacity = cap_w;              // every buffer is there
     }
     c->any_images = c->mixed_images = false;
@@ -1083,6 +1089,7 @@ static int zr_set_shading_impl(zr_ctx* c, uint32_t mode)
         if (mode == ZR_SHADING_FORWARD && !c->d_prim_b[b]) {
             if (dev_alloc(&c->d_prim_b[b], n) != hipSuccess) return zr_fail(c, ZR_ERR_DEVICE, "zr_set_shading: out of device memory");
             HIPCHK(c, hipMemset(c->d_prim_b[b], 0xFF, n * 4));
+            HIPCHK(c, hipDeviceSynchronize());      // (a null-stream fill; the frames run on non-blocking streams)
         }
         c->Gb[b].prim = mode == ZR_SHADING_FORWARD ? c->d_prim_b[b] : nullptr;
     }
@@ -1679,14 +1686,21 @@ extern "C" int zr_finish(zr_ctx* c)
             c->h_stats.shadow_occluded = 0; for (uint32_t v : sh.covered_part) c->h_stats.shadow_occluded += v;
             c->h_stats.shadow_late = sh.shadow_late;
             c->h_stats.survivors[0] += c->h_stats.shadow_occluded + c->h_stats.shadow_late;
-            c->h_stats.overflow |= sh.overflow; c->h_stats.overflow_sticky |= sh.overflow_sticky;
+            c->h_stats.overflow |= sh.overflow;
+            if (!c->h_stats.overflow_sticky) c->h_stats.overflow_sticky = sh.overflow_sticky;      // (a ZR_OVF_* code: the camera lane's, else the pipeline's)
         }
         c->h_stats.covered_shadow = 0;
         if (c->h_stats.overflow_sticky) {     // latched by ANY frame since the last zr_finish, not only the newest one
             HIPCHK(c, hipMemset(&c->d_stats->overflow_sticky, 0, sizeof(uint32_t)));
             HIPCHK(c, hipMemset(&c->d_sstats->overflow_sticky, 0, sizeof(uint32_t)));
+            HIPCHK(c, hipDeviceSynchronize());      // (null-stream fills: through before the next frame is enqueued on the library's streams)
             c->h_stats.overflow = 1u;
-            return zr_fail(c, ZR_ERR_OVERFLOW, "tile bin list overflow: a frame since the last zr_finish is incomplete");
+            static const char* const what[] = { "?", "shadow bin entries", "slow-triangle list (zr_set_limits)", "camera work-unit table", "triangle-record arrays (zr_set_limits)",
+                                                "late shadow bin entries" };
+            const uint32_t code = c->h_stats.overflow_sticky < 6u ? c->h_stats.overflow_sticky : 0u;
+            char msg[160];
+            snprintf(msg, sizeof msg, "tile bin list overflow (%s): a frame since the last zr_finish is incomplete", what[code]);
+            return zr_fail(c, ZR_ERR_OVERFLOW, msg);
         }
     }
     return ZR_OK;

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(1024) void k_scan(uint32_t* __restrict__ tile_count
         if (slot == 0) stats->overflow = part[1023] > capacity ? 1u : 0u;      // the pipeline's own block: reset here.  (Camera slots - A/B builds -
         else if (part[1023] > capacity) stats->overflow = 1u;                  // share the lane's block: round 2 must not clear round 1's flag)
         if (slot == 0) { stats->n_chunks[1] = 0; stats->chunk_counter[1] = 0; stats->shadow_late = 0; }      // (k_shadow_occlusion's late units)
-        if (part[1023] > capacity) stats->overflow_sticky = 1u;
+        if (part[1023] > capacity) stats->overflow_sticky = ZR_OVF_BINS;
     }
 }
 
@@ -320,7 +320,7 @@ void k_raster_chunks(ZrPass P, const ZrObject* __restrict__ objs, const uint4* _
                             if (pos < slow_cap) {
                                 for (int k = 0; k < 3; ++k) slow[4u * pos + (uint32_t)k] = make_uint4(zr_f2u(cc[k].x), zr_f2u(cc[k].y), zr_f2u(cc[k].z), zr_f2u(cc[k].w));
                                 slow[4u * pos + 3u] = make_uint4(prim, tile, 0u, 0u);
-                            } else { stats->overflow = 1u; stats->overflow_sticky = 1u; }
+                            } else { stats->overflow = 1u; stats->overflow_sticky = ZR_OVF_SLOW; }
                         } else raster_clipped<MODE>(cc[0], cc[1], cc[2], prim, T, P.hw, P.hh, ox, oy, keys64, keys32);
                     }
                 }
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void k_shadow_occlusion(ZrPass P, const ZrObje
                     const uint32_t pos = atomicAdd(&stats->n_chunks[1], 1u);      // (late entries are few; a light that jumps pays ~10 ns apiece here)
                     be.prim_base = ty * P.tiles_x + tx;
                     if (pos < room) bins[P.bin_capacity - 1u - pos] = be;
-                    else { stats->overflow = 1u; stats->overflow_sticky = 1u; }
+                    else { stats->overflow = 1u; stats->overflow_sticky = ZR_OVF_LATE; }
                 }
         }
       }

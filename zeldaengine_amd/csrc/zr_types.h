@@ -123,6 +123,12 @@ struct ZrPass {
 };
 
 // Frame statistics block in device memory (one per pass slot: [shadow, camera]).
+// what ran full (ZrDevStats::overflow_sticky; zr_finish names it)
+#define ZR_OVF_BINS 1u            // the shadow pass's (tile, meshlet) bin entries
+#define ZR_OVF_SLOW 2u            // a list of clipped / long triangles
+#define ZR_OVF_UNITS 3u           // the camera pass's work-unit table
+#define ZR_OVF_RECORDS 4u         // the camera pass's triangle-record arrays (a section of the overflow region)
+#define ZR_OVF_LATE 5u            // the shadow pass's late bin entries
 struct ZrDevStats {
     uint32_t survivors[3];           // slots: 0 shadow pass, 1 camera pass (round 1), 2 camera pass round 2 (after Hi-Z)
     uint32_t bin_entries[3];
@@ -140,7 +146,8 @@ struct ZrDevStats {
     uint32_t shadow_late;            //   ... and drawn in the late launch (not drawn last frame, not hidden this frame)
     uint32_t hiz_culled_geom;        // of hiz_culled: rejected by k_geom (exact vertex box / every triangle hidden), i.e. AFTER a wave transformed
                                      //   the meshlet's vertices; the rest fell to k_select's bounds before any vertex work
-    uint32_t overflow_sticky;        // from here on: NOT cleared at frame begin.  Set with `overflow`, cleared by zr_finish when it reports it
+    uint32_t overflow_sticky;        // from here on: NOT cleared at frame begin.  Set with `overflow` (to the ZR_OVF_* code of what ran full), cleared by
+                                     // zr_finish when it reports it
     uint32_t n_vis_work[2];          // meshlet-instances on the pass's work list (k_cull_instances); the list and its length stand while the
                                      // pass's matrices and the scene do - k_frame_begin zeroes a slot when the host is about to rebuild it
 };
