@@ -1,4 +1,4 @@
-"""Replay one seed of tests/test_gpu_fuzz.py and list the pixels whose depth differs from the oracle: python tools/fuzz_repro.py <seed> [flags]"""
+"""Replay one seed of tests/test_gpu_fuzz.py and list the pixels whose depth differs from the oracle: python tests/fuzz_repro.py <seed> [flags]"""
 import sys
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np

@@ -1,4 +1,4 @@
-"""A hunt with tests/test_gpu_fuzz.py's scenes at LARGE target and shadow-map sizes (overflows are reported with the statistics, mismatches with the targets): python tools/fuzz_hunt_large.py <first seed> <last seed>"""
+"""A hunt with tests/test_gpu_fuzz.py's scenes at LARGE target and shadow-map sizes (overflows are reported with the statistics, mismatches with the targets): python tests/hunt_fuzz_large.py <first seed> <last seed>"""
 import sys
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 import numpy as np
