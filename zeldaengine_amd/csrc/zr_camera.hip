@@ -146,12 +146,6 @@ __global__ __launch_bounds__(256) void k_select(ZrPass P, const ZrObject* __rest
 // tile id modulo) with its tile id beside it, and the tile's first work unit picks its records out of its section: slower, exact, and rare.  A frame without a usable plan (first frame
 // of a scene; the round structure changed) runs k_geom once more ahead of the round, counting only, and plans from that.
 __device__ __forceinline__ uint32_t pack_xy(int X, int Y) { return ((uint32_t)X & 0xFFFFu) | ((uint32_t)Y << 16); }
-// old with lane `l` replaced by v (both wave-uniform: scalar operands; the lane select goes through M0 - one scalar register per VALU instruction)
-__device__ __forceinline__ int lane_write(int v, int l, int old)
-{
-    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(v), "s"(l) : "m0");
-    return old;
-}
 typedef unsigned short zr_us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b)      // (a.lo - b.lo) mod 2^16 | (a.hi - b.hi) mod 2^16 << 16: one v_pk_sub_u16
 {
@@ -406,8 +400,7 @@ void k_geom(ZrPass P, const ZrBinEntry* __restrict__ sel, ZrHiz Z, ZrTriBins B, 
                 for (int k = 0; k < nn; ++k) {
                     const uint32_t bit = 1u << k;
                     const int n0 = __popcll(__ballot((cm[0] & bit) != 0u)), n1 = __popcll(__ballot((cm[1] & bit) != 0u));
-                    cnt0_i = lane_write(n0, k, cnt0_i); cnt_i = lane_write(n0 + n1, k, cnt_i);
-                    mtx = lane_write(tx, k, mtx); mty = lane_write(ty, k, mty);
+                    if ((int)lane == k) { cnt0_i = n0; cnt_i = n0 + n1; mtx = tx; mty = ty; }
                     if (++tx == TX0 + TW) { tx = TX0; ++ty; }
                 }
             }
