@@ -19,7 +19,7 @@ struct ZrMesh {
     ZrMeshletSet ms;
     bool has_meshlets = false, uploaded = false;
     float center[3] = { 0, 0, 0 }; float radius = 0;
-    XkVertex* d_v = nullptr; ZrRVertex* d_rv = nullptr; uint32_t* d_idx = nullptr; XkMeshlet* d_meshlets = nullptr;
+    XkVertex* d_v = nullptr; ZrRVertex* d_rv = nullptr; ZrRVertex* d_rt = nullptr; uint32_t* d_idx = nullptr; XkMeshlet* d_meshlets = nullptr;
     float4* d_mpos = nullptr; float4* d_mbox = nullptr; uint2* d_mtri = nullptr; uint32_t* d_tri_meshlet = nullptr;
 };
 

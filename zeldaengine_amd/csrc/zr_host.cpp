@@ -273,7 +273,7 @@ extern "C" int zr_create(const zr_config* cfg, zr_ctx** out)
 
 static void free_mesh_buffers(ZrMesh& m)
 {
-    dev_free(m.d_v); dev_free(m.d_rv); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mbox); dev_free(m.d_mtri); dev_free(m.d_tri_meshlet);
+    dev_free(m.d_v); dev_free(m.d_rv); dev_free(m.d_rt); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mbox); dev_free(m.d_mtri); dev_free(m.d_tri_meshlet);
     m.uploaded = false;
 }
 
@@ -290,7 +290,7 @@ static void free_scene(zr_ctx* c)
     for (auto& o : c->objects) { dev_free(o.d_inst); for (auto& t : o.d_tex) dev_free(t); }
     c->objects.clear();
     for (auto& m : c->meshes) {
-        dev_free(m.d_v); dev_free(m.d_rv); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mbox); dev_free(m.d_mtri); dev_free(m.d_tri_meshlet);
+        dev_free(m.d_v); dev_free(m.d_rv); dev_free(m.d_rt); dev_free(m.d_idx); dev_free(m.d_meshlets); dev_free(m.d_mpos); dev_free(m.d_mbox); dev_free(m.d_mtri); dev_free(m.d_tri_meshlet);
     }
     c->meshes.clear();
     c->profabs.clear();
@@ -713,6 +713,11 @@ static int upload_mesh(zr_ctx* c, ZrMesh& m)
         const zf3 n = zr_normalize(zr3(x.Normal[0], x.Normal[1], x.Normal[2]));
         rv[i] = ZrRVertex{ x.Position[0], x.Position[1], x.Position[2], x.TexCoord[0], n.x, n.y, n.z, x.TexCoord[1] };
     }
+    // ... and the same records per TRIANGLE CORNER in draw order (96 bytes a triangle): the resolve reaches a pixel's three corners from the
+    // primitive id in one round trip instead of two (index, then vertex) - the kernel waits for its chain of dependent loads, not for arithmetic
+    std::vector<ZrRVertex> rt(std::max<size_t>(1, m.idx.size()));
+    for (size_t i = 0; i < m.idx.size(); ++i) rt[i] = rv[m.idx[i]];
+    HIPCHK(c, upload(&m.d_rt, rt));
     HIPCHK(c, upload(&m.d_v, m.v)); HIPCHK(c, upload(&m.d_rv, rv)); HIPCHK(c, upload(&m.d_idx, m.idx)); HIPCHK(c, upload(&m.d_meshlets, m.ms.meshlets));
     // draw-order triangle -> meshlet (the resolve marks the meshlet-instances that own a pixel)
     std::vector<uint32_t> tri_meshlet(std::max<size_t>(1, m.idx.size() / 3), 0u);
@@ -751,7 +756,7 @@ static int finalize_scene(zr_ctx* c)
     uint64_t work = 0, prim = 0, inst_total = 0;
     auto emit = [&](const ZrSceneObject& o, const ZrMesh& m, uint32_t flags) {
         ZrObject d; memset(&d, 0, sizeof d);
-        d.verts = m.d_v; d.rverts = m.d_rv; d.indices = m.d_idx; d.meshlets = m.d_meshlets; d.mpos = m.d_mpos; d.mbox = m.d_mbox; d.mtri = m.d_mtri; d.tri_meshlet = m.d_tri_meshlet;
+        d.verts = m.d_v; d.rverts = m.d_rv; d.rtris = m.d_rt; d.indices = m.d_idx; d.meshlets = m.d_meshlets; d.mpos = m.d_mpos; d.mbox = m.d_mbox; d.mtri = m.d_mtri; d.tri_meshlet = m.d_tri_meshlet;
         d.inst = o.d_inst;
         d.n_meshlets = (uint32_t)m.ms.meshlets.size(); d.n_tris = (uint32_t)(m.idx.size() / 3);
         d.n_inst = o.n_inst; d.instanced = o.instanced; d.flags = flags;

@@ -104,7 +104,7 @@ __device__ __forceinline__ PixGeom pixel_geom(const ZrPass& P, const ZrObject* _
     if (vis_now) vis_now[O->work_base + inst_i * O->n_meshlets + ld_global(O->tri_meshlet + tri)] = (uint8_t)vis_mark;
     zf4 clip[3]; zf3 WP[3], WN[3]; float U[3], V[3]; uint32_t fl[3];
     for (int k = 0; k < 3; ++k) {
-        const float4* __restrict__ rv = (const float4*)(O->rverts + ld_global(O->indices + 3u * tri + (uint32_t)k));
+        const float4* __restrict__ rv = (const float4*)(O->rtris + 3u * tri + (uint32_t)k);       // (= rverts[indices[3 tri + k]])
         const float4 q0 = ld_global(rv), q1 = ld_global(rv + 1);       // position.xyz u | normalize(normal).xyz v
         const zf3 pos = vs_position(zr3(q0.x, q0.y, q0.z), I, instanced);
         clip[k] = zr_mat4_point(P.PVM, pos);

@@ -39,6 +39,7 @@ struct ZrTex { const uint8_t* data; uint32_t w, h, levels, _pad; };
 struct ZrObject {
     const XkVertex*   verts;
     const ZrRVertex*  rverts;        // the same vertices repacked for the resolve (see ZrRVertex)
+    const ZrRVertex*  rtris;         // ... and once more per triangle corner in draw order: rtris[3 * tri + k] = rverts[indices[3 * tri + k]]
     const uint32_t*   indices;       // draw-order index buffer (3 per triangle)
     const XkMeshlet*  meshlets;      // device copy; BindlessContext = tri_base (triangles in earlier meshlets)
     const float4*     mpos;          // flattened meshlet vertices: mpos[VertexOffset + k] = position of meshlet vertex k
