@@ -150,8 +150,8 @@ int  zr_mesh_get_meshlets(zr_ctx* ctx, uint32_t mesh_id, XkMeshlet* m, uint32_t*
 int  zr_object_add(zr_ctx* ctx, uint32_t mesh_id, const zr_material* mat,
                    const XkInstanceData* inst, uint32_t n_inst);
 /* Capacities of the camera pass's triangle-record arrays (record_chunks x 256 records of 32 bytes, + 4 bytes of tile id) and of its
- * clipped-triangle list; 0 = defaults (8 records per meshlet-instance of the scene, at least 32 Mi; 2^18 triangles).  A frame that
- * outgrows either reports ZR_ERR_OVERFLOW at zr_finish.  Takes effect at the next frame (the arrays are re-made). */
+ * clipped-triangle list; 0 = defaults (16 records per meshlet-instance of the scene, at least 32 Mi; 2^18 triangles).  A frame that
+ * outgrows either reports ZR_ERR_OVERFLOW at zr_finish (zr_last_error names which).  Takes effect at the next frame (the arrays are re-made). */
 int  zr_set_limits(zr_ctx* ctx, uint32_t record_chunks, uint32_t slow_triangles);
 /* The record arrays are laid out per frame as one bucket per screen tile, sized from the previous frame's count (+ 25 % + 128), and
  * an overflow region behind them for what a tile gets beyond its bucket.  percent (1..100, default 100) plans every bucket at that

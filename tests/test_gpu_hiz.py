@@ -178,6 +178,54 @@ def test_config4_scale_culling_paths_agree(gpu_engine):
     assert a[3]["hiz_culled"] > 100000 and a[3]["survivors"][1] < b[3]["survivors"][1] // 3
 
 
+def test_camera_cut_at_config4_scale_matches_a_fresh_context(gpu_engine):
+    """A camera CUT at 1 M instances / 3840x2160: the frame after it runs on a stale visibility history - round 2 then draws most of the
+    scene, tens of millions of records beyond the buckets planned from the frame before, into the sections of the overflow region
+    (the round's first bucketed build reported ZR_ERR_OVERFLOW here, and sifted quadratically before that).  Every target of that frame,
+    and of the one after it, must equal what a context that has only ever seen the new camera draws."""
+    import math
+    from zeldaengine_amd import engine as eng
+    cfg = scenes.config4(1000000, 16)
+
+    def cam(deg, h):
+        a = math.radians(deg)
+        return abi.make_camera((math.sqrt(50.0) * math.cos(a), math.sqrt(50.0) * math.sin(a), h), (0.0, 0.0, 0.0))
+
+    def frame(g, c):
+        g.update_uniforms(c, cfg["dir"], cfg["point"], cfg["spot"], 0.0, 0.0, 0.0)
+        g.render()
+
+    def grab(g):
+        g.finish()
+        st = g.stats()
+        assert st["overflow"] == 0, st
+        return g.color(), [g.gbuffer(t) for t in range(6)], g.shadowmap(), st
+
+    new_cam = cam(170.0, 2.0)
+    a = gpu_engine.Renderer(cfg["width"], cfg["height"], 1024)
+    eng.load_scene(a, cfg)
+    for _ in range(3):
+        frame(a, cam(45.0, 5.0))                     # a settled history and plan for the OLD camera
+    frame(a, new_cam)
+    cut = grab(a)                                    # the frame after the cut
+    frame(a, new_cam)
+    after = grab(a)                                  # ... and the next one (planned from the cut frame's counts)
+    a.close()
+    b = gpu_engine.Renderer(cfg["width"], cfg["height"], 1024)
+    eng.load_scene(b, cfg)
+    frame(b, new_cam)
+    fresh = grab(b)
+    b.close()
+    for name, got in (("cut", cut), ("after the cut", after)):
+        assert np.array_equal(got[0], fresh[0]), name
+        for t in range(6):
+            assert np.array_equal(got[1][t].view(np.uint8), fresh[1][t].view(np.uint8)), (name, "GBuffer target %d" % t)
+        assert np.array_equal(got[2].view(np.uint32), fresh[2].view(np.uint32)), name
+        assert got[3]["covered_pixels"] == fresh[3]["covered_pixels"], name
+    # the cut frame really went the overflow way: far more records than the settled frames before it
+    assert cut[3]["bin_entries"][1] > 3 * after[3]["bin_entries"][1], (cut[3], after[3])
+
+
 def test_soak_two_frames_in_flight(oracle_lib, gpu_engine):
     """600 frames enqueued back to back (no host synchronisation in between) with the camera, the stage and the lights moving every
     frame: the double-buffered uniforms / GBuffer / shadow map of the two-frames-in-flight schedule and the pinned upload ring must

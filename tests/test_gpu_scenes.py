@@ -525,7 +525,7 @@ def test_record_pool_and_slow_list_overflow_are_reported(oracle_lib, gpu_engine,
     o = oracle_lib.Oracle(W, H, SD)
     scene(o)
     o.render()
-    for limits in ((8, 0), (0, 2)):                    # (record chunks, clipped triangles); 0 = default
+    for limits, what in (((8, 0), "triangle-record arrays"), ((0, 2), "slow-triangle list")):      # (record chunks, clipped triangles); 0 = default
         g = gpu_engine.Renderer(W, H, SD)
         g.set_limits(*limits)
         scene(g)
@@ -533,6 +533,7 @@ def test_record_pool_and_slow_list_overflow_are_reported(oracle_lib, gpu_engine,
         with pytest.raises(gpu_engine.ZeldaRenderError) as e:
             g.finish()
         assert e.value.code == abi.ERR_OVERFLOW, (limits, e.value)
+        assert what in str(e.value), (limits, str(e.value))       # zr_last_error names the capacity that ran full
         g.set_limits(0, 0)                             # the same context with the default pools: the frame is whole again
         g.render(); g.render(); g.finish()
         d = compare_all(o, g)

@@ -5,16 +5,18 @@
 // First launch of a frame: zero the frame statistics (all but the sticky overflow latch) and, when the uniforms changed, copy
 // XkView from the pinned host ring slot into this frame's device copy.  (The runtime's own hipMemcpyAsync / hipMemsetAsync
 // paths cost two extra launches per frame, and the copy path stalls the host for milliseconds the first times it is used.)
-__global__ __launch_bounds__(1024) void k_frame_begin(uint32_t* __restrict__ stats, uint32_t n_stats, const uint32_t* __restrict__ view_src,
-                                                      uint32_t* __restrict__ view_dst, uint32_t n_view,
-                                                      uint32_t* __restrict__ n_vis_camera, uint32_t rebuild_lists)
+// (256-thread workgroups: beside the other lane's persistent kernels a 1024-thread workgroup waits until a whole CU's worth of wave
+// slots is free - the launch was seen taking 5 to 40 us at the head of the camera lane)
+__global__ __launch_bounds__(256) void k_frame_begin(uint32_t* __restrict__ stats, uint32_t n_stats, const uint32_t* __restrict__ view_src,
+                                                     uint32_t* __restrict__ view_dst, uint32_t n_view,
+                                                     uint32_t* __restrict__ n_vis_camera, uint32_t rebuild_lists)
 {
-    const uint32_t i0 = blockIdx.x * 1024u + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x < n_stats) stats[threadIdx.x] = 0u;
+    const uint32_t i0 = blockIdx.x * 256u + threadIdx.x;
+    if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < n_stats; i += 256u) stats[i] = 0u;
     // the passes' work lists (k_cull_instances) stand while camera / light matrices and scene do: only a list about to be rebuilt starts from 0
     // (the shadow pass's length sits in the shadow pipeline's own block and is reset on that pipeline's stream, see shadow_pass)
     if (blockIdx.x == 0 && threadIdx.x == 1u && (rebuild_lists & 2u)) *n_vis_camera = 0u;
-    if (view_src) for (uint32_t i = i0; i < n_view; i += gridDim.x * 1024u) view_dst[i] = view_src[i];
+    if (view_src) for (uint32_t i = i0; i < n_view; i += gridDim.x * 256u) view_dst[i] = view_src[i];
 }
 
 __global__ void k_fill32(uint32_t* __restrict__ p, uint32_t v, size_t n)
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void k_pack_tiles(const uint32_t* __restrict__
 void zr_launch_frame_begin(ZrDevStats* stats, const XkView* view_src_pinned, XkView* view_dst, uint32_t rebuild_lists, hipStream_t s)
 {
     static_assert(sizeof(XkView) % 4 == 0 && offsetof(ZrDevStats, overflow_sticky) % 4 == 0, "dword copies");
-    hipLaunchKernelGGL(k_frame_begin, dim3(view_src_pinned ? 4 : 1), dim3(1024), 0, s, (uint32_t*)stats, (uint32_t)(offsetof(ZrDevStats, overflow_sticky) / 4),
+    hipLaunchKernelGGL(k_frame_begin, dim3(view_src_pinned ? 16 : 1), dim3(256), 0, s, (uint32_t*)stats, (uint32_t)(offsetof(ZrDevStats, overflow_sticky) / 4),
                        (const uint32_t*)view_src_pinned, (uint32_t*)view_dst, (uint32_t)(sizeof(XkView) / 4), &stats->n_vis_work[1], rebuild_lists);
 }
 void zr_launch_fill32(uint32_t* p, uint32_t v, size_t n, hipStream_t s)

@@ -648,7 +648,7 @@ extern "C" int zr_object_add(zr_ctx* c, uint32_t mesh_id, const zr_material* mat
 }
 
 // Capacities of the triangle-record arrays (chunks of 256 records) and of the clipped-triangle list, for hosts that size them themselves
-// (0 = the default: 8 records per meshlet-instance, at least 32 Mi; 2^18 triangles).  Takes effect at the next frame.
+// (0 = the default: 16 records per meshlet-instance, at least 32 Mi; 2^18 triangles).  Takes effect at the next frame.
 extern "C" int zr_set_limits(zr_ctx* c, uint32_t record_chunks, uint32_t slow_triangles)
 {
     if (!c) return ZR_ERR_ARG;
@@ -813,11 +813,13 @@ static int finalize_scene(zr_ctx* c)
         }
         // triangle-binned camera pass: triangle records (32 B) live in per-tile BUCKETS of two 16-byte planes, laid out every frame by
         // k_plan from the previous frame's per-tile counts; what lies behind the last bucket is the frame's overflow region (what a tile gets
-        // beyond its bucket).  Sized from the scene: 8 records per meshlet-instance, at least 32 Mi - 1 GB of 288 reserved, touched as far as a frame
+        // beyond its bucket).  Sized from the scene: 16 records per meshlet-instance, at least 32 Mi - 1 GB of 288 reserved, touched as far as a frame
         // needs.  Planes that run full are reported like a bin overflow (zr_set_limits sizes them: 256 records per "chunk").
         free_tri_bins(c);
         c->tb.n_waves = 8192; c->tb.slow_cap = 1u << 18;
-        uint64_t n_rec = std::min<uint64_t>(std::max<uint64_t>(32ull << 20, 8ull * c->n_work), 0x3FFFFFFFull);
+        // (16 per meshlet-instance: the frame after a camera cut at config 4 puts ~ 60 M records - 5 per meshlet-instance - into the 64
+        // sections of the overflow region, unevenly; with 8 the fullest section ran over.  6 GB of 288 at 1 M instances.)
+        uint64_t n_rec = std::min<uint64_t>(std::max<uint64_t>(32ull << 20, 16ull * c->n_work), 0x3FFFFFFFull);
         if (c->limit_record_chunks) n_rec = 256ull * c->limit_record_chunks;      // zr_set_limits (a host sizing the planes; the overflow tests)
         if (c->limit_slow_triangles) c->tb.slow_cap = std::max(2u, c->limit_slow_triangles);
         c->tb.n_rec = (uint32_t)n_rec; c->tb.bucket_max = (uint32_t)(n_rec - n_rec / 8u);
