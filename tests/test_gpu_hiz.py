@@ -136,6 +136,33 @@ def test_tile_partitioned_ranks_keep_their_own_history(oracle_lib, gpu_engine):
             assert all(g.stats()["round1_survivors"] > 0 for g in ranks)
 
 
+def test_rank_contexts_with_small_buckets_draw_their_tiles_from_the_overflow_sections(oracle_lib, gpu_engine):
+    """Four rank contexts (screen super-tiles) with every record bucket planned at 25 % of its size (zr_set_bucket_share) over a
+    sequence of camera jumps: most of every owned tile's records take the overflow route - sections by tile number, of which a rank
+    owns only some - and the four packed quarters still assemble to the oracle's frame on every frame."""
+    from zeldaengine_amd import dist as zdist
+    W, H, SD = 352, 208, 128
+    o = oracle_lib.Oracle(W, H, SD)
+    ranks = [gpu_engine.Renderer(W, H, SD, tile_rank=r, tile_world=4) for r in range(4)]
+    for g in ranks:
+        g.set_bucket_share(25)
+    for r in [o] + ranks:
+        _crowd(r, 900, 7)
+    d, p, s = _lights()
+    for i, (pos, look) in enumerate(CAMS[:4] + CAMS[:2]):
+        cam = abi.make_camera(pos, look, fov=50.0)
+        for r in [o] + ranks:
+            r.update_uniforms(cam, d, p, s, 0.05 * i, 0.0, 1.0)
+        o.render(0)
+        want = o.color()
+        for k, g in enumerate(ranks):
+            g.render(); g.finish()
+            assert g.stats()["overflow"] == 0
+            assert np.array_equal(g.read_tiles(), zdist.pack_tiles(want, k, 4)), "frame %d rank %d" % (i, k)
+    for g in ranks:
+        g.close()
+
+
 def _three_frames_with_a_light_step(g, cfg):
     """Two still frames, then the shadow-casting light turns one degree about the scene: the third frame runs on a visibility history
     and on shadow-occlusion flags that belong to the old light."""
